@@ -1,0 +1,548 @@
+// Dense N-d convolution family (2-D handled as depth 1) as implicit GEMM on the fp32 matrix cores.
+//
+// Replaces the cuDNN calls behind nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d on the StereoDPNet
+// path (reference call sites: src/module/asm/basics.py:17-36, src/model/stereodpnet/modules.py:
+// 26-32,64-69,88-91,208-227,271-296, normal_module.py:14-19, dcn3d/modules/deform_conv.py:310-315).
+//
+//   dpf_conv_forward   out[n,k,o] = bias[k] + sum_{c,t} W[k,c,t] * x[n,c, o*s - p + t*dil]
+//   dpf_conv_transpose out[n,k,o] = bias[k] + sum_{c,t} W'[c,k,t] * x[n,c, (o + p - t*dil)/s]   (exact division only)
+//                      (= data gradient of the forward conv, and nn.ConvTranspose3d's forward)
+//   dpf_conv_wgrad     dW[k,c,t] += sum_{n,q} g[n,k,q] * x[n,c, q*s - p + t*dil]
+//
+// Mapping (MI355X-first, not a cuDNN/CUDA tiling): v_mfma_f32_32x32x2_f32, exact f32 (bitwise an
+// fmaf chain) at the f32 vector peak.  D[row = out channel][col = position]: the weight fragment is
+// the A operand (lane&31 = channel), the input patch the B operand (lane&31 = 32 consecutive W
+// positions, so every LDS read and every store of a wave half is one contiguous 128-B segment).
+// One workgroup (4 waves) owns ALL output channels of an 8x32 position tile of one (n, depth) plane,
+// so the input patch (with halo) is staged in LDS once per channel chunk and never re-read for
+// another channel tile.  Strided transposed convolutions are decomposed into s^3 parity classes,
+// each a dense stride-1 gather over the valid tap subset (no zero-insertion, no wasted MACs).
+#include "dpf_common.h"
+#include "dpf_repack.h"
+
+namespace {
+
+constexpr int TW = 32;       // positions along W per tile (= MFMA N)
+constexpr int NT = 2;        // rows per wave
+constexpr int TH = 4 * NT;   // rows per tile (4 waves)
+constexpr int MAXT = 27;
+
+struct ConvP {
+  int N, C, K;
+  int ID, IH, IW;   // x dims
+  int OD, OH, OW;   // out dims
+  int kd, kh, kw;
+  int sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int transposed;
+  int QD, tilesH, tilesW, ncls;   // grid decomposition (class-0 sizes)
+  int chanStrideMax;              // floats per channel of the LDS input tile (host worst case)
+  int ntmax;                      // max valid taps per class
+};
+
+struct DimTap {
+  int emin, emax;
+};
+
+// per-dimension tap geometry: input coordinate = q*sx + e(t)
+__device__ __forceinline__ bool tap_e(int t, int k, int s, int p, int dil, int r, int transposed, int& e) {
+  if (!transposed) {
+    e = t * dil - p;
+    return true;
+  }
+  const int num = r + p - t * dil;
+  int m = num % s;
+  if (m < 0) m += s;
+  if (m != 0) return false;
+  e = (num - m) / s;   // exact
+  return true;
+}
+
+__device__ __forceinline__ void dim_range(int k, int s, int p, int dil, int r, int transposed, int& emin, int& emax, int& nvalid) {
+  emin = 1 << 30;
+  emax = -(1 << 30);
+  nvalid = 0;
+  for (int t = 0; t < k; ++t) {
+    int e;
+    if (tap_e(t, k, s, p, dil, r, transposed, e)) {
+      emin = e < emin ? e : emin;
+      emax = e > emax ? e : emax;
+      ++nvalid;
+    }
+  }
+}
+
+template <int MT, int CC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                         const float* __restrict__ bias, float* __restrict__ out, ConvP p) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int KT = 32 * MT;
+  // LDS carve: [input tile CC*chanStrideMax][weights ntmax*CC*KT][tapoff MAXT][tapw MAXT][nv]
+  float* s_in = smem;
+  float* s_w = s_in + CC * p.chanStrideMax;
+  int* s_tapoff = (int*)(s_w + p.ntmax * CC * KT);
+  int* s_tapw = s_tapoff + MAXT;
+  int* s_nv = s_tapw + MAXT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int hh = lane >> 5;
+
+  int b = blockIdx.x;
+  const int tw = b % p.tilesW; b /= p.tilesW;
+  const int th = b % p.tilesH; b /= p.tilesH;
+  const int qd = b % p.QD; b /= p.QD;
+  const int n = b % p.N;
+  const int cls = b / p.N;
+
+  int rd = 0, rh = 0, rw = 0;
+  int sxd = p.sd, sxh = p.sh, sxw = p.sw;   // input step per output step
+  int sod = 1, soh = 1, sow = 1;            // output step per q step
+  if (p.transposed) {
+    rw = cls % p.sw;
+    rh = (cls / p.sw) % p.sh;
+    rd = cls / (p.sw * p.sh);
+    sxd = sxh = sxw = 1;
+    sod = p.sd; soh = p.sh; sow = p.sw;
+  }
+  // q-grid of this class
+  const int Qd = (p.OD - rd + sod - 1) / sod;
+  const int Qh = (p.OH - rh + soh - 1) / soh;
+  const int Qw = (p.OW - rw + sow - 1) / sow;
+  const int q0h = th * TH, q0w = tw * TW;
+  if (qd >= Qd || q0h >= Qh || q0w >= Qw) return;
+
+  int emin_d, emax_d, nvd, emin_h, emax_h, nvh, emin_w, emax_w, nvw;
+  dim_range(p.kd, p.sd, p.pd, p.dd, rd, p.transposed, emin_d, emax_d, nvd);
+  dim_range(p.kh, p.sh, p.ph, p.dh, rh, p.transposed, emin_h, emax_h, nvh);
+  dim_range(p.kw, p.sw, p.pw, p.dw, rw, p.transposed, emin_w, emax_w, nvw);
+  const int nvalid = nvd * nvh * nvw;
+
+  const int od = qd * sod + rd;
+  const long long out_plane = (long long)p.OH * p.OW;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
+
+  if (nvalid > 0) {
+    const int ext_d = emax_d - emin_d + 1;
+    const int ext_h = (TH - 1) * sxh + (emax_h - emin_h) + 1;
+    const int ext_w = (TW - 1) * sxw + (emax_w - emin_w) + 1;
+    const int planeStride = ext_h * ext_w;
+    const int chanStride = ext_d * planeStride;
+    const int i0d = qd * sxd + emin_d, i0h = q0h * sxh + emin_h, i0w = q0w * sxw + emin_w;
+
+    if (tid == 0) {
+      int nv = 0;
+      for (int a = 0; a < p.kd; ++a) {
+        int ed;
+        if (!tap_e(a, p.kd, p.sd, p.pd, p.dd, rd, p.transposed, ed)) continue;
+        for (int bb = 0; bb < p.kh; ++bb) {
+          int eh;
+          if (!tap_e(bb, p.kh, p.sh, p.ph, p.dh, rh, p.transposed, eh)) continue;
+          for (int c = 0; c < p.kw; ++c) {
+            int ew;
+            if (!tap_e(c, p.kw, p.sw, p.pw, p.dw, rw, p.transposed, ew)) continue;
+            s_tapoff[nv] = ((ed - emin_d) * ext_h + (eh - emin_h)) * ext_w + (ew - emin_w);
+            s_tapw[nv] = (a * p.kh + bb) * p.kw + c;
+            ++nv;
+          }
+        }
+      }
+      s_nv[0] = nv;
+    }
+
+    int lanebase[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) lanebase[t] = ((wave * NT + t) * sxh) * ext_w + l31 * sxw + hh * chanStride;
+
+    const int in_rows = CC * ext_d * ext_h;
+    const int rows_per_chan = ext_d * ext_h;
+    const long long x_chan = (long long)p.ID * p.IH * p.IW;
+    const float* xn = x + (long long)n * p.C * x_chan;
+
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+      __syncthreads();   // previous chunk fully consumed (also orders the tap table on the first trip)
+      // ---- stage the input patch: one LDS row per (channel, plane, row), lanes along W
+      for (int rowid = wave; rowid < in_rows; rowid += 4) {
+        const int cc = rowid / rows_per_chan;
+        const int rem = rowid - cc * rows_per_chan;
+        const int pl = rem / ext_h;
+        const int rr = rem - pl * ext_h;
+        const int ic = c0 + cc, id = i0d + pl, ih = i0h + rr;
+        const bool rowok = (ic < p.C) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
+        const float* src = xn + (long long)ic * x_chan + ((long long)id * p.IH + ih) * p.IW;
+        float* dst = s_in + cc * chanStride + rem * ext_w;
+        for (int col = lane; col < ext_w; col += 64) {
+          const int iw = i0w + col;
+          float v = 0.f;
+          if (rowok && iw >= 0 && iw < p.IW) v = src[iw];
+          dst[col] = v;
+        }
+      }
+      // ---- stage the weight slab of this channel chunk: [slot][cc][KT]
+      const int nv = nvalid;
+      for (int rowid = wave; rowid < nv * CC; rowid += 4) {
+        const int slot = rowid / CC;
+        const int cc = rowid - slot * CC;
+        const int ic = c0 + cc;
+        const float* src = wt + ((long long)s_tapw[slot] * p.C + ic) * KT;
+        float* dst = s_w + rowid * KT;
+        for (int k = lane; k < KT; k += 64) dst[k] = (ic < p.C) ? src[k] : 0.f;
+      }
+      __syncthreads();
+      // ---- MFMA over (tap, channel pair)
+      for (int slot = 0; slot < nv; ++slot) {
+        const int toff = s_tapoff[slot];
+        const float* wrow = s_w + (slot * CC + hh) * KT + l31;
+#pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp) {
+          float a[MT], bv[NT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a[m] = wrow[(2 * cp) * KT + m * 32];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) bv[t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[t], acc[m][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: D row = (j&3) + 8*(j>>2) + 4*(lane>>5), col = lane&31
+  const int qw = q0w + l31;
+  const int ow = qw * sow + rw;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int qh = q0h + wave * NT + t;
+    if (qh >= Qh || qw >= Qw) continue;
+    const int oh = qh * soh + rh;
+    const long long pos = ((long long)od * p.OH + oh) * p.OW + ow;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (k < p.K) {
+          float v = acc[m][t][j];
+          if (bias) v += bias[k];
+          out[((long long)n * p.K + k) * p.OD * out_plane + pos] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  dW[k][c][t] += sum_{n,q} g[n,k,q] * x[n,c, q*s - p + t*dil]
+// D[row = k][col = (c,t)],  reduction (MFMA K dim) over positions.
+struct WgP {
+  int N, C, K;
+  int ID, IH, IW;   // x ("big grid") dims
+  int QD, QH, QW;   // g ("small grid") dims
+  int kd, kh, kw, T;
+  int sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int CCW;          // channels per block
+  int nchunk;       // position chunks
+  int tilesH, tilesW;
+  long long ntiles;
+};
+
+constexpr int WTH = 4;            // rows per wgrad position tile
+constexpr int WPT = WTH * TW;     // 128 positions
+constexpr int WNT = 2;            // column tiles (of 32 (c,t) pairs) per wave
+
+template <int MT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                         float* __restrict__ dw, WgP p) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int KT = 32 * MT;
+  const int ext_d = (p.kd - 1) * p.dd + 1;
+  const int ext_h = (WTH - 1) * p.sh + (p.kh - 1) * p.dh + 1;
+  const int ext_w = (TW - 1) * p.sw + (p.kw - 1) * p.dw + 1;
+  const int planeStride = ext_h * ext_w;
+  const int chanStride = ext_d * planeStride;
+  float* s_x = smem;                         // [CCW][chanStride]
+  float* s_g = s_x + p.CCW * chanStride;     // [KT][WPT+1]
+  constexpr int GS = WPT + 1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int cchunk = blockIdx.x / p.nchunk;
+  const int pchunk = blockIdx.x % p.nchunk;
+  const int c0 = cchunk * p.CCW;
+  const int ncc = min(p.CCW, p.C - c0);
+  const int ncol = ncc * p.T;
+
+  // per-lane column descriptors
+  int colbase[WNT];
+  bool colok[WNT];
+#pragma unroll
+  for (int t = 0; t < WNT; ++t) {
+    const int coln = (wave * WNT + t) * 32 + l31;
+    colok[t] = coln < ncol;
+    const int cn = colok[t] ? coln : 0;
+    const int cc = cn / p.T;
+    const int tap = cn - cc * p.T;
+    const int tw_ = tap % p.kw;
+    const int th_ = (tap / p.kw) % p.kh;
+    const int td_ = tap / (p.kw * p.kh);
+    colbase[t] = cc * chanStride + (td_ * p.dd * ext_h + th_ * p.dh) * ext_w + tw_ * p.dw + hh * p.sw;
+  }
+
+  f32x16 acc[MT][WNT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < WNT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
+
+  const long long x_chan = (long long)p.ID * p.IH * p.IW;
+  const long long g_chan = (long long)p.QD * p.QH * p.QW;
+  const int rows_per_chan = ext_d * ext_h;
+
+  for (long long tile = pchunk; tile < p.ntiles; tile += p.nchunk) {
+    long long b = tile;
+    const int tw = (int)(b % p.tilesW); b /= p.tilesW;
+    const int th = (int)(b % p.tilesH); b /= p.tilesH;
+    const int qd = (int)(b % p.QD);
+    const int n = (int)(b / p.QD);
+    const int q0h = th * WTH, q0w = tw * TW;
+    const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, i0w = q0w * p.sw - p.pw;
+    __syncthreads();
+    // stage x patch
+    const float* xn = x + ((long long)n * p.C + c0) * x_chan;
+    for (int rowid = wave; rowid < ncc * rows_per_chan; rowid += 4) {
+      const int cc = rowid / rows_per_chan;
+      const int rem = rowid - cc * rows_per_chan;
+      const int pl = rem / ext_h;
+      const int rr = rem - pl * ext_h;
+      const int id = i0d + pl, ih = i0h + rr;
+      const bool rowok = (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
+      const float* src = xn + (long long)cc * x_chan + ((long long)id * p.IH + ih) * p.IW;
+      float* dst = s_x + cc * chanStride + rem * ext_w;
+      for (int col = lane; col < ext_w; col += 64) {
+        const int iw = i0w + col;
+        float v = 0.f;
+        if (rowok && iw >= 0 && iw < p.IW) v = src[iw];
+        dst[col] = v;
+      }
+    }
+    // stage g tile: [k][row*32+col]
+    const float* gn = g + (long long)n * p.K * g_chan + (long long)qd * p.QH * p.QW;
+    for (int rowid = wave; rowid < KT * WTH; rowid += 4) {
+      const int k = rowid / WTH;
+      const int r = rowid - k * WTH;
+      const int qh = q0h + r;
+      if (lane < 32) {
+        const int qw = q0w + lane;
+        float v = 0.f;
+        if (k < p.K && qh < p.QH && qw < p.QW) v = gn[(long long)k * g_chan + (long long)qh * p.QW + qw];
+        s_g[k * GS + r * 32 + lane] = v;
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < WTH; ++r) {
+      const int rowoff = (r * p.sh) * ext_w;
+#pragma unroll 4
+      for (int cs = 0; cs < 16; ++cs) {
+        const int pos = r * 32 + 2 * cs + hh;
+        float a[MT], bv[WNT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = s_g[(m * 32 + l31) * GS + pos];
+#pragma unroll
+        for (int t = 0; t < WNT; ++t) bv[t] = s_x[colbase[t] + rowoff + (2 * cs) * p.sw];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < WNT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[t], acc[m][t], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: atomics into dW[k][c][t]
+#pragma unroll
+  for (int t = 0; t < WNT; ++t) {
+    if (!colok[t]) continue;
+    const int coln = (wave * WNT + t) * 32 + l31;   // = cc*T + tap
+    const long long base = (long long)c0 * p.T + coln;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (k < p.K) atomicAdd(dw + (long long)k * p.C * p.T + base, acc[m][t][j]);
+      }
+  }
+}
+
+int out_dim(int I, int k, int s, int p, int d) { return (I + 2 * p - (d * (k - 1) + 1)) / s + 1; }
+
+template <int MT, int CC>
+int launch_igemm(const float* x, const float* wt, const float* bias, float* out, const ConvP& p, size_t lds, hipStream_t st) {
+  const long long blocks = (long long)p.ncls * p.N * p.QD * p.tilesH * p.tilesW;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
+  if (lds > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MT, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return DPF_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<MT, CC>), dim3((unsigned)blocks), dim3(256), lds, st, x, wt, bias, out, p);
+  return dpf_check_launch();
+}
+
+int conv_common(const float* x, const float* w, const float* bias, float* out, float* wt_ws, ConvP p, int repack_mode,
+                int wA, int wB, hipStream_t st) {
+  const int T = p.kd * p.kh * p.kw;
+  if (T > MAXT || T < 1) return DPF_ERR_UNSUPPORTED;
+  const int MT = (p.K + 31) / 32;
+  if (MT < 1 || MT > 4) return DPF_ERR_UNSUPPORTED;
+  const int KT = 32 * MT;
+  // repack weights -> wt_ws [T][C][KT]
+  {
+    const long long total = (long long)T * p.C * KT;
+    hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wt_ws, wA, wB, T, KT, repack_mode);
+    if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
+  }
+  // tile geometry (host worst case over classes)
+  int ext_d, ext_h, ext_w, ntmax;
+  if (!p.transposed) {
+    p.ncls = 1;
+    p.QD = p.OD;
+    p.tilesH = dpf_div_up(p.OH, TH);
+    p.tilesW = dpf_div_up(p.OW, TW);
+    ext_d = (p.kd - 1) * p.dd + 1;
+    ext_h = (TH - 1) * p.sh + (p.kh - 1) * p.dh + 1;
+    ext_w = (TW - 1) * p.sw + (p.kw - 1) * p.dw + 1;
+    ntmax = T;
+  } else {
+    p.ncls = p.sd * p.sh * p.sw;
+    p.QD = dpf_div_up(p.OD, p.sd);
+    p.tilesH = dpf_div_up(dpf_div_up(p.OH, p.sh), TH);
+    p.tilesW = dpf_div_up(dpf_div_up(p.OW, p.sw), TW);
+    ext_d = ((p.kd - 1) * p.dd) / p.sd + 1;
+    ext_h = (TH - 1) + ((p.kh - 1) * p.dh) / p.sh + 1;
+    ext_w = (TW - 1) + ((p.kw - 1) * p.dw) / p.sw + 1;
+    auto nvmax = [](int k, int s, int d) {   // max taps of one parity class along a dim
+      int best = 0;
+      for (int r = 0; r < s; ++r) {
+        int c = 0;
+        for (int t = 0; t < k; ++t) c += ((((r - t * d) % s) + s) % s == 0);
+        if (c > best) best = c;
+      }
+      // pad shifts the classes but not their sizes
+      return best;
+    };
+    ntmax = nvmax(p.kd, p.sd, p.dd) * nvmax(p.kh, p.sh, p.dh) * nvmax(p.kw, p.sw, p.dw);
+  }
+  p.chanStrideMax = ext_d * ext_h * ext_w;
+  p.ntmax = ntmax;
+  auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + ntmax * CC * KT + 2 * MAXT + 4) * sizeof(float); };
+  int CC = 8;
+  if (lds_bytes(8) > 64 * 1024 || p.C <= 4) CC = 4;
+  const size_t lds = lds_bytes(CC);
+  if (lds > 160 * 1024) return DPF_ERR_UNSUPPORTED;
+#define DPF_IG(M, Cc) return launch_igemm<M, Cc>(x, wt_ws, bias, out, p, lds, st)
+  if (CC == 8) {
+    switch (MT) { case 1: DPF_IG(1, 8); case 2: DPF_IG(2, 8); case 3: DPF_IG(3, 8); default: DPF_IG(4, 8); }
+  } else {
+    switch (MT) { case 1: DPF_IG(1, 4); case 2: DPF_IG(2, 4); case 3: DPF_IG(3, 4); default: DPF_IG(4, 4); }
+  }
+#undef DPF_IG
+}
+
+}  // namespace
+
+extern "C" {
+
+// workspace (floats) needed for the repacked weights of a conv with `T` taps, `reduce` reduction channels
+// and `outc` output channels
+long long dpf_conv_workspace_floats(int T, int reduce, int outc) { return (long long)T * reduce * (((outc + 31) / 32) * 32); }
+
+// x [N,C,ID,IH,IW], w [K,C,kd,kh,kw], bias [K] or NULL, out [N,K,OD,OH,OW]
+int dpf_conv_forward(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                     int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw,
+                     void* stream) {
+  if (!x || !w || !out || !ws || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
+  ConvP p{};
+  p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW;
+  p.kd = kd; p.kh = kh; p.kw = kw; p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw;
+  p.OD = out_dim(ID, kd, sd, pd, dd); p.OH = out_dim(IH, kh, sh, ph, dh); p.OW = out_dim(IW, kw, sw, pw, dw);
+  if (p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return DPF_ERR_INVALID_ARG;
+  p.transposed = 0;
+  return conv_common(x, w, bias, out, ws, p, /*mode*/ 0, K, C, (hipStream_t)stream);
+}
+
+// Transposed convolution.  x [N,C,ID,IH,IW] lives on the strided (small) grid, out [N,K,OD,OH,OW] on the dense grid;
+// (OD,OH,OW) are given by the caller (output_padding ambiguity).  `w_is_conv_layout` = 1: w is a forward-conv weight
+// [C(x chans = conv out), K(out chans = conv in), T] and this call is that conv's data gradient;
+// = 0: w is an nn.ConvTranspose3d weight [C_in = C, C_out = K, T].  Both are [C][K][T] in memory.
+int dpf_conv_transpose(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                       int K, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                       int dd, int dh, int dw, void* stream) {
+  if (!x || !w || !out || !ws || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
+  ConvP p{};
+  p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW; p.OD = OD; p.OH = OH; p.OW = OW;
+  p.kd = kd; p.kh = kh; p.kw = kw; p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw;
+  p.transposed = 1;
+  // w[C][K][T]: reduce = A (=C), out = B (=K)
+  return conv_common(x, w, bias, out, ws, p, /*mode*/ 1, C, K, (hipStream_t)stream);
+}
+
+// Forward conv with the weight stored transposed-conv style w[K_reduce=C? ...]:
+// data gradient of nn.ConvTranspose3d: out[n,ci,q] = sum_{co,t} w[ci][co][t] * g[n,co, q*s - p + t*dil]
+// i.e. a forward conv whose weight is indexed [out][reduce][t] -- identical to dpf_conv_forward (w[K][C][T]).
+
+// dW[K][C][T] += ...   (dw must be zero-initialised or hold the running gradient)
+// g [N,K,QD,QH,QW] on the small grid, x [N,C,ID,IH,IW] on the dense grid.
+int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
+                   int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream) {
+  if (!g || !x || !dw || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
+  WgP p{};
+  p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW; p.QD = QD; p.QH = QH; p.QW = QW;
+  p.kd = kd; p.kh = kh; p.kw = kw; p.T = kd * kh * kw;
+  p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw_;
+  if (p.T > MAXT) return DPF_ERR_UNSUPPORTED;
+  const int MT = (K + 31) / 32;
+  if (MT > 4) return DPF_ERR_UNSUPPORTED;
+  const int KT = 32 * MT;
+  int CCW = (4 * WNT * 32) / p.T;
+  if (CCW > C) CCW = C;
+  if (CCW < 1) CCW = 1;
+  const int ext_d = (kd - 1) * dd + 1;
+  const int ext_h = (WTH - 1) * sh + (kh - 1) * dh + 1;
+  const int ext_w = (TW - 1) * sw + (kw - 1) * dw_ + 1;
+  auto lds_bytes = [&](int ccw) { return (size_t)(ccw * ext_d * ext_h * ext_w + KT * (WPT + 1)) * sizeof(float); };
+  while (CCW > 1 && lds_bytes(CCW) > 96 * 1024) --CCW;
+  if (lds_bytes(CCW) > 160 * 1024) return DPF_ERR_UNSUPPORTED;
+  p.CCW = CCW;
+  p.tilesH = dpf_div_up(QH, WTH);
+  p.tilesW = dpf_div_up(QW, TW);
+  p.ntiles = (long long)N * QD * p.tilesH * p.tilesW;
+  const int cchunks = dpf_div_up(C, CCW);
+  long long nchunk = 2048 / cchunks;
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > p.ntiles) nchunk = p.ntiles;
+  p.nchunk = (int)nchunk;
+  const size_t lds = lds_bytes(CCW);
+  const dim3 grid((unsigned)(cchunks * p.nchunk));
+  hipStream_t st = (hipStream_t)stream;
+#define DPF_WG(M)                                                                                                           \
+  {                                                                                                                         \
+    if (lds > 48 * 1024 &&                                                                                                  \
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return DPF_ERR_LAUNCH;                                                                                                \
+    hipLaunchKernelGGL((conv_wgrad_kernel<M>), grid, dim3(256), lds, st, g, x, dw, p);                                      \
+  }
+  switch (MT) { case 1: DPF_WG(1); break; case 2: DPF_WG(2); break; case 3: DPF_WG(3); break; default: DPF_WG(4); break; }
+#undef DPF_WG
+  return dpf_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+// Dual-pixel cost-volume construction.
+//
+//   dpf_shift_triple_{forward,backward}: the three row-shifted copies of a feature map (nearest / bilinear /
+//     Fourier-phase) that subpixel_shift.forward produces (reference: src/module/asm/asm.py:87-127), expressed
+//     as a table-driven separable 2x2-tap sampler: out[b,c,m,y,x] = sum_{a,e} wy[m][a][y] * wx[m][e][x] *
+//     fea[b,c, iy[m][a][y], ix[m][e][x]].  The host builds the tables with the reference's own float32 op
+//     order (grid normalisation quirks Q2, un-keyed grid cache Q1); an integer phase shift is a row roll.
+//   dpf_cv_select_{forward,backward}: MaskingAttention's tail (asm.py:162-171): softmax over the three copies of
+//     sigmoid(mask), weighted mean, written straight into every cost-volume level that shares this shift
+//     (CostVolume.build_concat_volume, src/model/stereodpnet/modules.py:181-197).
+//   dpf_psm_volume_forward: PSMNet's integer-shift concat / group-wise-correlation volume
+//     (src/model/psmnet/modules.py:215-262, int() truncation Q14).
+// All HBM-bound; one thread per output element, lanes along W (coalesced 256-B rows per wave).
+#include "dpf_common.h"
+
+namespace {
+
+// tables: iy [3][2][h] int32 (-1 = no tap), wy [3][2][h] float, ix [3][2][w], wx [3][2][w]
+__global__ void shift_triple_fwd_kernel(const float* __restrict__ fea, float* __restrict__ out, const int* __restrict__ iy,
+                                        const float* __restrict__ wy, const int* __restrict__ ix, const float* __restrict__ wx,
+                                        long long BC, int h, int w) {
+  const long long total = BC * 3 * h * w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    const int m = (int)((i / ((long long)w * h)) % 3);
+    const long long bc = i / ((long long)w * h * 3);
+    const float* src = fea + bc * h * w;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int yy = iy[(m * 2 + a) * h + y];
+      if (yy < 0) continue;
+      const float wa = wy[(m * 2 + a) * h + y];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int xx = ix[(m * 2 + e) * w + x];
+        if (xx < 0) continue;
+        acc += (wa * wx[(m * 2 + e) * w + x]) * src[(long long)yy * w + xx];
+      }
+    }
+    out[i] = acc;
+  }
+}
+
+// adjoint: dfea (pre-zeroed) += scatter of g[B,C,3,h,w]
+__global__ void shift_triple_bwd_kernel(const float* __restrict__ g, float* __restrict__ dfea, const int* __restrict__ iy,
+                                        const float* __restrict__ wy, const int* __restrict__ ix, const float* __restrict__ wx,
+                                        long long BC, int h, int w) {
+  const long long total = BC * 3 * h * w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    const int m = (int)((i / ((long long)w * h)) % 3);
+    const long long bc = i / ((long long)w * h * 3);
+    float* dst = dfea + bc * h * w;
+    const float gv = g[i];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int yy = iy[(m * 2 + a) * h + y];
+      if (yy < 0) continue;
+      const float wa = wy[(m * 2 + a) * h + y];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int xx = ix[(m * 2 + e) * w + x];
+        if (xx < 0) continue;
+        const float wgt = wa * wx[(m * 2 + e) * w + x];
+        if (wgt != 0.f) atomicAdd(&dst[(long long)yy * w + xx], wgt * gv);
+      }
+    }
+  }
+}
+
+// x3, s: [B,C,3,h,w]; vol: [B, CV, L, h, w]; writes channels [choff, choff+C) of every level in `levels` (bit mask)
+__global__ void cv_select_fwd_kernel(const float* __restrict__ x3, const float* __restrict__ s, float* __restrict__ vol, int B, int C,
+                                     int h, int w, int CV, int L, int choff, unsigned levels) {
+  const long long hw = (long long)h * w;
+  const long long total = (long long)B * C * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i % hw;
+    const long long bc = i / hw;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    const long long base = bc * 3 * hw + pix;
+    const float s0 = s[base], s1 = s[base + hw], s2 = s[base + 2 * hw];
+    const float mx = fmaxf(s0, fmaxf(s1, s2));
+    const float e0 = expf(s0 - mx), e1 = expf(s1 - mx), e2 = expf(s2 - mx);
+    const float sum = e0 + e1 + e2;
+    const float v = (x3[base] * (e0 / sum) + x3[base + hw] * (e1 / sum) + x3[base + 2 * hw] * (e2 / sum)) / 3.0f;
+    float* dst = vol + (((long long)b * CV + choff + c) * L) * hw + pix;
+    for (int l = 0; l < L; ++l)
+      if ((levels >> l) & 1u) dst[(long long)l * hw] = v;
+  }
+}
+
+__global__ void cv_select_bwd_kernel(const float* __restrict__ x3, const float* __restrict__ s, const float* __restrict__ dvol,
+                                     float* __restrict__ dx3, float* __restrict__ ds, int B, int C, int h, int w, int CV, int L,
+                                     int choff, unsigned levels) {
+  const long long hw = (long long)h * w;
+  const long long total = (long long)B * C * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i % hw;
+    const long long bc = i / hw;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    const long long base = bc * 3 * hw + pix;
+    const float* src = dvol + (((long long)b * CV + choff + c) * L) * hw + pix;
+    float g = 0.f;
+    for (int l = 0; l < L; ++l)
+      if ((levels >> l) & 1u) g += src[(long long)l * hw];
+    g = g / 3.0f;
+    const float s0 = s[base], s1 = s[base + hw], s2 = s[base + 2 * hw];
+    const float mx = fmaxf(s0, fmaxf(s1, s2));
+    const float e0 = expf(s0 - mx), e1 = expf(s1 - mx), e2 = expf(s2 - mx);
+    const float sum = e0 + e1 + e2;
+    const float p0 = e0 / sum, p1 = e1 / sum, p2 = e2 / sum;
+    const float a0 = x3[base], a1 = x3[base + hw], a2 = x3[base + 2 * hw];
+    dx3[base] = p0 * g;
+    dx3[base + hw] = p1 * g;
+    dx3[base + 2 * hw] = p2 * g;
+    const float dp0 = a0 * g, dp1 = a1 * g, dp2 = a2 * g;
+    const float dot = p0 * dp0 + p1 * dp1 + p2 * dp2;
+    ds[base] = p0 * (dp0 - dot);
+    ds[base + hw] = p1 * (dp1 - dot);
+    ds[base + 2 * hw] = p2 * (dp2 - dot);
+  }
+}
+
+struct PsmP {
+  int B, C, h, w, L, G;   // G = number of correlation groups (0 = concat only)
+  int shift[16];
+};
+
+// vol [B, 2C + G, L, h, w]
+__global__ void psm_volume_kernel(const float* __restrict__ ref, const float* __restrict__ tar, float* __restrict__ vol, PsmP p) {
+  const int CV = 2 * p.C + p.G;
+  const long long hw = (long long)p.h * p.w;
+  const long long total = (long long)p.B * CV * p.L * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % p.w);
+    const int y = (int)((i / p.w) % p.h);
+    const int l = (int)((i / hw) % p.L);
+    const int cv = (int)((i / (hw * p.L)) % CV);
+    const int b = (int)(i / (hw * p.L * CV));
+    const int d = p.shift[l];
+    // rows written by the reference: d >= 0 -> y < h - d ; d < 0 -> y >= -d
+    const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);
+    float v = 0.f;
+    if (rowok) {
+      if (cv < p.C) {
+        v = ref[(((long long)b * p.C + cv) * p.h + y) * p.w + x];
+      } else if (cv < 2 * p.C) {
+        v = tar[(((long long)b * p.C + (cv - p.C)) * p.h + (y + d)) * p.w + x];
+      } else {
+        const int gi = cv - 2 * p.C;
+        const int cpg = p.C / p.G;
+        float acc = 0.f;
+        for (int j = 0; j < cpg; ++j) {
+          const int c = gi * cpg + j;
+          acc += ref[(((long long)b * p.C + c) * p.h + y) * p.w + x] * tar[(((long long)b * p.C + c) * p.h + (y + d)) * p.w + x];
+        }
+        v = -(acc / (float)cpg);
+      }
+    }
+    vol[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpf_shift_triple_forward(const float* fea, float* out, const int* iy, const float* wy, const int* ix, const float* wx, int B, int C,
+                             int h, int w, void* stream) {
+  if (!fea || !out || !iy || !wy || !ix || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
+  const long long BC = (long long)B * C;
+  hipLaunchKernelGGL(shift_triple_fwd_kernel, dim3(dpf_ew_grid(BC * 3 * h * w)), dim3(256), 0, (hipStream_t)stream, fea, out, iy, wy, ix,
+                     wx, BC, h, w);
+  return dpf_check_launch();
+}
+
+int dpf_shift_triple_backward(const float* g, float* dfea, const int* iy, const float* wy, const int* ix, const float* wx, int B, int C,
+                              int h, int w, void* stream) {
+  if (!g || !dfea || !iy || !wy || !ix || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
+  const long long BC = (long long)B * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dfea, 0, sizeof(float) * (size_t)BC * h * w, st) != hipSuccess) return DPF_ERR_LAUNCH;
+  hipLaunchKernelGGL(shift_triple_bwd_kernel, dim3(dpf_ew_grid(BC * 3 * h * w)), dim3(256), 0, st, g, dfea, iy, wy, ix, wx, BC, h, w);
+  return dpf_check_launch();
+}
+
+int dpf_cv_select_forward(const float* x3, const float* s, float* vol, int B, int C, int h, int w, int CV, int L, int choff,
+                          unsigned levels, void* stream) {
+  if (!x3 || !s || !vol || B <= 0 || C <= 0 || L <= 0 || L > 32 || choff < 0 || choff + C > CV) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(cv_select_fwd_kernel, dim3(dpf_ew_grid((long long)B * C * h * w)), dim3(256), 0, (hipStream_t)stream, x3, s, vol, B,
+                     C, h, w, CV, L, choff, levels);
+  return dpf_check_launch();
+}
+
+int dpf_cv_select_backward(const float* x3, const float* s, const float* dvol, float* dx3, float* ds, int B, int C, int h, int w, int CV,
+                           int L, int choff, unsigned levels, void* stream) {
+  if (!x3 || !s || !dvol || !dx3 || !ds || B <= 0 || C <= 0 || L <= 0 || L > 32 || choff < 0 || choff + C > CV) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(cv_select_bwd_kernel, dim3(dpf_ew_grid((long long)B * C * h * w)), dim3(256), 0, (hipStream_t)stream, x3, s, dvol,
+                     dx3, ds, B, C, h, w, CV, L, choff, levels);
+  return dpf_check_launch();
+}
+
+// shifts: L host ints (int(costrange[l]) truncated toward zero by the caller); groups = 0 -> 'psmnet', > 0 -> 'gwcnet'
+int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const int* shifts_host, int B, int C, int h, int w, int L,
+                           int groups, void* stream) {
+  if (!ref || !tar || !vol || !shifts_host || B <= 0 || C <= 0 || L <= 0 || L > 16 || groups < 0 || (groups > 0 && C % groups)) return DPF_ERR_INVALID_ARG;
+  PsmP p;
+  p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.G = groups;
+  for (int i = 0; i < 16; ++i) p.shift[i] = i < L ? shifts_host[i] : 0;
+  const long long total = (long long)B * (2 * C + groups) * L * h * w;
+  hipLaunchKernelGGL(psm_volume_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ref, tar, vol, p);
+  return dpf_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// Batch / instance normalisation with fused activation and residual adds, plus stand-alone activations
+// and per-channel reductions.  HBM-bound row kernels over the [N, C, S] view of an NCHW / NCDHW tensor:
+// one workgroup streams a chunk of one (n, c) row with 16-byte accesses, so no per-element index division.
+//
+// Replaces nn.BatchNorm2d/3d + ReLU/PReLU/LeakyReLU/Sigmoid + the residual adds of the reference
+// (src/module/asm/basics.py:17-58, src/model/stereodpnet/modules.py:26-52,241-260,310-325,
+// src/module/asm/asm.py:138-146 InstanceNorm3d, normal_module.py:14-19,48-51).
+//
+//   z = (x - mean[c]) * invstd[c] * w[c % wmod] + b[c % wmod] + res        y = act(z) + res2
+#include "dpf_common.h"
+
+namespace {
+
+constexpr int ROW_CHUNK = 4096;   // elements of one row handled by one block
+
+// ---------------------------------------------------------------- statistics (training)
+// sums[c] = { sum(x - K_c), sum((x - K_c)^2) } with the shift K_c = x[0, c, 0] (single pass, cancellation-safe)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ sums, int N, int C, long long S) {
+  __shared__ float sm[4];
+  const int row = blockIdx.y;   // n*C + c
+  const int c = row % C;
+  const float K = x[(long long)c * S];
+  const float* xr = x + (long long)row * S;
+  const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
+  const long long s1 = min(S, s0 + ROW_CHUNK);
+  float a = 0.f, b = 0.f;
+  if ((S & 3) == 0) {
+    for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + s);
+      const float d0 = v.x - K, d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
+      a += (d0 + d1) + (d2 + d3);
+      b += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  } else {
+    for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
+      const float d = xr[s] - K;
+      a += d;
+      b += d * d;
+    }
+  }
+  a = dpf_block_sum_256(a, sm);
+  b = dpf_block_sum_256(b, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[2 * c], a);
+    atomicAdd(&sums[2 * c + 1], b);
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ sums, int C, long long S, double count,
+                                   float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double K = x[(long long)c * S];
+  const double m1 = sums[2 * c] / count;
+  double var = sums[2 * c + 1] / count - m1 * m1;
+  if (var < 0) var = 0;
+  const double mu = K + m1;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+// eval mode: mean/invstd straight from the running statistics
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  invstd[c] = 1.0f / sqrtf(rv[c] + eps);
+}
+
+// ---------------------------------------------------------------- apply
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ w,
+                                                       const float* __restrict__ bsh, int wmod, const float* __restrict__ res,
+                                                       const float* __restrict__ res2, int act, const float* __restrict__ slope_p,
+                                                       float slope_c, float* __restrict__ y, int C, long long S) {
+  const int row = blockIdx.y;
+  const int c = row % C;
+  float scale = 1.f, shift = 0.f;
+  if (mean) {
+    const float g = w ? w[c % wmod] : 1.f;
+    const float be = bsh ? bsh[c % wmod] : 0.f;
+    scale = invstd[c] * g;
+    shift = be - mean[c] * scale;
+  }
+  const float slope = slope_p ? slope_p[0] : slope_c;
+  const long long base = (long long)row * S;
+  const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
+  const long long s1 = min(S, s0 + ROW_CHUNK);
+  if ((S & 3) == 0) {
+    for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
+      float4 v = *reinterpret_cast<const float4*>(x + base + s);
+      float4 r = res ? *reinterpret_cast<const float4*>(res + base + s) : make_float4(0, 0, 0, 0);
+      float4 r2 = res2 ? *reinterpret_cast<const float4*>(res2 + base + s) : make_float4(0, 0, 0, 0);
+      float4 o;
+      o.x = dpf_act(fmaf(v.x, scale, shift) + r.x, act, slope) + r2.x;
+      o.y = dpf_act(fmaf(v.y, scale, shift) + r.y, act, slope) + r2.y;
+      o.z = dpf_act(fmaf(v.z, scale, shift) + r.z, act, slope) + r2.z;
+      o.w = dpf_act(fmaf(v.w, scale, shift) + r.w, act, slope) + r2.w;
+      *reinterpret_cast<float4*>(y + base + s) = o;
+    }
+  } else {
+    for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
+      const float z = fmaf(x[base + s], scale, shift) + (res ? res[base + s] : 0.f);
+      y[base + s] = dpf_act(z, act, slope) + (res2 ? res2[base + s] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// sums[c] = { sum dz, sum dz*xhat, sum_{z<0} z*dy (PReLU slope gradient) }
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ w, const float* __restrict__ bsh, int wmod,
+                                                            const float* __restrict__ res, int act, const float* __restrict__ slope_p,
+                                                            float slope_c, float* __restrict__ sums, int C, long long S) {
+  __shared__ float sm[4];
+  const int row = blockIdx.y;
+  const int c = row % C;
+  float mu = 0.f, is = 1.f, g = 1.f, be = 0.f;
+  if (mean) {
+    mu = mean[c];
+    is = invstd[c];
+    g = w ? w[c % wmod] : 1.f;
+    be = bsh ? bsh[c % wmod] : 0.f;
+  }
+  const float slope = slope_p ? slope_p[0] : slope_c;
+  const long long base = (long long)row * S;
+  const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
+  const long long s1 = min(S, s0 + ROW_CHUNK);
+  float a = 0.f, b = 0.f, sl = 0.f;
+  for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
+    const float xh = (x[base + s] - mu) * is;
+    const float z = fmaf(xh, g, be) + (res ? res[base + s] : 0.f);
+    const float d = dy[base + s];
+    const float dz = d * dpf_dact(z, act, slope);
+    a += dz;
+    b += dz * xh;
+    if (act == DPF_ACT_PRELU && z <= 0.f) sl += z * d;
+  }
+  a = dpf_block_sum_256(a, sm);
+  b = dpf_block_sum_256(b, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[3 * c], a);
+    atomicAdd(&sums[3 * c + 1], b);
+  }
+  if (act == DPF_ACT_PRELU) {
+    sl = dpf_block_sum_256(sl, sm);
+    if (threadIdx.x == 0) atomicAdd(&sums[3 * c + 2], sl);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ w, const float* __restrict__ bsh, int wmod,
+                                                           const float* __restrict__ res, int act, const float* __restrict__ slope_p,
+                                                           float slope_c, const float* __restrict__ sums, float inv_count,
+                                                           int training, float* __restrict__ dx, float* __restrict__ dres, int C,
+                                                           long long S) {
+  const int row = blockIdx.y;
+  const int c = row % C;
+  float mu = 0.f, is = 1.f, g = 1.f, be = 0.f, m_dz = 0.f, m_dzx = 0.f;
+  if (mean) {
+    mu = mean[c];
+    is = invstd[c];
+    g = w ? w[c % wmod] : 1.f;
+    be = bsh ? bsh[c % wmod] : 0.f;
+    if (training) {
+      m_dz = sums[3 * c] * inv_count;
+      m_dzx = sums[3 * c + 1] * inv_count;
+    }
+  }
+  const float slope = slope_p ? slope_p[0] : slope_c;
+  const float gi = g * is;
+  const long long base = (long long)row * S;
+  const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
+  const long long s1 = min(S, s0 + ROW_CHUNK);
+  for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
+    const float xh = (x[base + s] - mu) * is;
+    const float z = fmaf(xh, g, be) + (res ? res[base + s] : 0.f);
+    const float dz = dy[base + s] * dpf_dact(z, act, slope);
+    if (dres) dres[base + s] = dz;
+    if (dx) dx[base + s] = mean ? gi * (dz - m_dz - xh * m_dzx) : dz;
+  }
+}
+
+// dweight[c'] = sum_{c % wmod == c'} sums[c][1], dbias likewise with [0], dslope = sum_c sums[c][2]
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, int wmod, float* __restrict__ dweight,
+                                       float* __restrict__ dbias, float* __restrict__ dslope) {
+  const int cp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cp < wmod) {
+    float a = 0.f, b = 0.f;
+    for (int c = cp; c < C; c += wmod) {
+      a += sums[3 * c];
+      b += sums[3 * c + 1];
+    }
+    if (dbias) atomicAdd(&dbias[cp], a);
+    if (dweight) atomicAdd(&dweight[cp], b);
+  }
+  if (dslope && cp == 0) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += sums[3 * c + 2];
+    atomicAdd(dslope, s);
+  }
+}
+
+// per-channel sum of g[N,C,S] -> out[C] (+=): conv bias gradients
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int C, long long S) {
+  __shared__ float sm[4];
+  const int row = blockIdx.y;
+  const int c = row % C;
+  const long long base = (long long)row * S;
+  const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
+  const long long s1 = min(S, s0 + ROW_CHUNK);
+  float a = 0.f;
+  for (long long s = s0 + threadIdx.x; s < s1; s += 256) a += g[base + s];
+  a = dpf_block_sum_256(a, sm);
+  if (threadIdx.x == 0) atomicAdd(&out[c], a);
+}
+
+inline dim3 row_grid(int rows, long long S) { return dim3((unsigned)dpf_div_up(S, ROW_CHUNK), (unsigned)rows); }
+
+}  // namespace
+
+extern "C" {
+
+// Training statistics of x[N,C,S].  ws: >= 2*C floats (zeroed here).  Writes mean/invstd [C]; updates the running
+// statistics in place when running_mean != NULL (momentum, unbiased variance -- nn.BatchNorm semantics).
+int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float momentum, float* running_mean, float* running_var,
+                 float* mean, float* invstd, float* ws, void* stream) {
+  if (!x || !mean || !invstd || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
+  hipLaunchKernelGGL(bn_stats_kernel, row_grid(N * C, S), dim3(256), 0, st, x, ws, N, C, S);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, st, x, ws, C, S, (double)N * (double)S, eps, momentum,
+                     running_mean, running_var, mean, invstd);
+  return dpf_check_launch();
+}
+
+int dpf_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd, void* stream) {
+  if (!running_mean || !running_var || !mean || !invstd || C <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, (hipStream_t)stream, running_mean, running_var, C, eps,
+                     mean, invstd);
+  return dpf_check_launch();
+}
+
+// y = act((x-mean)*invstd*w + b + res) + res2 ; mean == NULL -> pure activation/add.  slope: device pointer (PReLU) or NULL
+// (then slope_const is used, LeakyReLU).  w/b are indexed c % wmod (instance norm over a [1, B*C, S] view: wmod = C).
+int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd, const float* w, const float* b, int wmod,
+                         const float* res, const float* res2, int act, const float* slope, float slope_const, float* y, int N, int C,
+                         long long S, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
+  if (wmod <= 0) wmod = C;
+  hipLaunchKernelGGL(bn_apply_kernel, row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, w, b, wmod, res, res2, act,
+                     slope, slope_const, y, C, S);
+  return dpf_check_launch();
+}
+
+// Backward of dpf_norm_act_forward w.r.t. x, res, w, b, slope (res2's gradient is dy itself).
+// ws: >= 3*C floats.  dweight/dbias [wmod], dslope [1] are ACCUMULATED into (+=); any may be NULL.
+int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
+                          int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
+                          float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, void* stream) {
+  if (!x || !dy || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
+  if (wmod <= 0) wmod = C;
+  hipStream_t st = (hipStream_t)stream;
+  const bool need_reduce = (mean != nullptr) || (act == DPF_ACT_PRELU && dslope);
+  if (need_reduce) {
+    if (hipMemsetAsync(ws, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope,
+                       slope_const, ws, C, S);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpf_div_up(wmod, 64)), dim3(64), 0, st, ws, C, wmod, mean ? dweight : nullptr,
+                       mean ? dbias : nullptr, act == DPF_ACT_PRELU ? dslope : nullptr);
+  }
+  if (dx || dres) {
+    // instance-norm view (wmod < C): statistics are per row, count = S; batch norm: count = N*S
+    const double count = (double)N * (double)S;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope,
+                       slope_const, ws, (float)(1.0 / count), training, dx, dres, C, S);
+  }
+  return dpf_check_launch();
+}
+
+// out[C] += sum over n, s of g[N,C,S]
+int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void* stream) {
+  if (!g || !out || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(channel_sum_kernel, row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, g, out, C, S);
+  return dpf_check_launch();
+}
+
+}  // extern "C"

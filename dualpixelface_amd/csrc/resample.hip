@@ -1,0 +1,154 @@
+// Resampling kernels on NCHW planes (HBM-bound, one thread per output element, lanes along W).
+//
+//   dpf_upsample_bilinear2d_{forward,backward}  F.interpolate(mode='bilinear', align_corners=True)
+//        (reference: src/model/stereodpnet/modules.py:127-128, normal_module.py:22-29,69-72)
+//   dpf_upsample_nearest_add_{forward,backward} lat + F.interpolate(top, size=lat.shape[-2:], mode='nearest')
+//        (torchvision FeaturePyramidNetwork top-down path; call site modules.py:83-85,119)
+// Backward passes are gather-form (each source element sums the destinations whose footprint
+// contains it, using the same float32 index arithmetic as the forward) => deterministic, no atomics.
+#include "dpf_common.h"
+
+namespace {
+
+__device__ __forceinline__ void ac_src(int dst, float ratio, int in, int& i0, int& i1, float& lam) {
+  const float src = ratio * (float)dst;   // align_corners=True source index (ATen area_pixel_compute_source_index)
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long NC, int h, int w, int H, int W) {
+  const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  const float rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const long long total = NC * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    const int Y = (int)((i / W) % H);
+    const long long nc = i / ((long long)W * H);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    ac_src(Y, ry, h, y0, y1, ly);
+    ac_src(X, rx, w, x0, x1, lx);
+    const float* p = x + nc * h * w;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    y[i] = hy * (hx * p[y0 * w + x0] + lx * p[y0 * w + x1]) + ly * (hx * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+  }
+}
+
+// weight of destination index d on source index i along one axis
+__device__ __forceinline__ float ac_weight(int d, float ratio, int in, int i) {
+  int i0, i1;
+  float lam;
+  ac_src(d, ratio, in, i0, i1, lam);
+  float wgt = 0.f;
+  if (i0 == i) wgt += 1.f - lam;
+  if (i1 == i) wgt += lam;
+  return wgt;
+}
+
+__device__ __forceinline__ void cand_range(int i, float ratio, int out, int& lo, int& hi) {
+  if (ratio <= 0.f) { lo = 0; hi = out - 1; return; }
+  lo = (int)floorf((float)(i - 1) / ratio) - 1;
+  hi = (int)ceilf((float)(i + 1) / ratio) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+__global__ void bilinear_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, long long NC, int h, int w, int H, int W) {
+  const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  const float rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const long long total = NC * h * w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xs = (int)(i % w);
+    const int ys = (int)((i / w) % h);
+    const long long nc = i / ((long long)w * h);
+    int ylo, yhi, xlo, xhi;
+    cand_range(ys, ry, H, ylo, yhi);
+    cand_range(xs, rx, W, xlo, xhi);
+    const float* gp = g + nc * H * W;
+    float acc = 0.f;
+    for (int Y = ylo; Y <= yhi; ++Y) {
+      const float wy = ac_weight(Y, ry, h, ys);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int X = xlo; X <= xhi; ++X) {
+        const float wx = ac_weight(X, rx, w, xs);
+        if (wx != 0.f) row += wx * gp[(long long)Y * W + X];
+      }
+      acc += wy * row;
+    }
+    dx[i] = acc;
+  }
+}
+
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
+  int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+__global__ void nearest_add_fwd_kernel(const float* __restrict__ lat, const float* __restrict__ top, float* __restrict__ y,
+                                       long long NC, int h, int w, int H, int W) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const long long total = NC * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    const int Y = (int)((i / W) % H);
+    const long long nc = i / ((long long)W * H);
+    y[i] = lat[i] + top[nc * h * w + (long long)nearest_src(Y, sy, h) * w + nearest_src(X, sx, w)];
+  }
+}
+
+__global__ void nearest_bwd_kernel(const float* __restrict__ g, float* __restrict__ dtop, long long NC, int h, int w, int H, int W) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const long long total = NC * h * w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xs = (int)(i % w);
+    const int ys = (int)((i / w) % h);
+    const long long nc = i / ((long long)w * h);
+    int ylo = (int)floorf((float)ys / sy) - 1, yhi = (int)ceilf((float)(ys + 1) / sy) + 1;
+    int xlo = (int)floorf((float)xs / sx) - 1, xhi = (int)ceilf((float)(xs + 1) / sx) + 1;
+    ylo = ylo < 0 ? 0 : ylo; xlo = xlo < 0 ? 0 : xlo;
+    yhi = yhi > H - 1 ? H - 1 : yhi; xhi = xhi > W - 1 ? W - 1 : xhi;
+    const float* gp = g + nc * H * W;
+    float acc = 0.f;
+    for (int Y = ylo; Y <= yhi; ++Y) {
+      if (nearest_src(Y, sy, h) != ys) continue;
+      for (int X = xlo; X <= xhi; ++X)
+        if (nearest_src(X, sx, w) == xs) acc += gp[(long long)Y * W + X];
+    }
+    dtop[i] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpf_upsample_bilinear2d_forward(const float* x, float* y, long long NC, int h, int w, int H, int W, void* stream) {
+  if (!x || !y || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(dpf_ew_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC, h, w, H, W);
+  return dpf_check_launch();
+}
+
+int dpf_upsample_bilinear2d_backward(const float* g, float* dx, long long NC, int h, int w, int H, int W, void* stream) {
+  if (!g || !dx || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(dpf_ew_grid(NC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dx, NC, h, w, H, W);
+  return dpf_check_launch();
+}
+
+// y[NC,H,W] = lat[NC,H,W] + nearest_upsample(top[NC,h,w])
+int dpf_upsample_nearest_add_forward(const float* lat, const float* top, float* y, long long NC, int h, int w, int H, int W, void* stream) {
+  if (!lat || !top || !y || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(nearest_add_fwd_kernel, dim3(dpf_ew_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, lat, top, y, NC, h, w, H, W);
+  return dpf_check_launch();
+}
+
+// dtop[NC,h,w] = adjoint of the nearest upsample applied to g[NC,H,W]  (d lat = g itself)
+int dpf_upsample_nearest_backward(const float* g, float* dtop, long long NC, int h, int w, int H, int W, void* stream) {
+  if (!g || !dtop || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(nearest_bwd_kernel, dim3(dpf_ew_grid(NC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dtop, NC, h, w, H, W);
+  return dpf_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,213 @@
+// Disparity head: trilinear x4 upsampling (align_corners) of the [B,1,D,h,w] cost logits, softmax over the
+// 4*D hypotheses and the soft-argmin expectation, fused into one HBM-bound pass (reads D*h*w, writes H*W
+// (+ 4*D*H*W when the probability volume is requested)).
+//
+// Replaces F.interpolate(mode='trilinear', align_corners=True) + squeeze + F.softmax(dim=1) + sum(p*disp)
+// (reference: src/model/stereodpnet/modules.py:327-334 and :341-362).
+// Backward scatters d(logit) into the low-resolution volume through an LDS-privatised tile (one LDS atomic per
+// contribution, one global atomic per touched low-res cell and tile).
+#include "dpf_common.h"
+
+namespace {
+
+constexpr int MAXD = 8;     // low-res depth levels
+constexpr int MAXL = 32;    // upsampled hypotheses
+constexpr int TY = 8, TX = 32;
+
+struct HeadP {
+  int B, D, h, w, L, H, W;
+  float disp[MAXL];
+};
+
+__device__ __forceinline__ void ac_src(int dst, float ratio, int in, int& i0, int& i1, float& lam) {
+  const float src = ratio * (float)dst;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+
+__device__ __forceinline__ void pixel_probs(const float* __restrict__ k, const HeadP& p, int b, int Y, int X, float rd, float ry, float rx,
+                                            float* prob, float& pred, int& y0, int& y1, int& x0, int& x1, float& ly, float& lx) {
+  ac_src(Y, ry, p.h, y0, y1, ly);
+  ac_src(X, rx, p.w, x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  float bl[MAXD];
+  const float* kb = k + (long long)b * p.D * p.h * p.w;
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) {
+    if (d < p.D) {
+      const float* q = kb + (long long)d * p.h * p.w;
+      bl[d] = hy * (hx * q[y0 * p.w + x0] + lx * q[y0 * p.w + x1]) + ly * (hx * q[y1 * p.w + x0] + lx * q[y1 * p.w + x1]);
+    } else {
+      bl[d] = 0.f;
+    }
+  }
+  float mx = -3.4e38f;
+#pragma unroll
+  for (int l = 0; l < MAXL; ++l) {
+    if (l < p.L) {
+      int d0, d1;
+      float ld;
+      ac_src(l, rd, p.D, d0, d1, ld);
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d) {   // register-resident select (no runtime-indexed array)
+        v0 = (d == d0) ? bl[d] : v0;
+        v1 = (d == d1) ? bl[d] : v1;
+      }
+      prob[l] = (1.f - ld) * v0 + ld * v1;
+      mx = fmaxf(mx, prob[l]);
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int l = 0; l < MAXL; ++l)
+    if (l < p.L) {
+      prob[l] = expf(prob[l] - mx);
+      sum += prob[l];
+    }
+  pred = 0.f;
+#pragma unroll
+  for (int l = 0; l < MAXL; ++l)
+    if (l < p.L) {
+      prob[l] = prob[l] / sum;
+      pred += prob[l] * p.disp[l];
+    }
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ k, float* __restrict__ pred, float* __restrict__ prob, HeadP p) {
+  const float rd = p.L > 1 ? (float)(p.D - 1) / (float)(p.L - 1) : 0.f;
+  const float ry = p.H > 1 ? (float)(p.h - 1) / (float)(p.H - 1) : 0.f;
+  const float rx = p.W > 1 ? (float)(p.w - 1) / (float)(p.W - 1) : 0.f;
+  const long long total = (long long)p.B * p.H * p.W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % p.W);
+    const int Y = (int)((i / p.W) % p.H);
+    const int b = (int)(i / ((long long)p.W * p.H));
+    float pr[MAXL];
+    float e;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    pixel_probs(k, p, b, Y, X, rd, ry, rx, pr, e, y0, y1, x0, x1, ly, lx);
+    pred[i] = e;
+    if (prob) {
+      float* q = prob + (long long)b * p.L * p.H * p.W + (long long)Y * p.W + X;
+#pragma unroll
+      for (int l = 0; l < MAXL; ++l)
+        if (l < p.L) q[(long long)l * p.H * p.W] = pr[l];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ k, const float* __restrict__ gpred, float* __restrict__ dk, HeadP p) {
+  __shared__ float tile[MAXD][TY + 2][TX + 2];
+  __shared__ float s_bl[MAXD][256];   // per-thread bilinear values / gradients, thread index fastest (conflict-free)
+  __shared__ float s_db[MAXD][256];
+  const float rd = p.L > 1 ? (float)(p.D - 1) / (float)(p.L - 1) : 0.f;
+  const float ry = p.H > 1 ? (float)(p.h - 1) / (float)(p.H - 1) : 0.f;
+  const float rx = p.W > 1 ? (float)(p.w - 1) / (float)(p.W - 1) : 0.f;
+  const int tilesX = (p.W + TX - 1) / TX, tilesY = (p.H + TY - 1) / TY;
+  int bb = blockIdx.x;
+  const int tx = bb % tilesX; bb /= tilesX;
+  const int ty = bb % tilesY;
+  const int b = bb / tilesY;
+  const int Y0 = ty * TY, X0 = tx * TX;
+  int ybase, xbase, t1;
+  float tl;
+  ac_src(Y0, ry, p.h, ybase, t1, tl);
+  ac_src(X0, rx, p.w, xbase, t1, tl);
+  float* flat = &tile[0][0][0];
+  for (int i = threadIdx.x; i < MAXD * (TY + 2) * (TX + 2); i += 256) flat[i] = 0.f;
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int Y = Y0 + (tid >> 5), X = X0 + (tid & 31);
+  if (Y < p.H && X < p.W) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    ac_src(Y, ry, p.h, y0, y1, ly);
+    ac_src(X, rx, p.w, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* kb = k + (long long)b * p.D * p.h * p.w;
+    for (int d = 0; d < p.D; ++d) {
+      const float* q = kb + (long long)d * p.h * p.w;
+      s_bl[d][tid] = hy * (hx * q[y0 * p.w + x0] + lx * q[y0 * p.w + x1]) + ly * (hx * q[y1 * p.w + x0] + lx * q[y1 * p.w + x1]);
+      s_db[d][tid] = 0.f;
+    }
+    float mx = -3.4e38f;
+    for (int l = 0; l < p.L; ++l) {
+      int d0, d1;
+      float ld;
+      ac_src(l, rd, p.D, d0, d1, ld);
+      mx = fmaxf(mx, (1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid]);
+    }
+    float sum = 0.f, num = 0.f;
+    for (int l = 0; l < p.L; ++l) {
+      int d0, d1;
+      float ld;
+      ac_src(l, rd, p.D, d0, d1, ld);
+      const float e = expf((1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid] - mx);
+      sum += e;
+      num += e * p.disp[l];
+    }
+    const float pred = num / sum;
+    const float g = gpred[((long long)b * p.H + Y) * p.W + X];
+    for (int l = 0; l < p.L; ++l) {
+      int d0, d1;
+      float ld;
+      ac_src(l, rd, p.D, d0, d1, ld);
+      const float pr = expf((1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid] - mx) / sum;
+      const float dl = pr * (p.disp[l] - pred) * g;
+      s_db[d0][tid] += (1.f - ld) * dl;
+      s_db[d1][tid] += ld * dl;
+    }
+    const int ya = y0 - ybase, yb = y1 - ybase, xa = x0 - xbase, xb = x1 - xbase;
+    for (int d = 0; d < p.D; ++d) {
+      const float v = s_db[d][tid];
+      atomicAdd(&tile[d][ya][xa], hy * hx * v);
+      atomicAdd(&tile[d][ya][xb], hy * lx * v);
+      atomicAdd(&tile[d][yb][xa], ly * hx * v);
+      atomicAdd(&tile[d][yb][xb], ly * lx * v);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.D * (TY + 2) * (TX + 2); i += 256) {
+    const int xx = i % (TX + 2);
+    const int yy = (i / (TX + 2)) % (TY + 2);
+    const int d = i / ((TX + 2) * (TY + 2));
+    const float v = tile[d][yy][xx];
+    const int y = ybase + yy, x = xbase + xx;
+    if (v != 0.f && y < p.h && x < p.w) atomicAdd(&dk[(((long long)b * p.D + d) * p.h + y) * p.w + x], v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// logits [B,D,h,w] -> pred [B,H,W], prob [B,L,H,W] (NULL to skip).  disp: L host floats (hypothesis values).
+int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
+                           int H, int W, void* stream) {
+  if (!logits || !pred || !disp_host || B <= 0 || D <= 0 || D > MAXD || L <= 0 || L > MAXL) return DPF_ERR_INVALID_ARG;
+  HeadP p;
+  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W;
+  for (int i = 0; i < MAXL; ++i) p.disp[i] = i < L ? disp_host[i] : 0.f;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, logits, pred, prob, p);
+  return dpf_check_launch();
+}
+
+// d logits [B,D,h,w] (zeroed here) from d pred [B,H,W]
+int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
+                            int L, int H, int W, void* stream) {
+  if (!logits || !gpred || !dlogits || !disp_host || B <= 0 || D <= 0 || D > MAXD || L <= 0 || L > MAXL) return DPF_ERR_INVALID_ARG;
+  HeadP p;
+  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W;
+  for (int i = 0; i < MAXL; ++i) p.disp[i] = i < L ? disp_host[i] : 0.f;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dlogits, 0, sizeof(float) * (size_t)B * D * h * w, st) != hipSuccess) return DPF_ERR_LAUNCH;
+  const long long blocks = (long long)B * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p);
+  return dpf_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,589 @@
+"""Operator layer: torch.autograd.Functions whose forward/backward enqueue libdpf_hip kernels.
+
+PyTorch is plumbing here (device memory, the current HIP stream, the autograd tape); every arithmetic
+step runs in the hand-written HIP kernels reached through the C ABI (include/dpf_hip.h).  No function in
+this file has a CPU or eager-PyTorch fallback: tensors must be fp32, contiguous and on the GPU.
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, DpfError
+
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3, 4
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+_scratch = {}
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise DpfError('dualpixelface_amd ops need GPU tensors (no CPU fallback)')
+        if t.dtype != torch.float32 and t.dtype != torch.int32:
+            raise DpfError('unsupported dtype %s' % t.dtype)
+        if not t.is_contiguous():
+            raise DpfError('non-contiguous tensor passed to a HIP op')
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def scratch(nfloats, device, tag='ws'):
+    """Stream-ordered reusable scratch (all ops of one process run on the current stream)."""
+    key = (device, tag)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def _host_floats(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def _host_ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _t3(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+# ----------------------------------------------------------------------------------------------- convolution
+def _out_dim(i, k, s, p, d):
+    return (i + 2 * p - (d * (k - 1) + 1)) // s + 1
+
+
+def _conv_fwd_raw(x, w, bias, stride, pad, dil):
+    N, C, ID, IH, IW = x.shape
+    K, _, kd, kh, kw = w.shape
+    od = _out_dim(ID, kd, stride[0], pad[0], dil[0])
+    oh = _out_dim(IH, kh, stride[1], pad[1], dil[1])
+    ow = _out_dim(IW, kw, stride[2], pad[2], dil[2])
+    out = torch.empty((N, K, od, oh, ow), dtype=torch.float32, device=x.device)
+    L = lib()
+    ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
+    L.call('dpf_conv_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, kd, kh, kw,
+           *stride, *pad, *dil, _stream())
+    return out
+
+
+def _conv_transpose_raw(x, w, bias, out_dims, ksize, stride, pad, dil):
+    """x on the strided grid [N,C,...] -> out [N,K,*out_dims]; w is [C][K][T] in memory."""
+    N, C, ID, IH, IW = x.shape
+    K = w.shape[1]
+    kd, kh, kw = ksize
+    out = torch.empty((N, K) + tuple(out_dims), dtype=torch.float32, device=x.device)
+    L = lib()
+    ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
+    L.call('dpf_conv_transpose', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, *out_dims, kd, kh, kw,
+           *stride, *pad, *dil, _stream())
+    return out
+
+
+def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
+    """dW[K][C][T] for g [N,K,Q...] (strided grid) and x [N,C,I...] (dense grid)."""
+    N, C, ID, IH, IW = x.shape
+    K, QD, QH, QW = g.shape[1], g.shape[2], g.shape[3], g.shape[4]
+    kd, kh, kw = wshape[2:]
+    dw = torch.zeros(wshape, dtype=torch.float32, device=x.device)
+    lib().call('dpf_conv_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, QD, QH, QW, kd, kh, kw, *stride, *pad, *dil, _stream())
+    return dw
+
+
+def _channel_sum(g):
+    N, C = g.shape[0], g.shape[1]
+    S = g.numel() // (N * C)
+    out = torch.zeros(C, dtype=torch.float32, device=g.device)
+    lib().call('dpf_channel_sum', _ptr(g), _ptr(out), N, C, S, _stream())
+    return out
+
+
+class ConvFn(torch.autograd.Function):
+    """nn.Conv3d semantics on [N,C,D,H,W] (2-D callers use depth 1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil):
+        x, w = _c(x), _c(w)
+        _need(x, w, bias)
+        ctx.cfg = (stride, pad, dil)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return _conv_fwd_raw(x, w, bias, stride, pad, dil)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil = ctx.cfg
+        gy = _c(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv_transpose_raw(gy, w, None, x.shape[2:], w.shape[2:], stride, pad, dil)
+        if ctx.needs_input_grad[1]:
+            gw = _conv_wgrad_raw(gy, x, w.shape, stride, pad, dil)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _channel_sum(gy)
+        return gx, gw, gb, None, None, None
+
+
+class ConvTransposeFn(torch.autograd.Function):
+    """nn.ConvTranspose3d semantics; w is [C_in, C_out, kd, kh, kw]."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, outpad):
+        x, w = _c(x), _c(w)
+        _need(x, w)
+        ks = tuple(w.shape[2:])
+        dil = (1, 1, 1)
+        out_dims = tuple((x.shape[2 + i] - 1) * stride[i] - 2 * pad[i] + ks[i] + outpad[i] for i in range(3))
+        ctx.cfg = (stride, pad, dil)
+        ctx.save_for_backward(x, w)
+        return _conv_transpose_raw(x, w, None, out_dims, ks, stride, pad, dil)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil = ctx.cfg
+        gy = _c(gy)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv_fwd_raw(gy, w, None, stride, pad, dil)          # w read as [K=C_in][C=C_out][T]
+        if ctx.needs_input_grad[1]:
+            gw = _conv_wgrad_raw(x, gy, w.shape, stride, pad, dil)     # g := x (strided grid), x := gy (dense grid)
+        return gx, gw, None, None, None
+
+
+def conv3d(x, w, bias=None, stride=1, pad=0, dil=1):
+    return ConvFn.apply(x, w, bias, _t3(stride), _t3(pad), _t3(dil))
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
+    y = ConvFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride, stride), (0, pad, pad), (1, dil, dil))
+    return y.squeeze(2)
+
+
+def conv_transpose3d(x, w, stride=2, pad=1, outpad=1):
+    return ConvTransposeFn.apply(x, w, _t3(stride), _t3(pad), _t3(outpad))
+
+
+class DepthwiseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _c(x), _c(w)
+        _need(x, w)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        lib().call('dpf_depthwise_conv2d_forward', _ptr(x), _ptr(w), _ptr(y), N, C, H, W, 3, 1, _stream())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _c(gy)
+        N, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        lib().call('dpf_depthwise_conv2d_backward_data', _ptr(gy), _ptr(w), _ptr(gx), N, C, H, W, 3, 1, _stream())
+        gw = torch.zeros_like(w)
+        lib().call('dpf_depthwise_conv2d_backward_weight', _ptr(gy), _ptr(x), _ptr(gw), N, C, H, W, 3, 1, _stream())
+        return gx, gw
+
+
+def depthwise_conv3x3(x, w):
+    return DepthwiseFn.apply(x, w)
+
+
+# ----------------------------------------------------------------------------------------------- norm + activation
+class NormActFn(torch.autograd.Function):
+    """y = act(norm(x) * w + b + res) + res2 with norm = batch norm (training/eval) or instance norm, or no norm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const):
+        # mode: 0 none, 1 batch norm (training), 2 batch norm (eval), 3 instance norm
+        x = _c(x)
+        res = None if res is None else _c(res)
+        res2 = None if res2 is None else _c(res2)
+        _need(x, weight, bias, slope, res, res2)
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        L = lib()
+        mean = invstd = None
+        n_, c_, wmod = N, C, C
+        if mode == 1:
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            ws = scratch(2 * C, x.device)
+            L.call('dpf_bn_stats', _ptr(x), N, C, S, BN_EPS, BN_MOMENTUM, _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
+                   _ptr(ws), _stream())
+        elif mode == 2:
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            L.call('dpf_bn_eval_stats', _ptr(running_mean), _ptr(running_var), C, BN_EPS, _ptr(mean), _ptr(invstd), _stream())
+        elif mode == 3:
+            n_, c_ = 1, N * C
+            mean = torch.empty(c_, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            ws = scratch(2 * c_, x.device)
+            L.call('dpf_bn_stats', _ptr(x), n_, c_, S, BN_EPS, 0.0, None, None, _ptr(mean), _ptr(invstd), _ptr(ws), _stream())
+        y = torch.empty_like(x)
+        L.call('dpf_norm_act_forward', _ptr(x), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), wmod, _ptr(res), _ptr(res2), act,
+               _ptr(slope), float(slope_const), _ptr(y), n_, c_, S, _stream())
+        ctx.save_for_backward(x, weight, bias, slope, res, mean, invstd)
+        ctx.cfg = (mode, act, float(slope_const), n_, c_, S, wmod, res2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, slope, res, mean, invstd = ctx.saved_tensors
+        mode, act, slope_const, n_, c_, S, wmod, has_res2 = ctx.cfg
+        gy = _c(gy)
+        L = lib()
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[4]) else None
+        dweight = torch.zeros_like(weight) if (weight is not None and ctx.needs_input_grad[1]) else None
+        dbias = torch.zeros_like(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
+        dslope = torch.zeros_like(slope) if (slope is not None and ctx.needs_input_grad[3]) else None
+        ws = scratch(3 * c_, x.device)
+        training = 1 if mode in (1, 3) else 0
+        L.call('dpf_norm_act_backward', _ptr(x), _ptr(gy), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), wmod, _ptr(res), act,
+               _ptr(slope), slope_const, training, _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), _ptr(dslope), _ptr(ws), n_, c_, S,
+               _stream())
+        dres2 = gy if (has_res2 and ctx.needs_input_grad[5]) else None
+        return dx, dweight, dbias, dslope, dres, dres2, None, None, None, None, None
+
+
+def norm_act(x, weight=None, bias=None, slope=None, res=None, res2=None, running_mean=None, running_var=None, mode=0, act=ACT_NONE,
+             slope_const=0.0):
+    return NormActFn.apply(x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const)
+
+
+# ----------------------------------------------------------------------------------------------- resampling
+class BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        x = _c(x)
+        _need(x)
+        N, C, h, w = x.shape
+        y = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+        lib().call('dpf_upsample_bilinear2d_forward', _ptr(x), _ptr(y), N * C, h, w, H, W, _stream())
+        ctx.dims = (N, C, h, w, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, h, w, H, W = ctx.dims
+        gy = _c(gy)
+        dx = torch.empty((N, C, h, w), dtype=torch.float32, device=gy.device)
+        lib().call('dpf_upsample_bilinear2d_backward', _ptr(gy), _ptr(dx), N * C, h, w, H, W, _stream())
+        return dx, None, None
+
+
+def upsample_bilinear(x, scale):
+    return BilinearFn.apply(x, x.shape[2] * scale, x.shape[3] * scale)
+
+
+class NearestAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lat, top):
+        lat, top = _c(lat), _c(top)
+        _need(lat, top)
+        N, C, H, W = lat.shape
+        h, w = top.shape[2], top.shape[3]
+        y = torch.empty_like(lat)
+        lib().call('dpf_upsample_nearest_add_forward', _ptr(lat), _ptr(top), _ptr(y), N * C, h, w, H, W, _stream())
+        ctx.dims = (N, C, h, w, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, h, w, H, W = ctx.dims
+        gy = _c(gy)
+        dtop = torch.empty((N, C, h, w), dtype=torch.float32, device=gy.device)
+        lib().call('dpf_upsample_nearest_backward', _ptr(gy), _ptr(dtop), N * C, h, w, H, W, _stream())
+        return gy, dtop
+
+
+def nearest_up_add(lat, top):
+    return NearestAddFn.apply(lat, top)
+
+
+# ----------------------------------------------------------------------------------------------- cost volume
+class ShiftTripleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fea, iy, wy, ix, wx):
+        fea = _c(fea)
+        _need(fea, iy, wy, ix, wx)
+        B, C, h, w = fea.shape
+        out = torch.empty((B, C, 3, h, w), dtype=torch.float32, device=fea.device)
+        lib().call('dpf_shift_triple_forward', _ptr(fea), _ptr(out), _ptr(iy), _ptr(wy), _ptr(ix), _ptr(wx), B, C, h, w, _stream())
+        ctx.tables = (iy, wy, ix, wx)
+        ctx.dims = (B, C, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        iy, wy, ix, wx = ctx.tables
+        B, C, h, w = ctx.dims
+        g = _c(g)
+        dfea = torch.empty((B, C, h, w), dtype=torch.float32, device=g.device)
+        lib().call('dpf_shift_triple_backward', _ptr(g), _ptr(dfea), _ptr(iy), _ptr(wy), _ptr(ix), _ptr(wx), B, C, h, w, _stream())
+        return dfea, None, None, None, None
+
+
+def shift_triple(fea, tables):
+    return ShiftTripleFn.apply(fea, *tables)
+
+
+class CvSelectFn(torch.autograd.Function):
+    """Writes the [B, 2C, L, h, w] volume from groups of (x3_ref, s_ref, x3_tar, s_tar) sharing a level mask."""
+
+    @staticmethod
+    def forward(ctx, L, masks, *ts):
+        ts = [_c(t) for t in ts]
+        _need(*ts)
+        B, C, _, h, w = ts[0].shape
+        covered = 0
+        for m in masks:
+            covered |= m
+        alloc = torch.empty if covered == (1 << L) - 1 else torch.zeros
+        vol = alloc((B, 2 * C, L, h, w), dtype=torch.float32, device=ts[0].device)
+        lb = lib()
+        for gi, m in enumerate(masks):
+            x3f, sf, x3b, sb = ts[4 * gi:4 * gi + 4]
+            lb.call('dpf_cv_select_forward', _ptr(x3f), _ptr(sf), _ptr(vol), B, C, h, w, 2 * C, L, 0, m, _stream())
+            lb.call('dpf_cv_select_forward', _ptr(x3b), _ptr(sb), _ptr(vol), B, C, h, w, 2 * C, L, C, m, _stream())
+        ctx.save_for_backward(*ts)
+        ctx.cfg = (L, tuple(masks), B, C, h, w)
+        return vol
+
+    @staticmethod
+    def backward(ctx, dvol):
+        ts = ctx.saved_tensors
+        L, masks, B, C, h, w = ctx.cfg
+        dvol = _c(dvol)
+        lb = lib()
+        grads = []
+        for gi, m in enumerate(masks):
+            x3f, sf, x3b, sb = ts[4 * gi:4 * gi + 4]
+            for x3, s, off in ((x3f, sf, 0), (x3b, sb, C)):
+                dx3 = torch.empty_like(x3)
+                ds = torch.empty_like(s)
+                lb.call('dpf_cv_select_backward', _ptr(x3), _ptr(s), _ptr(dvol), _ptr(dx3), _ptr(ds), B, C, h, w, 2 * C, L, off, m, _stream())
+                grads += [dx3, ds]
+        return (None, None) + tuple(grads)
+
+
+def cv_select(L, masks, tensors):
+    return CvSelectFn.apply(L, list(masks), *tensors)
+
+
+def psm_volume(ref, tar, shifts, groups=0):
+    """PSMNet concat (groups=0) or concat + group-wise correlation volume; forward only (cross-model check)."""
+    ref, tar = _c(ref), _c(tar)
+    _need(ref, tar)
+    B, C, h, w = ref.shape
+    L = len(shifts)
+    vol = torch.empty((B, 2 * C + groups, L, h, w), dtype=torch.float32, device=ref.device)
+    lib().call('dpf_psm_volume_forward', _ptr(ref), _ptr(tar), _ptr(vol), _host_ints(shifts), B, C, h, w, L, groups, _stream())
+    return vol
+
+
+# ----------------------------------------------------------------------------------------------- disparity head
+class SoftArgminFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, disp_values, scale, want_prob):
+        logits = _c(logits)
+        _need(logits)
+        B, _, D, h, w = logits.shape
+        Lh, H, W = D * scale, h * scale, w * scale
+        pred = torch.empty((B, H, W), dtype=torch.float32, device=logits.device)
+        prob = torch.empty((B, Lh, H, W), dtype=torch.float32, device=logits.device) if want_prob else None
+        hd = _host_floats(disp_values)
+        lib().call('dpf_softargmin_forward', _ptr(logits), _ptr(pred), _ptr(prob), hd, B, D, h, w, Lh, H, W, _stream())
+        ctx.save_for_backward(logits)
+        ctx.cfg = (tuple(disp_values), B, D, h, w, Lh, H, W)
+        if prob is None:
+            prob = pred.new_empty(0)
+        ctx.mark_non_differentiable(prob)
+        return pred, prob
+
+    @staticmethod
+    def backward(ctx, gpred, _gprob):
+        (logits,) = ctx.saved_tensors
+        disp_values, B, D, h, w, Lh, H, W = ctx.cfg
+        gpred = _c(gpred)
+        dl = torch.empty_like(logits)
+        lib().call('dpf_softargmin_backward', _ptr(logits), _ptr(gpred), _ptr(dl), _host_floats(disp_values), B, D, h, w, Lh, H, W, _stream())
+        return dl, None, None, None
+
+
+def softargmin(logits, disp_values, scale=4, want_prob=True):
+    return SoftArgminFn.apply(logits, disp_values, scale, want_prob)
+
+
+# ----------------------------------------------------------------------------------------------- deformable conv
+def deform_conv_forward_raw(x, weight, bias, offset, stride, pad, dil, group=1, dgroup=1, step=64):
+    B, C, D, H, W = x.shape
+    K, _, kd, kh, kw = weight.shape
+    L = lib()
+    do = _out_dim(D, kd, stride[0], pad[0], dil[0])
+    ho = _out_dim(H, kh, stride[1], pad[1], dil[1])
+    wo = _out_dim(W, kw, stride[2], pad[2], dil[2])
+    out = torch.empty((B, K, do, ho, wo), dtype=torch.float32, device=x.device)
+    ws = scratch(L.call('dpf_deform_conv3d_workspace_floats', C, K, kd * kh * kw), x.device, 'convw')
+    L.call('dpf_deform_conv3d_forward', _ptr(x), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(out), _ptr(ws), B, C, D, H, W, K, kd, kh, kw,
+           *stride, *pad, *dil, group, dgroup, step, _stream())
+    return out
+
+
+def deform_conv_backward_raw(x, weight, bias, offset, go, stride, pad, dil, group=1, dgroup=1, step=64):
+    B, C, D, H, W = x.shape
+    K, _, kd, kh, kw = weight.shape
+    L = lib()
+    gi = torch.empty_like(x)
+    goff = torch.empty_like(offset)
+    gw = torch.empty_like(weight)
+    gb = torch.empty_like(bias)
+    ws = scratch(L.call('dpf_deform_conv3d_workspace_floats', C, K, kd * kh * kw), x.device, 'convw')
+    L.call('dpf_deform_conv3d_backward', _ptr(x), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(go), _ptr(gi), _ptr(goff), _ptr(gw), _ptr(gb),
+           _ptr(ws), B, C, D, H, W, K, kd, kh, kw, *stride, *pad, *dil, group, dgroup, step, _stream())
+    return gi, goff, gw, gb
+
+
+class DeformConvFn(torch.autograd.Function):
+    """Same contract as the reference's DeformConvFunction (src/module/dcn3d/functions/deform_conv_func.py:16-59)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, weight, bias, stride, pad, dil):
+        x, offset, weight, bias = _c(x), _c(offset), _c(weight), _c(bias)
+        _need(x, offset, weight, bias)
+        ctx.cfg = (stride, pad, dil)
+        ctx.save_for_backward(x, offset, weight, bias)
+        return deform_conv_forward_raw(x, weight, bias, offset, stride, pad, dil)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, offset, weight, bias = ctx.saved_tensors
+        gi, goff, gw, gb = deform_conv_backward_raw(x, weight, bias, offset, _c(go), *ctx.cfg)
+        return gi, goff, gw, gb, None, None, None
+
+
+def deform_conv3d(x, offset, weight, bias, stride=1, pad=1, dil=1):
+    return DeformConvFn.apply(x, offset, weight, bias, _t3(stride), _t3(pad), _t3(dil))
+
+
+# ----------------------------------------------------------------------------------------------- normal module glue
+class AnmVolumeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, disp_full, Kmat, abvalue, costrange, ksel):
+        cost, disp_full, Kmat, abvalue = _c(cost), _c(disp_full), _c(Kmat), _c(abvalue)
+        _need(cost, disp_full, Kmat, abvalue)
+        B, C, L, h, w = cost.shape
+        H, W = disp_full.shape[1], disp_full.shape[2]
+        dev = cost.device
+        idx = torch.empty((B, ksel, h, w), dtype=torch.int32, device=dev)
+        sdisp = torch.empty((B, ksel, h, w), dtype=torch.float32, device=dev)
+        lb = lib()
+        lb.call('dpf_anm_select', _ptr(disp_full), _ptr(idx), _ptr(sdisp), _host_floats(costrange), B, H, W, h, w, L, ksel, _stream())
+        vol = torch.empty((B, C + 3, ksel, h, w), dtype=torch.float32, device=dev)
+        mm = torch.empty(2 * B, dtype=torch.int32, device=dev)
+        lb.call('dpf_anm_volume_forward', _ptr(cost), _ptr(idx), _ptr(sdisp), _ptr(Kmat), _ptr(abvalue), _ptr(vol), _ptr(mm), B, C, L, ksel,
+                h, w, _stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, C, L, ksel, h, w)
+        ctx.mark_non_differentiable(idx)
+        return vol, idx
+
+    @staticmethod
+    def backward(ctx, dvol, _gidx):
+        (idx,) = ctx.saved_tensors
+        B, C, L, ksel, h, w = ctx.dims
+        dvol = _c(dvol)
+        dcost = torch.empty((B, C, L, h, w), dtype=torch.float32, device=dvol.device)
+        lib().call('dpf_anm_volume_backward', _ptr(dvol), _ptr(idx), _ptr(dcost), B, C, L, ksel, h, w, _stream())
+        return dcost, None, None, None, None, None
+
+
+def anm_volume(cost, disp_full, Kmat, abvalue, costrange, ksel):
+    return AnmVolumeFn.apply(cost, disp_full, Kmat, abvalue, tuple(costrange), ksel)
+
+
+class SigmoidMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, B, Dn):
+        u = _c(u)
+        _need(u)
+        CS = u.numel() // (B * Dn)
+        out = torch.empty((B,) + tuple(u.shape[1:]), dtype=torch.float32, device=u.device)
+        lib().call('dpf_sigmoid_mean_forward', _ptr(u), _ptr(out), B, Dn, CS, _stream())
+        ctx.save_for_backward(u)
+        ctx.dims = (B, Dn, CS)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        B, Dn, CS = ctx.dims
+        g = _c(g)
+        du = torch.empty_like(u)
+        lib().call('dpf_sigmoid_mean_backward', _ptr(u), _ptr(g), _ptr(du), B, Dn, CS, _stream())
+        return du, None, None
+
+
+def sigmoid_mean(u, B, Dn):
+    return SigmoidMeanFn.apply(u, B, Dn)
+
+
+# ----------------------------------------------------------------------------------------------- loss / optimiser
+class LossFn(torch.autograd.Function):
+    """-> tensor [3] = (smoothL1_loss, cosine_loss, final_loss)."""
+
+    @staticmethod
+    def forward(ctx, pred_depth, pred_normal, disp, normal, mask, head_weights, lam_d, lam_n):
+        pred_depth, disp, mask = _c(pred_depth), _c(disp), _c(mask)
+        pred_normal = None if pred_normal is None else _c(pred_normal)
+        normal = None if normal is None else _c(normal)
+        _need(pred_depth, pred_normal, disp, normal, mask)
+        B, n, H, W = pred_depth.shape
+        acc = torch.empty(n + 2, dtype=torch.float32, device=pred_depth.device)
+        out = torch.empty(3, dtype=torch.float32, device=pred_depth.device)
+        lib().call('dpf_loss_forward', _ptr(pred_depth), _ptr(pred_normal), _ptr(disp), _ptr(normal), _ptr(mask), _ptr(acc), _ptr(out), B, n,
+                   H, W, _host_floats(head_weights), float(lam_d), float(lam_n), _stream())
+        ctx.save_for_backward(pred_depth, pred_normal, disp, normal, mask, acc)
+        ctx.cfg = (tuple(head_weights), float(lam_d), float(lam_n), B, n, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred_depth, pred_normal, disp, normal, mask, acc = ctx.saved_tensors
+        head_weights, lam_d, lam_n, B, n, H, W = ctx.cfg
+        gout = _c(gout)
+        dpd = torch.empty_like(pred_depth)
+        dpn = torch.empty_like(pred_normal) if pred_normal is not None else None
+        lib().call('dpf_loss_backward', _ptr(pred_depth), _ptr(pred_normal), _ptr(disp), _ptr(normal), _ptr(mask), _ptr(acc), _ptr(gout),
+                   _ptr(dpd), _ptr(dpn), B, n, H, W, _host_floats(head_weights), lam_d, lam_n, _stream())
+        return dpd, dpn, None, None, None, None, None, None
+
+
+def stereo_losses(pred_depth, pred_normal, disp, normal, mask, head_weights, lam_d, lam_n):
+    return LossFn.apply(pred_depth, pred_normal, disp, normal, mask, tuple(head_weights), lam_d, lam_n)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-5, gscale=1.0):
+    _need(param, grad, exp_avg, exp_avg_sq)
+    lib().call('dpf_adam_step', _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step), float(lr), float(beta1),
+               float(beta2), float(eps), float(gscale), _stream())

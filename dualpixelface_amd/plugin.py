@@ -1,0 +1,94 @@
+"""``STEREODPNET``: the class the reference's ``model_selector`` instantiates
+(src/model/model_selector.py:11-15 -> src/model/stereodpnet/mainmodel.py:21), with the same methods PL / main.py call
+(mainmodel.py:67-177) plus an MI355X-native ``train_step`` (flat-arena gradients, fused Adam, optional RCCL all-reduce).
+"""
+import torch
+
+from . import ops
+from .losses import loss_selector
+from .selectors import metric_selector, optimizer_selector, scheduler_selector
+from .stereodpnet import StereoDPNetCore
+
+
+class STEREODPNET(StereoDPNetCore):
+    def __init__(self, option):
+        super(STEREODPNET, self).__init__(option)
+        self.loss_model = loss_selector(option)
+        self.metric_model = metric_selector(option)
+        self._adam = None
+
+    # ---- reference surface -------------------------------------------------------------------------------
+    def forward(self, batch):
+        results = self.network(batch)
+        self.last_taps = results.pop('_taps')
+        if self.training and 'disp' in batch:
+            results.update(self.loss_model.forward(results, batch))
+        return results
+
+    def _loaders(self, train, batch_size, shuffle):
+        import torch.utils.data as torch_data
+        from dataloader.loader_selector import loader_selector     # the reference's (or a user's) data package, CWD-relative
+        return torch_data.DataLoader(loader_selector(self.option, train), batch_size=batch_size, shuffle=shuffle,
+                                     num_workers=self.option.workers, drop_last=False, pin_memory=self.option.pin_memory)
+
+    def train_dataloader(self):
+        return self._loaders(True, self.option.batch_size, True)
+
+    def val_dataloader(self):
+        return self._loaders(False, 1, False)
+
+    def test_dataloader(self):
+        return self._loaders(False, self.option.batch_size, False)
+
+    def training_step(self, batch, batch_idx):
+        results = self.forward(batch)
+        losses = {}
+        for key, val in results.items():
+            if key != 'final_loss' and 'loss' in key:
+                losses[key] = val
+                self.log(key, val, prog_bar=True)
+        return {'loss': results['final_loss'], 'log': losses}
+
+    def validation_step(self, batch, batch_idx):
+        results = self.forward(batch)
+        if 'depth' in batch:
+            self.metric_model.forward(results, batch)
+        return results
+
+    def validation_epoch_end(self, outputs):
+        self.metric_model.viewer()
+
+    def test_step(self, batch, batch_idx):
+        return self.validation_step(batch, batch_idx)
+
+    def test_epoch_end(self, outputs):
+        if self.option.mode == 'test':
+            self.metric_model.viewer()
+
+    def configure_optimizers(self):
+        optimizer = optimizer_selector(self.parameters(), self.option)
+        scheduler = scheduler_selector(optimizer, self.option)
+        return [optimizer], ([scheduler] if scheduler is not None else [])
+
+    # ---- MI355X-native step ------------------------------------------------------------------------------
+    def train_step(self, batch, reducer=None, lr=None):
+        """forward + loss + backward + (gradient all-reduce) + fused Adam; returns the results dict."""
+        if self.option.optim != 'adam':
+            raise NotImplementedError('the fused step implements the shipped Adam configuration')
+        self.train()
+        flat_g = self.flat_gradients(zero=True)
+        if reducer is not None:
+            reducer.begin()
+        results = self.forward(batch)
+        results['final_loss'].backward()
+        gscale = 1.0
+        if reducer is not None:
+            reducer.finish()
+            gscale = 1.0 / reducer.world_size
+        if self._adam is None or self._adam['m'].device != flat_g.device:
+            self._adam = {'m': torch.zeros_like(flat_g), 'v': torch.zeros_like(flat_g), 'step': 0}
+        st = self._adam
+        st['step'] += 1
+        ops.adam_step(self.flat_parameters(), flat_g, st['m'], st['v'], st['step'], float(lr if lr is not None else self.option.init_lr),
+                      0.9, 0.999, 1e-5, gscale)
+        return results

@@ -1,0 +1,127 @@
+/* dpf_hip.h -- C ABI of libdpf_hip.so: the MI355X (gfx950) kernels behind the StereoDPNet train/eval path.
+ *
+ * Boundary conventions (all entry points):
+ *   - plain C: device pointers + sizes, no torch / ATen types; float = IEEE fp32; tensors are dense, contiguous
+ *     NCHW / NCDHW; `*_host` pointers are HOST memory (small constant tables), everything else is DEVICE memory.
+ *   - returns 0 on success, DPF_ERR_INVALID_ARG (-1), DPF_ERR_LAUNCH (-2) or DPF_ERR_UNSUPPORTED (-3).
+ *   - no allocation, no host synchronisation; work is enqueued on `stream` (a hipStream_t passed as void*), so a caller
+ *     may capture a sequence of calls in a hipGraph.  Scratch comes from the caller (`ws` arguments, sizes below).
+ *   - stateless and thread-safe (one stream per call).
+ *
+ * Each group cites the reference interface (relative to the MinJunKang/DualPixelFace tree) it stands in for.
+ */
+#ifndef DPF_HIP_H
+#define DPF_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPF_OK 0
+#define DPF_ERR_INVALID_ARG (-1)
+#define DPF_ERR_LAUNCH (-2)
+#define DPF_ERR_UNSUPPORTED (-3)
+
+/* activation codes of dpf_norm_act_* */
+#define DPF_ACT_NONE 0
+#define DPF_ACT_RELU 1
+#define DPF_ACT_PRELU 2
+#define DPF_ACT_LEAKY 3
+#define DPF_ACT_SIGMOID 4
+
+/* ---- dense convolutions: nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d (cuDNN in the reference) ---------------------
+ * call sites: src/module/asm/basics.py:17-36, src/model/stereodpnet/modules.py:26-32,64-69,88-91,208-227,271-296,
+ * src/model/stereodpnet/normal_module.py:14-19, src/module/dcn3d/modules/deform_conv.py:310-315 (conv_offset),
+ * src/module/asm/asm.py:141-146.  2-D tensors are passed with depth 1 (kd = 1, sd = 1, pd = 0, dd = 1).
+ * ws: dpf_conv_workspace_floats(T, reduce_channels, out_channels) floats (repacked weights). */
+long long dpf_conv_workspace_floats(int T, int reduce, int outc);
+int dpf_conv_forward(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                     int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw,
+                     void* stream);
+int dpf_conv_transpose(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                       int K, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                       int dd, int dh, int dw, void* stream);
+int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
+                   int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
+
+/* ---- depthwise 3x3: depthwise_separable_conv.depthwise (src/module/asm/basics.py:39-58) --------------------------- */
+int dpf_depthwise_conv2d_forward(const float* x, const float* w, float* y, int N, int C, int H, int W, int k, int pad, void* stream);
+int dpf_depthwise_conv2d_backward_data(const float* g, const float* w, float* dx, int N, int C, int H, int W, int k, int pad, void* stream);
+int dpf_depthwise_conv2d_backward_weight(const float* g, const float* x, float* dw, int N, int C, int H, int W, int k, int pad, void* stream);
+
+/* ---- BatchNorm2d/3d, InstanceNorm3d, ReLU/PReLU/LeakyReLU/Sigmoid, residual adds ---------------------------------
+ * src/module/asm/basics.py:17-58, src/model/stereodpnet/modules.py:37-52,241-260,310-325, src/module/asm/asm.py:138-146.
+ * x viewed as [N, C, S].  ws: 2*C floats (stats) / 3*C floats (backward). */
+int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float momentum, float* running_mean, float* running_var,
+                 float* mean, float* invstd, float* ws, void* stream);
+int dpf_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd, void* stream);
+int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd, const float* w, const float* b, int wmod,
+                         const float* res, const float* res2, int act, const float* slope, float slope_const, float* y, int N, int C,
+                         long long S, void* stream);
+int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
+                          int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
+                          float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, void* stream);
+int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void* stream);
+
+/* ---- resampling: F.interpolate(bilinear, align_corners=True) (modules.py:127-128, normal_module.py:22-29), FPN's
+ * nearest top-down add (torchvision.ops.FeaturePyramidNetwork, call site modules.py:83-85,119) ---------------------- */
+int dpf_upsample_bilinear2d_forward(const float* x, float* y, long long NC, int h, int w, int H, int W, void* stream);
+int dpf_upsample_bilinear2d_backward(const float* g, float* dx, long long NC, int h, int w, int H, int W, void* stream);
+int dpf_upsample_nearest_add_forward(const float* lat, const float* top, float* y, long long NC, int h, int w, int H, int W, void* stream);
+int dpf_upsample_nearest_backward(const float* g, float* dtop, long long NC, int h, int w, int H, int W, void* stream);
+
+/* ---- dual-pixel cost volume: subpixel_shift.forward (src/module/asm/asm.py:87-127), MaskingAttention tail
+ * (asm.py:162-171), CostVolume.build_concat_volume (src/model/stereodpnet/modules.py:181-197); PSMNet volume
+ * (src/model/psmnet/modules.py:215-262).  Sampler tables: iy/wy [3][2][h], ix/wx [3][2][w] (device). */
+int dpf_shift_triple_forward(const float* fea, float* out, const int* iy, const float* wy, const int* ix, const float* wx, int B, int C,
+                             int h, int w, void* stream);
+int dpf_shift_triple_backward(const float* g, float* dfea, const int* iy, const float* wy, const int* ix, const float* wx, int B, int C,
+                              int h, int w, void* stream);
+int dpf_cv_select_forward(const float* x3, const float* s, float* vol, int B, int C, int h, int w, int CV, int L, int choff,
+                          unsigned levels, void* stream);
+int dpf_cv_select_backward(const float* x3, const float* s, const float* dvol, float* dx3, float* ds, int B, int C, int h, int w, int CV,
+                           int L, int choff, unsigned levels, void* stream);
+int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const int* shifts_host, int B, int C, int h, int w, int L,
+                           int groups, void* stream);
+
+/* ---- disparity head: trilinear x4 + softmax + soft-argmin (modules.py:327-334,341-362) ---------------------------- */
+int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
+                           int H, int W, void* stream);
+int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
+                            int L, int H, int W, void* stream);
+
+/* ---- deformable conv3d: the reference's pybind module `DCN` (src/module/dcn3d/src/vision.cpp:4-7,
+ * src/module/dcn3d/src/deform_conv.h:10-29,49-69; deform_conv_cuda.cu:18-285) -- same argument order and meaning ----- */
+long long dpf_deform_conv3d_workspace_floats(int C, int K, int T);
+int dpf_deform_conv3d_forward(const float* input, const float* weight, const float* bias, const float* offset, float* output, float* ws,
+                              int B, int C, int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
+                              int pw, int dd, int dh, int dw, int group, int deformable_group, int im2col_step, void* stream);
+int dpf_deform_conv3d_backward(const float* input, const float* weight, const float* bias, const float* offset, const float* grad_output,
+                               float* grad_input, float* grad_offset, float* grad_weight, float* grad_bias, float* ws, int B, int C,
+                               int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd,
+                               int dh, int dw, int group, int deformable_group, int im2col_step, void* stream);
+
+/* ---- Adaptive Normal Module glue (src/model/stereodpnet/normal_module.py:80-138,154-167,185-190) ------------------ */
+int dpf_anm_select(const float* disp_full, int* idx, float* sdisp, const float* costrange_host, int B, int H, int W, int h, int w, int L,
+                   int K, void* stream);
+int dpf_anm_volume_forward(const float* cost, const int* idx, const float* sdisp, const float* Kmat, const float* abvalue, float* vol,
+                           unsigned* mm_ws, int B, int C, int L, int K, int h, int w, void* stream);
+int dpf_anm_volume_backward(const float* dvol, const int* idx, float* dcost, int B, int C, int L, int K, int h, int w, void* stream);
+int dpf_sigmoid_mean_forward(const float* u, float* out, int B, int Dn, long long CS, void* stream);
+int dpf_sigmoid_mean_backward(const float* u, const float* g, float* du, int B, int Dn, long long CS, void* stream);
+
+/* ---- losses (src/loss/loss_selector.py:29-42, src/loss/depth/smoothL1.py:15-49, src/loss/normal/cosine.py:15-53)
+ * and Adam (src/model/model_selector.py:31-34) --------------------------------------------------------------------- */
+int dpf_loss_forward(const float* pred_depth, const float* pred_normal, const float* disp, const float* normal, const float* mask,
+                     float* acc_ws, float* out, int B, int n, int H, int W, const float* head_weights_host, float lambda_depth,
+                     float lambda_normal, void* stream);
+int dpf_loss_backward(const float* pred_depth, const float* pred_normal, const float* disp, const float* normal, const float* mask,
+                      const float* acc_ws, const float* gout, float* d_pred_depth, float* d_pred_normal, int B, int n, int H, int W,
+                      const float* head_weights_host, float lambda_depth, float lambda_normal, void* stream);
+int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
+                  float beta2, float eps, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPF_HIP_H */

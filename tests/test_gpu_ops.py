@@ -1,0 +1,336 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): every HIP operator, called through the C ABI, against the CPU
+oracle (plain PyTorch-CPU restatements of the reference, oracle/) on the same seeded inputs.
+
+Tolerances: fp32 kernels with different summation orders -> rtol 1e-4 of the tensor's scale (stated per test);
+index outputs are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _ops():
+    from dualpixelface_amd import ops
+    return ops
+
+
+def close(a, b, tol=1e-4, name=''):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, '%s: max err %.3e vs scale %.3e (rel %.3e)' % (name, err, scale, err / scale)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # N, C, D, H, W, K, k(3), stride(3), pad(3), dil(3)
+    (2, 32, 4, 10, 40, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (1, 64, 8, 16, 24, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (2, 32, 8, 16, 24, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),
+    (1, 35, 4, 9, 33, 81, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (2, 32, 8, 9, 20, 1, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (2, 32, 3, 12, 36, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    (2, 32, 3, 12, 36, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    (2, 3, 1, 32, 48, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),
+    (2, 32, 1, 16, 24, 64, (1, 3, 3), (1, 2, 2), (0, 2, 2), (1, 2, 2)),
+    (1, 96, 1, 17, 35, 32, (1, 3, 3), (1, 1, 1), (0, 5, 5), (1, 5, 5)),
+    (3, 64, 1, 12, 20, 96, (1, 3, 3), (1, 1, 1), (0, 8, 8), (1, 8, 8)),
+    (2, 128, 1, 6, 9, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    (2, 32, 1, 16, 24, 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),
+    (4, 32, 1, 8, 12, 3, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward_backward(case):
+    ops = _ops()
+    N, C, D, H, W, K, ks, st, pd, dl = case
+    x = rnd(N, C, D, H, W, seed=1).requires_grad_()
+    w = rnd(K, C, *ks, seed=2, scale=0.1).requires_grad_()
+    b = rnd(K, seed=3).requires_grad_()
+    y_ref = F.conv3d(x, w, b, st, pd, dl)
+    go = rnd(*y_ref.shape, seed=4)
+    gx_r, gw_r, gb_r = torch.autograd.grad(y_ref, (x, w, b), go)
+    xg, wg, bg = [t.detach().to(DEV).requires_grad_() for t in (x, w, b)]
+    y = ops.ConvFn.apply(xg, wg, bg, st, pd, dl)
+    close(y, y_ref, 1e-4, 'conv fwd')
+    gx, gw, gb = torch.autograd.grad(y, (xg, wg, bg), go.to(DEV))
+    close(gx, gx_r, 1e-4, 'conv dgrad')
+    close(gw, gw_r, 2e-4, 'conv wgrad')
+    close(gb, gb_r, 1e-4, 'conv bgrad')
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 2, 4, 6, 64), (1, 64, 4, 8, 12, 32), (2, 64, 1, 3, 5, 32)])
+def test_conv_transpose3d(shape):
+    ops = _ops()
+    N, Ci, D, H, W, Co = shape
+    x = rnd(N, Ci, D, H, W, seed=5).requires_grad_()
+    w = rnd(Ci, Co, 3, 3, 3, seed=6, scale=0.1).requires_grad_()
+    y_ref = F.conv_transpose3d(x, w, None, 2, 1, 1)
+    go = rnd(*y_ref.shape, seed=7)
+    gx_r, gw_r = torch.autograd.grad(y_ref, (x, w), go)
+    xg, wg = x.detach().to(DEV).requires_grad_(), w.detach().to(DEV).requires_grad_()
+    y = ops.conv_transpose3d(xg, wg)
+    close(y, y_ref, 1e-4, 'convT fwd')
+    gx, gw = torch.autograd.grad(y, (xg, wg), go.to(DEV))
+    close(gx, gx_r, 1e-4, 'convT dgrad')
+    close(gw, gw_r, 2e-4, 'convT wgrad')
+
+
+def test_depthwise():
+    ops = _ops()
+    x = rnd(2, 64, 9, 14, seed=8).requires_grad_()
+    w = rnd(64, 1, 3, 3, seed=9).requires_grad_()
+    y_ref = F.conv2d(x, w, None, 1, 1, 1, 64)
+    go = rnd(*y_ref.shape, seed=10)
+    gx_r, gw_r = torch.autograd.grad(y_ref, (x, w), go)
+    xg, wg = x.detach().to(DEV).requires_grad_(), w.detach().to(DEV).requires_grad_()
+    y = ops.depthwise_conv3x3(xg, wg)
+    close(y, y_ref, 1e-5, 'dw fwd')
+    gx, gw = torch.autograd.grad(y, (xg, wg), go.to(DEV))
+    close(gx, gx_r, 1e-5, 'dw dgrad')
+    close(gw, gw_r, 1e-4, 'dw wgrad')
+
+
+@pytest.mark.parametrize('act', ['none', 'relu', 'prelu'])
+@pytest.mark.parametrize('shape', [(2, 32, 7, 9), (3, 64, 4, 6, 10)])
+def test_batchnorm_train(act, shape):
+    ops = _ops()
+    x = (rnd(*shape, seed=11) * 2 + 0.7).requires_grad_()
+    C = shape[1]
+    w = (torch.rand(C, generator=torch.Generator().manual_seed(12)) + 0.5).requires_grad_()
+    b = rnd(C, seed=13).requires_grad_()
+    res = rnd(*shape, seed=14).requires_grad_()
+    res2 = rnd(*shape, seed=15).requires_grad_()
+    slope = torch.tensor([0.17], requires_grad=True)
+    rm, rv = rnd(C, seed=16) * 0.1, torch.rand(C, generator=torch.Generator().manual_seed(17)) + 0.5
+    rm_r, rv_r = rm.clone(), rv.clone()
+    z = F.batch_norm(x, rm_r, rv_r, w, b, True, 0.1, 1e-5) + res
+    y_ref = {'none': z, 'relu': F.relu(z), 'prelu': F.prelu(z, slope)}[act] + res2
+    go = rnd(*shape, seed=18)
+    grads_r = torch.autograd.grad(y_ref, (x, w, b, res, res2) + ((slope,) if act == 'prelu' else ()), go)
+    xg, wg, bg, rg, r2g, sg = [t.detach().to(DEV).requires_grad_() for t in (x, w, b, res, res2, slope)]
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    code = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'prelu': ops.ACT_PRELU}[act]
+    y = ops.norm_act(xg, wg, bg, sg if act == 'prelu' else None, rg, r2g, rmg, rvg, 1, code)
+    close(y, y_ref, 1e-5, 'bn fwd')
+    close(rmg, rm_r, 1e-5, 'running_mean')
+    close(rvg, rv_r, 1e-5, 'running_var')
+    grads = torch.autograd.grad(y, (xg, wg, bg, rg, r2g) + ((sg,) if act == 'prelu' else ()), go.to(DEV))
+    for g, gr, nm in zip(grads, grads_r, ('dx', 'dw', 'db', 'dres', 'dres2', 'dslope')):
+        close(g, gr, 2e-4, 'bn ' + nm)
+
+
+def test_batchnorm_eval_and_instance_norm_and_leaky():
+    ops = _ops()
+    x = rnd(2, 32, 3, 6, 8, seed=20)
+    w, b = torch.rand(32) + 0.5, rnd(32, seed=21)
+    rm, rv = rnd(32, seed=22) * 0.2, torch.rand(32) + 0.5
+    y_ref = F.relu(F.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5))
+    y = ops.norm_act(x.to(DEV), w.to(DEV), b.to(DEV), None, None, None, rm.to(DEV), rv.to(DEV), 2, ops.ACT_RELU)
+    close(y, y_ref, 1e-5, 'bn eval')
+    # instance norm + sigmoid (asm.py:138,154,162)
+    xr = x.clone().requires_grad_()
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    y_ref = torch.sigmoid(F.instance_norm(xr, None, None, wr, br, True, 0.1, 1e-5))
+    go = rnd(*x.shape, seed=23)
+    gr = torch.autograd.grad(y_ref, (xr, wr, br), go)
+    xg, wg, bg = [t.detach().to(DEV).requires_grad_() for t in (x, w, b)]
+    y = ops.norm_act(xg, wg, bg, mode=3, act=ops.ACT_SIGMOID)
+    close(y, y_ref, 1e-5, 'in fwd')
+    gg = torch.autograd.grad(y, (xg, wg, bg), go.to(DEV))
+    for a, r, nm in zip(gg, gr, ('dx', 'dw', 'db')):
+        close(a, r, 2e-4, 'in ' + nm)
+    # stand-alone LeakyReLU(0.1) and a plain add
+    xr = x.clone().requires_grad_()
+    y_ref = F.leaky_relu(xr, 0.1)
+    (gr,) = torch.autograd.grad(y_ref, xr, go)
+    xg = x.to(DEV).requires_grad_()
+    y = ops.norm_act(xg, act=ops.ACT_LEAKY, slope_const=0.1)
+    close(y, y_ref, 1e-6, 'leaky')
+    (gg,) = torch.autograd.grad(y, xg, go.to(DEV))
+    close(gg, gr, 1e-6, 'leaky bwd')
+
+
+@pytest.mark.parametrize('scale', [2, 4])
+def test_bilinear_and_nearest(scale):
+    ops = _ops()
+    x = rnd(2, 5, 7, 11, seed=30).requires_grad_()
+    y_ref = F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=True)
+    go = rnd(*y_ref.shape, seed=31)
+    (gr,) = torch.autograd.grad(y_ref, x, go)
+    xg = x.detach().to(DEV).requires_grad_()
+    y = ops.upsample_bilinear(xg, scale)
+    close(y, y_ref, 1e-5, 'bilinear fwd')
+    (gg,) = torch.autograd.grad(y, xg, go.to(DEV))
+    close(gg, gr, 1e-5, 'bilinear bwd')
+    lat = rnd(2, 5, 7 * scale, 11 * scale, seed=32).requires_grad_()
+    top = rnd(2, 5, 7, 11, seed=33).requires_grad_()
+    y_ref = lat + F.interpolate(top, size=lat.shape[-2:], mode='nearest')
+    gl_r, gt_r = torch.autograd.grad(y_ref, (lat, top), go)
+    lg, tg = lat.detach().to(DEV).requires_grad_(), top.detach().to(DEV).requires_grad_()
+    y = ops.nearest_up_add(lg, tg)
+    close(y, y_ref, 1e-6, 'nearest fwd')
+    gl, gt = torch.autograd.grad(y, (lg, tg), go.to(DEV))
+    close(gl, gl_r, 1e-6, 'nearest dlat')
+    close(gt, gt_r, 1e-5, 'nearest dtop')
+
+
+@pytest.mark.parametrize('delta', [-1.0, 1.0, 2.0])
+def test_shift_triple(delta):
+    from oracle.stereodpnet import StereoDPNetOracle
+    from dualpixelface_amd.sampler_tables import build_shift_tables
+    ops = _ops()
+    fea = rnd(2, 8, 12, 20, seed=40).requires_grad_()
+    ref = torch.stack(StereoDPNetOracle.shift_triple(fea, delta), 2)
+    go = rnd(*ref.shape, seed=41)
+    (gr,) = torch.autograd.grad(ref, fea, go)
+    tables = tuple(t.to(DEV) for t in build_shift_tables(12, 20, delta))
+    fg = fea.detach().to(DEV).requires_grad_()
+    out = ops.shift_triple(fg, tables)
+    close(out, ref, 1e-5, 'shift fwd')
+    (gg,) = torch.autograd.grad(out, fg, go.to(DEV))
+    close(gg, gr, 1e-4, 'shift bwd')
+
+
+def test_cv_select():
+    ops = _ops()
+    B, C, h, w, L = 2, 8, 6, 10, 8
+    ts = [rnd(B, C, 3, h, w, seed=50 + i).requires_grad_() for i in range(4)]
+    ts[1] = torch.sigmoid(ts[1].detach()).requires_grad_()
+    ts[3] = torch.sigmoid(ts[3].detach()).requires_grad_()
+
+    def sel(x3, s):
+        return torch.mean(x3 * F.softmax(s, dim=2), 2)
+    ref = torch.cat([sel(ts[0], ts[1]), sel(ts[2], ts[3])], 1).unsqueeze(2).expand(-1, -1, L, -1, -1)
+    go = rnd(B, 2 * C, L, h, w, seed=55)
+    gr = torch.autograd.grad(ref, ts, go)
+    tg = [t.detach().to(DEV).requires_grad_() for t in ts]
+    vol = ops.cv_select(L, [(1 << L) - 1], tg)
+    close(vol, ref, 1e-5, 'cv_select fwd')
+    gg = torch.autograd.grad(vol, tg, go.to(DEV))
+    for a, r in zip(gg, gr):
+        close(a, r, 1e-4, 'cv_select bwd')
+
+
+def test_softargmin():
+    ops = _ops()
+    B, D, h, w = 2, 8, 6, 10
+    logits = rnd(B, 1, D, h, w, seed=60, scale=2.0).requires_grad_()
+    disp = [-4 + 0.5 * i for i in range(32)]
+    up = F.interpolate(logits, scale_factor=4, mode='trilinear', align_corners=True).squeeze(1)
+    prob_r = F.softmax(up, 1)
+    pred_r = torch.sum(prob_r * torch.tensor(disp).view(1, -1, 1, 1), 1)
+    go = rnd(*pred_r.shape, seed=61)
+    (gr,) = torch.autograd.grad(pred_r, logits, go)
+    lg = logits.detach().to(DEV).requires_grad_()
+    pred, prob = ops.softargmin(lg, disp, 4, True)
+    close(pred, pred_r, 1e-5, 'softargmin pred')
+    close(prob, prob_r, 1e-5, 'softargmin prob')
+    (gg,) = torch.autograd.grad(pred, lg, go.to(DEV))
+    close(gg, gr, 1e-4, 'softargmin bwd')
+
+
+@pytest.mark.parametrize('cfg', [(2, 35, 64, 4, 6, 9), (1, 64, 64, 4, 8, 12), (2, 5, 7, 3, 5, 6)])
+def test_deform_conv(cfg):
+    from oracle import dcn3d
+    ops = _ops()
+    B, C, K, D, H, W = cfg
+    x = rnd(B, C, D, H, W, seed=70)
+    off = rnd(B, 81, D, H, W, seed=71, scale=1.5)
+    wt = rnd(K, C, 3, 3, 3, seed=72, scale=0.1)
+    bs = rnd(K, seed=73)
+    y_ref = dcn3d.deform_conv3d_forward(x, off, wt, bs)
+    go = rnd(*y_ref.shape, seed=74)
+    gr = dcn3d.deform_conv3d_backward(x, off, wt, bs, go)
+    xg, og, wg, bg = [t.to(DEV).requires_grad_() for t in (x, off, wt, bs)]
+    y = ops.deform_conv3d(xg, og, wg, bg)
+    close(y, y_ref, 1e-4, 'dcn fwd')
+    gg = torch.autograd.grad(y, (xg, og, wg, bg), go.to(DEV))
+    for a, r, nm in zip(gg, gr, ('grad_input', 'grad_offset', 'grad_weight', 'grad_bias')):
+        close(a, r, 2e-4, 'dcn ' + nm)
+    # known answer: zero offsets == plain conv3d
+    y0 = ops.deform_conv3d(xg, torch.zeros_like(og), wg, bg)
+    close(y0, F.conv3d(x, wt, bs, padding=1), 1e-4, 'dcn zero offset')
+
+
+def test_anm_volume_and_sigmoid_mean():
+    from oracle import recipe_state
+    from oracle.stereodpnet import StereoDPNetOracle
+    from dualpixelface_amd.recipe import synthetic_batch
+    ops = _ops()
+    B, C, L, h, w = 2, 32, 8, 6, 10
+    orc = StereoDPNetOracle({}, training=True)
+    cost = rnd(B, C, L, h, w, seed=80).requires_grad_()
+    batch = synthetic_batch(B, 4 * h, 4 * w, seed=1)
+    disp_full = torch.rand(B, 4 * h, 4 * w, generator=torch.Generator().manual_seed(81)) * 16 - 4
+    vol_r = orc.anm_front(cost, disp_full, batch['K'], batch['abvalue'])
+    go = rnd(*vol_r.shape, seed=82)
+    (gr,) = torch.autograd.grad(vol_r, cost, go)
+    cg = cost.detach().to(DEV).requires_grad_()
+    vol, idx = ops.anm_volume(cg, disp_full.to(DEV), batch['K'].to(DEV), batch['abvalue'].to(DEV), orc.cfg.costrange, 4)
+    assert torch.equal(idx.cpu().long(), orc.taps['anm_idx']), 'sampled level indices must be bit-exact'
+    close(vol[:, :C], vol_r[:, :C], 1e-6, 'anm gathered cost')
+    close(vol[:, C:], vol_r[:, C:], 1e-4, 'anm xyz')
+    (gg,) = torch.autograd.grad(vol, cg, go.to(DEV))
+    close(gg, gr, 1e-6, 'anm bwd')
+    u = rnd(B * 4, 3, 8, 12, seed=83).requires_grad_()
+    y_ref = torch.sigmoid(u).view(B, 4, 3, 8, 12).mean(1) * 2.0 - 1.0
+    go = rnd(*y_ref.shape, seed=84)
+    (gr,) = torch.autograd.grad(y_ref, u, go)
+    ug = u.detach().to(DEV).requires_grad_()
+    y = ops.sigmoid_mean(ug, B, 4)
+    close(y, y_ref, 1e-5, 'sigmoid_mean')
+    (gg,) = torch.autograd.grad(y, ug, go.to(DEV))
+    close(gg, gr, 1e-5, 'sigmoid_mean bwd')
+
+
+@pytest.mark.parametrize('mode', ['ones', 'bern'])
+def test_losses_against_reference_fixture(mode, golden_dir):
+    ops = _ops()
+    g = np.load(golden_dir + '/loss.npz')
+    t = lambda k: torch.from_numpy(g[mode + '_' + k]).to(DEV)
+    pd, pn = t('pred_depth').requires_grad_(), t('pred_normal').requires_grad_()
+    out = ops.stereo_losses(pd, pn[:, 0], t('disp'), t('normal'), t('mask'), [1.0, 0.7, 0.5], 1.0, 1.0)
+    for i, k in enumerate(('smoothL1_loss', 'cosine_loss', 'final_loss')):
+        close(out[i], torch.from_numpy(g[mode + '_' + k]), 1e-5, k)
+    gpd, gpn = torch.autograd.grad(out[2], (pd, pn))
+    close(gpd, torch.from_numpy(g[mode + '_g_pred_depth']), 1e-4, 'd pred_depth')
+    close(gpn, torch.from_numpy(g[mode + '_g_pred_normal']), 1e-4, 'd pred_normal')
+
+
+def test_adam_step():
+    from oracle.stereodpnet import adam_step as adam_ref
+    ops = _ops()
+    n = 10007
+    p, g = rnd(n, seed=90), rnd(n, seed=91, scale=0.01)
+    pr, m, v = {'p': p.clone()}, {'p': torch.zeros(n)}, {'p': torch.zeros(n)}
+    pg, mg, vg, gg = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), g.to(DEV)
+    for step in (1, 2, 3):
+        adam_ref(pr, {'p': g}, m, v, step)
+        ops.adam_step(pg, gg, mg, vg, step, 1e-4)
+    close(pg, pr['p'], 1e-6, 'adam param')
+    close(mg, m['p'], 1e-5, 'adam m')
+    close(vg, v['p'], 1e-5, 'adam v')
+
+
+def test_psm_volume_against_reference_fixture(golden_dir):
+    ops = _ops()
+    g = np.load(golden_dir + '/psmnet_volume.npz')
+    ref, tar = torch.from_numpy(g['ref']).to(DEV), torch.from_numpy(g['tar']).to(DEV)
+    costrange = [i * 0.5 - 1.0 for i in range(8)]
+    shifts = [int(c) for c in costrange]                      # psmnet/modules.py:229 (truncation toward zero)
+    assert shifts == [-1, 0, 0, 0, 1, 1, 2, 2]
+    close(ops.psm_volume(ref, tar, shifts, 0), torch.from_numpy(g['vol_psmnet']), 0.0, 'psmnet volume')
+    close(ops.psm_volume(ref, tar, shifts, 40), torch.from_numpy(g['vol_gwcnet']), 1e-6, 'gwcnet volume')
