@@ -17,6 +17,7 @@ _CTYPES = {
     'unsigned': ctypes.c_uint,
     'long long': ctypes.c_longlong,
     'float': ctypes.c_float,
+    'double': ctypes.c_double,
 }
 
 ERRORS = {-1: 'DPF_ERR_INVALID_ARG', -2: 'DPF_ERR_LAUNCH', -3: 'DPF_ERR_UNSUPPORTED'}

@@ -146,11 +146,11 @@ __global__ void loss_backward_kernel(const float* __restrict__ pd, const float* 
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                            float gscale, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float eps) {
+                            float gscale, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float omb1, float omb2, float eps) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * gi * gi;
     m[i] = mi;
     v[i] = vi;
     p[i] = p[i] - lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
@@ -195,12 +195,12 @@ int dpf_loss_backward(const float* pred_depth, const float* pred_normal, const f
 }
 
 // One fused Adam step over a flat arena of n floats; grad is pre-scaled by gscale (1/world_size after an all-reduce SUM).
-int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
-                  float beta2, float eps, float gscale, void* stream) {
+int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, double lr, double beta1,
+                  double beta2, double eps, float gscale, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return DPF_ERR_INVALID_ARG;
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, gscale,
-                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps);
+                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
   return dpf_check_launch();
 }
 

@@ -118,8 +118,8 @@ int dpf_loss_forward(const float* pred_depth, const float* pred_normal, const fl
 int dpf_loss_backward(const float* pred_depth, const float* pred_normal, const float* disp, const float* normal, const float* mask,
                       const float* acc_ws, const float* gout, float* d_pred_depth, float* d_pred_normal, int B, int n, int H, int W,
                       const float* head_weights_host, float lambda_depth, float lambda_normal, void* stream);
-int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
-                  float beta2, float eps, float gscale, void* stream);
+int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, double lr, double beta1,
+                  double beta2, double eps, float gscale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,91 @@
+"""CPU: host-side logic of the product (no GPU compute): ABI surface, sampler tables, state_dict contract, config."""
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from dualpixelface_amd import _lib, load_option
+from dualpixelface_amd.sampler_tables import build_shift_tables, apply_tables_reference
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_declares_and_library_exports_every_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'dualpixelface_amd', 'csrc'), '-j8'])
+    protos = _lib.parse_header()
+    assert len(protos) >= 30
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(cdll, name), name
+    nm = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in nm.splitlines() if ' T dpf_' in l}
+    assert exported == set(protos), exported ^ set(protos)
+    # plain-C boundary: no torch / ATen types in the header
+    text = open(_lib.HEADER_PATH).read()
+    assert 'at::' not in text and '#include <torch' not in text and 'Tensor' not in text
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    from dualpixelface_amd import ops
+    from dualpixelface_amd._lib import DpfError
+    x = torch.randn(1, 4, 1, 8, 8)
+    w = torch.randn(4, 4, 1, 3, 3)
+    with pytest.raises(DpfError):
+        ops.conv3d(x, w, None, 1, (0, 1, 1), 1)
+
+
+def test_shift_tables_reproduce_reference_sampling(golden_dir):
+    g = np.load(golden_dir + '/e2e_train_32x48_b2.npz')
+    for fea_k, pre, d in (('fea_ref', 'shift_fwd_', -1.0), ('fea_tar', 'shift_bwd_', +1.0)):
+        fea = torch.from_numpy(g[fea_k])
+        out = apply_tables_reference(fea, build_shift_tables(fea.shape[2], fea.shape[3], d))
+        for j, nm in enumerate(('nearest', 'bilinear', 'phase')):
+            assert (out[:, :, j] - torch.from_numpy(g[pre + nm])).abs().max() < 1e-6, pre + nm
+    # the nearest branch zero-fills the last column
+    iy, wy, ix, wx = build_shift_tables(16, 24, -1.0)
+    assert ix[0, 0, -1] == -1 and (ix[0, 0, :-1] >= 0).all()
+    with pytest.raises(NotImplementedError):
+        build_shift_tables(16, 24, 0.5)
+
+
+def test_state_dict_contract_and_flat_arena(golden_dir):
+    from dualpixelface_amd.plugin import STEREODPNET
+    from dualpixelface_amd.recipe import fill_by_recipe
+    model = STEREODPNET(load_option())
+    ref = json.load(open(golden_dir + '/state_dict_keys.json'))
+    sd = model.state_dict()
+    assert set(sd) == set(ref) and len(sd) == 511
+    assert all(list(sd[k].shape) == ref[k] for k in ref)
+    flat = model.flat_parameters()
+    assert flat.numel() == 3670492
+    fill_by_recipe(model)
+    p = dict(model.named_parameters())['aggregation.dres2.conv1.0.0.weight']
+    assert p.data_ptr() >= flat.data_ptr() and p.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+    # alias keys of the doubly registered InstanceNorm are the same storage
+    assert sd['cost_volume.attention_layer.normalize.weight'].data_ptr() == sd['cost_volume.attention_layer.mask_convs.3.1.weight'].data_ptr()
+    # round trip + arena survives a dtype/device move
+    other = STEREODPNET(load_option())
+    other.load_state_dict(sd, strict=True)
+    other.float()
+    assert torch.equal(other.flat_parameters(), flat)
+    opt, sched = model.configure_optimizers()
+    assert opt[0].defaults['eps'] == 1e-5 and len(sched) == 1
+
+
+def test_reference_style_plugin_entry():
+    from runpy import run_path
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        ns = run_path(os.path.join('src', 'model', 'stereodpnet', 'mainmodel.py'))
+        assert 'STEREODPNET' in ns
+        ls = run_path(os.path.join('src', 'loss', 'depth', 'smoothL1.py'))
+        assert 'SMOOTHL1Loss' in ls
+        assert 'COSINELoss' in run_path(os.path.join('src', 'loss', 'normal', 'cosine.py'))
+    finally:
+        os.chdir(cwd)
