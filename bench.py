@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""bench.py -- StereoDPNet train-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = forward + loss + backward + gradient all-reduce (RCCL, N > 1) + fused Adam on one synthetic batch of
+`--batch` dual-pixel pairs of `--height` x `--width` per GPU (weak scaling), inputs resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line (contract in the task description) including
+  "roofline":     the dominant kernel (implicit-GEMM convolution on the fp32 matrix cores) -- algorithmic FLOPs per
+                  launch / average launch duration, measured live with HIP events on the launch stream;
+  "cpu_baseline": the CPU oracle (oracle/, a PyTorch-CPU restatement of the reference) timed on this host's cores on a
+                  bounded sample (one 1x256x256 train step), scaled to 1024x1536 samples/s by pixel count.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PIXEL_FWD_BWD = 2.708e6        # SURVEY.md section 8d (fwd 902 764 FLOP/pixel/pair, fwd+bwd = 3x)
+PEAK_F32_TFLOPS = 157.3                 # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+
+
+def cpu_baseline(threads):
+    from dualpixelface_amd.recipe import synthetic_batch
+    from oracle import recipe_state
+    from oracle.stereodpnet import StereoDPNetOracle
+    torch.set_num_threads(threads)
+    H = W = 256
+    batch = synthetic_batch(1, H, W, seed=7)
+    st = recipe_state()
+    orc = StereoDPNetOracle(st, training=True)
+    t0 = time.time()
+    res = orc.forward(batch)
+    res['final_loss'].backward()
+    dt = time.time() - t0
+    return {'value': (1.0 / dt) * (H * W) / (1024.0 * 1536.0), 'unit': 'samples/s (1024x1536 equivalent)', 'cores': threads,
+            'kind': 'port', 'sample': 'one 1x256x256 forward+loss+backward of the CPU oracle (%.1f s), scaled by pixel count' % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=4, help='samples per GPU (BASELINE configs[2]: 32 over 8 GPUs)')
+    ap.add_argument('--height', type=int, default=1024)
+    ap.add_argument('--width', type=int, default=1536)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from dualpixelface_amd import load_option, ops
+    from dualpixelface_amd.distributed import init_from_env, make_reducer, broadcast_flat
+    from dualpixelface_amd.plugin import STEREODPNET
+    from dualpixelface_amd.recipe import synthetic_batch
+    import torch.distributed as dist
+
+    rank, world, local = init_from_env()
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(1)
+    model = STEREODPNET(load_option())          # reference initialisation scheme, random weights
+    model.to(dev)
+    broadcast_flat(model.flat_parameters(), 0)
+    reducer = make_reducer(model) if world > 1 else None
+    batch = {k: v.to(dev) for k, v in synthetic_batch(args.batch, args.height, args.width, seed=rank).items()}
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step(batch, reducer)
+    sync()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = model.train_step(batch, reducer)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    loss = float(res['final_loss'])
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        global_batch = args.batch * world
+        value = global_batch * args.steps / elapsed
+        fam = {}
+        for family, flops, e0, e1 in prof:
+            f = fam.setdefault(family, [0.0, 0.0, 0])
+            f[0] += flops
+            f[1] += e0.elapsed_time(e1) * 1e-3
+            f[2] += 1
+        dom = max(fam, key=lambda k: fam[k][1]) if fam else None
+        roof = None
+        if dom:
+            flops, secs, n = fam[dom]
+            ach = flops / secs / 1e12
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
+                    'traffic': None, 'launches': n, 'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed,
+                    'families': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3} for k, v in fam.items()}}
+        pixels = args.height * args.width
+        line = {
+            'metric': 'train samples/sec, StereoDPNet 1024x1536 DP pair', 'value': value, 'unit': 'samples/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'StereoDPNet train step (fwd+loss+bwd+grad all-reduce+Adam), %d x %dx%d synthetic DP pairs per GPU'
+                                   % (args.batch, args.height, args.width),
+                       'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,
+                       'batchnorm': 'per-rank statistics'},
+            'final_loss': loss,
+            'flop_frac_of_f32_peak': value * FLOP_PER_PIXEL_FWD_BWD * pixels / (world * PEAK_F32_TFLOPS * 1e12),
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

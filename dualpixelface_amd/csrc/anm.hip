@@ -183,6 +183,7 @@ extern "C" {
 // disp_full [B,H,W] -> idx [B,K,h,w] (int32, ascending), sdisp [B,K,h,w];  costrange: L host floats
 int dpf_anm_select(const float* disp_full, int* idx, float* sdisp, const float* costrange_host, int B, int H, int W, int h, int w, int L,
                    int K, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!disp_full || !idx || !sdisp || !costrange_host || B <= 0 || L <= 0 || L > MAXLV || K <= 0 || K > L) return DPF_ERR_INVALID_ARG;
   SelP p;
   p.B = B; p.h = h; p.w = w; p.H = H; p.W = W; p.L = L; p.K = K;
@@ -194,6 +195,7 @@ int dpf_anm_select(const float* disp_full, int* idx, float* sdisp, const float* 
 // cost [B,C,L,h,w], idx/sdisp [B,K,h,w], Kmat [B,3,3], abvalue [B,2] -> vol [B,C+3,K,h,w];  mm_ws: 2*B uint32
 int dpf_anm_volume_forward(const float* cost, const int* idx, const float* sdisp, const float* Kmat, const float* abvalue, float* vol,
                            unsigned* mm_ws, int B, int C, int L, int K, int h, int w, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!cost || !idx || !sdisp || !Kmat || !abvalue || !vol || !mm_ws || B <= 0 || B > 65535) return DPF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int CV = C + 3;
@@ -208,6 +210,7 @@ int dpf_anm_volume_forward(const float* cost, const int* idx, const float* sdisp
 
 // dvol [B,C+3,K,h,w] -> dcost [B,C,L,h,w] (fully written)
 int dpf_anm_volume_backward(const float* dvol, const int* idx, float* dcost, int B, int C, int L, int K, int h, int w, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!dvol || !idx || !dcost || B <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(anm_gather_bwd_kernel, dim3(dpf_ew_grid((long long)B * C * L * h * w)), dim3(256), 0, (hipStream_t)stream, dvol, idx,
                      dcost, B, C, L, K, h, w, C + 3);
@@ -216,11 +219,13 @@ int dpf_anm_volume_backward(const float* dvol, const int* idx, float* dcost, int
 
 // u [B*Dn, CS] -> out [B, CS]
 int dpf_sigmoid_mean_forward(const float* u, float* out, int B, int Dn, long long CS, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!u || !out || B <= 0 || Dn <= 0 || CS <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(sigmoid_mean_fwd_kernel, dim3(dpf_ew_grid((long long)B * CS)), dim3(256), 0, (hipStream_t)stream, u, out, B, Dn, CS);
   return dpf_check_launch();
 }
 int dpf_sigmoid_mean_backward(const float* u, const float* g, float* du, int B, int Dn, long long CS, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!u || !g || !du || B <= 0 || Dn <= 0 || CS <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(sigmoid_mean_bwd_kernel, dim3(dpf_ew_grid((long long)B * Dn * CS)), dim3(256), 0, (hipStream_t)stream, u, g, du, B, Dn, CS);
   return dpf_check_launch();

@@ -69,6 +69,7 @@ extern "C" {
 
 // x [N,C,H,W], w [C,1,k,k] -> y [N,C,H,W] (stride 1, dilation 1, padding `pad`)
 int dpf_depthwise_conv2d_forward(const float* x, const float* w, float* y, int N, int C, int H, int W, int k, int pad, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !w || !y || N <= 0 || C <= 0 || 2 * pad != k - 1) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(dw_conv_kernel, dim3(dpf_ew_grid((long long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, w, y,
                      (long long)N * C, C, H, W, k, pad, 0);
@@ -76,6 +77,7 @@ int dpf_depthwise_conv2d_forward(const float* x, const float* w, float* y, int N
 }
 
 int dpf_depthwise_conv2d_backward_data(const float* g, const float* w, float* dx, int N, int C, int H, int W, int k, int pad, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !w || !dx || N <= 0 || C <= 0 || 2 * pad != k - 1) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(dw_conv_kernel, dim3(dpf_ew_grid((long long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, g, w, dx,
                      (long long)N * C, C, H, W, k, pad, 1);
@@ -84,6 +86,7 @@ int dpf_depthwise_conv2d_backward_data(const float* g, const float* w, float* dx
 
 // dw [C,1,3,3] += ...   (k must be 3)
 int dpf_depthwise_conv2d_backward_weight(const float* g, const float* x, float* dw, int N, int C, int H, int W, int k, int pad, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !x || !dw || N <= 0 || C <= 0 || k != 3 || pad != 1 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(dw_wgrad_kernel, dim3((unsigned)dpf_div_up((long long)H * W, 4096), (unsigned)(N * C)), dim3(256), 0,
                      (hipStream_t)stream, g, x, dw, C, H, W, pad);

@@ -35,6 +35,7 @@ struct ConvP {
   int sd, sh, sw, pd, ph, pw, dd, dh, dw;
   int transposed;
   int QD, tilesH, tilesW, ncls;   // grid decomposition (class-0 sizes)
+  int Ktot, k0;                   // out tensor has Ktot channels; this launch writes [k0, k0 + K)
   int chanStrideMax;              // floats per channel of the LDS input tile (host worst case)
   int ntmax;                      // max valid taps per class
 };
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
         const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
         if (k < p.K) {
           float v = acc[m][t][j];
-          if (bias) v += bias[k];
-          out[((long long)n * p.K + k) * p.OD * out_plane + pos] = v;
+          if (bias) v += bias[p.k0 + k];
+          out[((long long)n * p.Ktot + p.k0 + k) * p.OD * out_plane + pos] = v;
         }
       }
     }
@@ -397,19 +398,33 @@ int launch_igemm(const float* x, const float* wt, const float* bias, float* out,
   return dpf_check_launch();
 }
 
+int conv_launch(const float* x, const float* wt_ws, const float* bias, float* out, ConvP p, hipStream_t st);
+
 int conv_common(const float* x, const float* w, const float* bias, float* out, float* wt_ws, ConvP p, int repack_mode,
                 int wA, int wB, hipStream_t st) {
   const int T = p.kd * p.kh * p.kw;
   if (T > MAXT || T < 1) return DPF_ERR_UNSUPPORTED;
-  const int MT = (p.K + 31) / 32;
-  if (MT < 1 || MT > 4) return DPF_ERR_UNSUPPORTED;
-  const int KT = 32 * MT;
-  // repack weights -> wt_ws [T][C][KT]
-  {
+  // one launch covers up to 128 output channels (4 MFMA row tiles); wider outputs are split
+  const int Kfull = p.K;
+  p.Ktot = Kfull;
+  for (int k0 = 0; k0 < Kfull; k0 += 128) {
+    const int Kc = Kfull - k0 < 128 ? Kfull - k0 : 128;
+    const int KT = 32 * ((Kc + 31) / 32);
     const long long total = (long long)T * p.C * KT;
-    hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wt_ws, wA, wB, T, KT, repack_mode);
+    hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wt_ws, wA, wB, T, KT, repack_mode, k0, Kc);
     if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
+    p.K = Kc;
+    p.k0 = k0;
+    const int rc = conv_launch(x, wt_ws, bias, out, p, st);
+    if (rc != DPF_OK) return rc;
   }
+  return DPF_OK;
+}
+
+int conv_launch(const float* x, const float* wt_ws, const float* bias, float* out, ConvP p, hipStream_t st) {
+  const int T = p.kd * p.kh * p.kw;
+  const int MT = (p.K + 31) / 32;
+  const int KT = 32 * MT;
   // tile geometry (host worst case over classes)
   int ext_d, ext_h, ext_w, ntmax;
   if (!p.transposed) {
@@ -469,6 +484,7 @@ long long dpf_conv_workspace_floats(int T, int reduce, int outc) { return (long 
 int dpf_conv_forward(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
                      int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw,
                      void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !w || !out || !ws || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
   ConvP p{};
   p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW;
@@ -486,6 +502,7 @@ int dpf_conv_forward(const float* x, const float* w, const float* bias, float* o
 int dpf_conv_transpose(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
                        int K, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
                        int dd, int dh, int dw, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !w || !out || !ws || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
   ConvP p{};
   p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW; p.OD = OD; p.OH = OH; p.OW = OW;
@@ -503,6 +520,7 @@ int dpf_conv_transpose(const float* x, const float* w, const float* bias, float*
 // g [N,K,QD,QH,QW] on the small grid, x [N,C,ID,IH,IW] on the dense grid.
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !x || !dw || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
   WgP p{};
   p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW; p.QD = QD; p.QH = QH; p.QW = QW;

@@ -172,6 +172,7 @@ extern "C" {
 
 int dpf_shift_triple_forward(const float* fea, float* out, const int* iy, const float* wy, const int* ix, const float* wx, int B, int C,
                              int h, int w, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!fea || !out || !iy || !wy || !ix || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
   const long long BC = (long long)B * C;
   hipLaunchKernelGGL(shift_triple_fwd_kernel, dim3(dpf_ew_grid(BC * 3 * h * w)), dim3(256), 0, (hipStream_t)stream, fea, out, iy, wy, ix,
@@ -181,6 +182,7 @@ int dpf_shift_triple_forward(const float* fea, float* out, const int* iy, const 
 
 int dpf_shift_triple_backward(const float* g, float* dfea, const int* iy, const float* wy, const int* ix, const float* wx, int B, int C,
                               int h, int w, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !dfea || !iy || !wy || !ix || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
   const long long BC = (long long)B * C;
   hipStream_t st = (hipStream_t)stream;
@@ -191,6 +193,7 @@ int dpf_shift_triple_backward(const float* g, float* dfea, const int* iy, const 
 
 int dpf_cv_select_forward(const float* x3, const float* s, float* vol, int B, int C, int h, int w, int CV, int L, int choff,
                           unsigned levels, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x3 || !s || !vol || B <= 0 || C <= 0 || L <= 0 || L > 32 || choff < 0 || choff + C > CV) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(cv_select_fwd_kernel, dim3(dpf_ew_grid((long long)B * C * h * w)), dim3(256), 0, (hipStream_t)stream, x3, s, vol, B,
                      C, h, w, CV, L, choff, levels);
@@ -199,6 +202,7 @@ int dpf_cv_select_forward(const float* x3, const float* s, float* vol, int B, in
 
 int dpf_cv_select_backward(const float* x3, const float* s, const float* dvol, float* dx3, float* ds, int B, int C, int h, int w, int CV,
                            int L, int choff, unsigned levels, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x3 || !s || !dvol || !dx3 || !ds || B <= 0 || C <= 0 || L <= 0 || L > 32 || choff < 0 || choff + C > CV) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(cv_select_bwd_kernel, dim3(dpf_ew_grid((long long)B * C * h * w)), dim3(256), 0, (hipStream_t)stream, x3, s, dvol,
                      dx3, ds, B, C, h, w, CV, L, choff, levels);
@@ -208,6 +212,7 @@ int dpf_cv_select_backward(const float* x3, const float* s, const float* dvol, f
 // shifts: L host ints (int(costrange[l]) truncated toward zero by the caller); groups = 0 -> 'psmnet', > 0 -> 'gwcnet'
 int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const int* shifts_host, int B, int C, int h, int w, int L,
                            int groups, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!ref || !tar || !vol || !shifts_host || B <= 0 || C <= 0 || L <= 0 || L > 16 || groups < 0 || (groups > 0 && C % groups)) return DPF_ERR_INVALID_ARG;
   PsmP p;
   p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.G = groups;

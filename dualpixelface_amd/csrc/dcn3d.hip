@@ -351,6 +351,7 @@ long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
 int dpf_deform_conv3d_forward(const float* input, const float* weight, const float* bias, const float* offset, float* output, float* ws,
                               int B, int C, int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
                               int pw, int dd, int dh, int dw, int group, int deformable_group, int im2col_step, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   (void)im2col_step;
   if (!input || !weight || !offset || !output || !ws) return DPF_ERR_INVALID_ARG;
   if (group != 1 || deformable_group != 1) return DPF_ERR_UNSUPPORTED;
@@ -378,6 +379,7 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
                                float* grad_input, float* grad_offset, float* grad_weight, float* grad_bias, float* ws, int B, int C,
                                int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd,
                                int dh, int dw, int group, int deformable_group, int im2col_step, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   (void)im2col_step; (void)bias;
   if (!input || !weight || !offset || !grad_output || !grad_input || !grad_offset || !grad_weight || !ws) return DPF_ERR_INVALID_ARG;
   if (group != 1 || deformable_group != 1) return DPF_ERR_UNSUPPORTED;

@@ -13,6 +13,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+static inline void dpf_clear_error() { (void)hipGetLastError(); }
+
 static inline int dpf_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DPF_OK : DPF_ERR_LAUNCH;

@@ -172,6 +172,7 @@ extern "C" {
 int dpf_loss_forward(const float* pred_depth, const float* pred_normal, const float* disp, const float* normal, const float* mask,
                      float* acc_ws, float* out, int B, int n, int H, int W, const float* head_weights_host, float lambda_depth,
                      float lambda_normal, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if ((n > 0 && !pred_depth) || (n > 0 && !disp) || !mask || !acc_ws || !out || !head_weights_host || n < 0 || n > MAXHEADS || (pred_normal && !normal)) return DPF_ERR_INVALID_ARG;
   LossP p;
   fill(p, B, n, H, W, head_weights_host, lambda_depth, lambda_normal);
@@ -186,6 +187,7 @@ int dpf_loss_forward(const float* pred_depth, const float* pred_normal, const fl
 int dpf_loss_backward(const float* pred_depth, const float* pred_normal, const float* disp, const float* normal, const float* mask,
                       const float* acc_ws, const float* gout, float* d_pred_depth, float* d_pred_normal, int B, int n, int H, int W,
                       const float* head_weights_host, float lambda_depth, float lambda_normal, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if ((n > 0 && (!pred_depth || !disp || !d_pred_depth)) || !mask || !acc_ws || !gout || n < 0 || n > MAXHEADS) return DPF_ERR_INVALID_ARG;
   LossP p;
   fill(p, B, n, H, W, head_weights_host, lambda_depth, lambda_normal);
@@ -197,6 +199,7 @@ int dpf_loss_backward(const float* pred_depth, const float* pred_normal, const f
 // One fused Adam step over a flat arena of n floats; grad is pre-scaled by gscale (1/world_size after an all-reduce SUM).
 int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, double lr, double beta1,
                   double beta2, double eps, float gscale, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return DPF_ERR_INVALID_ARG;
   const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, gscale,

@@ -234,6 +234,7 @@ extern "C" {
 // statistics in place when running_mean != NULL (momentum, unbiased variance -- nn.BatchNorm semantics).
 int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float momentum, float* running_mean, float* running_var,
                  float* mean, float* invstd, float* ws, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !mean || !invstd || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
@@ -244,6 +245,7 @@ int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float mom
 }
 
 int dpf_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!running_mean || !running_var || !mean || !invstd || C <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, (hipStream_t)stream, running_mean, running_var, C, eps,
                      mean, invstd);
@@ -255,6 +257,7 @@ int dpf_bn_eval_stats(const float* running_mean, const float* running_var, int C
 int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd, const float* w, const float* b, int wmod,
                          const float* res, const float* res2, int act, const float* slope, float slope_const, float* y, int N, int C,
                          long long S, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !y || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   if (wmod <= 0) wmod = C;
   hipLaunchKernelGGL(bn_apply_kernel, row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, w, b, wmod, res, res2, act,
@@ -267,6 +270,7 @@ int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd,
 int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
                           int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
                           float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !dy || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   if (wmod <= 0) wmod = C;
   hipStream_t st = (hipStream_t)stream;
@@ -289,6 +293,7 @@ int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, co
 
 // out[C] += sum over n, s of g[N,C,S]
 int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !out || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(channel_sum_kernel, row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, g, out, C, S);
   return dpf_check_launch();

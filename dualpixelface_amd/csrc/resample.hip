@@ -126,12 +126,14 @@ __global__ void nearest_bwd_kernel(const float* __restrict__ g, float* __restric
 extern "C" {
 
 int dpf_upsample_bilinear2d_forward(const float* x, float* y, long long NC, int h, int w, int H, int W, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !y || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(dpf_ew_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC, h, w, H, W);
   return dpf_check_launch();
 }
 
 int dpf_upsample_bilinear2d_backward(const float* g, float* dx, long long NC, int h, int w, int H, int W, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !dx || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(dpf_ew_grid(NC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dx, NC, h, w, H, W);
   return dpf_check_launch();
@@ -139,6 +141,7 @@ int dpf_upsample_bilinear2d_backward(const float* g, float* dx, long long NC, in
 
 // y[NC,H,W] = lat[NC,H,W] + nearest_upsample(top[NC,h,w])
 int dpf_upsample_nearest_add_forward(const float* lat, const float* top, float* y, long long NC, int h, int w, int H, int W, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!lat || !top || !y || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(nearest_add_fwd_kernel, dim3(dpf_ew_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, lat, top, y, NC, h, w, H, W);
   return dpf_check_launch();
@@ -146,6 +149,7 @@ int dpf_upsample_nearest_add_forward(const float* lat, const float* top, float* 
 
 // dtop[NC,h,w] = adjoint of the nearest upsample applied to g[NC,H,W]  (d lat = g itself)
 int dpf_upsample_nearest_backward(const float* g, float* dtop, long long NC, int h, int w, int H, int W, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !dtop || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(nearest_bwd_kernel, dim3(dpf_ew_grid(NC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dtop, NC, h, w, H, W);
   return dpf_check_launch();

@@ -188,6 +188,7 @@ extern "C" {
 // logits [B,D,h,w] -> pred [B,H,W], prob [B,L,H,W] (NULL to skip).  disp: L host floats (hypothesis values).
 int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
                            int H, int W, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!logits || !pred || !disp_host || B <= 0 || D <= 0 || D > MAXD || L <= 0 || L > MAXL) return DPF_ERR_INVALID_ARG;
   HeadP p;
   p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W;
@@ -199,6 +200,7 @@ int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const 
 // d logits [B,D,h,w] (zeroed here) from d pred [B,H,W]
 int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
                             int L, int H, int W, void* stream) {
+  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!logits || !gpred || !dlogits || !disp_host || B <= 0 || D <= 0 || D > MAXD || L <= 0 || L > MAXL) return DPF_ERR_INVALID_ARG;
   HeadP p;
   p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W;

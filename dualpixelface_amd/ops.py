@@ -15,6 +15,28 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 _scratch = {}
 
+# Optional live kernel timing (bench.py): a list that receives (family, algorithmic_flops, start_event, end_event) for
+# every dense-convolution launch; events are recorded on the stream the kernels are launched on.
+PROFILE = None
+
+
+class _Timed(object):
+    def __init__(self, family, flops):
+        self.family, self.flops = family, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.family, self.flops, self.e0, self.e1))
+        return False
+
 
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -76,8 +98,9 @@ def _conv_fwd_raw(x, w, bias, stride, pad, dil):
     out = torch.empty((N, K, od, oh, ow), dtype=torch.float32, device=x.device)
     L = lib()
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
-    L.call('dpf_conv_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, kd, kh, kw,
-           *stride, *pad, *dil, _stream())
+    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * od * oh * ow):
+        L.call('dpf_conv_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, kd, kh, kw,
+               *stride, *pad, *dil, _stream())
     return out
 
 
@@ -89,8 +112,9 @@ def _conv_transpose_raw(x, w, bias, out_dims, ksize, stride, pad, dil):
     out = torch.empty((N, K) + tuple(out_dims), dtype=torch.float32, device=x.device)
     L = lib()
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
-    L.call('dpf_conv_transpose', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, *out_dims, kd, kh, kw,
-           *stride, *pad, *dil, _stream())
+    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW):
+        L.call('dpf_conv_transpose', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, *out_dims, kd, kh, kw,
+               *stride, *pad, *dil, _stream())
     return out
 
 
@@ -100,7 +124,8 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
     K, QD, QH, QW = g.shape[1], g.shape[2], g.shape[3], g.shape[4]
     kd, kh, kw = wshape[2:]
     dw = torch.zeros(wshape, dtype=torch.float32, device=x.device)
-    lib().call('dpf_conv_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, QD, QH, QW, kd, kh, kw, *stride, *pad, *dil, _stream())
+    with _Timed('conv_wgrad', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW):
+        lib().call('dpf_conv_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, QD, QH, QW, kd, kh, kw, *stride, *pad, *dil, _stream())
     return dw
 
 

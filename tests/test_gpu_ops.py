@@ -49,6 +49,8 @@ CONV_CASES = [
     (2, 128, 1, 6, 9, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
     (2, 32, 1, 16, 24, 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),
     (4, 32, 1, 8, 12, 3, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    (1, 192, 1, 6, 9, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),      # data gradient has 192 channels (> one launch)
+    (1, 40, 2, 5, 7, 160, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
 ]
 
 
