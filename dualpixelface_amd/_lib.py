@@ -8,6 +8,10 @@ import ctypes
 import os
 import re
 
+# Load order matters: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7; importing torch first makes the dynamic
+# loader bind libdpf_hip.so to that same HIP runtime (two runtimes in one process cannot share streams or pointers).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdpf_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dpf_hip.h')

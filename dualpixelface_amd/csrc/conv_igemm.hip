@@ -251,6 +251,7 @@ struct WgP {
   int QD, QH, QW;   // g ("small grid") dims
   int kd, kh, kw, T;
   int sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int Ktot, k0;     // g has Ktot channels; this launch covers [k0, k0 + K)
   int CCW;          // channels per block
   int nchunk;       // position chunks
   int tilesH, tilesW;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
       }
     }
     // stage g tile: [k][row*32+col]
-    const float* gn = g + (long long)n * p.K * g_chan + (long long)qd * p.QH * p.QW;
+    const float* gn = g + ((long long)n * p.Ktot + p.k0) * g_chan + (long long)qd * p.QH * p.QW;
     for (int rowid = wave; rowid < KT * WTH; rowid += 4) {
       const int k = rowid / WTH;
       const int r = rowid - k * WTH;
@@ -527,8 +528,12 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   p.kd = kd; p.kh = kh; p.kw = kw; p.T = kd * kh * kw;
   p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw_;
   if (p.T > MAXT) return DPF_ERR_UNSUPPORTED;
-  const int MT = (K + 31) / 32;
-  if (MT > 4) return DPF_ERR_UNSUPPORTED;
+  p.Ktot = K;
+  for (int k0 = 0; k0 < K; k0 += 128) {   // one launch covers up to 128 g-channels (4 MFMA row tiles)
+  p.k0 = k0;
+  p.K = K - k0 < 128 ? K - k0 : 128;
+  float* dwk = dw + (long long)k0 * C * p.T;
+  const int MT = (p.K + 31) / 32;
   const int KT = 32 * MT;
   int CCW = (4 * WNT * 32) / p.T;
   if (CCW > C) CCW = C;
@@ -556,10 +561,11 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
     if (lds > 48 * 1024 &&                                                                                                  \
         hipFuncSetAttribute((const void*)conv_wgrad_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return DPF_ERR_LAUNCH;                                                                                                \
-    hipLaunchKernelGGL((conv_wgrad_kernel<M>), grid, dim3(256), lds, st, g, x, dw, p);                                      \
+    hipLaunchKernelGGL((conv_wgrad_kernel<M>), grid, dim3(256), lds, st, g, x, dwk, p);                                      \
   }
   switch (MT) { case 1: DPF_WG(1); break; case 2: DPF_WG(2); break; case 3: DPF_WG(3); break; default: DPF_WG(4); break; }
 #undef DPF_WG
+  }
   return dpf_check_launch();
 }
 
