@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------ backward: input + offset
 // MTC = ceil(CP/32) row tiles of gcol[c][p] = sum_k W[k][c][t] * go[k][p]
-template <int MTC>
+template <int MTC, bool DO_DX>
 __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                            const float* __restrict__ wt2 /*[T][K][CT]*/, const float* __restrict__ go,
                                                            float* __restrict__ dx, float* __restrict__ doff, DcnP p) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
         for (int j = 0; j < 8; ++j) {
           if (idx[j] < 0) continue;
           const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
-          atomicAdd(&dxc[idx[j]], wg[j] * gcv);                                  // cuh:313-331
+          if (DO_DX) atomicAdd(&dxc[idx[j]], wg[j] * gcv);                       // cuh:313-331 (fallback path)
           const float v = xc[idx[j]] * gcv;
           const float fd = jd ? cn.ld : 1.f - cn.ld, fh = jh ? cn.lh : 1.f - cn.lh, fw = jw ? cn.lw : 1.f - cn.lw;
           gd += (jd ? 1.f : -1.f) * fh * fw * v;                                  // cuh:131-187
@@ -236,6 +236,155 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
       if (pos < p.P) {
         const float* r = s_red + dir * 4 * TP + p2;
         doff_b[(long long)(3 * t + dir) * p.P + pos] = (r[0] + r[TP]) + (r[2 * TP] + r[3 * TP]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward: input, LDS-privatised
+// grad_input[b,c,v] = sum_{p,t,corner: voxel(p,t,corner)=v} w * gcol[c,t,p],  gcol = W^T . grad_out.
+// The reference scatters every contribution with a global atomicAdd (deform_im2col_cuda.cuh:313-331): 27*8*C atomics per
+// output voxel, which on MI355X execute at the memory side.  Here a workgroup owns TZ x 2 x 32 output voxels, keeps the
+// haloed input region [RZ][RY][RX] x 16 channels in LDS, computes gcol with v_mfma_f32_16x16x4_f32 so that a lane owns one
+// channel of 4 voxels (D row = voxel, col = channel), adds the 8 corner contributions with conflict-free LDS atomics
+// (16 consecutive channels per voxel) and flushes the region once with row-contiguous global atomics.  Samples that leave
+// the region (|offset| >~ 2) fall back to a direct global atomic.
+constexpr int GI_TY = 2, GI_TX = 32, GI_R = 2, GI_CH = 16, GI_CS = 17;   // halo R on top of the kernel extent; padded channel stride
+
+struct GiP {
+  int TZ, RZmax, RY, RX;     // tile depth, region dims
+  int tilesZ, tilesY, tilesX;
+};
+
+template <int NST>   // position sub-tiles of 16 per wave (positions per block = 64 * NST)
+__global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][K][CT]*/,
+                                                            const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT) {
+  extern __shared__ __align__(16) float smem[];
+  const int npos = 64 * NST;
+  float* s_reg = smem;                                         // [RZ*RY*RX][GI_CS]
+  const int regvox = q.RZmax * q.RY * q.RX;
+  int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + 3) & ~3));   // [npos][8] local voxel index or -1 (16-B aligned)
+  int* s_vox = s_lidx + npos * 8;                              // [npos][8] global voxel index or -1
+  float* s_w = (float*)(s_vox + npos * 8);                     // [npos][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+
+  int bb = blockIdx.x;
+  const int tx = bb % q.tilesX; bb /= q.tilesX;
+  const int ty = bb % q.tilesY; bb /= q.tilesY;
+  const int tz = bb % q.tilesZ;
+  const int b = bb / q.tilesZ;
+  const int z0 = tz * q.TZ, y0 = ty * GI_TY, x0 = tx * GI_TX;
+  // region origin (input coordinates) and clipped depth range
+  const int rz0u = z0 * p.sd - p.pd - GI_R, ry0 = y0 * p.sh - p.ph - GI_R, rx0 = x0 * p.sw - p.pw - GI_R;
+  const int rz0 = rz0u < 0 ? 0 : rz0u;
+  int rz1 = rz0u + (q.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * GI_R;
+  if (rz1 > p.D) rz1 = p.D;
+  int RZ = rz1 - rz0;
+  if (RZ > q.RZmax) RZ = q.RZmax;
+
+  const long long chan = (long long)p.D * p.H * p.W;
+  const float* off_b = offset + (long long)b * 3 * p.T * p.P;
+  float* dxb = dx + (long long)b * p.C * chan;
+
+  // this thread's output voxel (corner tables): tid < npos
+  const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
+  const int zo = z0 + pdz, yo = y0 + pdy, xo = x0 + pdx;
+  const bool pvalid = tid < npos && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;   // p.P => make_corner returns invalid
+
+  // A fragments: go[k][voxel] for this wave's NST sub-tiles, all k (K <= 64 -> 16 k-steps of 4), kept in registers
+  float afrag[NST][16];
+#pragma unroll
+  for (int st = 0; st < NST; ++st) {
+    const int pl = (wave * NST + st) * 16 + l15;               // voxel index within the tile
+    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+    const int gz = z0 + az, gy = y0 + ay, gx = x0 + ax;
+    const bool ok = az < q.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
+    const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = 4 * ks + lg;
+      afrag[st][ks] = (ok && k < p.K) ? go[((long long)b * p.K + k) * p.P + gpos] : 0.f;
+    }
+  }
+
+  for (int c0 = 0; c0 < p.C; c0 += GI_CH) {
+    __syncthreads();                                            // previous chunk flushed
+    for (int i = tid; i < regvox * GI_CS; i += 256) s_reg[i] = 0.f;
+    const int cc = c0 + l15;
+    const bool cok = cc < p.C;
+    for (int t = 0; t < p.T; ++t) {
+      __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
+      if (tid < npos) {
+        const Corner cn = make_corner(p, off_b, t, ppos);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float wg;
+          const long long v = corner_index(p, cn, j, wg);
+          int li = -1;
+          if (v >= 0) {
+            const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
+            const int lz = cn.d0 + jd - rz0, ly = cn.h0 + jh - ry0, lx = cn.w0 + jw - rx0;
+            if (lz >= 0 && lz < RZ && ly >= 0 && ly < q.RY && lx >= 0 && lx < q.RX) li = (lz * q.RY + ly) * q.RX + lx;
+          }
+          s_lidx[tid * 8 + j] = li;
+          s_vox[tid * 8 + j] = (int)v;
+          s_w[tid * 8 + j] = wg;
+        }
+      }
+      // B fragments: W[k][c0 + l15][t] for the 16 k-steps
+      float bfrag[16];
+      const float* wtt = wt2 + (long long)t * p.K * CT + c0 + l15;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int k = 4 * ks + lg;
+        bfrag[ks] = (cok && k < p.K) ? wtt[(long long)k * CT] : 0.f;
+      }
+      __syncthreads();                                          // tables visible
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
+        if (cok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pl = (wave * NST + st) * 16 + 4 * lg + r;   // D row = voxel
+            const float g = acc[r];
+            const int4 la = *reinterpret_cast<const int4*>(&s_lidx[pl * 8]);
+            const int4 lb = *reinterpret_cast<const int4*>(&s_lidx[pl * 8 + 4]);
+            const float4 wa = *reinterpret_cast<const float4*>(&s_w[pl * 8]);
+            const float4 wb = *reinterpret_cast<const float4*>(&s_w[pl * 8 + 4]);
+            const int li[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+            const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (li[j] >= 0) {
+                atomicAdd(&s_reg[li[j] * GI_CS + l15], wv[j] * g);
+              } else {
+                const int v = s_vox[pl * 8 + j];
+                if (v >= 0) atomicAdd(&dxb[(long long)cc * chan + v], wv[j] * g);   // left the region: direct scatter
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // flush: lanes along x (row-contiguous global atomics); LDS stride GI_CS = 17 floats is conflict-free
+    const int rowlen = q.RX;
+    const int nrows = RZ * q.RY * GI_CH;
+    for (int row = wave; row < nrows; row += 4) {
+      const int c = row % GI_CH;
+      const int zy = row / GI_CH;
+      const int ly = zy % q.RY, lz = zy / q.RY;
+      const int gz = rz0 + lz, gy = ry0 + ly;
+      if (c0 + c >= p.C || gy < 0 || gy >= p.H) continue;
+      float* dst = dxb + (long long)(c0 + c) * chan + ((long long)gz * p.H + gy) * p.W;
+      for (int lx = lane; lx < rowlen; lx += 64) {
+        const int gx = rx0 + lx;
+        const float v = s_reg[((lz * q.RY + ly) * q.RX + lx) * GI_CS + c];
+        if (v != 0.f && gx >= 0 && gx < p.W) atomicAdd(&dst[gx], v);
       }
     }
   }
@@ -393,13 +542,46 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
   if (hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)K * C * p.T, st) != hipSuccess) return DPF_ERR_LAUNCH;
   // wt2[T][K][CT]: reduce = K (A), out = C (B)
   hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * K * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1);
+  // grad_input: LDS-privatised scatter when the haloed region fits, else the reference-style global atomics
+  bool dx_done = false;
+  if (K <= 64) {
+    GiP q{};
+    q.TZ = p.Do < 4 ? p.Do : 4;
+    int RZ = (q.TZ - 1) * sd + (kd - 1) * dd + 1 + 2 * GI_R;
+    if (RZ > D) RZ = D;
+    q.RZmax = RZ;
+    q.RY = (GI_TY - 1) * sh + (kh - 1) * dh + 1 + 2 * GI_R;
+    q.RX = (GI_TX - 1) * sw + (kw - 1) * dw + 1 + 2 * GI_R;
+    q.tilesZ = dpf_div_up(p.Do, q.TZ);
+    q.tilesY = dpf_div_up(p.Ho, GI_TY);
+    q.tilesX = dpf_div_up(p.Wo, GI_TX);
+    const int npos = 64 * q.TZ;
+    const size_t lds = sizeof(float) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + 3) & ~(size_t)3) + (size_t)npos * 24);
+    const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
+    if (lds <= 150 * 1024 && blocks < 0x7fffffffLL) {
+      const dim3 grid((unsigned)blocks);
+#define DPF_GI(NS)                                                                                                   \
+  {                                                                                                                  \
+    if (set_lds(dcn_bwd_input_kernel<NS>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                     \
+    hipLaunchKernelGGL((dcn_bwd_input_kernel<NS>), grid, dim3(256), lds, st, offset, ws, grad_output, grad_input, p, q, CT); \
+  }
+      switch (q.TZ) { case 1: DPF_GI(1); break; case 2: DPF_GI(2); break; case 3: DPF_GI(3); break; default: DPF_GI(4); break; }
+#undef DPF_GI
+      dx_done = true;
+    }
+  }
   {
     const size_t lds = sizeof(float) * ((size_t)K * SP + (size_t)CT * SP + 3 * 4 * TP);
     const dim3 grid((unsigned)(B * p.tiles_per_b));
 #define DPF_D(M)                                                                                                       \
   {                                                                                                                    \
-    if (set_lds(dcn_bwd_data_kernel<M>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                         \
-    hipLaunchKernelGGL((dcn_bwd_data_kernel<M>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_input, grad_offset, p); \
+    if (dx_done) {                                                                                                     \
+      if (set_lds(dcn_bwd_data_kernel<M, false>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                \
+      hipLaunchKernelGGL((dcn_bwd_data_kernel<M, false>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_input, grad_offset, p); \
+    } else {                                                                                                           \
+      if (set_lds(dcn_bwd_data_kernel<M, true>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                 \
+      hipLaunchKernelGGL((dcn_bwd_data_kernel<M, true>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_input, grad_offset, p); \
+    }                                                                                                                  \
   }
     switch (MTC) { case 1: DPF_D(1); break; case 2: DPF_D(2); break; case 3: DPF_D(3); break; default: DPF_D(4); break; }
 #undef DPF_D

@@ -110,4 +110,4 @@ def test_gradients_and_adam_step_vs_fp64_oracle(golden_dir):
     assert checked > 250 and not bad, bad[:10]
     # Adam: first step moves every parameter with a gradient by ~lr (bias-corrected m/sqrt(v) = sign(g))
     delta = (model.flat_parameters() - p_before).abs()
-    assert delta.max().item() <= 1.0001e-4 and delta.mean().item() > 5e-5
+    assert delta.max().item() <= 1.001e-4 and delta.mean().item() > 5e-5
