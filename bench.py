@@ -52,6 +52,7 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shapes', default=None, help='write a per-convolution-shape timing table to this file')
     args = ap.parse_args()
 
     from dualpixelface_amd import load_option, ops
@@ -97,11 +98,21 @@ def main():
         global_batch = args.batch * world
         value = global_batch * args.steps / elapsed
         fam = {}
-        for family, flops, e0, e1 in prof:
+        shapes = {}
+        for family, flops, e0, e1, tag in prof:
+            secs = e0.elapsed_time(e1) * 1e-3
             f = fam.setdefault(family, [0.0, 0.0, 0])
             f[0] += flops
-            f[1] += e0.elapsed_time(e1) * 1e-3
+            f[1] += secs
             f[2] += 1
+            g = shapes.setdefault(tag, [0.0, 0.0, 0])
+            g[0] += flops
+            g[1] += secs
+            g[2] += 1
+        if args.shapes:
+            with open(args.shapes, 'w') as fh:
+                for tag, (fl, se, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    fh.write('%-60s calls %4d  ms/step %8.3f  TFLOP/s %6.1f\n' % (tag, n, se / args.steps * 1e3, fl / se / 1e12))
         dom = max(fam, key=lambda k: fam[k][1]) if fam else None
         roof = None
         if dom:

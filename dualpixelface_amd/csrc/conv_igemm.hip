@@ -19,12 +19,11 @@
 // each a dense stride-1 gather over the valid tap subset (no zero-insertion, no wasted MACs).
 #include "dpf_common.h"
 #include "dpf_repack.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int TW = 32;       // positions along W per tile (= MFMA N)
-constexpr int NT = 2;        // rows per wave
-constexpr int TH = 4 * NT;   // rows per tile (4 waves)
 constexpr int MAXT = 27;
 
 struct ConvP {
@@ -72,11 +71,12 @@ __device__ __forceinline__ void dim_range(int k, int s, int p, int dil, int r, i
   }
 }
 
-template <int MT, int CC>
+template <int MT, int CC, int NT>   // NT rows of 32 positions per wave; tile = (4*NT) x 32 positions
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, float* __restrict__ out, ConvP p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32 * MT;
+  constexpr int TH = 4 * NT;
   // LDS carve: [input tile CC*chanStrideMax][weights ntmax*CC*KT][tapoff MAXT][tapw MAXT][nv]
   float* s_in = smem;
   float* s_w = s_in + CC * p.chanStrideMax;
@@ -198,21 +198,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
         for (int k = lane; k < KT; k += 64) dst[k] = (ic < p.C) ? src[k] : 0.f;
       }
       __syncthreads();
-      // ---- MFMA over (tap, channel pair)
-      for (int slot = 0; slot < nv; ++slot) {
-        const int toff = s_tapoff[slot];
-        const float* wrow = s_w + (slot * CC + hh) * KT + l31;
+      // ---- MFMA over (tap, channel pair); the operands of tap slot+1 are fetched from LDS while the MFMAs of
+      //      tap `slot` issue (software pipeline, two register sets)
+      float a_cur[CC / 2][MT], b_cur[CC / 2][NT], a_nxt[CC / 2][MT], b_nxt[CC / 2][NT];
+      {
+        const int toff = s_tapoff[0];
+        const float* wrow = s_w + hh * KT + l31;
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp) {
-          float a[MT], bv[NT];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) a[m] = wrow[(2 * cp) * KT + m * 32];
+          for (int m = 0; m < MT; ++m) a_cur[cp][m] = wrow[(2 * cp) * KT + m * 32];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) bv[t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
+          for (int t = 0; t < NT; ++t) b_cur[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
+        }
+      }
+      for (int slot = 0; slot < nv; ++slot) {
+        if (slot + 1 < nv) {
+          const int toff = s_tapoff[slot + 1];
+          const float* wrow = s_w + ((slot + 1) * CC + hh) * KT + l31;
+#pragma unroll
+          for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a_nxt[cp][m] = wrow[(2 * cp) * KT + m * 32];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b_nxt[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
+          }
+        }
+#pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp)
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[t], acc[m][t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cp][m], b_cur[cp][t], acc[m][t], 0, 0, 0);
+#pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a_cur[cp][m] = a_nxt[cp][m];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) b_cur[cp][t] = b_nxt[cp][t];
         }
       }
     }
@@ -387,15 +410,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 
 int out_dim(int I, int k, int s, int p, int d) { return (I + 2 * p - (d * (k - 1) + 1)) / s + 1; }
 
-template <int MT, int CC>
+template <int MT, int CC, int NT>
 int launch_igemm(const float* x, const float* wt, const float* bias, float* out, const ConvP& p, size_t lds, hipStream_t st) {
   const long long blocks = (long long)p.ncls * p.N * p.QD * p.tilesH * p.tilesW;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
   if (lds > 48 * 1024) {
-    if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MT, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MT, CC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return DPF_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<MT, CC>), dim3((unsigned)blocks), dim3(256), lds, st, x, wt, bias, out, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<MT, CC, NT>), dim3((unsigned)blocks), dim3(256), lds, st, x, wt, bias, out, p);
   return dpf_check_launch();
 }
 
@@ -426,6 +449,8 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   const int T = p.kd * p.kh * p.kw;
   const int MT = (p.K + 31) / 32;
   const int KT = 32 * MT;
+  const int NT = MT == 1 ? 4 : 2;   // narrow outputs: more position tiles per wave so each weight fragment feeds 4 MFMAs
+  const int TH = 4 * NT;
   // tile geometry (host worst case over classes)
   int ext_d, ext_h, ext_w, ntmax;
   if (!p.transposed) {
@@ -461,14 +486,15 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   p.ntmax = ntmax;
   auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + ntmax * CC * KT + 2 * MAXT + 4) * sizeof(float); };
   int CC = 8;
-  if (lds_bytes(8) > 64 * 1024 || p.C <= 4) CC = 4;
+  static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 64 * 1024;   // tuning knob
+  if (lds_bytes(8) > (size_t)lds_cap || p.C <= 4) CC = 4;
   const size_t lds = lds_bytes(CC);
   if (lds > 160 * 1024) return DPF_ERR_UNSUPPORTED;
-#define DPF_IG(M, Cc) return launch_igemm<M, Cc>(x, wt_ws, bias, out, p, lds, st)
+#define DPF_IG(M, Cc, Nt) return launch_igemm<M, Cc, Nt>(x, wt_ws, bias, out, p, lds, st)
   if (CC == 8) {
-    switch (MT) { case 1: DPF_IG(1, 8); case 2: DPF_IG(2, 8); case 3: DPF_IG(3, 8); default: DPF_IG(4, 8); }
+    switch (MT) { case 1: DPF_IG(1, 8, 4); case 2: DPF_IG(2, 8, 2); case 3: DPF_IG(3, 8, 2); default: DPF_IG(4, 8, 2); }
   } else {
-    switch (MT) { case 1: DPF_IG(1, 4); case 2: DPF_IG(2, 4); case 3: DPF_IG(3, 4); default: DPF_IG(4, 4); }
+    switch (MT) { case 1: DPF_IG(1, 4, 4); case 2: DPF_IG(2, 4, 2); case 3: DPF_IG(3, 4, 2); default: DPF_IG(4, 4, 2); }
   }
 #undef DPF_IG
 }

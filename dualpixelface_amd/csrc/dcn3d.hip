@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
 // channel of 4 voxels (D row = voxel, col = channel), adds the 8 corner contributions with conflict-free LDS atomics
 // (16 consecutive channels per voxel) and flushes the region once with row-contiguous global atomics.  Samples that leave
 // the region (|offset| >~ 2) fall back to a direct global atomic.
-constexpr int GI_TY = 2, GI_TX = 32, GI_R = 2, GI_CH = 16, GI_CS = 17;   // halo R on top of the kernel extent; padded channel stride
+constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 16, GI_CS = 17;   // halo R on top of the kernel extent; padded channel stride
 
 struct GiP {
   int TZ, RZmax, RY, RX;     // tile depth, region dims

@@ -21,8 +21,8 @@ PROFILE = None
 
 
 class _Timed(object):
-    def __init__(self, family, flops):
-        self.family, self.flops = family, flops
+    def __init__(self, family, flops, tag=''):
+        self.family, self.flops, self.tag = family, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -34,7 +34,7 @@ class _Timed(object):
     def __exit__(self, *a):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.family, self.flops, self.e0, self.e1))
+            PROFILE.append((self.family, self.flops, self.e0, self.e1, self.tag))
         return False
 
 
@@ -97,8 +97,14 @@ def _conv_fwd_raw(x, w, bias, stride, pad, dil):
     ow = _out_dim(IW, kw, stride[2], pad[2], dil[2])
     out = torch.empty((N, K, od, oh, ow), dtype=torch.float32, device=x.device)
     L = lib()
+    if K <= 4 and K * C * kd * kh * kw * 4 <= 64 * 1024:
+        with _Timed('conv_smallk', 2.0 * N * K * C * kd * kh * kw * od * oh * ow, 'skf N%d C%d K%d in%dx%dx%d' % (N, C, K, ID, IH, IW)):
+            L.call('dpf_conv_smallk_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), N, C, ID, IH, IW, K, kd, kh, kw, *stride, *pad, *dil,
+                   _stream())
+        return out
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
-    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * od * oh * ow):
+    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * od * oh * ow,
+                'fwd N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2])):
         L.call('dpf_conv_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, kd, kh, kw,
                *stride, *pad, *dil, _stream())
     return out
@@ -112,7 +118,8 @@ def _conv_transpose_raw(x, w, bias, out_dims, ksize, stride, pad, dil):
     out = torch.empty((N, K) + tuple(out_dims), dtype=torch.float32, device=x.device)
     L = lib()
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
-    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW):
+    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW,
+                'tr  N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2])):
         L.call('dpf_conv_transpose', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, *out_dims, kd, kh, kw,
                *stride, *pad, *dil, _stream())
     return out
@@ -124,7 +131,12 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
     K, QD, QH, QW = g.shape[1], g.shape[2], g.shape[3], g.shape[4]
     kd, kh, kw = wshape[2:]
     dw = torch.zeros(wshape, dtype=torch.float32, device=x.device)
-    with _Timed('conv_wgrad', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW):
+    if K <= 4 and 16 * kd * kh * kw <= 512:
+        with _Timed('conv_smallk', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW, 'skw N%d C%d K%d x%dx%dx%d' % (N, C, K, ID, IH, IW)):
+            lib().call('dpf_conv_smallk_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, kd, kh, kw, *stride, *pad, *dil, _stream())
+        return dw
+    with _Timed('conv_wgrad', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW,
+                'wg  N%d C%d K%d x%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2])):
         lib().call('dpf_conv_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, QD, QH, QW, kd, kh, kw, *stride, *pad, *dil, _stream())
     return dw
 

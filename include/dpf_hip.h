@@ -44,6 +44,13 @@ int dpf_conv_transpose(const float* x, const float* w, const float* bias, float*
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
 
+/* narrow outputs (K <= 4): the 32 -> 1 cost heads (modules.py:286-296) and the 32 -> 3 normal conv (normal_module.py:65);
+ * same conventions as dpf_conv_forward / dpf_conv_wgrad, direct (non-MFMA) HBM-bound kernels */
+int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, float* out, int N, int C, int ID, int IH, int IW, int K, int kd,
+                            int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw, void* stream);
+int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int sd,
+                          int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
+
 /* ---- depthwise 3x3: depthwise_separable_conv.depthwise (src/module/asm/basics.py:39-58) --------------------------- */
 int dpf_depthwise_conv2d_forward(const float* x, const float* w, float* y, int N, int C, int H, int W, int k, int pad, void* stream);
 int dpf_depthwise_conv2d_backward_data(const float* g, const float* w, float* dx, int N, int C, int H, int W, int k, int pad, void* stream);
