@@ -165,37 +165,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 
     const int in_rows = CC * ext_d * ext_h;
     const int rows_per_chan = ext_d * ext_h;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform row bookkeeping on the scalar unit
     const long long x_chan = (long long)p.ID * p.IH * p.IW;
     const float* xn = x + (long long)n * p.C * x_chan;
 
     for (int c0 = 0; c0 < p.C; c0 += CC) {
       __syncthreads();   // previous chunk fully consumed (also orders the tap table on the first trip)
-      // ---- stage the input patch: one LDS row per (channel, plane, row), lanes along W
-      for (int rowid = wave; rowid < in_rows; rowid += 4) {
-        const int cc = rowid / rows_per_chan;
-        const int rem = rowid - cc * rows_per_chan;
-        const int pl = rem / ext_h;
-        const int rr = rem - pl * ext_h;
-        const int ic = c0 + cc, id = i0d + pl, ih = i0h + rr;
-        const bool rowok = (ic < p.C) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
-        const float* src = xn + (long long)ic * x_chan + ((long long)id * p.IH + ih) * p.IW;
-        float* dst = s_in + cc * chanStride + rem * ext_w;
-        for (int col = lane; col < ext_w; col += 64) {
-          const int iw = i0w + col;
-          float v = 0.f;
-          if (rowok && iw >= 0 && iw < p.IW) v = src[iw];
-          dst[col] = v;
+      // ---- stage the input patch: one LDS row per (channel, plane, row), lanes along W.  SU rows are fetched
+      //      back-to-back before any is written so each wave keeps SU (x2) global loads in flight.
+      constexpr int SU = 8;
+      for (int r0 = wave_u * SU; r0 < in_rows; r0 += 4 * SU) {
+        float v0[SU], v1[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int rowid = r0 + u;
+          const int cc = rowid / rows_per_chan;
+          const int rem = rowid - cc * rows_per_chan;
+          const int pl = rem / ext_h;
+          const int rr = rem - pl * ext_h;
+          const int ic = c0 + cc, id = i0d + pl, ih = i0h + rr;
+          const bool rowok = (rowid < in_rows) && (ic < p.C) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
+          const float* src = xn + (long long)ic * x_chan + ((long long)id * p.IH + ih) * p.IW;
+          const int iw0 = i0w + lane, iw1 = iw0 + 64;
+          v0[u] = (rowok && lane < ext_w && iw0 >= 0 && iw0 < p.IW) ? src[iw0] : 0.f;
+          v1[u] = (rowok && lane + 64 < ext_w && iw1 >= 0 && iw1 < p.IW) ? src[iw1] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int rowid = r0 + u;
+          if (rowid < in_rows) {
+            float* dst = s_in + rowid * ext_w;   // rows are contiguous: cc*chanStride + rem*ext_w == rowid*ext_w
+            if (lane < ext_w) dst[lane] = v0[u];
+            if (lane + 64 < ext_w) dst[lane + 64] = v1[u];
+          }
         }
       }
       // ---- stage the weight slab of this channel chunk: [slot][cc][KT]
       const int nv = nvalid;
-      for (int rowid = wave; rowid < nv * CC; rowid += 4) {
-        const int slot = rowid / CC;
-        const int cc = rowid - slot * CC;
-        const int ic = c0 + cc;
-        const float* src = wt + ((long long)s_tapw[slot] * p.C + ic) * KT;
-        float* dst = s_w + rowid * KT;
-        for (int k = lane; k < KT; k += 64) dst[k] = (ic < p.C) ? src[k] : 0.f;
+      for (int r0 = wave_u * SU; r0 < nv * CC; r0 += 4 * SU) {
+        float w0[SU], w1[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int rowid = r0 + u;
+          const int slot = rowid / CC;
+          const int cc = rowid - slot * CC;
+          const int ic = c0 + cc;
+          const bool ok = rowid < nv * CC && ic < p.C;
+          const float* src = wt + ((long long)s_tapw[ok ? slot : 0] * p.C + (ok ? ic : 0)) * KT;
+          w0[u] = (ok && lane < KT) ? src[lane] : 0.f;
+          w1[u] = (ok && lane + 64 < KT) ? src[lane + 64] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int rowid = r0 + u;
+          if (rowid < nv * CC) {
+            float* dst = s_w + rowid * KT;
+            if (lane < KT) dst[lane] = w0[u];
+            if (KT > 64 && lane + 64 < KT) dst[lane + 64] = w1[u];
+          }
+        }
       }
       __syncthreads();
       // ---- MFMA over (tap, channel pair); the operands of tap slot+1 are fetched from LDS while the MFMAs of
@@ -300,6 +328,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   constexpr int GS = WPT + 1;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int cchunk = blockIdx.x / p.nchunk;
   const int pchunk = blockIdx.x % p.nchunk;
   const int c0 = cchunk * p.CCW;
@@ -343,35 +372,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     const int q0h = th * WTH, q0w = tw * TW;
     const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, i0w = q0w * p.sw - p.pw;
     __syncthreads();
-    // stage x patch
+    // stage x patch (SU rows fetched back-to-back, then written)
+    constexpr int SU = 8;
     const float* xn = x + ((long long)n * p.C + c0) * x_chan;
-    for (int rowid = wave; rowid < ncc * rows_per_chan; rowid += 4) {
-      const int cc = rowid / rows_per_chan;
-      const int rem = rowid - cc * rows_per_chan;
-      const int pl = rem / ext_h;
-      const int rr = rem - pl * ext_h;
-      const int id = i0d + pl, ih = i0h + rr;
-      const bool rowok = (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
-      const float* src = xn + (long long)cc * x_chan + ((long long)id * p.IH + ih) * p.IW;
-      float* dst = s_x + cc * chanStride + rem * ext_w;
-      for (int col = lane; col < ext_w; col += 64) {
-        const int iw = i0w + col;
-        float v = 0.f;
-        if (rowok && iw >= 0 && iw < p.IW) v = src[iw];
-        dst[col] = v;
+    const int xrows = ncc * rows_per_chan;
+    for (int r0 = wave_u * SU; r0 < xrows; r0 += 4 * SU) {
+      float v0[SU], v1[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int rowid = r0 + u;
+        const int cc = rowid / rows_per_chan;
+        const int rem = rowid - cc * rows_per_chan;
+        const int pl = rem / ext_h;
+        const int rr = rem - pl * ext_h;
+        const int id = i0d + pl, ih = i0h + rr;
+        const bool rowok = (rowid < xrows) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
+        const float* src = xn + (long long)cc * x_chan + ((long long)id * p.IH + ih) * p.IW;
+        const int iw0 = i0w + lane, iw1 = iw0 + 64;
+        v0[u] = (rowok && lane < ext_w && iw0 >= 0 && iw0 < p.IW) ? src[iw0] : 0.f;
+        v1[u] = (rowok && lane + 64 < ext_w && iw1 >= 0 && iw1 < p.IW) ? src[iw1] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int rowid = r0 + u;
+        if (rowid < xrows) {
+          float* dst = s_x + rowid * ext_w;
+          if (lane < ext_w) dst[lane] = v0[u];
+          if (lane + 64 < ext_w) dst[lane + 64] = v1[u];
+        }
       }
     }
-    // stage g tile: [k][row*32+col]
+    // stage g tile: [k][row*32+col]; two (k, row) pairs per wave instruction (one per half)
     const float* gn = g + ((long long)n * p.Ktot + p.k0) * g_chan + (long long)qd * p.QH * p.QW;
-    for (int rowid = wave; rowid < KT * WTH; rowid += 4) {
-      const int k = rowid / WTH;
-      const int r = rowid - k * WTH;
-      const int qh = q0h + r;
-      if (lane < 32) {
-        const int qw = q0w + lane;
-        float v = 0.f;
-        if (k < p.K && qh < p.QH && qw < p.QW) v = gn[(long long)k * g_chan + (long long)qh * p.QW + qw];
-        s_g[k * GS + r * 32 + lane] = v;
+    for (int r0 = wave_u * SU; r0 < KT * WTH / 2; r0 += 4 * SU) {
+      float gv[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int rowid = 2 * (r0 + u) + hh;
+        const int k = rowid / WTH;
+        const int r = rowid - k * WTH;
+        const int qh = q0h + r, qw = q0w + l31;
+        gv[u] = (rowid < KT * WTH && k < p.K && qh < p.QH && qw < p.QW) ? gn[(long long)k * g_chan + (long long)qh * p.QW + qw] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int rowid = 2 * (r0 + u) + hh;
+        if (rowid < KT * WTH) {
+          const int k = rowid / WTH;
+          const int r = rowid - k * WTH;
+          s_g[k * GS + r * 32 + l31] = gv[u];
+        }
       }
     }
     __syncthreads();
@@ -482,6 +532,7 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
     };
     ntmax = nvmax(p.kd, p.sd, p.dd) * nvmax(p.kh, p.sh, p.dh) * nvmax(p.kw, p.sw, p.dw);
   }
+  if (ext_w > 128) return DPF_ERR_UNSUPPORTED;   // staging handles two 64-lane column groups
   p.chanStrideMax = ext_d * ext_h * ext_w;
   p.ntmax = ntmax;
   auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + ntmax * CC * KT + 2 * MAXT + 4) * sizeof(float); };
@@ -567,6 +618,7 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   const int ext_d = (kd - 1) * dd + 1;
   const int ext_h = (WTH - 1) * sh + (kh - 1) * dh + 1;
   const int ext_w = (TW - 1) * sw + (kw - 1) * dw_ + 1;
+  if (ext_w > 128) return DPF_ERR_UNSUPPORTED;
   auto lds_bytes = [&](int ccw) { return (size_t)(ccw * ext_d * ext_h * ext_w + KT * (WPT + 1)) * sizeof(float); };
   while (CCW > 1 && lds_bytes(CCW) > 96 * 1024) --CCW;
   if (lds_bytes(CCW) > 160 * 1024) return DPF_ERR_UNSUPPORTED;
