@@ -9,6 +9,7 @@
 // matrix cores against the [K x C] weight slice of that tap, so columns never reach HBM.
 #include "dpf_common.h"
 #include "dpf_repack.h"
+#include <cstdlib>
 
 namespace {
 
@@ -458,6 +459,331 @@ __global__ __launch_bounds__(256) void dcn_wgrad_kernel(const float* __restrict_
   }
 }
 
+// ==========================================================================================================
+// Region-staged kernels.  A workgroup owns TZ x 2 x 32 output voxels (TZ = min(Do, 4)); the haloed input region
+// [RZ][RY][RX] (halo RG_R on top of the kernel extent) of a 16-channel chunk is staged in LDS once and all 27 taps sample it
+// with ds_reads (8 per sample) instead of 8 scattered global loads; samples whose 2x2x2 corner block leaves the staged box
+// take a global-memory slow path.  Channel-first LDS image [16][RV]: lanes are consecutive voxels, so the reads of a
+// wave land on consecutive banks whenever the offsets are smooth.
+constexpr int RG_R = 3, RG_CH = 16, RG_TY = 2, RG_TX = 32;
+
+struct RegGeo {
+  int TZ, RZmax, RY, RX, RV;
+  int tilesZ, tilesY, tilesX;
+};
+
+struct RegCtx {
+  int b, z0, y0, x0;       // tile origin (output coordinates)
+  int rz0, ry0, rx0, RZ;   // region origin (input coordinates) and clipped depth
+};
+
+__device__ __forceinline__ RegCtx region_ctx(const DcnP& p, const RegGeo& g, int blk) {
+  RegCtx c;
+  const int tx = blk % g.tilesX; blk /= g.tilesX;
+  const int ty = blk % g.tilesY; blk /= g.tilesY;
+  const int tz = blk % g.tilesZ;
+  c.b = blk / g.tilesZ;
+  c.z0 = tz * g.TZ; c.y0 = ty * RG_TY; c.x0 = tx * RG_TX;
+  const int rz0u = c.z0 * p.sd - p.pd - RG_R;
+  c.rz0 = rz0u < 0 ? 0 : rz0u;
+  int rz1 = rz0u + (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * RG_R;
+  if (rz1 > p.D) rz1 = p.D;
+  c.RZ = rz1 - c.rz0;
+  if (c.RZ > g.RZmax) c.RZ = g.RZmax;
+  c.ry0 = c.y0 * p.sh - p.ph - RG_R;
+  c.rx0 = c.x0 * p.sw - p.pw - RG_R;
+  return c;
+}
+
+// stage x[b, c0 .. c0+nch) over the region into s_reg[ch][RV] (zeros outside the volume / beyond C)
+__device__ __forceinline__ void stage_region(const DcnP& p, const RegGeo& g, const RegCtx& c, const float* __restrict__ xb, int c0, float* s_reg,
+                                             int wave_u, int lane) {
+  const long long chan = (long long)p.D * p.H * p.W;
+  const int rows_per_ch = c.RZ * g.RY;
+  const int nrows = RG_CH * rows_per_ch;
+  constexpr int SU = 8;
+  for (int r0 = wave_u * SU; r0 < nrows; r0 += 4 * SU) {
+    float v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int row = r0 + u;
+      const int ch = row / rows_per_ch;
+      const int rem = row - ch * rows_per_ch;
+      const int lz = rem / g.RY, ly = rem - lz * g.RY;
+      const int gz = c.rz0 + lz, gy = c.ry0 + ly, gx = c.rx0 + lane;
+      const bool ok = row < nrows && (c0 + ch) < p.C && gy >= 0 && gy < p.H && lane < g.RX && gx >= 0 && gx < p.W;
+      v[u] = ok ? xb[(long long)(c0 + ch) * chan + ((long long)gz * p.H + gy) * p.W + gx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int row = r0 + u;
+      if (row < nrows && lane < g.RX) {
+        const int ch = row / rows_per_ch;
+        const int rem = row - ch * rows_per_ch;
+        s_reg[ch * g.RV + rem * g.RX + lane] = v[u];
+      }
+    }
+  }
+}
+
+struct Samp {
+  int base;            // LDS index of the (low,low,low) corner (clamped), fast path only
+  int dzs;             // LDS stride to the high-z corner (0 when clamped)
+  float wz[2], wy[2], wx[2];   // trilinear factors with the in-volume masks folded in
+  float mz[2], my[2], mx[2];   // in-volume masks (for the coordinate derivatives)
+  bool valid, fast;
+};
+
+__device__ __forceinline__ Samp make_samp(const DcnP& p, const RegGeo& g, const RegCtx& c, const Corner& cn) {
+  Samp s;
+  s.valid = cn.valid != 0;
+  s.fast = false;
+  s.base = 0; s.dzs = 0;
+  const bool zl = cn.d0 >= 0 && cn.d0 <= p.D - 1, zh = cn.d0 + 1 >= 0 && cn.d0 + 1 <= p.D - 1;
+  const bool yl = cn.h0 >= 0 && cn.h0 <= p.H - 1, yh = cn.h0 + 1 >= 0 && cn.h0 + 1 <= p.H - 1;
+  const bool xl = cn.w0 >= 0 && cn.w0 <= p.W - 1, xh = cn.w0 + 1 >= 0 && cn.w0 + 1 <= p.W - 1;
+  s.mz[0] = zl ? 1.f : 0.f; s.mz[1] = zh ? 1.f : 0.f;
+  s.my[0] = yl ? 1.f : 0.f; s.my[1] = yh ? 1.f : 0.f;
+  s.mx[0] = xl ? 1.f : 0.f; s.mx[1] = xh ? 1.f : 0.f;
+  s.wz[0] = (1.f - cn.ld) * s.mz[0]; s.wz[1] = cn.ld * s.mz[1];
+  s.wy[0] = (1.f - cn.lh) * s.my[0]; s.wy[1] = cn.lh * s.my[1];
+  s.wx[0] = (1.f - cn.lw) * s.mx[0]; s.wx[1] = cn.lw * s.mx[1];
+  if (!s.valid) return s;
+  const int lz = cn.d0 - c.rz0, ly = cn.h0 - c.ry0, lx = cn.w0 - c.rx0;
+  const bool yx_in = ly >= 0 && ly + 1 < g.RY && lx >= 0 && lx + 1 < g.RX;
+  const bool zlo_in = lz >= 0 && lz < c.RZ, zhi_in = lz + 1 >= 0 && lz + 1 < c.RZ;
+  if (yx_in && (zlo_in || !zl) && (zhi_in || !zh)) {
+    s.fast = true;
+    const int iz0 = zlo_in ? lz : (zhi_in ? lz + 1 : 0);
+    const int iz1 = zhi_in ? lz + 1 : iz0;
+    s.base = (iz0 * g.RY + ly) * g.RX + lx;
+    s.dzs = (iz1 - iz0) * g.RY * g.RX;
+  }
+  return s;
+}
+
+// the 8 corner values of channel `ch` (LDS fast path or global slow path); v[jd][jh][jw]
+__device__ __forceinline__ void corner_values(const DcnP& p, const RegGeo& g, const Samp& s, const Corner& cn, const float* s_reg, int ch,
+                                              const float* __restrict__ xc /* global x[b, c] or nullptr */, float v[2][2][2]) {
+  if (s.fast) {
+    const float* r = s_reg + ch * g.RV + s.base;
+    v[0][0][0] = r[0];          v[0][0][1] = r[1];
+    v[0][1][0] = r[g.RX];       v[0][1][1] = r[g.RX + 1];
+    v[1][0][0] = r[s.dzs];      v[1][0][1] = r[s.dzs + 1];
+    v[1][1][0] = r[s.dzs + g.RX]; v[1][1][1] = r[s.dzs + g.RX + 1];
+  } else {
+#pragma unroll
+    for (int jd = 0; jd < 2; ++jd)
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+        for (int jw = 0; jw < 2; ++jw) {
+          const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
+          const bool in = xc && d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
+          v[jd][jh][jw] = in ? xc[((long long)d * p.H + h) * p.W + w] : 0.f;
+        }
+  }
+}
+
+constexpr int ST = 256 + 4;   // padded row of the [16][256] sample / gcol tile
+
+// ---------------------------------------------------------------------------------------------------- forward
+template <int MT>
+__global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                             const float* __restrict__ wt /*[T][C][KT]*/, const float* __restrict__ bias,
+                                                             float* __restrict__ out, DcnP p, RegGeo g) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int KT = 32 * MT;
+  float* s_reg = smem;                       // [16][RV]
+  float* s_S = s_reg + RG_CH * g.RV;         // [16][ST]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const RegCtx c = region_ctx(p, g, blockIdx.x);
+  const long long chan = (long long)p.D * p.H * p.W;
+  const float* xb = x + (long long)c.b * p.C * chan;
+  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
+  // this thread's output voxel
+  const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
+  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
+  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
+
+  for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
+    __syncthreads();                                   // previous chunk's region / S tile consumed
+    stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t) {
+      // weight fragments of this tap: issue early, consume after the sampling phase
+      float a[RG_CH / 2][MT];
+      const float* wtt = wt + ((long long)t * p.C + c0) * KT + l31;
+#pragma unroll
+      for (int sx = 0; sx < RG_CH / 2; ++sx) {
+        const int cc = 2 * sx + hh;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[sx][m] = (c0 + cc < p.C) ? wtt[(long long)cc * KT + m * 32] : 0.f;
+      }
+      const Corner cn = make_corner(p, off_b, t, ppos);
+      const Samp sp = make_samp(p, g, c, cn);
+      if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
+      for (int ch = 0; ch < RG_CH; ++ch) {
+        float val = 0.f;
+        if (sp.valid && c0 + ch < p.C) {
+          float v[2][2][2];
+          corner_values(p, g, sp, cn, s_reg, ch, xb + (long long)(c0 + ch) * chan, v);
+          val = sp.wz[0] * (sp.wy[0] * (sp.wx[0] * v[0][0][0] + sp.wx[1] * v[0][0][1]) + sp.wy[1] * (sp.wx[0] * v[0][1][0] + sp.wx[1] * v[0][1][1])) +
+                sp.wz[1] * (sp.wy[0] * (sp.wx[0] * v[1][0][0] + sp.wx[1] * v[1][0][1]) + sp.wy[1] * (sp.wx[0] * v[1][1][0] + sp.wx[1] * v[1][1][1]));
+        }
+        s_S[ch * ST + tid] = val;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sx = 0; sx < RG_CH / 2; ++sx) {
+        float bv[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bv[nt] = s_S[(2 * sx + hh) * ST + wave * 64 + nt * 32 + l31];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sx][m], bv[nt], acc[m][nt], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: D row = out channel, col = voxel (wave*64 + nt*32 + l31)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int pl = wave * 64 + nt * 32 + l31;
+    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+    const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
+    if (az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo) {
+      const long long pos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (k < p.K) out[((long long)c.b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- grad_offset
+// gcol[c][p] = sum_k W[k][c][t] go[k][p] on v_mfma_f32_16x16x4_f32 (D row = channel, col = voxel), then
+// grad_offset[3t+dir][p] = sum_c gcol[c][p] * d sample(c,p,t) / d coord_dir   (cuh:111-190, 336-405)
+__global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                                    const float* __restrict__ wt2 /*[T][K][CT]*/, const float* __restrict__ go,
+                                                                    float* __restrict__ doff, DcnP p, RegGeo g, int CT) {
+  extern __shared__ __align__(16) float smem[];
+  float* s_reg = smem;                       // [16][RV]
+  float* s_gc = s_reg + RG_CH * g.RV;        // [16][ST]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const RegCtx c = region_ctx(p, g, blockIdx.x);
+  const long long chan = (long long)p.D * p.H * p.W;
+  const float* xb = x + (long long)c.b * p.C * chan;
+  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
+  float* doff_b = doff + (long long)c.b * 3 * p.T * p.P;
+  const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
+  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
+  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
+
+  // B fragments: go[k][voxel] for this wave's 4 sub-tiles of 16 voxels, all k (K <= 64)
+  float bfrag[4][16];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int pl = wave * 64 + st * 16 + l15;
+    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+    const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
+    const bool ok = az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
+    const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = 4 * ks + lg;
+      bfrag[st][ks] = (ok && k < p.K) ? go[((long long)c.b * p.K + k) * p.P + gpos] : 0.f;
+    }
+  }
+
+  for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
+    __syncthreads();
+    stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
+    for (int t = 0; t < p.T; ++t) {
+      // A fragments: W[k][c0 + l15][t]
+      float afrag[16];
+      const float* wtt = wt2 + (long long)t * p.K * CT + c0 + l15;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int k = 4 * ks + lg;
+        afrag[ks] = (c0 + l15 < p.C && k < p.K) ? wtt[(long long)k * CT] : 0.f;
+      }
+      const Corner cn = make_corner(p, off_b, t, ppos);
+      const Samp sp = make_samp(p, g, c, cn);
+      __syncthreads();                                 // previous tap's s_gc consumed (and region staged)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], bfrag[st][ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_gc[(4 * lg + r) * ST + wave * 64 + st * 16 + l15] = acc[r];   // D row = channel, col = voxel
+      }
+      __syncthreads();
+      float gd = 0.f, gh = 0.f, gw = 0.f;
+      if (sp.valid) {
+        for (int ch = 0; ch < RG_CH; ++ch) {
+          if (c0 + ch >= p.C) break;
+          float v[2][2][2];
+          corner_values(p, g, sp, cn, s_reg, ch, xb + (long long)(c0 + ch) * chan, v);
+          const float gcv = s_gc[ch * ST + tid];
+          // d/dd: high-z plane minus low-z plane, bilinear in (h, w); in-volume masks as in cuh:131-187
+          const float pz0 = sp.wy[0] * (sp.wx[0] * v[0][0][0] + sp.wx[1] * v[0][0][1]) + sp.wy[1] * (sp.wx[0] * v[0][1][0] + sp.wx[1] * v[0][1][1]);
+          const float pz1 = sp.wy[0] * (sp.wx[0] * v[1][0][0] + sp.wx[1] * v[1][0][1]) + sp.wy[1] * (sp.wx[0] * v[1][1][0] + sp.wx[1] * v[1][1][1]);
+          gd += gcv * (sp.mz[1] * pz1 - sp.mz[0] * pz0);
+          const float py0 = sp.wz[0] * (sp.wx[0] * v[0][0][0] + sp.wx[1] * v[0][0][1]) + sp.wz[1] * (sp.wx[0] * v[1][0][0] + sp.wx[1] * v[1][0][1]);
+          const float py1 = sp.wz[0] * (sp.wx[0] * v[0][1][0] + sp.wx[1] * v[0][1][1]) + sp.wz[1] * (sp.wx[0] * v[1][1][0] + sp.wx[1] * v[1][1][1]);
+          gh += gcv * (sp.my[1] * py1 - sp.my[0] * py0);
+          const float px0 = sp.wz[0] * (sp.wy[0] * v[0][0][0] + sp.wy[1] * v[0][1][0]) + sp.wz[1] * (sp.wy[0] * v[1][0][0] + sp.wy[1] * v[1][1][0]);
+          const float px1 = sp.wz[0] * (sp.wy[0] * v[0][0][1] + sp.wy[1] * v[0][1][1]) + sp.wz[1] * (sp.wy[0] * v[1][0][1] + sp.wy[1] * v[1][1][1]);
+          gw += gcv * (sp.mx[1] * px1 - sp.mx[0] * px0);
+        }
+      }
+      if (pvalid) {   // this thread owns (t, voxel): accumulate over channel chunks with plain read-modify-write
+        float* q = doff_b + (long long)(3 * t) * p.P + ppos;
+        if (c0 == 0) {
+          q[0] = gd; q[p.P] = gh; q[2 * p.P] = gw;
+        } else {
+          q[0] += gd; q[p.P] += gh; q[2 * p.P] += gw;
+        }
+      }
+    }
+  }
+}
+
+int region_geo(RegGeo& g, const DcnP& p) {
+  g.TZ = p.Do < 4 ? p.Do : 4;
+  int RZ = (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * RG_R;
+  if (RZ > p.D) RZ = p.D;
+  g.RZmax = RZ;
+  g.RY = (RG_TY - 1) * p.sh + (p.kh - 1) * p.dh + 1 + 2 * RG_R;
+  g.RX = (RG_TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + 2 * RG_R;
+  g.RV = g.RZmax * g.RY * g.RX;
+  g.tilesZ = dpf_div_up(p.Do, g.TZ);
+  g.tilesY = dpf_div_up(p.Ho, RG_TY);
+  g.tilesX = dpf_div_up(p.Wo, RG_TX);
+  const size_t lds = sizeof(float) * ((size_t)RG_CH * g.RV + (size_t)RG_CH * ST);
+  const long long blocks = (long long)p.B * g.tilesZ * g.tilesY * g.tilesX;
+  if (g.RX > 64 || lds > 150 * 1024 || blocks >= 0x7fffffffLL || p.K > 128) return DPF_ERR_UNSUPPORTED;
+  return DPF_OK;
+}
+
 int fill_params(DcnP& p, int B, int C, int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
                 int dd, int dh, int dw) {
   if (B <= 0 || C <= 0 || K <= 0 || C > MAXC || K > MAXC) return DPF_ERR_UNSUPPORTED;
@@ -510,6 +836,19 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
   hipStream_t st = (hipStream_t)stream;
   const int MT = (K + 31) / 32, KT = 32 * MT;
   hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * C * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0);
+  RegGeo g{};
+  if (region_geo(g, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
+    const size_t lds = sizeof(float) * ((size_t)RG_CH * g.RV + (size_t)RG_CH * ST);
+    const dim3 grid((unsigned)((long long)B * g.tilesZ * g.tilesY * g.tilesX));
+#define DPF_FR(M)                                                                                                  \
+  {                                                                                                                \
+    if (set_lds(dcn_fwd_region_kernel<M>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                   \
+    hipLaunchKernelGGL((dcn_fwd_region_kernel<M>), grid, dim3(256), lds, st, input, offset, ws, bias, output, p, g); \
+  }
+    switch (MT) { case 1: DPF_FR(1); break; case 2: DPF_FR(2); break; case 3: DPF_FR(3); break; default: DPF_FR(4); break; }
+#undef DPF_FR
+    return dpf_check_launch();
+  }
   const size_t lds = sizeof(float) * (size_t)p.CP * SP;
   const dim3 grid((unsigned)(B * p.tiles_per_b));
 #define DPF_F(M)                                                                                   \
@@ -570,6 +909,13 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
       dx_done = true;
     }
   }
+  RegGeo rg{};
+  if (dx_done && K <= 64 && region_geo(rg, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
+    const size_t lds = sizeof(float) * ((size_t)RG_CH * rg.RV + (size_t)RG_CH * ST);
+    const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
+    if (set_lds(dcn_bwd_offset_region_kernel, lds) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL(dcn_bwd_offset_region_kernel, grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, p, rg, CT);
+  } else
   {
     const size_t lds = sizeof(float) * ((size_t)K * SP + (size_t)CT * SP + 3 * 4 * TP);
     const dim3 grid((unsigned)(B * p.tiles_per_b));
