@@ -250,24 +250,29 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
 // channel of 4 voxels (D row = voxel, col = channel), adds the 8 corner contributions with conflict-free LDS atomics
 // (16 consecutive channels per voxel) and flushes the region once with row-contiguous global atomics.  Samples that leave
 // the region (|offset| >~ 2) fall back to a direct global atomic.
-constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 16, GI_CS = 17;   // halo R on top of the kernel extent; padded channel stride
+constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8, GI_CS = 9;   // 8 channels per pass, padded channel stride (doubles)
 
 struct GiP {
   int TZ, RZmax, RY, RX;     // tile depth, region dims
   int tilesZ, tilesY, tilesX;
 };
 
+// Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 sustains 0.33 lanes/clk/CU whatever the address pattern,
+// ds_add_f64 3.1 and ds_add_u64 4.8-5.4.  The region therefore accumulates in fp64 (also the more accurate sum); it is
+// converted to fp32 once, at the flush.
 template <int NST>   // position sub-tiles of 16 per wave (positions per block = 64 * NST)
 __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][K][CT]*/,
                                                             const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT) {
-  extern __shared__ __align__(16) float smem[];
+  extern __shared__ __align__(16) double smem_d[];
   const int npos = 64 * NST;
-  float* s_reg = smem;                                         // [RZ*RY*RX][GI_CS]
+  double* s_reg = smem_d;                                      // [RZ*RY*RX][GI_CS]
   const int regvox = q.RZmax * q.RY * q.RX;
-  int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + 3) & ~3));   // [npos][8] local voxel index or -1 (16-B aligned)
+  int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + 1) & ~1));   // [npos][8] local voxel index or -1 (16-B aligned)
   int* s_vox = s_lidx + npos * 8;                              // [npos][8] global voxel index or -1
   float* s_w = (float*)(s_vox + npos * 8);                     // [npos][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int lc = l15 & 7;            // channel within the chunk; lanes 8..15 of a group mirror lanes 0..7 ...
+  const int jb = (l15 >> 3) * 4;     // ... and scatter corners 4..7 instead of 0..3
 
   int bb = blockIdx.x;
   const int tx = bb % q.tilesX; bb /= q.tilesX;
@@ -275,7 +280,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   const int tz = bb % q.tilesZ;
   const int b = bb / q.tilesZ;
   const int z0 = tz * q.TZ, y0 = ty * GI_TY, x0 = tx * GI_TX;
-  // region origin (input coordinates) and clipped depth range
   const int rz0u = z0 * p.sd - p.pd - GI_R, ry0 = y0 * p.sh - p.ph - GI_R, rx0 = x0 * p.sw - p.pw - GI_R;
   const int rz0 = rz0u < 0 ? 0 : rz0u;
   int rz1 = rz0u + (q.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * GI_R;
@@ -287,17 +291,16 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   const float* off_b = offset + (long long)b * 3 * p.T * p.P;
   float* dxb = dx + (long long)b * p.C * chan;
 
-  // this thread's output voxel (corner tables): tid < npos
   const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
   const int zo = z0 + pdz, yo = y0 + pdy, xo = x0 + pdx;
   const bool pvalid = tid < npos && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
-  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;   // p.P => make_corner returns invalid
+  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
 
   // A fragments: go[k][voxel] for this wave's NST sub-tiles, all k (K <= 64 -> 16 k-steps of 4), kept in registers
   float afrag[NST][16];
 #pragma unroll
   for (int st = 0; st < NST; ++st) {
-    const int pl = (wave * NST + st) * 16 + l15;               // voxel index within the tile
+    const int pl = (wave * NST + st) * 16 + l15;
     const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
     const int gz = z0 + az, gy = y0 + ay, gx = x0 + ax;
     const bool ok = az < q.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
@@ -311,8 +314,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 
   for (int c0 = 0; c0 < p.C; c0 += GI_CH) {
     __syncthreads();                                            // previous chunk flushed
-    for (int i = tid; i < regvox * GI_CS; i += 256) s_reg[i] = 0.f;
-    const int cc = c0 + l15;
+    for (int i = tid; i < regvox * GI_CS; i += 256) s_reg[i] = 0.0;
+    const int cc = c0 + lc;
     const bool cok = cc < p.C;
     for (int t = 0; t < p.T; ++t) {
       __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
@@ -333,9 +336,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
           s_w[tid * 8 + j] = wg;
         }
       }
-      // B fragments: W[k][c0 + l15][t] for the 16 k-steps
+      // B fragments: W[k][c0 + lc][t] (both lane halves of a group hold the same 8 channels)
       float bfrag[16];
-      const float* wtt = wt2 + (long long)t * p.K * CT + c0 + l15;
+      const float* wtt = wt2 + (long long)t * p.K * CT + cc;
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const int k = 4 * ks + lg;
@@ -352,18 +355,16 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
           for (int r = 0; r < 4; ++r) {
             const int pl = (wave * NST + st) * 16 + 4 * lg + r;   // D row = voxel
             const float g = acc[r];
-            const int4 la = *reinterpret_cast<const int4*>(&s_lidx[pl * 8]);
-            const int4 lb = *reinterpret_cast<const int4*>(&s_lidx[pl * 8 + 4]);
-            const float4 wa = *reinterpret_cast<const float4*>(&s_w[pl * 8]);
-            const float4 wb = *reinterpret_cast<const float4*>(&s_w[pl * 8 + 4]);
-            const int li[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
-            const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            const int4 la = *reinterpret_cast<const int4*>(&s_lidx[pl * 8 + jb]);
+            const float4 wa = *reinterpret_cast<const float4*>(&s_w[pl * 8 + jb]);
+            const int li[4] = {la.x, la.y, la.z, la.w};
+            const float wv[4] = {wa.x, wa.y, wa.z, wa.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
               if (li[j] >= 0) {
-                atomicAdd(&s_reg[li[j] * GI_CS + l15], wv[j] * g);
+                atomicAdd(&s_reg[li[j] * GI_CS + lc], (double)(wv[j] * g));
               } else {
-                const int v = s_vox[pl * 8 + j];
+                const int v = s_vox[pl * 8 + jb + j];
                 if (v >= 0) atomicAdd(&dxb[(long long)cc * chan + v], wv[j] * g);   // left the region: direct scatter
               }
             }
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       }
     }
     __syncthreads();
-    // flush: lanes along x (row-contiguous global atomics); LDS stride GI_CS = 17 floats is conflict-free
+    // flush: lanes along x (row-contiguous global atomics); odd channel stride keeps the LDS reads conflict-light
     const int rowlen = q.RX;
     const int nrows = RZ * q.RY * GI_CH;
     for (int row = wave; row < nrows; row += 4) {
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       float* dst = dxb + (long long)(c0 + c) * chan + ((long long)gz * p.H + gy) * p.W;
       for (int lx = lane; lx < rowlen; lx += 64) {
         const int gx = rx0 + lx;
-        const float v = s_reg[((lz * q.RY + ly) * q.RX + lx) * GI_CS + c];
+        const float v = (float)s_reg[((lz * q.RY + ly) * q.RX + lx) * GI_CS + c];
         if (v != 0.f && gx >= 0 && gx < p.W) atomicAdd(&dst[gx], v);
       }
     }
@@ -895,7 +896,7 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
     q.tilesY = dpf_div_up(p.Ho, GI_TY);
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
     const int npos = 64 * q.TZ;
-    const size_t lds = sizeof(float) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + 3) & ~(size_t)3) + (size_t)npos * 24);
+    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + 1) & ~(size_t)1)) + sizeof(float) * (size_t)npos * 24;
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
     if (lds <= 150 * 1024 && blocks < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
