@@ -37,6 +37,7 @@ struct ConvP {
   int Ktot, k0;                   // out tensor has Ktot channels; this launch writes [k0, k0 + K)
   int chanStrideMax;              // floats per channel of the LDS input tile (host worst case)
   int ntmax;                      // max valid taps per class
+  int maxrows;                    // LDS input-tile rows per channel chunk (host worst case)
 };
 
 struct DimTap {
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
   int* s_tapoff = (int*)(s_w + p.ntmax * CC * KT);
   int* s_tapw = s_tapoff + MAXT;
   int* s_nv = s_tapw + MAXT;
+  int* s_rowoff = s_nv + 4;             // per staged row: source offset relative to (n, c0, i0d, i0h) -- no divisions in the loop
+  int* s_rowpr = s_rowoff + p.maxrows;  // (plane << 16) | row
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -168,9 +171,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform row bookkeeping on the scalar unit
     const long long x_chan = (long long)p.ID * p.IH * p.IW;
     const float* xn = x + (long long)n * p.C * x_chan;
+    for (int rowid = tid; rowid < in_rows; rowid += 256) {
+      const int cc = rowid / rows_per_chan;
+      const int rem = rowid - cc * rows_per_chan;
+      const int pl = rem / ext_h;
+      const int rr = rem - pl * ext_h;
+      s_rowoff[rowid] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + rr) * p.IW);
+      s_rowpr[rowid] = (pl << 16) | rr | (cc << 24);
+    }
 
     for (int c0 = 0; c0 < p.C; c0 += CC) {
-      __syncthreads();   // previous chunk fully consumed (also orders the tap table on the first trip)
+      __syncthreads();   // previous chunk fully consumed (also orders the tap / row tables on the first trip)
+      const float* xbase = xn + (long long)c0 * x_chan + ((long long)i0d * p.IH + i0h) * p.IW;
       // ---- stage the input patch: one LDS row per (channel, plane, row), lanes along W.  SU rows are fetched
       //      back-to-back before any is written so each wave keeps SU (x2) global loads in flight.
       constexpr int SU = 8;
@@ -179,13 +191,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
           const int rowid = r0 + u;
-          const int cc = rowid / rows_per_chan;
-          const int rem = rowid - cc * rows_per_chan;
-          const int pl = rem / ext_h;
-          const int rr = rem - pl * ext_h;
+          const int rsafe = rowid < in_rows ? rowid : 0;
+          const int pr = s_rowpr[rsafe];
+          const int cc = pr >> 24, pl = (pr >> 16) & 0xff, rr = pr & 0xffff;
           const int ic = c0 + cc, id = i0d + pl, ih = i0h + rr;
           const bool rowok = (rowid < in_rows) && (ic < p.C) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
-          const float* src = xn + (long long)ic * x_chan + ((long long)id * p.IH + ih) * p.IW;
+          const float* src = xbase + s_rowoff[rsafe];
           const int iw0 = i0w + lane, iw1 = iw0 + 64;
           v0[u] = (rowok && lane < ext_w && iw0 >= 0 && iw0 < p.IW) ? src[iw0] : 0.f;
           v1[u] = (rowok && lane + 64 < ext_w && iw1 >= 0 && iw1 < p.IW) ? src[iw1] : 0.f;
@@ -326,6 +337,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   float* s_x = smem;                         // [CCW][chanStride]
   float* s_g = s_x + p.CCW * chanStride;     // [KT][WPT+1]
   constexpr int GS = WPT + 1;
+  int* s_rowoff = (int*)(s_g + KT * GS);     // per staged row: source offset relative to (n, c0, i0d, i0h)
+  int* s_rowpr = s_rowoff + p.CCW * ext_d * ext_h;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -362,6 +375,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   const long long x_chan = (long long)p.ID * p.IH * p.IW;
   const long long g_chan = (long long)p.QD * p.QH * p.QW;
   const int rows_per_chan = ext_d * ext_h;
+  for (int rowid = tid; rowid < ncc * rows_per_chan; rowid += 256) {
+    const int cc = rowid / rows_per_chan;
+    const int rem = rowid - cc * rows_per_chan;
+    const int pl = rem / ext_h;
+    const int rr = rem - pl * ext_h;
+    s_rowoff[rowid] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + rr) * p.IW);
+    s_rowpr[rowid] = (pl << 16) | rr;
+  }
 
   for (long long tile = pchunk; tile < p.ntiles; tile += p.nchunk) {
     long long b = tile;
@@ -374,20 +395,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     __syncthreads();
     // stage x patch (SU rows fetched back-to-back, then written)
     constexpr int SU = 8;
-    const float* xn = x + ((long long)n * p.C + c0) * x_chan;
+    const float* xbase = x + ((long long)n * p.C + c0) * x_chan + ((long long)i0d * p.IH + i0h) * p.IW;
     const int xrows = ncc * rows_per_chan;
     for (int r0 = wave_u * SU; r0 < xrows; r0 += 4 * SU) {
       float v0[SU], v1[SU];
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         const int rowid = r0 + u;
-        const int cc = rowid / rows_per_chan;
-        const int rem = rowid - cc * rows_per_chan;
-        const int pl = rem / ext_h;
-        const int rr = rem - pl * ext_h;
+        const int rsafe = rowid < xrows ? rowid : 0;
+        const int pr = s_rowpr[rsafe];
+        const int pl = pr >> 16, rr = pr & 0xffff;
         const int id = i0d + pl, ih = i0h + rr;
         const bool rowok = (rowid < xrows) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
-        const float* src = xn + (long long)cc * x_chan + ((long long)id * p.IH + ih) * p.IW;
+        const float* src = xbase + s_rowoff[rsafe];
         const int iw0 = i0w + lane, iw1 = iw0 + 64;
         v0[u] = (rowok && lane < ext_w && iw0 >= 0 && iw0 < p.IW) ? src[iw0] : 0.f;
         v1[u] = (rowok && lane + 64 < ext_w && iw1 >= 0 && iw1 < p.IW) ? src[iw1] : 0.f;
@@ -535,12 +555,13 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   if (ext_w > 128) return DPF_ERR_UNSUPPORTED;   // staging handles two 64-lane column groups
   p.chanStrideMax = ext_d * ext_h * ext_w;
   p.ntmax = ntmax;
-  auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + ntmax * CC * KT + 2 * MAXT + 4) * sizeof(float); };
+  auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + ntmax * CC * KT + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float); };
   int CC = 8;
   static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 64 * 1024;   // tuning knob
   if (lds_bytes(8) > (size_t)lds_cap || p.C <= 4) CC = 4;
   const size_t lds = lds_bytes(CC);
   if (lds > 160 * 1024) return DPF_ERR_UNSUPPORTED;
+  p.maxrows = CC * ext_d * ext_h;
 #define DPF_IG(M, Cc, Nt) return launch_igemm<M, Cc, Nt>(x, wt_ws, bias, out, p, lds, st)
   if (CC == 8) {
     switch (MT) { case 1: DPF_IG(1, 8, 4); case 2: DPF_IG(2, 8, 2); case 3: DPF_IG(3, 8, 2); default: DPF_IG(4, 8, 2); }
@@ -619,7 +640,7 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   const int ext_h = (WTH - 1) * sh + (kh - 1) * dh + 1;
   const int ext_w = (TW - 1) * sw + (kw - 1) * dw_ + 1;
   if (ext_w > 128) return DPF_ERR_UNSUPPORTED;
-  auto lds_bytes = [&](int ccw) { return (size_t)(ccw * ext_d * ext_h * ext_w + KT * (WPT + 1)) * sizeof(float); };
+  auto lds_bytes = [&](int ccw) { return (size_t)(ccw * ext_d * ext_h * ext_w + KT * (WPT + 1) + 2 * ccw * ext_d * ext_h) * sizeof(float); };
   while (CCW > 1 && lds_bytes(CCW) > 96 * 1024) --CCW;
   if (lds_bytes(CCW) > 160 * 1024) return DPF_ERR_UNSUPPORTED;
   p.CCW = CCW;
