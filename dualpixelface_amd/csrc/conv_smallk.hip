@@ -17,82 +17,104 @@ struct SkP {
   int sd, sh, sw, pd, ph, pw, dd, dh, dw;
 };
 
+// forward, stride-1 W: one thread owns XB = 4 consecutive outputs along W of one (n, od, oh) row; for every (channel, kd, kh)
+// it loads the XB + (kw-1)*dw input values once and reuses them for the kw taps (weights are wave-uniform -> scalar loads).
+constexpr int XB = 4;
+constexpr int MAXSPAN = XB + 2;       // kw <= 3, dw == 1
+
 __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, SkP p) {
-  extern __shared__ float s_w[];   // [K][C][T]
-  for (int i = threadIdx.x; i < p.K * p.C * p.T; i += 256) s_w[i] = w[i];
-  __syncthreads();
   const long long oplane = (long long)p.OH * p.OW, ovol = oplane * p.OD;
   const long long ivol = (long long)p.ID * p.IH * p.IW;
-  const long long total = (long long)p.N * ovol;
+  const int wq = (p.OW + XB - 1) / XB;
+  const long long total = (long long)p.N * p.OD * p.OH * wq;
+  const int span = XB + (p.kw - 1);                 // stride 1, dilation 1 along W (checked by the host)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int ow = (int)(i % p.OW);
-    const int oh = (int)((i / p.OW) % p.OH);
-    const int od = (int)((i / oplane) % p.OD);
-    const int n = (int)(i / ovol);
-    float acc[MAXK];
+    const int ow0 = (int)(i % wq) * XB;
+    const int oh = (int)((i / wq) % p.OH);
+    const int od = (int)((i / ((long long)wq * p.OH)) % p.OD);
+    const int n = (int)(i / ((long long)wq * p.OH * p.OD));
+    float acc[MAXK][XB];
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) acc[k] = (bias && k < p.K) ? bias[k] : 0.f;
+    for (int k = 0; k < MAXK; ++k)
+#pragma unroll
+      for (int j = 0; j < XB; ++j) acc[k][j] = (bias && k < p.K) ? bias[k] : 0.f;
     const float* xn = x + (long long)n * p.C * ivol;
-    for (int a = 0; a < p.kd; ++a) {
-      const int id = od * p.sd - p.pd + a * p.dd;
-      if (id < 0 || id >= p.ID) continue;
-      for (int b = 0; b < p.kh; ++b) {
-        const int ih = oh * p.sh - p.ph + b * p.dh;
-        if (ih < 0 || ih >= p.IH) continue;
-        for (int c2 = 0; c2 < p.kw; ++c2) {
-          const int iw = ow * p.sw - p.pw + c2 * p.dw;
-          if (iw < 0 || iw >= p.IW) continue;
-          const int t = (a * p.kh + b) * p.kw + c2;
-          const float* xp = xn + ((long long)id * p.IH + ih) * p.IW + iw;
-          for (int c = 0; c < p.C; ++c) {
-            const float v = xp[(long long)c * ivol];
+    const int iw0 = ow0 - p.pw;
+    for (int c = 0; c < p.C; ++c) {
+      for (int a = 0; a < p.kd; ++a) {
+        const int id = od * p.sd - p.pd + a * p.dd;
+        if (id < 0 || id >= p.ID) continue;
+        for (int b = 0; b < p.kh; ++b) {
+          const int ih = oh * p.sh - p.ph + b * p.dh;
+          if (ih < 0 || ih >= p.IH) continue;
+          const float* row = xn + (long long)c * ivol + ((long long)id * p.IH + ih) * p.IW;
+          float v[MAXSPAN];
 #pragma unroll
-            for (int k = 0; k < MAXK; ++k)
-              if (k < p.K) acc[k] = fmaf(s_w[(k * p.C + c) * p.T + t], v, acc[k]);
+          for (int u = 0; u < MAXSPAN; ++u) {
+            const int iw = iw0 + u;
+            v[u] = (u < span && iw >= 0 && iw < p.IW) ? row[iw] : 0.f;
+          }
+          const int tb = (a * p.kh + b) * p.kw;
+#pragma unroll
+          for (int k = 0; k < MAXK; ++k) {
+            if (k < p.K) {
+              const float* wk = w + ((long long)k * p.C + c) * p.T + tb;
+              for (int c2 = 0; c2 < p.kw; ++c2) {
+                const float wv = wk[c2];
+#pragma unroll
+                for (int j = 0; j < XB; ++j) {
+                  const float xv = c2 == 0 ? v[j] : (c2 == 1 ? v[j + 1] : v[j + 2]);
+                  acc[k][j] = fmaf(wv, xv, acc[k][j]);
+                }
+              }
+            }
           }
         }
       }
     }
+    const long long obase = ((long long)od * p.OH + oh) * p.OW + ow0;
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
-      if (k < p.K) out[((long long)n * p.K + k) * ovol + (i % ovol)] = acc[k];
+      if (k < p.K)
+#pragma unroll
+        for (int j = 0; j < XB; ++j)
+          if (ow0 + j < p.OW) out[((long long)n * p.K + k) * ovol + obase + j] = acc[k][j];
   }
 }
 
-// grid = cchunks * nblk; block: channels [c0, c0+CCH), tiles pchunk, pchunk+nblk, ...; thread = (cc, tap) pair
+// grid = cchunks * nblk; block: channels [c0, c0+CCH), tiles pchunk, pchunk+nblk, ...
+// thread = (channel, kd, kh) triple x row group; it marches along W with a 3-deep sliding window of g so that each
+// staged x value (one LDS read) feeds the kw = 3 taps: 2 LDS reads per 3*K FMAs.
 template <int CCH>
 __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw, SkP p,
                                                            int nblk, int tilesH, int tilesW, long long ntiles) {
   extern __shared__ float smem[];
   const int ext_d = (p.kd - 1) * p.dd + 1;
   const int ext_h = (TH - 1) * p.sh + (p.kh - 1) * p.dh + 1;
-  const int ext_w = (TW - 1) * p.sw + (p.kw - 1) * p.dw + 1;
+  const int ext_w = TW + p.kw - 1;                     // stride 1, dilation 1 along W (host-checked)
   const int chanStride = ext_d * ext_h * ext_w;
   float* s_x = smem;                       // [CCH][chanStride]
-  float* s_g = s_x + CCH * chanStride;     // [K][TH*TW]
+  float* s_g = s_x + CCH * chanStride;     // [K][TH][TW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cchunk = blockIdx.x / nblk, pchunk = blockIdx.x % nblk;
   const int c0 = cchunk * CCH;
   const int ncc = min(CCH, p.C - c0);
-  const int npair = ncc * p.T;
-  // up to two (cc, tap) pairs per thread (CCH * T <= 512)
-  int base[2];
-  bool ok[2];
+  const int ntrip = ncc * p.kd * p.kh;
+  int nrg = 256 / ntrip;                   // row groups
+  nrg = nrg >= 8 ? 8 : (nrg >= 4 ? 4 : (nrg >= 2 ? 2 : 1));
+  const bool active = tid < ntrip * nrg;
+  const int trip = active ? tid % ntrip : 0;
+  const int rg = active ? tid / ntrip : 0;
+  const int cc = trip / (p.kd * p.kh);
+  const int tdh = trip - cc * (p.kd * p.kh);
+  const int td_ = tdh / p.kh, th_ = tdh - td_ * p.kh;
+  const int base = cc * chanStride + (td_ * p.dd * ext_h + th_ * p.dh) * ext_w;
+  float acc[MAXK][3];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int pr = tid + 256 * u;
-    ok[u] = pr < npair;
-    const int q = ok[u] ? pr : 0;
-    const int cc = q / p.T, t = q - cc * p.T;
-    const int tw_ = t % p.kw, th_ = (t / p.kw) % p.kh, td_ = t / (p.kw * p.kh);
-    base[u] = cc * chanStride + (td_ * p.dd * ext_h + th_ * p.dh) * ext_w + tw_ * p.dw;
-  }
-  float acc[2][MAXK];
+  for (int k = 0; k < MAXK; ++k)
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) acc[u][k] = 0.f;
+    for (int j = 0; j < 3; ++j) acc[k][j] = 0.f;
   const long long xvol = (long long)p.ID * p.IH * p.IW, gvol = (long long)p.OD * p.OH * p.OW;
   const int rows_per_chan = ext_d * ext_h;
   for (long long tile = pchunk; tile < ntiles; tile += nblk) {
@@ -102,20 +124,20 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restri
     const int qd = (int)(b % p.OD);
     const int n = (int)(b / p.OD);
     const int q0h = th * TH, q0w = tw * TW;
-    const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, i0w = q0w * p.sw - p.pw;
+    const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, i0w = q0w - p.pw;
     __syncthreads();
     const float* xn = x + ((long long)n * p.C + c0) * xvol;
     for (int rowid = wave; rowid < ncc * rows_per_chan; rowid += 4) {
-      const int cc = rowid / rows_per_chan;
-      const int rem = rowid - cc * rows_per_chan;
+      const int c2 = rowid / rows_per_chan;
+      const int rem = rowid - c2 * rows_per_chan;
       const int pl = rem / ext_h, rr = rem - pl * ext_h;
       const int id = i0d + pl, ih = i0h + rr;
       const bool rowok = id >= 0 && id < p.ID && ih >= 0 && ih < p.IH;
-      const float* src = xn + (long long)cc * xvol + ((long long)id * p.IH + ih) * p.IW;
-      float* dst = s_x + cc * chanStride + rem * ext_w;
-      for (int col = lane; col < ext_w; col += 64) {
-        const int iw = i0w + col;
-        dst[col] = (rowok && iw >= 0 && iw < p.IW) ? src[iw] : 0.f;
+      const float* src = xn + (long long)c2 * xvol + ((long long)id * p.IH + ih) * p.IW;
+      float* dst = s_x + c2 * chanStride + rem * ext_w;
+      if (lane < ext_w) {
+        const int iw = i0w + lane;
+        dst[lane] = (rowok && iw >= 0 && iw < p.IW) ? src[iw] : 0.f;
       }
     }
     for (int i = tid; i < p.K * TH * TW; i += 256) {
@@ -124,28 +146,36 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restri
       s_g[i] = (qh < p.OH && qw < p.OW) ? g[((long long)n * p.K + k) * gvol + ((long long)qd * p.OH + qh) * p.OW + qw] : 0.f;
     }
     __syncthreads();
-    for (int r = 0; r < TH; ++r) {
-      for (int cx = 0; cx < TW; ++cx) {
-        const int posoff = (r * p.sh) * ext_w + cx * p.sw;
-        float gv[MAXK];
+    if (active) {
+      for (int r = rg; r < TH; r += nrg) {
+        const float* xr = s_x + base + (r * p.sh) * ext_w;
+        const float* gr = s_g + r * TW;
+        float g0[MAXK], g1[MAXK], g2[MAXK];      // g[xi], g[xi-1], g[xi-2]
 #pragma unroll
-        for (int k = 0; k < MAXK; ++k) gv[k] = k < p.K ? s_g[k * TH * TW + r * TW + cx] : 0.f;
+        for (int k = 0; k < MAXK; ++k) g0[k] = g1[k] = g2[k] = 0.f;
+#pragma unroll 2
+        for (int xi = 0; xi < TW + 2; ++xi) {
+          const float xv = xi < ext_w ? xr[xi] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const float xv = s_x[base[u] + posoff];
-#pragma unroll
-          for (int k = 0; k < MAXK; ++k) acc[u][k] = fmaf(gv[k], xv, acc[u][k]);
+          for (int k = 0; k < MAXK; ++k) {
+            g2[k] = g1[k];
+            g1[k] = g0[k];
+            g0[k] = (k < p.K && xi < TW) ? gr[k * TH * TW + xi] : 0.f;
+            // x column xi pairs with output column xi - tw for tap tw
+            acc[k][0] = fmaf(g0[k], xv, acc[k][0]);
+            acc[k][1] = fmaf(g1[k], xv, acc[k][1]);
+            acc[k][2] = fmaf(g2[k], xv, acc[k][2]);
+          }
         }
       }
     }
   }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (!ok[u]) continue;
-    const int pr = tid + 256 * u;
+  if (active) {
+    const int tbase = (td_ * p.kh + th_) * p.kw;
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
-      if (k < p.K) atomicAdd(&dw[((long long)k * p.C + c0) * p.T + pr], acc[u][k]);
+      if (k < p.K)
+        for (int j = 0; j < p.kw; ++j) atomicAdd(&dw[((long long)k * p.C + c0 + cc) * p.T + tbase + j], acc[k][j]);
   }
 }
 
@@ -166,7 +196,7 @@ int fill(SkP& p, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, in
 
 extern "C" {
 
-// same tensor conventions as dpf_conv_forward; K <= 4 and K*C*T*4 bytes <= 64 KiB
+// same tensor conventions as dpf_conv_forward; K <= 4, stride 1 / dilation 1 / kw <= 3 along W
 int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, float* out, int N, int C, int ID, int IH, int IW, int K, int kd,
                             int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw, void* stream) {
   dpf_clear_error();
@@ -174,12 +204,9 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
   SkP p{};
   int rc = fill(p, N, C, ID, IH, IW, K, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw);
   if (rc != DPF_OK) return rc;
-  const size_t lds = sizeof(float) * (size_t)K * C * p.T;
-  if (lds > 64 * 1024) return DPF_ERR_UNSUPPORTED;
-  if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)smallk_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return DPF_ERR_LAUNCH;
-  const long long total = (long long)N * p.OD * p.OH * p.OW;
-  hipLaunchKernelGGL(smallk_fwd_kernel, dim3(dpf_ew_grid(total)), dim3(256), lds, (hipStream_t)stream, x, w, bias, out, p);
+  if (sw != 1 || dw != 1 || kw > 3) return DPF_ERR_UNSUPPORTED;
+  const long long total = (long long)N * p.OD * p.OH * ((p.OW + XB - 1) / XB);
+  hipLaunchKernelGGL(smallk_fwd_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, p);
   return dpf_check_launch();
 }
 
@@ -192,8 +219,8 @@ int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int 
   int rc = fill(p, N, C, ID, IH, IW, K, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_);
   if (rc != DPF_OK) return rc;
   constexpr int CCH = 16;
-  if (CCH * p.T > 512) return DPF_ERR_UNSUPPORTED;
-  const int ext_d = (kd - 1) * dd + 1, ext_h = (TH - 1) * sh + (kh - 1) * dh + 1, ext_w = (TW - 1) * sw + (kw - 1) * dw_ + 1;
+  if (sw != 1 || dw_ != 1 || kw > 3 || CCH * kd * kh > 256) return DPF_ERR_UNSUPPORTED;
+  const int ext_d = (kd - 1) * dd + 1, ext_h = (TH - 1) * sh + (kh - 1) * dh + 1, ext_w = TW + kw - 1;
   const size_t lds = sizeof(float) * ((size_t)CCH * ext_d * ext_h * ext_w + (size_t)K * TH * TW);
   if (lds > 150 * 1024) return DPF_ERR_UNSUPPORTED;
   if (lds > 48 * 1024 &&

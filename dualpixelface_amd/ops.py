@@ -97,7 +97,7 @@ def _conv_fwd_raw(x, w, bias, stride, pad, dil):
     ow = _out_dim(IW, kw, stride[2], pad[2], dil[2])
     out = torch.empty((N, K, od, oh, ow), dtype=torch.float32, device=x.device)
     L = lib()
-    if K <= 4 and K * C * kd * kh * kw * 4 <= 64 * 1024:
+    if K <= 4 and stride[2] == 1 and dil[2] == 1 and kw <= 3:
         with _Timed('conv_smallk', 2.0 * N * K * C * kd * kh * kw * od * oh * ow, 'skf N%d C%d K%d in%dx%dx%d' % (N, C, K, ID, IH, IW)):
             L.call('dpf_conv_smallk_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), N, C, ID, IH, IW, K, kd, kh, kw, *stride, *pad, *dil,
                    _stream())
@@ -131,7 +131,7 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
     K, QD, QH, QW = g.shape[1], g.shape[2], g.shape[3], g.shape[4]
     kd, kh, kw = wshape[2:]
     dw = torch.zeros(wshape, dtype=torch.float32, device=x.device)
-    if K <= 4 and 16 * kd * kh * kw <= 512:
+    if K <= 4 and stride[2] == 1 and dil[2] == 1 and kw <= 3 and 16 * kd * kh <= 256:
         with _Timed('conv_smallk', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW, 'skw N%d C%d K%d x%dx%dx%d' % (N, C, K, ID, IH, IW)):
             lib().call('dpf_conv_smallk_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, kd, kh, kw, *stride, *pad, *dil, _stream())
         return dw
