@@ -96,10 +96,24 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restri
   const int chanStride = ext_d * ext_h * ext_w;
   float* s_x = smem;                       // [CCH][chanStride]
   float* s_g = s_x + CCH * chanStride;     // [K][TH][TW]
+  int* s_rowoff = (int*)(s_g + MAXK * TH * TW);      // staged-row source offsets (no divisions in the tile loop)
+  int* s_rowpr = s_rowoff + CCH * ext_d * ext_h;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int cchunk = blockIdx.x / nblk, pchunk = blockIdx.x % nblk;
   const int c0 = cchunk * CCH;
   const int ncc = min(CCH, p.C - c0);
+  {
+    const long long xv_ = (long long)p.ID * p.IH * p.IW;
+    const int rpc = ext_d * ext_h;
+    for (int rowid = tid; rowid < ncc * rpc; rowid += 256) {
+      const int c2 = rowid / rpc;
+      const int rem = rowid - c2 * rpc;
+      const int pl = rem / ext_h, rr = rem - pl * ext_h;
+      s_rowoff[rowid] = (int)((long long)c2 * xv_ + ((long long)pl * p.IH + rr) * p.IW);
+      s_rowpr[rowid] = (pl << 16) | rr;
+    }
+  }
   const int ntrip = ncc * p.kd * p.kh;
   int nrg = 256 / ntrip;                   // row groups
   nrg = nrg >= 8 ? 8 : (nrg >= 4 ? 4 : (nrg >= 2 ? 2 : 1));
@@ -126,18 +140,25 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restri
     const int q0h = th * TH, q0w = tw * TW;
     const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, i0w = q0w - p.pw;
     __syncthreads();
-    const float* xn = x + ((long long)n * p.C + c0) * xvol;
-    for (int rowid = wave; rowid < ncc * rows_per_chan; rowid += 4) {
-      const int c2 = rowid / rows_per_chan;
-      const int rem = rowid - c2 * rows_per_chan;
-      const int pl = rem / ext_h, rr = rem - pl * ext_h;
-      const int id = i0d + pl, ih = i0h + rr;
-      const bool rowok = id >= 0 && id < p.ID && ih >= 0 && ih < p.IH;
-      const float* src = xn + (long long)c2 * xvol + ((long long)id * p.IH + ih) * p.IW;
-      float* dst = s_x + c2 * chanStride + rem * ext_w;
-      if (lane < ext_w) {
+    const float* xbase = x + ((long long)n * p.C + c0) * xvol + ((long long)i0d * p.IH + i0h) * p.IW;
+    constexpr int SU = 8;
+    const int xrows = ncc * rows_per_chan;
+    for (int r0 = wave_u * SU; r0 < xrows; r0 += 4 * SU) {
+      float v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int rowid = r0 + u;
+        const int rsafe = rowid < xrows ? rowid : 0;
+        const int pr = s_rowpr[rsafe];
+        const int id = i0d + (pr >> 16), ih = i0h + (pr & 0xffff);
         const int iw = i0w + lane;
-        dst[lane] = (rowok && iw >= 0 && iw < p.IW) ? src[iw] : 0.f;
+        const bool ok = rowid < xrows && lane < ext_w && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+        v[u] = ok ? xbase[s_rowoff[rsafe] + iw] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int rowid = r0 + u;
+        if (rowid < xrows && lane < ext_w) s_x[rowid * ext_w + lane] = v[u];
       }
     }
     for (int i = tid; i < p.K * TH * TW; i += 256) {
@@ -221,7 +242,7 @@ int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int 
   constexpr int CCH = 16;
   if (sw != 1 || dw_ != 1 || kw > 3 || CCH * kd * kh > 256) return DPF_ERR_UNSUPPORTED;
   const int ext_d = (kd - 1) * dd + 1, ext_h = (TH - 1) * sh + (kh - 1) * dh + 1, ext_w = TW + kw - 1;
-  const size_t lds = sizeof(float) * ((size_t)CCH * ext_d * ext_h * ext_w + (size_t)K * TH * TW);
+  const size_t lds = sizeof(float) * ((size_t)CCH * ext_d * ext_h * ext_w + (size_t)MAXK * TH * TW + 2 * (size_t)CCH * ext_d * ext_h);
   if (lds > 150 * 1024) return DPF_ERR_UNSUPPORTED;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute((const void*)smallk_wgrad_kernel<CCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -35,7 +35,22 @@ struct Corner {   // per output voxel and tap
   int valid;
 };
 
-__device__ __forceinline__ Corner make_corner(const DcnP& p, const float* __restrict__ off_b, int t, long long pos) {
+struct Off3 {
+  float d, h, w;
+};
+
+// the three offset components of tap t at output voxel pos (cuh:238-243); zeros beyond the volume / tap range
+__device__ __forceinline__ Off3 load_off(const DcnP& p, const float* __restrict__ off_b, int t, long long pos) {
+  Off3 o = {0.f, 0.f, 0.f};
+  if (pos < p.P && t < p.T) {
+    o.d = off_b[(long long)(3 * t) * p.P + pos];
+    o.h = off_b[(long long)(3 * t + 1) * p.P + pos];
+    o.w = off_b[(long long)(3 * t + 2) * p.P + pos];
+  }
+  return o;
+}
+
+__device__ __forceinline__ Corner corner_from(const DcnP& p, int t, long long pos, const Off3& o) {
   Corner c;
   c.valid = 0;
   c.d0 = c.h0 = c.w0 = 0;
@@ -45,12 +60,9 @@ __device__ __forceinline__ Corner make_corner(const DcnP& p, const float* __rest
   const int yo = (int)((pos / p.Wo) % p.Ho);
   const int zo = (int)(pos / ((long long)p.Wo * p.Ho));
   const int tk = t % p.kw, tj = (t / p.kw) % p.kh, ti = t / (p.kw * p.kh);
-  const float od = off_b[(long long)(3 * t) * p.P + pos];
-  const float oh = off_b[(long long)(3 * t + 1) * p.P + pos];
-  const float ow = off_b[(long long)(3 * t + 2) * p.P + pos];
-  const float fd = (float)(zo * p.sd - p.pd + ti * p.dd) + od;
-  const float fh = (float)(yo * p.sh - p.ph + tj * p.dh) + oh;
-  const float fw = (float)(xo * p.sw - p.pw + tk * p.dw) + ow;
+  const float fd = (float)(zo * p.sd - p.pd + ti * p.dd) + o.d;
+  const float fh = (float)(yo * p.sh - p.ph + tj * p.dh) + o.h;
+  const float fw = (float)(xo * p.sw - p.pw + tk * p.dw) + o.w;
   if (fd > -1.f && fh > -1.f && fw > -1.f && fd < (float)p.D && fh < (float)p.H && fw < (float)p.W) {   // cuh:248
     const float d0 = floorf(fd), h0 = floorf(fh), w0 = floorf(fw);
     c.d0 = (int)d0; c.h0 = (int)h0; c.w0 = (int)w0;
@@ -58,6 +70,10 @@ __device__ __forceinline__ Corner make_corner(const DcnP& p, const float* __rest
     c.valid = 1;
   }
   return c;
+}
+
+__device__ __forceinline__ Corner make_corner(const DcnP& p, const float* __restrict__ off_b, int t, long long pos) {
+  return corner_from(p, t, pos, load_off(p, off_b, t, pos));
 }
 
 // corner j = (jd, jh, jw) bits; returns flat voxel index or -1 (cuh:43-65), weight (cuh:67-68)
@@ -317,10 +333,19 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
     for (int i = tid; i < regvox * GI_CS; i += 256) s_reg[i] = 0.0;
     const int cc = c0 + lc;
     const bool cok = cc < p.C;
+    Off3 onext = load_off(p, off_b, 0, ppos);
+    float bnext[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = 4 * ks + lg;
+      bnext[ks] = (cok && k < p.K) ? wt2[(long long)k * CT + cc] : 0.f;
+    }
     for (int t = 0; t < p.T; ++t) {
       __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
+      const Off3 ocur = onext;
+      onext = load_off(p, off_b, t + 1, ppos);                  // prefetch: consumed one barrier-to-barrier phase later
       if (tid < npos) {
-        const Corner cn = make_corner(p, off_b, t, ppos);
+        const Corner cn = corner_from(p, t, ppos, ocur);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float wg;
@@ -336,13 +361,17 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
           s_w[tid * 8 + j] = wg;
         }
       }
-      // B fragments: W[k][c0 + lc][t] (both lane halves of a group hold the same 8 channels)
+      // B fragments: W[k][c0 + lc][t] (both lane halves of a group hold the same 8 channels); next tap's are prefetched
       float bfrag[16];
-      const float* wtt = wt2 + (long long)t * p.K * CT + cc;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int k = 4 * ks + lg;
-        bfrag[ks] = (cok && k < p.K) ? wtt[(long long)k * CT] : 0.f;
+      for (int ks = 0; ks < 16; ++ks) bfrag[ks] = bnext[ks];
+      if (t + 1 < p.T) {
+        const float* wtn = wt2 + (long long)(t + 1) * p.K * CT + cc;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const int k = 4 * ks + lg;
+          bnext[ks] = (cok && k < p.K) ? wtn[(long long)k * CT] : 0.f;
+        }
       }
       __syncthreads();                                          // tables visible
 #pragma unroll
@@ -620,8 +649,11 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
   for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
     __syncthreads();                                   // previous chunk's region / S tile consumed
     stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
+    Off3 onext = load_off(p, off_b, 0, ppos);
     __syncthreads();
     for (int t = 0; t < p.T; ++t) {
+      const Off3 ocur = onext;
+      onext = load_off(p, off_b, t + 1, ppos);         // prefetch the next tap's offsets
       // weight fragments of this tap: issue early, consume after the sampling phase
       float a[RG_CH / 2][MT];
       const float* wtt = wt + ((long long)t * p.C + c0) * KT + l31;
@@ -631,7 +663,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
 #pragma unroll
         for (int m = 0; m < MT; ++m) a[sx][m] = (c0 + cc < p.C) ? wtt[(long long)cc * KT + m * 32] : 0.f;
       }
-      const Corner cn = make_corner(p, off_b, t, ppos);
+      const Corner cn = corner_from(p, t, ppos, ocur);
       const Samp sp = make_samp(p, g, c, cn);
       if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
       for (int ch = 0; ch < RG_CH; ++ch) {
@@ -716,7 +748,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
   for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
     __syncthreads();
     stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
+    Off3 onext = load_off(p, off_b, 0, ppos);
     for (int t = 0; t < p.T; ++t) {
+      const Off3 ocur = onext;
+      onext = load_off(p, off_b, t + 1, ppos);         // prefetch the next tap's offsets
       // A fragments: W[k][c0 + l15][t]
       float afrag[16];
       const float* wtt = wt2 + (long long)t * p.K * CT + c0 + l15;
@@ -725,7 +760,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
         const int k = 4 * ks + lg;
         afrag[ks] = (c0 + l15 < p.C && k < p.K) ? wtt[(long long)k * CT] : 0.f;
       }
-      const Corner cn = make_corner(p, off_b, t, ppos);
+      const Corner cn = corner_from(p, t, ppos, ocur);
       const Samp sp = make_samp(p, g, c, cn);
       __syncthreads();                                 // previous tap's s_gc consumed (and region staged)
 #pragma unroll
