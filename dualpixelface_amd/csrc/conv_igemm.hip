@@ -78,10 +78,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32 * MT;
   constexpr int TH = 4 * NT;
-  // LDS carve: [input tile CC*chanStrideMax][weights ntmax*CC*KT][tapoff MAXT][tapw MAXT][nv]
+  // LDS carve: [input tile CC*chanStrideMax][tapoff MAXT][tapw MAXT][nv][row tables]
   float* s_in = smem;
-  float* s_w = s_in + CC * p.chanStrideMax;
-  int* s_tapoff = (int*)(s_w + p.ntmax * CC * KT);
+  int* s_tapoff = (int*)(s_in + CC * p.chanStrideMax);
   int* s_tapw = s_tapoff + MAXT;
   int* s_nv = s_tapw + MAXT;
   int* s_rowoff = s_nv + 4;             // per staged row: source offset relative to (n, c0, i0d, i0h) -- no divisions in the loop
@@ -211,42 +210,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
           }
         }
       }
-      // ---- stage the weight slab of this channel chunk: [slot][cc][KT]
       const int nv = nvalid;
-      for (int r0 = wave_u * SU; r0 < nv * CC; r0 += 4 * SU) {
-        float w0[SU], w1[SU];
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          const int rowid = r0 + u;
-          const int slot = rowid / CC;
-          const int cc = rowid - slot * CC;
-          const int ic = c0 + cc;
-          const bool ok = rowid < nv * CC && ic < p.C;
-          const float* src = wt + ((long long)s_tapw[ok ? slot : 0] * p.C + (ok ? ic : 0)) * KT;
-          w0[u] = (ok && lane < KT) ? src[lane] : 0.f;
-          w1[u] = (ok && lane + 64 < KT) ? src[lane + 64] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          const int rowid = r0 + u;
-          if (rowid < nv * CC) {
-            float* dst = s_w + rowid * KT;
-            if (lane < KT) dst[lane] = w0[u];
-            if (KT > 64 && lane + 64 < KT) dst[lane + 64] = w1[u];
-          }
-        }
-      }
       __syncthreads();
       // ---- MFMA over (tap, channel pair); the operands of tap slot+1 are fetched from LDS while the MFMAs of
       //      tap `slot` issue (software pipeline, two register sets)
+      // The weight fragments (A operand) come straight from the repacked [tap][channel][KT] tensor in global memory: every
+      // workgroup reads the same <= 442 KB, so they are L2-resident, each half-wave load is one contiguous 128-B segment,
+      // and keeping them out of LDS leaves room for more resident workgroups.
       float a_cur[CC / 2][MT], b_cur[CC / 2][NT], a_nxt[CC / 2][MT], b_nxt[CC / 2][NT];
       {
         const int toff = s_tapoff[0];
-        const float* wrow = s_w + hh * KT + l31;
+        const float* wrow = wt + ((long long)s_tapw[0] * p.C + c0 + hh) * KT + l31;
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp) {
+          const bool cok = c0 + 2 * cp + hh < p.C;
 #pragma unroll
-          for (int m = 0; m < MT; ++m) a_cur[cp][m] = wrow[(2 * cp) * KT + m * 32];
+          for (int m = 0; m < MT; ++m) a_cur[cp][m] = cok ? wrow[(2 * cp) * KT + m * 32] : 0.f;
 #pragma unroll
           for (int t = 0; t < NT; ++t) b_cur[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
         }
@@ -254,11 +233,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
       for (int slot = 0; slot < nv; ++slot) {
         if (slot + 1 < nv) {
           const int toff = s_tapoff[slot + 1];
-          const float* wrow = s_w + ((slot + 1) * CC + hh) * KT + l31;
+          const float* wrow = wt + ((long long)s_tapw[slot + 1] * p.C + c0 + hh) * KT + l31;
 #pragma unroll
           for (int cp = 0; cp < CC / 2; ++cp) {
+            const bool cok = c0 + 2 * cp + hh < p.C;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a_nxt[cp][m] = wrow[(2 * cp) * KT + m * 32];
+            for (int m = 0; m < MT; ++m) a_nxt[cp][m] = cok ? wrow[(2 * cp) * KT + m * 32] : 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) b_nxt[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
           }
@@ -555,7 +535,7 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   if (ext_w > 128) return DPF_ERR_UNSUPPORTED;   // staging handles two 64-lane column groups
   p.chanStrideMax = ext_d * ext_h * ext_w;
   p.ntmax = ntmax;
-  auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + ntmax * CC * KT + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float); };
+  auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float); };
   int CC = 8;
   static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 64 * 1024;   // tuning knob
   if (lds_bytes(8) > (size_t)lds_cap || p.C <= 4) CC = 4;
