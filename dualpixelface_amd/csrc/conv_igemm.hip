@@ -217,31 +217,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
       // The weight fragments (A operand) come straight from the repacked [tap][channel][KT] tensor in global memory: every
       // workgroup reads the same <= 442 KB, so they are L2-resident, each half-wave load is one contiguous 128-B segment,
       // and keeping them out of LDS leaves room for more resident workgroups.
-      float a_cur[CC / 2][MT], b_cur[CC / 2][NT], a_nxt[CC / 2][MT], b_nxt[CC / 2][NT];
-      {
-        const int toff = s_tapoff[0];
-        const float* wrow = wt + ((long long)s_tapw[0] * p.C + c0 + hh) * KT + l31;
+      float a_cur[CC / 2][MT], b_cur[CC / 2][NT], a_n1[CC / 2][MT], a_n2[CC / 2][MT], b_nxt[CC / 2][NT];
+      auto load_a = [&](int slot, float (&dst)[CC / 2][MT]) {
+        const int sl = slot < nv ? slot : nv - 1;
+        const float* wrow = wt + ((long long)s_tapw[sl] * p.C + c0 + hh) * KT + l31;
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp) {
           const bool cok = c0 + 2 * cp + hh < p.C;
 #pragma unroll
-          for (int m = 0; m < MT; ++m) a_cur[cp][m] = cok ? wrow[(2 * cp) * KT + m * 32] : 0.f;
+          for (int m = 0; m < MT; ++m) dst[cp][m] = cok ? wrow[(2 * cp) * KT + m * 32] : 0.f;
+        }
+      };
+      load_a(0, a_cur);
+      load_a(1, a_n1);
+      {
+        const int toff = s_tapoff[0];
+#pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp)
 #pragma unroll
           for (int t = 0; t < NT; ++t) b_cur[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
-        }
       }
       for (int slot = 0; slot < nv; ++slot) {
-        if (slot + 1 < nv) {
+        load_a(slot + 2, a_n2);                       // weights: two taps ahead (L2 latency)
+        if (slot + 1 < nv) {                          // input patch: one tap ahead (LDS latency)
           const int toff = s_tapoff[slot + 1];
-          const float* wrow = wt + ((long long)s_tapw[slot + 1] * p.C + c0 + hh) * KT + l31;
 #pragma unroll
-          for (int cp = 0; cp < CC / 2; ++cp) {
-            const bool cok = c0 + 2 * cp + hh < p.C;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a_nxt[cp][m] = cok ? wrow[(2 * cp) * KT + m * 32] : 0.f;
+          for (int cp = 0; cp < CC / 2; ++cp)
 #pragma unroll
             for (int t = 0; t < NT; ++t) b_nxt[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
-          }
         }
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp)
@@ -252,7 +255,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) a_cur[cp][m] = a_nxt[cp][m];
+          for (int m = 0; m < MT; ++m) {
+            a_cur[cp][m] = a_n1[cp][m];
+            a_n1[cp][m] = a_n2[cp][m];
+          }
 #pragma unroll
           for (int t = 0; t < NT; ++t) b_cur[cp][t] = b_nxt[cp][t];
         }
@@ -537,7 +543,7 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   p.ntmax = ntmax;
   auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float); };
   int CC = 8;
-  static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 64 * 1024;   // tuning knob
+  static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 40 * 1024;   // tuning knob
   if (lds_bytes(8) > (size_t)lds_cap || p.C <= 4) CC = 4;
   const size_t lds = lds_bytes(CC);
   if (lds > 160 * 1024) return DPF_ERR_UNSUPPORTED;
