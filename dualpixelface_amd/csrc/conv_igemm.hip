@@ -38,7 +38,6 @@ struct ConvP {
   int chanStrideMax;              // floats per channel of the LDS input tile (host worst case)
   int ntmax;                      // max valid taps per class
   int maxrows;                    // LDS input-tile rows per channel chunk (host worst case)
-  int dbuf;                       // 1: two LDS input buffers (stage chunk i+1 while computing chunk i)
 };
 
 struct DimTap {
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
   constexpr int TH = 4 * NT;
   // LDS carve: [input tile CC*chanStrideMax][tapoff MAXT][tapw MAXT][nv][row tables]
   float* s_in = smem;
-  int* s_tapoff = (int*)(s_in + (p.dbuf ? 2 : 1) * CC * p.chanStrideMax);
+  int* s_tapoff = (int*)(s_in + CC * p.chanStrideMax);
   int* s_tapw = s_tapoff + MAXT;
   int* s_nv = s_tapw + MAXT;
   int* s_rowoff = s_nv + 4;             // per staged row: source offset relative to (n, c0, i0d, i0h) -- no divisions in the loop
@@ -180,61 +179,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
       s_rowpr[rowid] = (pl << 16) | rr | (cc << 24);
     }
 
-    // ---- global -> LDS staging of one channel chunk, in batches of SU rows per wave (one LDS row per (channel, plane,
-    //      row), lanes along W; two 64-lane column groups).  issue() only starts the loads, commit() writes them to LDS,
-    //      so a batch can be in flight while MFMAs of the current chunk issue.
-    constexpr int SU = 8;
-    const int nbatch = (in_rows + 4 * SU - 1) / (4 * SU);   // batches per wave
-    float v0[SU], v1[SU];
-    auto issue = [&](int bi, int c0s) {
-      const float* xbase = xn + (long long)c0s * x_chan + ((long long)i0d * p.IH + i0h) * p.IW;
-      const int r0 = (bi * 4 + wave_u) * SU;
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+      __syncthreads();   // previous chunk fully consumed (also orders the tap / row tables on the first trip)
+      const float* xbase = xn + (long long)c0 * x_chan + ((long long)i0d * p.IH + i0h) * p.IW;
+      // ---- stage the input patch: one LDS row per (channel, plane, row), lanes along W.  SU rows are fetched
+      //      back-to-back before any is written so each wave keeps SU (x2) global loads in flight.
+      constexpr int SU = 8;
+      for (int r0 = wave_u * SU; r0 < in_rows; r0 += 4 * SU) {
+        float v0[SU], v1[SU];
 #pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int rowid = r0 + u;
-        const int rsafe = rowid < in_rows ? rowid : 0;
-        const int pr = s_rowpr[rsafe];
-        const int cc = pr >> 24, pl = (pr >> 16) & 0xff, rr = pr & 0xffff;
-        const int ic = c0s + cc, id = i0d + pl, ih = i0h + rr;
-        const bool rowok = (rowid < in_rows) && (ic < p.C) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
-        const float* src = xbase + s_rowoff[rsafe];
-        const int iw0 = i0w + lane, iw1 = iw0 + 64;
-        v0[u] = (rowok && lane < ext_w && iw0 >= 0 && iw0 < p.IW) ? src[iw0] : 0.f;
-        v1[u] = (rowok && lane + 64 < ext_w && iw1 >= 0 && iw1 < p.IW) ? src[iw1] : 0.f;
-      }
-    };
-    auto commit = [&](int bi, float* buf) {
-      const int r0 = (bi * 4 + wave_u) * SU;
+        for (int u = 0; u < SU; ++u) {
+          const int rowid = r0 + u;
+          const int rsafe = rowid < in_rows ? rowid : 0;
+          const int pr = s_rowpr[rsafe];
+          const int cc = pr >> 24, pl = (pr >> 16) & 0xff, rr = pr & 0xffff;
+          const int ic = c0 + cc, id = i0d + pl, ih = i0h + rr;
+          const bool rowok = (rowid < in_rows) && (ic < p.C) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
+          const float* src = xbase + s_rowoff[rsafe];
+          const int iw0 = i0w + lane, iw1 = iw0 + 64;
+          v0[u] = (rowok && lane < ext_w && iw0 >= 0 && iw0 < p.IW) ? src[iw0] : 0.f;
+          v1[u] = (rowok && lane + 64 < ext_w && iw1 >= 0 && iw1 < p.IW) ? src[iw1] : 0.f;
+        }
 #pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int rowid = r0 + u;
-        if (rowid < in_rows) {
-          float* dst = buf + rowid * ext_w;   // rows are contiguous: cc*chanStride + rem*ext_w == rowid*ext_w
-          if (lane < ext_w) dst[lane] = v0[u];
-          if (lane + 64 < ext_w) dst[lane + 64] = v1[u];
+        for (int u = 0; u < SU; ++u) {
+          const int rowid = r0 + u;
+          if (rowid < in_rows) {
+            float* dst = s_in + rowid * ext_w;   // rows are contiguous: cc*chanStride + rem*ext_w == rowid*ext_w
+            if (lane < ext_w) dst[lane] = v0[u];
+            if (lane + 64 < ext_w) dst[lane + 64] = v1[u];
+          }
         }
       }
-    };
-
-    const int nv = nvalid;
-    float* bufs[2] = {s_in, s_in + (p.dbuf ? CC * p.chanStrideMax : 0)};
-    int cur = 0;
-    __syncthreads();                       // tap / row tables visible
-    for (int bi = 0; bi < nbatch; ++bi) {  // prologue: first chunk
-      issue(bi, 0);
-      commit(bi, bufs[0]);
-    }
-    __syncthreads();
-
-    for (int c0 = 0; c0 < p.C; c0 += CC) {
-      const float* cbuf = bufs[cur];
-      float* nbuf = bufs[cur ^ 1];
-      const bool prefetch = p.dbuf && (c0 + CC < p.C);
-      // ---- MFMA over (tap, channel pair).  The weight fragments (A operand) come straight from the repacked
-      //      [tap][channel][KT] tensor in global memory (every workgroup reads the same <= 442 KB: L2-resident, one
-      //      contiguous 128-B segment per half-wave), fetched two taps ahead; the input fragments (B operand) come
-      //      from LDS one tap ahead; and one staging batch of the NEXT channel chunk is issued per tap and committed to
-      //      the other LDS buffer one tap later, so global latency hides behind the 16+ MFMAs of a tap.
+      const int nv = nvalid;
+      __syncthreads();
+      // ---- MFMA over (tap, channel pair); the operands of tap slot+1 are fetched from LDS while the MFMAs of
+      //      tap `slot` issue (software pipeline, two register sets)
+      // The weight fragments (A operand) come straight from the repacked [tap][channel][KT] tensor in global memory: every
+      // workgroup reads the same <= 442 KB, so they are L2-resident, each half-wave load is one contiguous 128-B segment,
+      // and keeping them out of LDS leaves room for more resident workgroups.
       float a_cur[CC / 2][MT], b_cur[CC / 2][NT], a_n1[CC / 2][MT], a_n2[CC / 2][MT], b_nxt[CC / 2][NT];
       auto load_a = [&](int slot, float (&dst)[CC / 2][MT]) {
         const int sl = slot < nv ? slot : nv - 1;
@@ -253,20 +235,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) b_cur[cp][t] = cbuf[lanebase[t] + (2 * cp) * chanStride + toff];
+          for (int t = 0; t < NT; ++t) b_cur[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
       }
       for (int slot = 0; slot < nv; ++slot) {
-        if (prefetch) {
-          if (slot >= 1 && slot - 1 < nbatch) commit(slot - 1, nbuf);
-          if (slot < nbatch) issue(slot, c0 + CC);
-        }
         load_a(slot + 2, a_n2);                       // weights: two taps ahead (L2 latency)
         if (slot + 1 < nv) {                          // input patch: one tap ahead (LDS latency)
           const int toff = s_tapoff[slot + 1];
 #pragma unroll
           for (int cp = 0; cp < CC / 2; ++cp)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b_nxt[cp][t] = cbuf[lanebase[t] + (2 * cp) * chanStride + toff];
+            for (int t = 0; t < NT; ++t) b_nxt[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
         }
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp)
@@ -283,25 +261,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
           }
 #pragma unroll
           for (int t = 0; t < NT; ++t) b_cur[cp][t] = b_nxt[cp][t];
-        }
-      }
-      if (c0 + CC < p.C) {
-        if (p.dbuf) {
-          // batches the tap loop did not get to (few-tap kernels): finish them here
-          if (nv - 1 < nbatch && nv >= 1) commit(nv - 1, nbuf);
-          for (int bi = nv; bi < nbatch; ++bi) {
-            issue(bi, c0 + CC);
-            commit(bi, nbuf);
-          }
-          __syncthreads();                  // next buffer complete, current buffer free
-          cur ^= 1;
-        } else {
-          __syncthreads();                  // single buffer: everyone done reading before it is overwritten
-          for (int bi = 0; bi < nbatch; ++bi) {
-            issue(bi, c0 + CC);
-            commit(bi, nbuf);
-          }
-          __syncthreads();
         }
       }
     }
@@ -582,22 +541,13 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   if (ext_w > 128) return DPF_ERR_UNSUPPORTED;   // staging handles two 64-lane column groups
   p.chanStrideMax = ext_d * ext_h * ext_w;
   p.ntmax = ntmax;
-  auto lds_bytes = [&](int CC, int dbuf) {
-    return (size_t)((dbuf ? 2 : 1) * CC * p.chanStrideMax + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float);
-  };
-  // tuning knobs (bytes): prefer 8-channel chunks and double buffering while the workgroup's LDS stays under the cap
-  static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 64 * 1024;
-  static const int want_dbuf = getenv("DPF_CONV_DBUF") ? atoi(getenv("DPF_CONV_DBUF")) : 1;
-  int CC = 8, dbuf = want_dbuf && p.C > 8;
-  if (p.C <= 4 || lds_bytes(8, dbuf) > (size_t)lds_cap) {
-    CC = 4;
-    dbuf = want_dbuf && p.C > 4;
-    if (lds_bytes(4, dbuf) > 150 * 1024) dbuf = 0;
-  }
-  const size_t lds = lds_bytes(CC, dbuf);
+  auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float); };
+  int CC = 8;
+  static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 40 * 1024;   // tuning knob
+  if (lds_bytes(8) > (size_t)lds_cap || p.C <= 4) CC = 4;
+  const size_t lds = lds_bytes(CC);
   if (lds > 160 * 1024) return DPF_ERR_UNSUPPORTED;
   p.maxrows = CC * ext_d * ext_h;
-  p.dbuf = dbuf;
 #define DPF_IG(M, Cc, Nt) return launch_igemm<M, Cc, Nt>(x, wt_ws, bias, out, p, lds, st)
   if (CC == 8) {
     switch (MT) { case 1: DPF_IG(1, 8, 4); case 2: DPF_IG(2, 8, 2); case 3: DPF_IG(3, 8, 2); default: DPF_IG(4, 8, 2); }
