@@ -493,9 +493,11 @@ __global__ __launch_bounds__(256) void dcn_wgrad_kernel(const float* __restrict_
 // Region-staged kernels.  A workgroup owns TZ x 2 x 32 output voxels (TZ = min(Do, 4)); the haloed input region
 // [RZ][RY][RX] (halo RG_R on top of the kernel extent) of a 16-channel chunk is staged in LDS once and all 27 taps sample it
 // with ds_reads (8 per sample) instead of 8 scattered global loads; samples whose 2x2x2 corner block leaves the staged box
-// take a global-memory slow path.  Channel-first LDS image [16][RV]: lanes are consecutive voxels, so the reads of a
-// wave land on consecutive banks whenever the offsets are smooth.
+// take a global-memory slow path.
 constexpr int RG_R = 3, RG_CH = 16, RG_TY = 2, RG_TX = 32;
+constexpr int RG_VS = 20;   // floats per voxel in the channel-last LDS image [RV][RG_VS]: 16 channels + 4 pad.  A lane reads the 16
+                            // channels of a corner as 4 ds_read_b128; 5*vox mod 16 is a permutation, so 16 consecutive voxels are
+                            // bank-conflict free
 
 struct RegGeo {
   int TZ, RZmax, RY, RX, RV;
@@ -550,7 +552,7 @@ __device__ __forceinline__ void stage_region(const DcnP& p, const RegGeo& g, con
       if (row < nrows && lane < g.RX) {
         const int ch = row / rows_per_ch;
         const int rem = row - ch * rows_per_ch;
-        s_reg[ch * g.RV + rem * g.RX + lane] = v[u];
+        s_reg[(rem * g.RX + lane) * RG_VS + ch] = v[u];
       }
     }
   }
@@ -592,27 +594,21 @@ __device__ __forceinline__ Samp make_samp(const DcnP& p, const RegGeo& g, const 
   return s;
 }
 
-// the 8 corner values of channel `ch` (LDS fast path or global slow path); v[jd][jh][jw]
-__device__ __forceinline__ void corner_values(const DcnP& p, const RegGeo& g, const Samp& s, const Corner& cn, const float* s_reg, int ch,
-                                              const float* __restrict__ xc /* global x[b, c] or nullptr */, float v[2][2][2]) {
-  if (s.fast) {
-    const float* r = s_reg + ch * g.RV + s.base;
-    v[0][0][0] = r[0];          v[0][0][1] = r[1];
-    v[0][1][0] = r[g.RX];       v[0][1][1] = r[g.RX + 1];
-    v[1][0][0] = r[s.dzs];      v[1][0][1] = r[s.dzs + 1];
-    v[1][1][0] = r[s.dzs + g.RX]; v[1][1][1] = r[s.dzs + g.RX + 1];
-  } else {
+// 16 channels of corner (jd, jh, jw): 4 x ds_read_b128 from the channel-last image (fast path)
+__device__ __forceinline__ void corner_vec(const RegGeo& g, const Samp& s, const float* s_reg, int jd, int jh, int jw, float v[RG_CH]) {
+  const float4* r = reinterpret_cast<const float4*>(s_reg + (s.base + jd * s.dzs + jh * g.RX + jw) * RG_VS);
 #pragma unroll
-    for (int jd = 0; jd < 2; ++jd)
-#pragma unroll
-      for (int jh = 0; jh < 2; ++jh)
-#pragma unroll
-        for (int jw = 0; jw < 2; ++jw) {
-          const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
-          const bool in = xc && d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
-          v[jd][jh][jw] = in ? xc[((long long)d * p.H + h) * p.W + w] : 0.f;
-        }
+  for (int q = 0; q < RG_CH / 4; ++q) {
+    const float4 f = r[q];
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
   }
+}
+
+// one corner value of channel pointer xc from global memory (slow path); 0 outside the volume
+__device__ __forceinline__ float corner_global(const DcnP& p, const Corner& cn, const float* __restrict__ xc, int jd, int jh, int jw) {
+  const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
+  const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
+  return in ? xc[((long long)d * p.H + h) * p.W + w] : 0.f;
 }
 
 constexpr int ST = 256 + 4;   // padded row of the [16][256] sample / gcol tile
@@ -624,8 +620,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
                                                              float* __restrict__ out, DcnP p, RegGeo g) {
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32 * MT;
-  float* s_reg = smem;                       // [16][RV]
-  float* s_S = s_reg + RG_CH * g.RV;         // [16][ST]
+  float* s_reg = smem;                       // [RV][RG_VS]
+  float* s_S = s_reg + RG_VS * g.RV;         // [16][ST]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const RegCtx c = region_ctx(p, g, blockIdx.x);
@@ -666,15 +662,28 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
       const Corner cn = corner_from(p, t, ppos, ocur);
       const Samp sp = make_samp(p, g, c, cn);
       if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
-      for (int ch = 0; ch < RG_CH; ++ch) {
-        float val = 0.f;
-        if (sp.valid && c0 + ch < p.C) {
-          float v[2][2][2];
-          corner_values(p, g, sp, cn, s_reg, ch, xb + (long long)(c0 + ch) * chan, v);
-          val = sp.wz[0] * (sp.wy[0] * (sp.wx[0] * v[0][0][0] + sp.wx[1] * v[0][0][1]) + sp.wy[1] * (sp.wx[0] * v[0][1][0] + sp.wx[1] * v[0][1][1])) +
-                sp.wz[1] * (sp.wy[0] * (sp.wx[0] * v[1][0][0] + sp.wx[1] * v[1][0][1]) + sp.wy[1] * (sp.wx[0] * v[1][1][0] + sp.wx[1] * v[1][1][1]));
+      {
+        float val[RG_CH];
+#pragma unroll
+        for (int ch = 0; ch < RG_CH; ++ch) val[ch] = 0.f;
+        if (sp.valid) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+            const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+            if (sp.fast) {
+              float v[RG_CH];
+              corner_vec(g, sp, s_reg, jd, jh, jw, v);
+#pragma unroll
+              for (int ch = 0; ch < RG_CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+            } else if (wj != 0.f) {
+              for (int ch = 0; ch < RG_CH; ++ch)
+                if (c0 + ch < p.C) val[ch] = fmaf(wj, corner_global(p, cn, xb + (long long)(c0 + ch) * chan, jd, jh, jw), val[ch]);
+            }
+          }
         }
-        s_S[ch * ST + tid] = val;
+#pragma unroll
+        for (int ch = 0; ch < RG_CH; ++ch) s_S[ch * ST + tid] = val[ch];
       }
       __syncthreads();
 #pragma unroll
@@ -715,8 +724,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
                                                                     const float* __restrict__ wt2 /*[T][K][CT]*/, const float* __restrict__ go,
                                                                     float* __restrict__ doff, DcnP p, RegGeo g, int CT) {
   extern __shared__ __align__(16) float smem[];
-  float* s_reg = smem;                       // [16][RV]
-  float* s_gc = s_reg + RG_CH * g.RV;        // [16][ST]
+  float* s_reg = smem;                       // [RV][RG_VS]
+  float* s_gc = s_reg + RG_VS * g.RV;        // [16][ST]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const RegCtx c = region_ctx(p, g, blockIdx.x);
@@ -774,21 +783,27 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
       __syncthreads();
       float gd = 0.f, gh = 0.f, gw = 0.f;
       if (sp.valid) {
-        for (int ch = 0; ch < RG_CH; ++ch) {
-          if (c0 + ch >= p.C) break;
-          float v[2][2][2];
-          corner_values(p, g, sp, cn, s_reg, ch, xb + (long long)(c0 + ch) * chan, v);
-          const float gcv = s_gc[ch * ST + tid];
-          // d/dd: high-z plane minus low-z plane, bilinear in (h, w); in-volume masks as in cuh:131-187
-          const float pz0 = sp.wy[0] * (sp.wx[0] * v[0][0][0] + sp.wx[1] * v[0][0][1]) + sp.wy[1] * (sp.wx[0] * v[0][1][0] + sp.wx[1] * v[0][1][1]);
-          const float pz1 = sp.wy[0] * (sp.wx[0] * v[1][0][0] + sp.wx[1] * v[1][0][1]) + sp.wy[1] * (sp.wx[0] * v[1][1][0] + sp.wx[1] * v[1][1][1]);
-          gd += gcv * (sp.mz[1] * pz1 - sp.mz[0] * pz0);
-          const float py0 = sp.wz[0] * (sp.wx[0] * v[0][0][0] + sp.wx[1] * v[0][0][1]) + sp.wz[1] * (sp.wx[0] * v[1][0][0] + sp.wx[1] * v[1][0][1]);
-          const float py1 = sp.wz[0] * (sp.wx[0] * v[0][1][0] + sp.wx[1] * v[0][1][1]) + sp.wz[1] * (sp.wx[0] * v[1][1][0] + sp.wx[1] * v[1][1][1]);
-          gh += gcv * (sp.my[1] * py1 - sp.my[0] * py0);
-          const float px0 = sp.wz[0] * (sp.wy[0] * v[0][0][0] + sp.wy[1] * v[0][1][0]) + sp.wz[1] * (sp.wy[0] * v[1][0][0] + sp.wy[1] * v[1][1][0]);
-          const float px1 = sp.wz[0] * (sp.wy[0] * v[0][0][1] + sp.wy[1] * v[0][1][1]) + sp.wz[1] * (sp.wy[0] * v[1][0][1] + sp.wy[1] * v[1][1][1]);
-          gw += gcv * (sp.mx[1] * px1 - sp.mx[0] * px0);
+        float gcv[RG_CH];
+#pragma unroll
+        for (int ch = 0; ch < RG_CH; ++ch) gcv[ch] = (c0 + ch < p.C) ? s_gc[ch * ST + tid] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+          // dot_j = sum_ch gcol[ch] * x[corner j][ch]; the three coordinate derivatives weight it with the other two
+          // trilinear factors and the signed in-volume mask of their own axis (cuh:131-187)
+          float dot = 0.f;
+          if (sp.fast) {
+            float v[RG_CH];
+            corner_vec(g, sp, s_reg, jd, jh, jw, v);
+#pragma unroll
+            for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
+          } else {
+            for (int ch = 0; ch < RG_CH; ++ch)
+              if (c0 + ch < p.C) dot = fmaf(gcv[ch], corner_global(p, cn, xb + (long long)(c0 + ch) * chan, jd, jh, jw), dot);
+          }
+          gd += (jd ? sp.mz[1] : -sp.mz[0]) * sp.wy[jh] * sp.wx[jw] * dot;
+          gh += (jh ? sp.my[1] : -sp.my[0]) * sp.wz[jd] * sp.wx[jw] * dot;
+          gw += (jw ? sp.mx[1] : -sp.mx[0]) * sp.wz[jd] * sp.wy[jh] * dot;
         }
       }
       if (pvalid) {   // this thread owns (t, voxel): accumulate over channel chunks with plain read-modify-write
@@ -814,7 +829,7 @@ int region_geo(RegGeo& g, const DcnP& p) {
   g.tilesZ = dpf_div_up(p.Do, g.TZ);
   g.tilesY = dpf_div_up(p.Ho, RG_TY);
   g.tilesX = dpf_div_up(p.Wo, RG_TX);
-  const size_t lds = sizeof(float) * ((size_t)RG_CH * g.RV + (size_t)RG_CH * ST);
+  const size_t lds = sizeof(float) * ((size_t)RG_VS * g.RV + (size_t)RG_CH * ST);
   const long long blocks = (long long)p.B * g.tilesZ * g.tilesY * g.tilesX;
   if (g.RX > 64 || lds > 150 * 1024 || blocks >= 0x7fffffffLL || p.K > 128) return DPF_ERR_UNSUPPORTED;
   return DPF_OK;
@@ -874,7 +889,7 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
   hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * C * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0);
   RegGeo g{};
   if (region_geo(g, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
-    const size_t lds = sizeof(float) * ((size_t)RG_CH * g.RV + (size_t)RG_CH * ST);
+    const size_t lds = sizeof(float) * ((size_t)RG_VS * g.RV + (size_t)RG_CH * ST);
     const dim3 grid((unsigned)((long long)B * g.tilesZ * g.tilesY * g.tilesX));
 #define DPF_FR(M)                                                                                                  \
   {                                                                                                                \
@@ -947,7 +962,7 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
   }
   RegGeo rg{};
   if (dx_done && K <= 64 && region_geo(rg, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
-    const size_t lds = sizeof(float) * ((size_t)RG_CH * rg.RV + (size_t)RG_CH * ST);
+    const size_t lds = sizeof(float) * ((size_t)RG_VS * rg.RV + (size_t)RG_CH * ST);
     const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
     if (set_lds(dcn_bwd_offset_region_kernel, lds) != DPF_OK) return DPF_ERR_LAUNCH;
     hipLaunchKernelGGL(dcn_bwd_offset_region_kernel, grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, p, rg, CT);
