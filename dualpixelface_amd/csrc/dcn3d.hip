@@ -611,6 +611,42 @@ __device__ __forceinline__ float corner_global(const DcnP& p, const Corner& cn, 
   return in ? xc[((long long)d * p.H + h) * p.W + w] : 0.f;
 }
 
+// slow path: the 16 channels of corner (jd, jh, jw) from global memory, issued as 16 independent loads
+__device__ __forceinline__ void corner_vec_global(const DcnP& p, const Corner& cn, const float* __restrict__ xb, int c0, long long chan, int jd,
+                                                  int jh, int jw, float v[RG_CH]) {
+  const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
+  const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
+  const long long vox = in ? ((long long)d * p.H + h) * p.W + w : 0;
+#pragma unroll
+  for (int ch = 0; ch < RG_CH; ++ch) {
+    const int c = c0 + ch < p.C ? c0 + ch : p.C - 1;
+    const float x = xb[(long long)c * chan + vox];
+    v[ch] = (in && c0 + ch < p.C) ? x : 0.f;
+  }
+}
+
+// trilinear samples of the 16 channels of the staged chunk at one (voxel, tap)
+__device__ __forceinline__ void sample_chunk(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
+                                             const float* __restrict__ xb, int c0, long long chan, float val[RG_CH]) {
+#pragma unroll
+  for (int ch = 0; ch < RG_CH; ++ch) val[ch] = 0.f;
+  if (!sp.valid) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+    const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+    float v[RG_CH];
+    if (sp.fast) {
+      corner_vec(g, sp, s_reg, jd, jh, jw, v);
+    } else {
+      if (wj == 0.f) continue;
+      corner_vec_global(p, cn, xb, c0, chan, jd, jh, jw, v);
+    }
+#pragma unroll
+    for (int ch = 0; ch < RG_CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+  }
+}
+
 constexpr int ST = 256 + 4;   // padded row of the [16][256] sample / gcol tile
 
 // ---------------------------------------------------------------------------------------------------- forward
@@ -664,24 +700,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
       if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
       {
         float val[RG_CH];
-#pragma unroll
-        for (int ch = 0; ch < RG_CH; ++ch) val[ch] = 0.f;
-        if (sp.valid) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-            const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
-            if (sp.fast) {
-              float v[RG_CH];
-              corner_vec(g, sp, s_reg, jd, jh, jw, v);
-#pragma unroll
-              for (int ch = 0; ch < RG_CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
-            } else if (wj != 0.f) {
-              for (int ch = 0; ch < RG_CH; ++ch)
-                if (c0 + ch < p.C) val[ch] = fmaf(wj, corner_global(p, cn, xb + (long long)(c0 + ch) * chan, jd, jh, jw), val[ch]);
-            }
-          }
-        }
+        sample_chunk(p, g, sp, cn, s_reg, xb, c0, chan, val);
 #pragma unroll
         for (int ch = 0; ch < RG_CH; ++ch) s_S[ch * ST + tid] = val[ch];
       }
@@ -798,8 +817,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
 #pragma unroll
             for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
           } else {
-            for (int ch = 0; ch < RG_CH; ++ch)
-              if (c0 + ch < p.C) dot = fmaf(gcv[ch], corner_global(p, cn, xb + (long long)(c0 + ch) * chan, jd, jh, jw), dot);
+            float v[RG_CH];
+            corner_vec_global(p, cn, xb, c0, chan, jd, jh, jw, v);
+#pragma unroll
+            for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
           }
           gd += (jd ? sp.mz[1] : -sp.mz[0]) * sp.wy[jh] * sp.wx[jw] * dot;
           gh += (jh ? sp.my[1] : -sp.my[0]) * sp.wz[jd] * sp.wx[jw] * dot;
@@ -815,6 +836,84 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- grad_weight
+// dW[k][c][t] = sum_{b,p} go[k][p] * S[c][p;t].  Per (chunk, tap) the sampled tile S[16][256] goes to LDS and each wave
+// contracts it against its 16 output channels of go (kept in registers) with v_mfma_f32_16x16x4_f32 (D row = k, col = c);
+// the [64 x 16] partial is added into one of NREP replicas of a [T][chunk][64][16] scratch tensor (64-B contiguous atomics,
+// replicas spread the same-address contention of the 6144 workgroups) that a second kernel folds into dW[k][c][t].
+constexpr int WG_NREP = 8;
+
+__global__ __launch_bounds__(256) void dcn_wgrad_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                               const float* __restrict__ go, float* __restrict__ dwtmp, DcnP p, RegGeo g,
+                                                               int nchunk) {
+  extern __shared__ __align__(16) float smem[];
+  float* s_reg = smem;                       // [RV][RG_VS]
+  float* s_S = s_reg + RG_VS * g.RV;         // [16][ST]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const RegCtx c = region_ctx(p, g, blockIdx.x);
+  const long long chan = (long long)p.D * p.H * p.W;
+  const float* xb = x + (long long)c.b * p.C * chan;
+  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
+  const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
+  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
+  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
+
+  // A fragments: go[k = 16*wave + l15][voxel 4*ks + lg], 64 k-steps over the 256 voxels of the tile
+  float afrag[64];
+  const int kk = 16 * wave + l15;
+#pragma unroll
+  for (int ks = 0; ks < 64; ++ks) {
+    const int pl = 4 * ks + lg;
+    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+    const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
+    const bool ok = kk < p.K && az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
+    afrag[ks] = ok ? go[((long long)c.b * p.K + kk) * p.P + ((long long)gz * p.Ho + gy) * p.Wo + gx] : 0.f;
+  }
+  float* rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
+
+  for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
+    __syncthreads();
+    stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
+    Off3 onext = load_off(p, off_b, 0, ppos);
+    for (int t = 0; t < p.T; ++t) {
+      const Off3 ocur = onext;
+      onext = load_off(p, off_b, t + 1, ppos);
+      const Corner cn = corner_from(p, t, ppos, ocur);
+      const Samp sp = make_samp(p, g, c, cn);
+      __syncthreads();                                 // region staged / previous tap's s_S consumed
+      {
+        float val[RG_CH];
+        sample_chunk(p, g, sp, cn, s_reg, xb, c0, chan, val);
+#pragma unroll
+        for (int ch = 0; ch < RG_CH; ++ch) s_S[ch * ST + tid] = val[ch];
+      }
+      __syncthreads();
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], s_S[l15 * ST + 4 * ks + lg], acc, 0, 0, 0);
+      if (c0 + l15 < p.C) {
+        float* dst = rep + ((long long)(t * nchunk + c0 / RG_CH) * 64 + 16 * wave + 4 * lg) * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * wave + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], acc[r]);
+      }
+    }
+  }
+}
+
+// dW[k][c][t] = sum_rep tmp[rep][t][c/16][k][c%16]
+__global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __restrict__ dw, int K, int C, int T, int nchunk) {
+  const int total = K * C * T;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int t = i % T, cc = (i / T) % C, k = i / (T * C);
+    float s = 0.f;
+    for (int r = 0; r < WG_NREP; ++r) s += dwtmp[(((long long)r * T + t) * nchunk + cc / RG_CH) * 64 * 16 + k * 16 + (cc % RG_CH)];
+    dw[i] = s;
   }
 }
 
@@ -869,7 +968,8 @@ int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void*
 long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
   const long long a = (long long)T * C * (((K + 31) / 32) * 32);
   const long long b = (long long)T * K * (((C + 31) / 32) * 32);
-  return a > b ? a : b;
+  const long long repack = ((a > b ? a : b) + 63) & ~63LL;
+  return repack + (long long)WG_NREP * T * ((C + RG_CH - 1) / RG_CH) * 64 * 16;   // + grad_weight scratch replicas
 }
 
 // Mirrors DCN.deform_conv_forward(input, weight, bias, offset, kd,kh,kw, sd,sh,sw, pd,ph,pw, dd,dh,dw, group, deformable_group,
@@ -983,6 +1083,19 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
     switch (MTC) { case 1: DPF_D(1); break; case 2: DPF_D(2); break; case 3: DPF_D(3); break; default: DPF_D(4); break; }
 #undef DPF_D
   }
+  RegGeo wg{};
+  if (K <= 64 && region_geo(wg, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
+    const long long a_ = (long long)p.T * C * (((K + 31) / 32) * 32), b_ = (long long)p.T * K * (((C + 31) / 32) * 32);
+    float* dwtmp = ws + (((a_ > b_ ? a_ : b_) + 63) & ~63LL);
+    const int nchunk = (C + RG_CH - 1) / RG_CH;
+    const size_t tmp_bytes = sizeof(float) * (size_t)WG_NREP * p.T * nchunk * 64 * 16;
+    if (hipMemsetAsync(dwtmp, 0, tmp_bytes, st) != hipSuccess) return DPF_ERR_LAUNCH;
+    const size_t lds = sizeof(float) * ((size_t)RG_VS * wg.RV + (size_t)RG_CH * ST);
+    const dim3 grid((unsigned)((long long)B * wg.tilesZ * wg.tilesY * wg.tilesX));
+    if (set_lds(dcn_wgrad_region_kernel, lds) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL(dcn_wgrad_region_kernel, grid, dim3(256), lds, st, input, offset, grad_output, dwtmp, p, wg, nchunk);
+    hipLaunchKernelGGL(dcn_wgrad_fold_kernel, dim3(dpf_ew_grid((long long)K * C * p.T)), dim3(256), 0, st, dwtmp, grad_weight, K, C, p.T, nchunk);
+  } else
   {
     const long long ntile = (long long)B * p.tiles_per_b;
     long long nchunk = 2048 / p.T;
