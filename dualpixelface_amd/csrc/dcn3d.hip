@@ -271,6 +271,7 @@ constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8, GI_CS = 9;   // 8 chan
 struct GiP {
   int TZ, RZmax, RY, RX;     // tile depth, region dims
   int tilesZ, tilesY, tilesX;
+  int dbg;                   // timing experiments only (DPF_DCN_DBG): 1 = skip the LDS atomics, 2 = skip the MFMAs, 4 = skip tables
 };
 
 // Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 sustains 0.33 lanes/clk/CU whatever the address pattern,
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
       const Off3 ocur = onext;
       onext = load_off(p, off_b, t + 1, ppos);                  // prefetch: consumed one barrier-to-barrier phase later
-      if (tid < npos) {
+      if (tid < npos && !((q.dbg & 4) && t > 0)) {
         const Corner cn = corner_from(p, t, ppos, ocur);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -378,7 +379,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       for (int st = 0; st < NST; ++st) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
+        if (!(q.dbg & 2))
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
         if (cok) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               if (li[j] >= 0) {
-                atomicAdd(&s_reg[li[j] * GI_CS + lc], (double)(wv[j] * g));
+                if (!(q.dbg & 1)) atomicAdd(&s_reg[li[j] * GI_CS + lc], (double)(wv[j] * g));
               } else {
                 const int v = s_vox[pl * 8 + jb + j];
                 if (v >= 0) atomicAdd(&dxb[(long long)cc * chan + v], wv[j] * g);   // left the region: direct scatter
@@ -1045,6 +1048,7 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
     q.tilesZ = dpf_div_up(p.Do, q.TZ);
     q.tilesY = dpf_div_up(p.Ho, GI_TY);
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
+    q.dbg = getenv("DPF_DCN_DBG") ? atoi(getenv("DPF_DCN_DBG")) : 0;
     const int npos = 64 * q.TZ;
     const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + 1) & ~(size_t)1)) + sizeof(float) * (size_t)npos * 24;
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
