@@ -378,10 +378,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 #pragma unroll
       for (int st = 0; st < NST; ++st) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        if (!(q.dbg & 2))
+        if (!(q.dbg & 2)) {
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
+        }
         if (cok) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
