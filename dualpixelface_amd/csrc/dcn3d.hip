@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 
   for (int c0 = 0; c0 < p.C; c0 += GI_CH) {
     __syncthreads();                                            // previous chunk flushed
-    for (int i = tid; i < regvox * GI_CS; i += 256) s_reg[i] = 0.0;
+    if (!(q.dbg & 16))
+      for (int i = tid; i < regvox * GI_CS; i += 256) s_reg[i] = 0.0;
     const int cc = c0 + lc;
     const bool cok = cc < p.C;
     Off3 onext = load_off(p, off_b, 0, ppos);
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       for (int lx = lane; lx < rowlen; lx += 64) {
         const int gx = rx0 + lx;
         const float v = (float)s_reg[((lz * q.RY + ly) * q.RX + lx) * GI_CS + c];
-        if (v != 0.f && gx >= 0 && gx < p.W) atomicAdd(&dst[gx], v);
+        if (v != 0.f && gx >= 0 && gx < p.W && !(q.dbg & 8)) atomicAdd(&dst[gx], v);
       }
     }
   }
