@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
     for (int t = 0; t < p.T; ++t) {
       __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
       const Off3 ocur = onext;
-      onext = load_off(p, off_b, t + 1, ppos);                  // prefetch: consumed one barrier-to-barrier phase later
+      if (!(q.dbg & 128)) onext = load_off(p, off_b, t + 1, ppos);   // prefetch: consumed one barrier-to-barrier phase later
       if (tid < npos && !((q.dbg & 4) && t > 0)) {
         const Corner cn = corner_from(p, t, ppos, ocur);
 #pragma unroll
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       float bfrag[16];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) bfrag[ks] = bnext[ks];
-      if (t + 1 < p.T) {
+      if (t + 1 < p.T && !(q.dbg & 64)) {
         const float* wtn = wt2 + (long long)(t + 1) * p.K * CT + cc;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
         }
-        if (cok) {
+        if (cok && !(q.dbg & 32)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int pl = (wave * NST + st) * 16 + 4 * lg + r;   // D row = voxel
