@@ -284,9 +284,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   const int npos = 64 * NST;
   double* s_reg = smem_d;                                      // [RZ*RY*RX][GI_CS]
   const int regvox = q.RZmax * q.RY * q.RX;
-  int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + 1) & ~1));   // [npos][8] local voxel index or -1 (16-B aligned)
+  int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + GI_CS + 1) & ~1));   // [npos][8] local voxel index or -1 (16-B aligned); GI_CS dummy doubles before it
   int* s_vox = s_lidx + npos * 8;                              // [npos][8] global voxel index or -1
   float* s_w = (float*)(s_vox + npos * 8);                     // [npos][8]
+  int* s_far = (int*)(s_w + npos * 8);                         // [2] per-tap flag (double-buffered by tap parity): a corner left the region
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int lc = l15 & 7;            // channel within the chunk; lanes 8..15 of a group mirror lanes 0..7 ...
   const int jb = (l15 >> 3) * 4;     // ... and scatter corners 4..7 instead of 0..3
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   for (int c0 = 0; c0 < p.C; c0 += GI_CH) {
     __syncthreads();                                            // previous chunk flushed
     if (!(q.dbg & 16))
-      for (int i = tid; i < regvox * GI_CS; i += 256) s_reg[i] = 0.0;
+      for (int i = tid; i < regvox * GI_CS + GI_CS; i += 256) s_reg[i] = 0.0;
     const int cc = c0 + lc;
     const bool cok = cc < p.C;
     Off3 onext = load_off(p, off_b, 0, ppos);
@@ -344,6 +345,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
     }
     for (int t = 0; t < p.T; ++t) {
       __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
+      if (tid == 0) s_far[0] = 0;
+      __syncthreads();
       const Off3 ocur = onext;
       if (!(q.dbg & 128)) onext = load_off(p, off_b, t + 1, ppos);   // prefetch: consumed one barrier-to-barrier phase later
       if (tid < npos && !((q.dbg & 4) && t > 0)) {
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
           s_lidx[tid * 8 + j] = li;
           s_vox[tid * 8 + j] = (int)v;
           s_w[tid * 8 + j] = wg;
+          if (li < 0 && v >= 0) s_far[0] = 1;
         }
       }
       // B fragments: W[k][c0 + lc][t] (both lane halves of a group hold the same 8 channels); next tap's are prefetched
@@ -384,6 +388,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
           for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
         }
         if (cok && !(q.dbg & 32)) {
+          // straight-line scatter: corners outside the region (or invalid) add 0.0 to a dummy slot, so no branch (and no
+          // LDS wait) separates the eight ds_add_f64 of a voxel; the rare far corners are handled in a second, branchy pass
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int pl = (wave * NST + st) * 16 + 4 * lg + r;   // D row = voxel
@@ -394,11 +400,21 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
             const float wv[4] = {wa.x, wa.y, wa.z, wa.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              if (li[j] >= 0) {
-                if (!(q.dbg & 1)) atomicAdd(&s_reg[li[j] * GI_CS + lc], (double)(wv[j] * g));
-              } else {
+              const bool in = li[j] >= 0;
+              const int a = in ? li[j] * GI_CS + lc : regvox * GI_CS + lc;
+              const double val = in ? (double)(wv[j] * g) : 0.0;
+              if (!(q.dbg & 1)) atomicAdd(&s_reg[a], val);
+            }
+          }
+          if (s_far[0] != 0) {                                     // block-uniform: some corner of this tap left the region
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int pl = (wave * NST + st) * 16 + 4 * lg + r;
+              const float g = acc[r];
+              for (int j = 0; j < 4; ++j) {
                 const int v = s_vox[pl * 8 + jb + j];
-                if (v >= 0) atomicAdd(&dxb[(long long)cc * chan + v], wv[j] * g);   // left the region: direct scatter
+                if (s_lidx[pl * 8 + jb + j] < 0 && v >= 0)
+                  atomicAdd(&dxb[(long long)cc * chan + v], s_w[pl * 8 + jb + j] * g);   // direct scatter
               }
             }
           }
@@ -635,19 +651,26 @@ __device__ __forceinline__ void sample_chunk(const DcnP& p, const RegGeo& g, con
 #pragma unroll
   for (int ch = 0; ch < RG_CH; ++ch) val[ch] = 0.f;
   if (!sp.valid) return;
+  if (sp.fast) {       // straight-line: the 32 ds_read_b128 of the 8 corners can all be in flight
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-    const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
-    float v[RG_CH];
-    if (sp.fast) {
+    for (int j = 0; j < 8; ++j) {
+      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+      const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+      float v[RG_CH];
       corner_vec(g, sp, s_reg, jd, jh, jw, v);
-    } else {
-      if (wj == 0.f) continue;
-      corner_vec_global(p, cn, xb, c0, chan, jd, jh, jw, v);
-    }
 #pragma unroll
-    for (int ch = 0; ch < RG_CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+      for (int ch = 0; ch < RG_CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+    }
+  } else {
+    for (int j = 0; j < 8; ++j) {
+      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+      const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+      if (wj == 0.f) continue;
+      float v[RG_CH];
+      corner_vec_global(p, cn, xb, c0, chan, jd, jh, jw, v);
+#pragma unroll
+      for (int ch = 0; ch < RG_CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+    }
   }
 }
 
@@ -809,26 +832,36 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
         float gcv[RG_CH];
 #pragma unroll
         for (int ch = 0; ch < RG_CH; ++ch) gcv[ch] = (c0 + ch < p.C) ? s_gc[ch * ST + tid] : 0.f;
+        // dot_j = sum_ch gcol[ch] * x[corner j][ch]; the three coordinate derivatives weight it with the other two
+        // trilinear factors and the signed in-volume mask of their own axis (cuh:131-187)
+        float dots[8];
+        if (sp.fast) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v[RG_CH];
+            corner_vec(g, sp, s_reg, j >> 2, (j >> 1) & 1, j & 1, v);
+            float dot = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
+            dots[j] = dot;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v[RG_CH];
+            corner_vec_global(p, cn, xb, c0, chan, j >> 2, (j >> 1) & 1, j & 1, v);
+            float dot = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
+            dots[j] = dot;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-          // dot_j = sum_ch gcol[ch] * x[corner j][ch]; the three coordinate derivatives weight it with the other two
-          // trilinear factors and the signed in-volume mask of their own axis (cuh:131-187)
-          float dot = 0.f;
-          if (sp.fast) {
-            float v[RG_CH];
-            corner_vec(g, sp, s_reg, jd, jh, jw, v);
-#pragma unroll
-            for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
-          } else {
-            float v[RG_CH];
-            corner_vec_global(p, cn, xb, c0, chan, jd, jh, jw, v);
-#pragma unroll
-            for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
-          }
-          gd += (jd ? sp.mz[1] : -sp.mz[0]) * sp.wy[jh] * sp.wx[jw] * dot;
-          gh += (jh ? sp.my[1] : -sp.my[0]) * sp.wz[jd] * sp.wx[jw] * dot;
-          gw += (jw ? sp.mx[1] : -sp.mx[0]) * sp.wz[jd] * sp.wy[jh] * dot;
+          gd += (jd ? sp.mz[1] : -sp.mz[0]) * sp.wy[jh] * sp.wx[jw] * dots[j];
+          gh += (jh ? sp.my[1] : -sp.my[0]) * sp.wz[jd] * sp.wx[jw] * dots[j];
+          gw += (jw ? sp.mx[1] : -sp.mx[0]) * sp.wz[jd] * sp.wy[jh] * dots[j];
         }
       }
       if (pvalid) {   // this thread owns (t, voxel): accumulate over channel chunks with plain read-modify-write
@@ -1051,7 +1084,7 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
     q.dbg = getenv("DPF_DCN_DBG") ? atoi(getenv("DPF_DCN_DBG")) : 0;
     const int npos = 64 * q.TZ;
-    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + 1) & ~(size_t)1)) + sizeof(float) * (size_t)npos * 24;
+    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 24 + 4);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
     if (lds <= 150 * 1024 && blocks < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
