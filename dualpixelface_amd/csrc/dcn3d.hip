@@ -271,7 +271,6 @@ constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8, GI_CS = 9;   // 8 chan
 struct GiP {
   int TZ, RZmax, RY, RX;     // tile depth, region dims
   int tilesZ, tilesY, tilesX;
-  int dbg;                   // timing experiments only (DPF_DCN_DBG): 1 = skip the LDS atomics, 2 = skip the MFMAs, 4 = skip tables
 };
 
 // Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 sustains 0.33 lanes/clk/CU whatever the address pattern,
@@ -287,7 +286,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + GI_CS + 1) & ~1));   // [npos][8] local voxel index or -1 (16-B aligned); GI_CS dummy doubles before it
   int* s_vox = s_lidx + npos * 8;                              // [npos][8] global voxel index or -1
   float* s_w = (float*)(s_vox + npos * 8);                     // [npos][8]
-  int* s_far = (int*)(s_w + npos * 8);                         // [2] per-tap flag (double-buffered by tap parity): a corner left the region
+  int* s_far = (int*)(s_w + npos * 8);                         // [4] per-tap flag: some corner left the region
+  int* s_farm = s_far + 4;                                      // [npos] per-voxel flag
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int lc = l15 & 7;            // channel within the chunk; lanes 8..15 of a group mirror lanes 0..7 ...
   const int jb = (l15 >> 3) * 4;     // ... and scatter corners 4..7 instead of 0..3
@@ -332,8 +332,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 
   for (int c0 = 0; c0 < p.C; c0 += GI_CH) {
     __syncthreads();                                            // previous chunk flushed
-    if (!(q.dbg & 16))
-      for (int i = tid; i < regvox * GI_CS + GI_CS; i += 256) s_reg[i] = 0.0;
+    for (int i = tid; i < regvox * GI_CS + GI_CS; i += 256) s_reg[i] = 0.0;
     const int cc = c0 + lc;
     const bool cok = cc < p.C;
     Off3 onext = load_off(p, off_b, 0, ppos);
@@ -348,9 +347,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       if (tid == 0) s_far[0] = 0;
       __syncthreads();
       const Off3 ocur = onext;
-      if (!(q.dbg & 128)) onext = load_off(p, off_b, t + 1, ppos);   // prefetch: consumed one barrier-to-barrier phase later
-      if (tid < npos && !((q.dbg & 4) && t > 0)) {
+      onext = load_off(p, off_b, t + 1, ppos);                  // prefetch: consumed one barrier-to-barrier phase later
+      if (tid < npos) {
         const Corner cn = corner_from(p, t, ppos, ocur);
+        int anyfar = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float wg;
@@ -364,14 +364,16 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
           s_lidx[tid * 8 + j] = li;
           s_vox[tid * 8 + j] = (int)v;
           s_w[tid * 8 + j] = wg;
-          if (li < 0 && v >= 0) s_far[0] = 1;
+          if (li < 0 && v >= 0) anyfar = 1;
         }
+        s_farm[tid] = anyfar;
+        if (anyfar) s_far[0] = 1;
       }
       // B fragments: W[k][c0 + lc][t] (both lane halves of a group hold the same 8 channels); next tap's are prefetched
       float bfrag[16];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) bfrag[ks] = bnext[ks];
-      if (t + 1 < p.T && !(q.dbg & 64)) {
+      if (t + 1 < p.T) {
         const float* wtn = wt2 + (long long)(t + 1) * p.K * CT + cc;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -383,11 +385,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 #pragma unroll
       for (int st = 0; st < NST; ++st) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (!(q.dbg & 2)) {
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
-        }
-        if (cok && !(q.dbg & 32)) {
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
+        if (cok) {
           // straight-line scatter: corners outside the region (or invalid) add 0.0 to a dummy slot, so no branch (and no
           // LDS wait) separates the eight ds_add_f64 of a voxel; the rare far corners are handled in a second, branchy pass
 #pragma unroll
@@ -403,13 +403,14 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
               const bool in = li[j] >= 0;
               const int a = in ? li[j] * GI_CS + lc : regvox * GI_CS + lc;
               const double val = in ? (double)(wv[j] * g) : 0.0;
-              if (!(q.dbg & 1)) atomicAdd(&s_reg[a], val);
+              atomicAdd(&s_reg[a], val);
             }
           }
           if (s_far[0] != 0) {                                     // block-uniform: some corner of this tap left the region
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int pl = (wave * NST + st) * 16 + 4 * lg + r;
+              if (s_farm[pl] == 0) continue;
               const float g = acc[r];
               for (int j = 0; j < 4; ++j) {
                 const int v = s_vox[pl * 8 + jb + j];
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       for (int lx = lane; lx < rowlen; lx += 64) {
         const int gx = rx0 + lx;
         const float v = (float)s_reg[((lz * q.RY + ly) * q.RX + lx) * GI_CS + c];
-        if (v != 0.f && gx >= 0 && gx < p.W && !(q.dbg & 8)) atomicAdd(&dst[gx], v);
+        if (v != 0.f && gx >= 0 && gx < p.W) atomicAdd(&dst[gx], v);
       }
     }
   }
@@ -1082,9 +1083,8 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
     q.tilesZ = dpf_div_up(p.Do, q.TZ);
     q.tilesY = dpf_div_up(p.Ho, GI_TY);
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
-    q.dbg = getenv("DPF_DCN_DBG") ? atoi(getenv("DPF_DCN_DBG")) : 0;
     const int npos = 64 * q.TZ;
-    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 24 + 4);
+    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 25 + 4);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
     if (lds <= 150 * 1024 && blocks < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
