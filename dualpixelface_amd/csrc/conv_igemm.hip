@@ -72,8 +72,10 @@ __device__ __forceinline__ void dim_range(int k, int s, int p, int dil, int r, i
   }
 }
 
-template <int MT, int CC, int NT>   // NT rows of 32 positions per wave; tile = (4*NT) x 32 positions
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+// NT rows of 32 positions per wave; tile = (4*NT) x 32 positions.  The 4-channel-chunk variants with <= 64 output channels fit
+// 128 registers without spilling, so they ask for 4 waves/SIMD (4 resident workgroups per CU hide the staging phases).
+template <int MT, int CC, int NT>
+__global__ __launch_bounds__(256, (CC == 4 && MT <= 2) ? 4 : 2) void conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, float* __restrict__ out, ConvP p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32 * MT;
