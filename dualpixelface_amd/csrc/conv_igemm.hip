@@ -545,7 +545,7 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   p.ntmax = ntmax;
   auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float); };
   int CC = 8;
-  static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 40 * 1024;   // tuning knob
+  static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 20000;   // tuning knob
   if (lds_bytes(8) > (size_t)lds_cap || p.C <= 4) CC = 4;
   const size_t lds = lds_bytes(CC);
   if (lds > 160 * 1024) return DPF_ERR_UNSUPPORTED;

@@ -1,0 +1,50 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel-family HBM traffic per launch.
+
+usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json]
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (MI355X_MICROARCH.md: hbm_bytes = (FETCH + WRITE) * 1024); on gfx950
+FETCH_SIZE under-counts wide coalesced reads by 2x -- the raw value is kept and the corrected one (x2) reported beside it.
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def family(name):
+    for key in ('conv_igemm_kernel', 'conv_wgrad_kernel', 'dcn_bwd_input', 'dcn_fwd_region', 'dcn_bwd_offset', 'dcn_wgrad_region',
+                'smallk', 'bn_', 'head_'):
+        if key in name:
+            return key
+    return None
+
+
+def agg(path, counter):
+    tot = collections.defaultdict(float)
+    n = collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        fam = family(r['Kernel_Name'])
+        if fam is None or r['Counter_Name'] != counter:
+            continue
+        tot[fam] += float(r['Counter_Value'])
+        if r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id'])
+            n[fam] += 1
+    return tot, n
+
+
+def main():
+    fetch, nf = agg(sys.argv[1], 'FETCH_SIZE')
+    write, nw = agg(sys.argv[2], 'WRITE_SIZE')
+    out = {}
+    for fam in sorted(set(fetch) | set(write)):
+        launches = max(nf.get(fam, 0), nw.get(fam, 0), 1)
+        f = fetch.get(fam, 0.0) * 1024.0 / max(nf.get(fam, 1), 1)
+        w = write.get(fam, 0.0) * 1024.0 / max(nw.get(fam, 1), 1)
+        out[fam] = {'launches': launches, 'fetch_bytes_per_launch_raw': f, 'fetch_bytes_per_launch_x2': 2 * f,
+                    'write_bytes_per_launch': w, 'hbm_bytes_per_launch': 2 * f + w}
+    json.dump(out, open(sys.argv[3], 'w') if len(sys.argv) > 3 else sys.stdout, indent=1)
+
+
+if __name__ == '__main__':
+    main()
