@@ -118,8 +118,15 @@ def main():
         if dom:
             flops, secs, n = fam[dom]
             ach = flops / secs / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                fam_key = {'conv_igemm': 'conv_igemm_kernel', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dom)
+                rec = json.load(open(tpath)).get(fam_key)
+                if rec:
+                    traffic = rec['hbm_bytes_per_launch']
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
-                    'traffic': None, 'launches': n, 'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed,
+                    'traffic': traffic, 'launches': n, 'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed,
                     'families': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3} for k, v in fam.items()}}
         pixels = args.height * args.width
         line = {
