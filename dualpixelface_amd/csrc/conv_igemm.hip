@@ -308,11 +308,10 @@ struct WgP {
   long long ntiles;
 };
 
-constexpr int WTH = 4;            // rows per wgrad position tile
-constexpr int WPT = WTH * TW;     // 128 positions
 constexpr int WNT = 2;            // column tiles (of 32 (c,t) pairs) per wave
 
-template <int MT>
+// WTH rows of 32 positions per tile: 8 for K <= 32 (the G tile is small, so the bigger tile halves the barriers per MFMA)
+template <int MT, int WTH = (MT == 1 ? 8 : 4)>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                          float* __restrict__ dw, WgP p) {
   extern __shared__ __align__(16) float smem[];
@@ -323,6 +322,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   const int planeStride = ext_h * ext_w;
   const int chanStride = ext_d * planeStride;
   float* s_x = smem;                         // [CCW][chanStride]
+  constexpr int WPT = WTH * TW;
   float* s_g = s_x + p.CCW * chanStride;     // [KT][WPT+1]
   constexpr int GS = WPT + 1;
   int* s_rowoff = (int*)(s_g + KT * GS);     // per staged row: source offset relative to (n, c0, i0d, i0h)
@@ -625,6 +625,7 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   if (CCW > C) CCW = C;
   if (CCW < 1) CCW = 1;
   const int ext_d = (kd - 1) * dd + 1;
+  const int WTH = MT == 1 ? 8 : 4, WPT = WTH * TW;
   const int ext_h = (WTH - 1) * sh + (kh - 1) * dh + 1;
   const int ext_w = (TW - 1) * sw + (kw - 1) * dw_ + 1;
   if (ext_w > 128) return DPF_ERR_UNSUPPORTED;
