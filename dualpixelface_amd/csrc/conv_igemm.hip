@@ -292,239 +292,6 @@ __global__ __launch_bounds__(256, (CC == 4 && MT <= 2) ? 4 : 2) void conv_igemm_
   }
 }
 
-// Wave-specialised variant: a 512-thread workgroup = 4 MFMA waves (one per SIMD, same tile geometry as above) + 4 loader
-// waves.  While the MFMA waves run the tap loop on LDS buffer `cur`, the loader waves stage the next channel chunk into the
-// other buffer with the same batched row loads; one barrier per chunk.  The loaders' VALU / memory instructions issue from
-// different waves than the MFMAs, so they overlap instead of stalling the in-order MFMA stream (the in-loop software
-// pipeline of one wave did stall it: 43.9 vs 57.5 TFLOP/s).
-template <int MT, int CC, int NT>
-__global__ __launch_bounds__(512, 2) void conv_igemm_ws_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                         const float* __restrict__ bias, float* __restrict__ out, ConvP p) {
-  extern __shared__ __align__(16) float smem[];
-  constexpr int KT = 32 * MT;
-  constexpr int TH = 4 * NT;
-  // LDS carve: [input tile CC*chanStrideMax][tapoff MAXT][tapw MAXT][nv][row tables]
-  float* s_in = smem;
-  int* s_tapoff = (int*)(s_in + 2 * CC * p.chanStrideMax);
-  int* s_tapw = s_tapoff + MAXT;
-  int* s_nv = s_tapw + MAXT;
-  int* s_rowoff = s_nv + 4;             // per staged row: source offset relative to (n, c0, i0d, i0h) -- no divisions in the loop
-  int* s_rowpr = s_rowoff + p.maxrows;  // (plane << 16) | row
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave8 = tid >> 6;            // 0..3 MFMA waves, 4..7 loader waves
-  const bool loader = wave8 >= 4;
-  const int wave = wave8 & 3;
-  const int l31 = lane & 31;
-  const int hh = lane >> 5;
-
-  int b = blockIdx.x;
-  const int tw = b % p.tilesW; b /= p.tilesW;
-  const int th = b % p.tilesH; b /= p.tilesH;
-  const int qd = b % p.QD; b /= p.QD;
-  const int n = b % p.N;
-  const int cls = b / p.N;
-
-  int rd = 0, rh = 0, rw = 0;
-  int sxd = p.sd, sxh = p.sh, sxw = p.sw;   // input step per output step
-  int sod = 1, soh = 1, sow = 1;            // output step per q step
-  if (p.transposed) {
-    rw = cls % p.sw;
-    rh = (cls / p.sw) % p.sh;
-    rd = cls / (p.sw * p.sh);
-    sxd = sxh = sxw = 1;
-    sod = p.sd; soh = p.sh; sow = p.sw;
-  }
-  // q-grid of this class
-  const int Qd = (p.OD - rd + sod - 1) / sod;
-  const int Qh = (p.OH - rh + soh - 1) / soh;
-  const int Qw = (p.OW - rw + sow - 1) / sow;
-  const int q0h = th * TH, q0w = tw * TW;
-  if (qd >= Qd || q0h >= Qh || q0w >= Qw) return;
-
-  int emin_d, emax_d, nvd, emin_h, emax_h, nvh, emin_w, emax_w, nvw;
-  dim_range(p.kd, p.sd, p.pd, p.dd, rd, p.transposed, emin_d, emax_d, nvd);
-  dim_range(p.kh, p.sh, p.ph, p.dh, rh, p.transposed, emin_h, emax_h, nvh);
-  dim_range(p.kw, p.sw, p.pw, p.dw, rw, p.transposed, emin_w, emax_w, nvw);
-  const int nvalid = nvd * nvh * nvw;
-
-  const int od = qd * sod + rd;
-  const long long out_plane = (long long)p.OH * p.OW;
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
-
-  if (nvalid > 0) {
-    const int ext_d = emax_d - emin_d + 1;
-    const int ext_h = (TH - 1) * sxh + (emax_h - emin_h) + 1;
-    const int ext_w = (TW - 1) * sxw + (emax_w - emin_w) + 1;
-    const int planeStride = ext_h * ext_w;
-    const int chanStride = ext_d * planeStride;
-    const int i0d = qd * sxd + emin_d, i0h = q0h * sxh + emin_h, i0w = q0w * sxw + emin_w;
-
-    if (tid == 0) {
-      int nv = 0;
-      for (int a = 0; a < p.kd; ++a) {
-        int ed;
-        if (!tap_e(a, p.kd, p.sd, p.pd, p.dd, rd, p.transposed, ed)) continue;
-        for (int bb = 0; bb < p.kh; ++bb) {
-          int eh;
-          if (!tap_e(bb, p.kh, p.sh, p.ph, p.dh, rh, p.transposed, eh)) continue;
-          for (int c = 0; c < p.kw; ++c) {
-            int ew;
-            if (!tap_e(c, p.kw, p.sw, p.pw, p.dw, rw, p.transposed, ew)) continue;
-            s_tapoff[nv] = ((ed - emin_d) * ext_h + (eh - emin_h)) * ext_w + (ew - emin_w);
-            s_tapw[nv] = (a * p.kh + bb) * p.kw + c;
-            ++nv;
-          }
-        }
-      }
-      s_nv[0] = nv;
-    }
-
-    int lanebase[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) lanebase[t] = ((wave * NT + t) * sxh) * ext_w + l31 * sxw + hh * chanStride;
-
-    const int in_rows = CC * ext_d * ext_h;
-    const int rows_per_chan = ext_d * ext_h;
-    const long long x_chan = (long long)p.ID * p.IH * p.IW;
-    const float* xn = x + (long long)n * p.C * x_chan;
-    for (int rowid = tid; rowid < in_rows; rowid += 512) {
-      const int cc = rowid / rows_per_chan;
-      const int rem = rowid - cc * rows_per_chan;
-      const int pl = rem / ext_h;
-      const int rr = rem - pl * ext_h;
-      s_rowoff[rowid] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + rr) * p.IW);
-      s_rowpr[rowid] = (pl << 16) | rr | (cc << 24);
-    }
-
-    // staging of one channel chunk by `nsw` waves (this wave is number `sw`): SU rows fetched back-to-back, then written
-    constexpr int SU = 8;
-    auto stage = [&](int c0s, float* buf, int sw, int nsw) {
-      const float* xbase = xn + (long long)c0s * x_chan + ((long long)i0d * p.IH + i0h) * p.IW;
-      for (int r0 = sw * SU; r0 < in_rows; r0 += nsw * SU) {
-        float v0[SU], v1[SU];
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          const int rowid = r0 + u;
-          const int rsafe = rowid < in_rows ? rowid : 0;
-          const int pr = s_rowpr[rsafe];
-          const int cc = pr >> 24, pl = (pr >> 16) & 0xff, rr = pr & 0xffff;
-          const int ic = c0s + cc, id = i0d + pl, ih = i0h + rr;
-          const bool rowok = (rowid < in_rows) && (ic < p.C) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
-          const float* src = xbase + s_rowoff[rsafe];
-          const int iw0 = i0w + lane, iw1 = iw0 + 64;
-          v0[u] = (rowok && lane < ext_w && iw0 >= 0 && iw0 < p.IW) ? src[iw0] : 0.f;
-          v1[u] = (rowok && lane + 64 < ext_w && iw1 >= 0 && iw1 < p.IW) ? src[iw1] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          const int rowid = r0 + u;
-          if (rowid < in_rows) {
-            float* dst = buf + rowid * ext_w;
-            if (lane < ext_w) dst[lane] = v0[u];
-            if (lane + 64 < ext_w) dst[lane + 64] = v1[u];
-          }
-        }
-      }
-    };
-    const int wave8_u = __builtin_amdgcn_readfirstlane(wave8);
-    float* bufs[2] = {s_in, s_in + CC * p.chanStrideMax};
-    int cur = 0;
-    const int nv = nvalid;
-    __syncthreads();                       // tap / row tables visible
-    stage(0, bufs[0], wave8_u, 8);         // prologue: all 8 waves stage the first chunk
-    __syncthreads();
-
-    for (int c0 = 0; c0 < p.C; c0 += CC) {
-      const float* cbuf = bufs[cur];
-      if (loader) {
-        if (c0 + CC < p.C) stage(c0 + CC, bufs[cur ^ 1], wave8_u - 4, 4);
-      } else {
-        float a_cur[CC / 2][MT], b_cur[CC / 2][NT], a_n1[CC / 2][MT], a_n2[CC / 2][MT], b_nxt[CC / 2][NT];
-        auto load_a = [&](int slot, float (&dst)[CC / 2][MT]) {
-          const int sl = slot < nv ? slot : nv - 1;
-          const float* wrow = wt + ((long long)s_tapw[sl] * p.C + c0 + hh) * KT + l31;
-#pragma unroll
-          for (int cp = 0; cp < CC / 2; ++cp) {
-            const bool cok = c0 + 2 * cp + hh < p.C;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) dst[cp][m] = cok ? wrow[(2 * cp) * KT + m * 32] : 0.f;
-          }
-        };
-        load_a(0, a_cur);
-        load_a(1, a_n1);
-        {
-          const int toff = s_tapoff[0];
-#pragma unroll
-          for (int cp = 0; cp < CC / 2; ++cp)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b_cur[cp][t] = cbuf[lanebase[t] + (2 * cp) * chanStride + toff];
-        }
-        for (int slot = 0; slot < nv; ++slot) {
-          load_a(slot + 2, a_n2);
-          if (slot + 1 < nv) {
-            const int toff = s_tapoff[slot + 1];
-#pragma unroll
-            for (int cp = 0; cp < CC / 2; ++cp)
-#pragma unroll
-              for (int t = 0; t < NT; ++t) b_nxt[cp][t] = cbuf[lanebase[t] + (2 * cp) * chanStride + toff];
-          }
-#pragma unroll
-          for (int cp = 0; cp < CC / 2; ++cp)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-              for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cp][m], b_cur[cp][t], acc[m][t], 0, 0, 0);
-#pragma unroll
-          for (int cp = 0; cp < CC / 2; ++cp) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-              a_cur[cp][m] = a_n1[cp][m];
-              a_n1[cp][m] = a_n2[cp][m];
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b_cur[cp][t] = b_nxt[cp][t];
-          }
-        }
-      }
-      __syncthreads();                     // next buffer complete, current buffer free
-      cur ^= 1;
-    }
-  }
-  if (loader) return;
-
-  // ---- epilogue: D row = (j&3) + 8*(j>>2) + 4*(lane>>5), col = lane&31
-  const int qw = q0w + l31;
-  const int ow = qw * sow + rw;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int qh = q0h + wave * NT + t;
-    if (qh >= Qh || qw >= Qw) continue;
-    const int oh = qh * soh + rh;
-    const long long pos = ((long long)od * p.OH + oh) * p.OW + ow;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        if (k < p.K) {
-          float v = acc[m][t][j];
-          if (bias) v += bias[p.k0 + k];
-          out[((long long)n * p.Ktot + p.k0 + k) * p.OD * out_plane + pos] = v;
-        }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // weight gradient:  dW[k][c][t] += sum_{n,q} g[n,k,q] * x[n,c, q*s - p + t*dil]
 // D[row = k][col = (c,t)],  reduction (MFMA K dim) over positions.
@@ -544,7 +311,7 @@ struct WgP {
 constexpr int WNT = 2;            // column tiles (of 32 (c,t) pairs) per wave
 
 // WTH rows of 32 positions per tile: 8 for K <= 32 (the G tile is small, so the bigger tile halves the barriers per MFMA)
-template <int MT, int WTH = 4>
+template <int MT, int WTH = (MT == 1 ? 8 : 4)>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                          float* __restrict__ dw, WgP p) {
   extern __shared__ __align__(16) float smem[];
@@ -702,18 +469,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 int out_dim(int I, int k, int s, int p, int d) { return (I + 2 * p - (d * (k - 1) + 1)) / s + 1; }
 
 template <int MT, int CC, int NT>
-int launch_igemm_ws(const float* x, const float* wt, const float* bias, float* out, const ConvP& p, size_t lds, hipStream_t st) {
-  const long long blocks = (long long)p.ncls * p.N * p.QD * p.tilesH * p.tilesW;
-  if (blocks <= 0 || blocks > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
-  if (lds > 48 * 1024) {
-    if (hipFuncSetAttribute((const void*)conv_igemm_ws_kernel<MT, CC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return DPF_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL((conv_igemm_ws_kernel<MT, CC, NT>), dim3((unsigned)blocks), dim3(512), lds, st, x, wt, bias, out, p);
-  return dpf_check_launch();
-}
-
-template <int MT, int CC, int NT>
 int launch_igemm(const float* x, const float* wt, const float* bias, float* out, const ConvP& p, size_t lds, hipStream_t st) {
   const long long blocks = (long long)p.ncls * p.N * p.QD * p.tilesH * p.tilesW;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
@@ -789,20 +544,6 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   p.chanStrideMax = ext_d * ext_h * ext_w;
   p.ntmax = ntmax;
   auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float); };
-  // wave-specialised path (tuning knob DPF_CONV_WS, default on): 8-channel chunks, two LDS buffers
-  static const int want_ws = getenv("DPF_CONV_WS") ? atoi(getenv("DPF_CONV_WS")) : 1;
-  if (want_ws && p.C > 8) {
-    const size_t lds2 = (size_t)(2 * 8 * p.chanStrideMax + 2 * MAXT + 4 + 2 * 8 * ext_d * ext_h) * sizeof(float);
-    if (lds2 <= 150 * 1024) {
-      p.maxrows = 8 * ext_d * ext_h;
-      switch (MT) {
-        case 1: return launch_igemm_ws<1, 8, 4>(x, wt_ws, bias, out, p, lds2, st);
-        case 2: return launch_igemm_ws<2, 8, 2>(x, wt_ws, bias, out, p, lds2, st);
-        case 3: return launch_igemm_ws<3, 8, 2>(x, wt_ws, bias, out, p, lds2, st);
-        default: return launch_igemm_ws<4, 8, 2>(x, wt_ws, bias, out, p, lds2, st);
-      }
-    }
-  }
   int CC = 8;
   static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 20000;   // tuning knob
   if (lds_bytes(8) > (size_t)lds_cap || p.C <= 4) CC = 4;
@@ -884,7 +625,7 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   if (CCW > C) CCW = C;
   if (CCW < 1) CCW = 1;
   const int ext_d = (kd - 1) * dd + 1;
-  const int WTH = 4, WPT = WTH * TW;
+  const int WTH = MT == 1 ? 8 : 4, WPT = WTH * TW;
   const int ext_h = (WTH - 1) * sh + (kh - 1) * dh + 1;
   const int ext_w = (TW - 1) * sw + (kw - 1) * dw_ + 1;
   if (ext_w > 128) return DPF_ERR_UNSUPPORTED;
