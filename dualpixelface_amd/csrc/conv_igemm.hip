@@ -310,8 +310,8 @@ struct WgP {
 
 constexpr int WNT = 2;            // column tiles (of 32 (c,t) pairs) per wave
 
-// WTH rows of 32 positions per tile: 8 for K <= 32 (the G tile is small, so the bigger tile halves the barriers per MFMA)
-template <int MT, int WTH = (MT == 1 ? 8 : 4)>
+// WTH rows of 32 positions per tile (8-row tiles for K <= 32 measured slower: 49 vs 52 TFLOP/s)
+template <int MT, int WTH = 4>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                          float* __restrict__ dw, WgP p) {
   extern __shared__ __align__(16) float smem[];
@@ -625,7 +625,7 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   if (CCW > C) CCW = C;
   if (CCW < 1) CCW = 1;
   const int ext_d = (kd - 1) * dd + 1;
-  const int WTH = MT == 1 ? 8 : 4, WPT = WTH * TW;
+  const int WTH = 4, WPT = WTH * TW;
   const int ext_h = (WTH - 1) * sh + (kh - 1) * dh + 1;
   const int ext_w = (TW - 1) * sw + (kw - 1) * dw_ + 1;
   if (ext_w > 128) return DPF_ERR_UNSUPPORTED;
