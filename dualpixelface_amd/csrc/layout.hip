@@ -1,0 +1,105 @@
+// Pure data-movement kernels that keep the model's tensor plumbing off eager PyTorch: channel-range copies
+// (torch.cat / torch.stack / slicing in the reference: src/model/stereodpnet/modules.py:42,129, mainmodel.py:98-100),
+// the [B,C,D,S] <-> [B,D,C,S] permutation in front of the shared 2-D normal convs (normal_module.py:185,187), the channel
+// maximum returned as `ref_feature` (mainmodel.py:104) and the closed-form replay of the attention BatchNorm's running
+// statistics.  All HBM-bound, float4 where the row length allows.
+#include "dpf_common.h"
+
+namespace {
+
+// dst[n, cd0 + c, s] = src[n, cs0 + c, s]   for c < ncopy;  src has Cs channels, dst has Cd
+__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Cs, int cs0, int Cd, int cd0, int ncopy,
+                                     long long S, int accumulate) {
+  const long long per = (long long)ncopy * S;
+  const long long total = (long long)N * per;
+  if ((S & 3) == 0) {
+    const long long total4 = total >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+      const long long e = i << 2;
+      const long long n = e / per, r = e - n * per;
+      const float4 v = *reinterpret_cast<const float4*>(src + ((long long)n * Cs + cs0) * S + r);
+      float4* d = reinterpret_cast<float4*>(dst + ((long long)n * Cd + cd0) * S + r);
+      if (accumulate) {
+        float4 o = *d;
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        *d = o;
+      } else {
+        *d = v;
+      }
+    }
+  } else {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+      const long long n = e / per, r = e - n * per;
+      const float v = src[((long long)n * Cs + cs0) * S + r];
+      float* d = dst + ((long long)n * Cd + cd0) * S + r;
+      *d = accumulate ? *d + v : v;
+    }
+  }
+}
+
+// dst[b, d, c, s] = src[b, c, d, s]   (A = C, Bd = D)  -- the same kernel inverts itself with A and Bd swapped
+__global__ void swap_axes_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int A, int Bd, long long S) {
+  const long long total = (long long)B * A * Bd * S;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i % S;
+    const int c = (int)((i / S) % A);          // dst index order: [b][d][c][s]
+    const int d = (int)((i / (S * A)) % Bd);
+    const long long b = i / (S * A * Bd);
+    dst[i] = src[((b * A + c) * Bd + d) * S + s];
+  }
+}
+
+__global__ void channel_max_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, long long S) {
+  const long long total = (long long)N * S;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / S, s = i - n * S;
+    float m = x[(n * C) * S + s];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[(n * C + c) * S + s]);
+    y[i] = m;
+  }
+}
+
+// r <- keep^(2L) r + keep*G*a_f + G*a_b  (a_* = momentum * batch statistic of the ref / target call), G = sum_{j<L} keep^(2j)
+__global__ void bn_replay_kernel(float* __restrict__ r, const float* __restrict__ a_f, const float* __restrict__ a_b, int C, float decay,
+                                 float cf, float cb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) r[c] = decay * r[c] + cf * a_f[c] + cb * a_b[c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpf_copy_channels(const float* src, float* dst, int N, int Cs, int cs0, int Cd, int cd0, int ncopy, long long S, int accumulate,
+                      void* stream) {
+  dpf_clear_error();
+  if (!src || !dst || N <= 0 || ncopy <= 0 || cs0 < 0 || cd0 < 0 || cs0 + ncopy > Cs || cd0 + ncopy > Cd || S <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(dpf_ew_grid((long long)N * ncopy * S / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, dst, N,
+                     Cs, cs0, Cd, cd0, ncopy, S, accumulate);
+  return dpf_check_launch();
+}
+
+// src [B, A, Bd, S] -> dst [B, Bd, A, S]
+int dpf_swap_axes(const float* src, float* dst, int B, int A, int Bd, long long S, void* stream) {
+  dpf_clear_error();
+  if (!src || !dst || B <= 0 || A <= 0 || Bd <= 0 || S <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(swap_axes_kernel, dim3(dpf_ew_grid((long long)B * A * Bd * S)), dim3(256), 0, (hipStream_t)stream, src, dst, B, A, Bd, S);
+  return dpf_check_launch();
+}
+
+// x [N, C, S] -> y [N, S]
+int dpf_channel_max(const float* x, float* y, int N, int C, long long S, void* stream) {
+  dpf_clear_error();
+  if (!x || !y || N <= 0 || C <= 0 || S <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(channel_max_kernel, dim3(dpf_ew_grid((long long)N * S)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, S);
+  return dpf_check_launch();
+}
+
+int dpf_bn_replay(float* running, const float* a_f, const float* a_b, int C, float decay, float cf, float cb, void* stream) {
+  dpf_clear_error();
+  if (!running || !a_f || !a_b || C <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bn_replay_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, (hipStream_t)stream, running, a_f, a_b, C, decay, cf, cb);
+  return dpf_check_launch();
+}
+
+}  // extern "C"

@@ -585,6 +585,94 @@ def sigmoid_mean(u, B, Dn):
     return SigmoidMeanFn.apply(u, B, Dn)
 
 
+# ----------------------------------------------------------------------------------------------- tensor plumbing
+def _copy_channels(src, dst, cs0, cd0, ncopy, accumulate=0):
+    N, Cs, Cd = src.shape[0], src.shape[1], dst.shape[1]
+    S = src.numel() // (N * Cs)
+    lib().call('dpf_copy_channels', _ptr(src), _ptr(dst), N, Cs, cs0, Cd, cd0, ncopy, S, accumulate, _stream())
+
+
+class ConcatFn(torch.autograd.Function):
+    """torch.cat(tensors, dim=1) for [N, C_i, ...] tensors with equal trailing dims."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ts = [_c(t) for t in ts]
+        _need(*ts)
+        chans = [t.shape[1] for t in ts]
+        out = torch.empty((ts[0].shape[0], sum(chans)) + tuple(ts[0].shape[2:]), dtype=torch.float32, device=ts[0].device)
+        off = 0
+        for t, c in zip(ts, chans):
+            _copy_channels(t, out, 0, off, c)
+            off += c
+        ctx.chans = chans
+        ctx.shapes = [tuple(t.shape) for t in ts]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        outs, off = [], 0
+        for c, shp in zip(ctx.chans, ctx.shapes):
+            d = torch.empty(shp, dtype=torch.float32, device=g.device)
+            _copy_channels(g, d, off, 0, c)
+            outs.append(d)
+            off += c
+        return tuple(outs)
+
+
+def concat_channels(tensors):
+    return ConcatFn.apply(*tensors)
+
+
+def stack_dim1(tensors):
+    """torch.stack(tensors, 1) for [N, ...] tensors."""
+    return ConcatFn.apply(*[t.unsqueeze(1) for t in tensors])
+
+
+class SwapAxesFn(torch.autograd.Function):
+    """[B, A, Bd, *S] -> [B, Bd, A, *S] (contiguous)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        _need(x)
+        B, A, Bd = x.shape[:3]
+        S = x.numel() // (B * A * Bd)
+        y = torch.empty((B, Bd, A) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
+        lib().call('dpf_swap_axes', _ptr(x), _ptr(y), B, A, Bd, S, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        B, Bd, A = g.shape[:3]
+        S = g.numel() // (B * A * Bd)
+        dx = torch.empty((B, A, Bd) + tuple(g.shape[3:]), dtype=torch.float32, device=g.device)
+        lib().call('dpf_swap_axes', _ptr(g), _ptr(dx), B, Bd, A, S, _stream())
+        return dx
+
+
+def swap_axes12(x):
+    return SwapAxesFn.apply(x)
+
+
+def channel_max(x):
+    """x.max(1)[0] (no gradient: visualisation output only)."""
+    x = _c(x.detach())
+    _need(x)
+    N, C = x.shape[0], x.shape[1]
+    S = x.numel() // (N * C)
+    y = torch.empty((N,) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    lib().call('dpf_channel_max', _ptr(x), _ptr(y), N, C, S, _stream())
+    return y
+
+
+def bn_replay(running, a_f, a_b, decay, cf, cb):
+    _need(running, a_f, a_b)
+    lib().call('dpf_bn_replay', _ptr(running), _ptr(a_f), _ptr(a_b), running.numel(), float(decay), float(cf), float(cb), _stream())
+
+
 # ----------------------------------------------------------------------------------------------- loss / optimiser
 class LossFn(torch.autograd.Function):
     """-> tensor [3] = (smoothL1_loss, cosine_loss, final_loss)."""

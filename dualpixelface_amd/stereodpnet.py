@@ -306,7 +306,7 @@ class StereoDPNetCore(_Base):
         P = self._P
         o1 = self._convbn2(x, p + '.conv1.0', act=ACT_PRELU, slope=P[p + '.conv1.1.weight'])
         o2 = self._convbn2(o1, p + '.conv2.0', act=ACT_PRELU, slope=P[p + '.conv2.1.weight'])
-        o2 = torch.cat([self._convbn2(o2, p + '.conv_dilate.%d' % i, 1, 2 * i + 1, 2 * i + 1) for i in range(3)], 1)
+        o2 = ops.concat_channels([self._convbn2(o2, p + '.conv_dilate.%d' % i, 1, 2 * i + 1, 2 * i + 1) for i in range(3)])
         o = self._convbn2(o2, p + '.conv3', act=ACT_PRELU, slope=P[p + '.prelu.weight'], res=o1)       # prelu(conv3 + out1)
         o = self._convbn2(o, p + '.conv4.0', s, s, 2, act=ACT_PRELU, slope=P[p + '.conv4.1.weight'])
         d = ops.depthwise_conv3x3(o, P[p + '.conv5.depthwise.weight'])
@@ -337,7 +337,7 @@ class StereoDPNetCore(_Base):
         mid = out(1, last)
         last = ops.nearest_up_add(lat(0, o1), last)
         hi = out(0, last)
-        x = torch.cat([hi, ops.upsample_bilinear(mid, 2), ops.upsample_bilinear(lo, 4)], 1)
+        x = ops.concat_channels([hi, ops.upsample_bilinear(mid, 2), ops.upsample_bilinear(lo, 4)])
         x = self._convbn2(x, p + '.lastconv.0', act=ACT_RELU)
         return self._convbn2(x, p + '.lastconv.2', act=ACT_RELU)
 
@@ -388,8 +388,7 @@ class StereoDPNetCore(_Base):
                 keep = 1.0 - ops.BN_MOMENTUM
                 G = sum((keep * keep) ** j for j in range(L))
                 for name, a_f, a_b in (('.running_mean', z[0], z[2]), ('.running_var', z[1], z[3])):
-                    r = self._B[q + name]
-                    r.mul_(keep ** (2 * L)).add_(a_f, alpha=keep * G).add_(a_b, alpha=G)
+                    ops.bn_replay(self._B[q + name], a_f, a_b, keep ** (2 * L), keep * G, G)
                 key = q + '.num_batches_tracked'
                 self._pending_counts[key] = self._pending_counts.get(key, 0) + 2 * L
             return ops.cv_select(L, [(1 << L) - 1], [x3f, sf, x3b, sb])
@@ -467,7 +466,7 @@ class StereoDPNetCore(_Base):
             v2 = self._convbn3(v1, p + '.original_conv.2', 1, ACT_RELU)
             off1 = off2 = None
         Dn = v2.shape[2]
-        f = v2.permute(0, 2, 1, 3, 4).reshape(B * Dn, v2.shape[1], h, w)
+        f = ops.swap_axes12(v2).view(B * Dn, v2.shape[1], h, w)
         for i, dil in enumerate((1, 2, 4, 8, 1, 1)):
             f = ops.conv2d(f, P['%s.n_convs.%d.0.weight' % (p, i)], None, 1, dil, dil)
             f = ops.norm_act(f, act=ACT_LEAKY, slope_const=0.1)
@@ -495,6 +494,6 @@ class StereoDPNetCore(_Base):
         normal = None
         if opt.model.predict_normal:
             normal, _, _ = self._normals(costs[0], preds[0], batch)
-        return {'pred_depth': torch.stack(preds, 1), 'prob_depth': torch.stack(probs, 1),
+        return {'pred_depth': ops.stack_dim1(preds), 'prob_depth': ops.stack_dim1(probs),
                 'pred_normal': normal.unsqueeze(1) if normal is not None else None,
-                'ref_feature': ref.max(1)[0], '_taps': {'fea_ref': ref, 'fea_tar': tar, 'volume': vol, 'out3': costs[0]}}
+                'ref_feature': ops.channel_max(ref), '_taps': {'fea_ref': ref, 'fea_tar': tar, 'volume': vol, 'out3': costs[0]}}

@@ -117,6 +117,15 @@ int dpf_anm_volume_backward(const float* dvol, const int* idx, float* dcost, int
 int dpf_sigmoid_mean_forward(const float* u, float* out, int B, int Dn, long long CS, void* stream);
 int dpf_sigmoid_mean_backward(const float* u, const float* g, float* du, int B, int Dn, long long CS, void* stream);
 
+/* ---- tensor plumbing kept off eager PyTorch: channel-range copies (torch.cat / stack / slices: modules.py:42,129,
+ * mainmodel.py:98-100), [B,A,Bd,S] -> [B,Bd,A,S] (normal_module.py:185,187), channel max (mainmodel.py:104), closed-form
+ * replay of the shared attention BatchNorm's running statistics (asm.py:141-146 called 2*level times) ----------------- */
+int dpf_copy_channels(const float* src, float* dst, int N, int Cs, int cs0, int Cd, int cd0, int ncopy, long long S, int accumulate,
+                      void* stream);
+int dpf_swap_axes(const float* src, float* dst, int B, int A, int Bd, long long S, void* stream);
+int dpf_channel_max(const float* x, float* y, int N, int C, long long S, void* stream);
+int dpf_bn_replay(float* running, const float* a_f, const float* a_b, int C, float decay, float cf, float cb, void* stream);
+
 /* ---- losses (src/loss/loss_selector.py:29-42, src/loss/depth/smoothL1.py:15-49, src/loss/normal/cosine.py:15-53)
  * and Adam (src/model/model_selector.py:31-34) --------------------------------------------------------------------- */
 int dpf_loss_forward(const float* pred_depth, const float* pred_normal, const float* disp, const float* normal, const float* mask,

@@ -336,3 +336,32 @@ def test_psm_volume_against_reference_fixture(golden_dir):
     assert shifts == [-1, 0, 0, 0, 1, 1, 2, 2]
     close(ops.psm_volume(ref, tar, shifts, 0), torch.from_numpy(g['vol_psmnet']), 0.0, 'psmnet volume')
     close(ops.psm_volume(ref, tar, shifts, 40), torch.from_numpy(g['vol_gwcnet']), 1e-6, 'gwcnet volume')
+
+
+def test_layout_kernels():
+    ops = _ops()
+    a, b, c = rnd(2, 5, 3, 7, seed=100).requires_grad_(), rnd(2, 8, 3, 7, seed=101).requires_grad_(), rnd(2, 1, 3, 7, seed=102).requires_grad_()
+    ref = torch.cat([a, b, c], 1)
+    go = rnd(*ref.shape, seed=103)
+    gr = torch.autograd.grad(ref, (a, b, c), go)
+    ag, bg, cg = [t.detach().to(DEV).requires_grad_() for t in (a, b, c)]
+    out = ops.concat_channels([ag, bg, cg])
+    close(out, ref, 0.0, 'concat')
+    for g1, g2 in zip(torch.autograd.grad(out, (ag, bg, cg), go.to(DEV)), gr):
+        close(g1, g2, 0.0, 'concat bwd')
+    xs = [rnd(3, 4, 6, seed=110 + i) for i in range(3)]
+    close(ops.stack_dim1([t.to(DEV) for t in xs]), torch.stack(xs, 1), 0.0, 'stack')
+    x = rnd(2, 6, 4, 5, 3, seed=120).requires_grad_()
+    ref = x.permute(0, 2, 1, 3, 4).contiguous()
+    go = rnd(*ref.shape, seed=121)
+    (gr,) = torch.autograd.grad(ref, x, go)
+    xg = x.detach().to(DEV).requires_grad_()
+    y = ops.swap_axes12(xg)
+    close(y, ref, 0.0, 'swap axes')
+    (gg,) = torch.autograd.grad(y, xg, go.to(DEV))
+    close(gg, gr, 0.0, 'swap axes bwd')
+    close(ops.channel_max(x.detach().to(DEV)), x.detach().max(1)[0], 0.0, 'channel max')
+    r, af, ab = rnd(32, seed=130), rnd(32, seed=131), rnd(32, seed=132)
+    rg = r.to(DEV)
+    ops.bn_replay(rg, af.to(DEV), ab.to(DEV), 0.9 ** 16, 0.9 * 4.2, 4.2)
+    close(rg, r * 0.9 ** 16 + af * (0.9 * 4.2) + ab * 4.2, 1e-6, 'bn replay')
