@@ -43,6 +43,45 @@ def cpu_baseline(threads):
             'kind': 'port', 'sample': 'one 1x256x256 forward+loss+backward of the CPU oracle (%.1f s), scaled by pixel count' % dt}
 
 
+def stage_bench(args):
+    """HBM-bound stages in isolation: achieved = algorithmic bytes / HIP-event time, peak = 8 TB/s."""
+    from dualpixelface_amd import load_option, ops
+    from dualpixelface_amd.plugin import STEREODPNET
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    B, h, w, C, L = args.batch, args.height // 4, args.width // 4, 32, 8
+    g = torch.Generator().manual_seed(3)
+    ref = torch.randn(B, C, h, w, generator=g).to(dev)
+    tar = torch.randn(B, C, h, w, generator=g).to(dev)
+    alg_bytes = float(B) * (2 * C + 2 * C * L) * h * w * 4          # read both feature maps once, write the [2C, L] volume once
+    if args.workload == 'psm_volume':
+        shifts = [int(i * 0.5 - 1.0) for i in range(L)]
+        fn = lambda: ops.psm_volume(ref, tar, shifts, 0)
+        name = 'PSMNet concat cost volume (BASELINE configs[3])'
+    else:
+        model = STEREODPNET(load_option()).to(dev)
+        model.train()
+        fn = lambda: model._cost_volume(ref, tar)
+        name = 'StereoDPNet cost volume: shift triple + masking attention + volume assembly, forward (SURVEY a2-a4)'
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+    secs = e0.elapsed_time(e1) * 1e-3 / args.steps
+    gbs = alg_bytes / secs / 1e9
+    print(json.dumps({'metric': 'stage throughput (not the BASELINE metric)', 'workload': name, 'value': B / secs, 'unit': 'samples/s',
+                      'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': secs * 1e3, 'dtype': 'f32', 'data': 'synthetic',
+                      'config': {'workload': name, 'batch': B, 'height': args.height, 'width': args.width},
+                      'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0, 'traffic': None,
+                                   'algorithmic_bytes_per_step': alg_bytes}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -53,6 +92,8 @@ def main():
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shapes', default=None, help='write a per-convolution-shape timing table to this file')
+    ap.add_argument('--workload', default='train', choices=['train', 'psm_volume', 'cost_volume'],
+                    help="'train' = the BASELINE metric; the other two time one HBM-bound stage in isolation (BASELINE configs[3], SURVEY a2-a4)")
     args = ap.parse_args()
 
     from dualpixelface_amd import load_option, ops
@@ -61,6 +102,8 @@ def main():
     from dualpixelface_amd.recipe import synthetic_batch
     import torch.distributed as dist
 
+    if args.workload != 'train':
+        return stage_bench(args)
     rank, world, local = init_from_env()
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     dev = torch.device('cuda', local)
