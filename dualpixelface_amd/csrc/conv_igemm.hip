@@ -310,8 +310,8 @@ struct WgP {
 
 
 // WTH rows of 32 positions per tile (8-row tiles for K <= 32 measured slower: 49 vs 52 TFLOP/s)
-// WNT column tiles (of 32 (c,t) pairs) per wave: 4 for K <= 32 so that one G fragment feeds 4 MFMAs
-template <int MT, int WTH = 4, int WNT = (MT == 1 ? 4 : 2)>
+// WNT column tiles (of 32 (c,t) pairs) per wave (4 tiles for K <= 32 measured no faster: 48.5 vs 52 TFLOP/s)
+template <int MT, int WTH = 4, int WNT = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                          float* __restrict__ dw, WgP p) {
   extern __shared__ __align__(16) float smem[];
@@ -621,7 +621,7 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   float* dwk = dw + (long long)k0 * C * p.T;
   const int MT = (p.K + 31) / 32;
   const int KT = 32 * MT;
-  const int WNT = MT == 1 ? 4 : 2;
+  const int WNT = 2;
   int CCW = (4 * WNT * 32) / p.T;
   if (CCW > C) CCW = C;
   if (CCW < 1) CCW = 1;

@@ -127,3 +127,46 @@ def test_train_step_with_flat_grad_reducer_single_rank(golden_dir):
     res2 = model.train_step(load_batch(g), red)          # second step: hooks re-armed, loss moved
     assert abs(float(res2['final_loss']) - float(res['final_loss'])) > 0
     red.remove()
+
+
+@pytest.mark.parametrize('shape', [(3, 48, 80), (1, 96, 64)])
+def test_other_shapes_against_the_oracle(shape):
+    """Ragged sizes (odd batch, H != W, tiles that do not divide the kernels' 8x32 / 2x32 blocks): HIP model vs the CPU
+    oracle on the same recipe weights and synthetic batch, train mode, Bernoulli mask."""
+    from oracle import recipe_state
+    from oracle.stereodpnet import StereoDPNetOracle
+    from dualpixelface_amd.recipe import synthetic_batch
+    B, H, W = shape
+    batch = synthetic_batch(B, H, W, seed=11, mask_mode='bern')
+    orc = StereoDPNetOracle(recipe_state(requires_grad=False), training=True)
+    with torch.no_grad():
+        ref = orc.forward(batch)
+    model = build_model(True)
+    res = model({k: v.to(DEV) for k, v in batch.items()})
+    close(model.last_taps['volume'], orc.taps['volume'], 2e-4, 'volume')
+    close(res['pred_depth'], ref['pred_depth'], None, 'pred_depth', atol=3e-3)
+    close(res['pred_normal'], ref['pred_normal'], None, 'pred_normal', atol=1e-3)
+    for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
+        close(res[k], ref[k], 2e-4, k)
+    res['final_loss'].backward()          # backward runs at these shapes too (values are covered by the fixture test)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_dcn_compat_module_matches_reference_signature():
+    """The `DCN` drop-in (dualpixelface_amd.dcn_compat) called exactly as functions/deform_conv_func.py:27-35,45-56 does."""
+    import dualpixelface_amd.dcn_compat as DCN
+    from oracle import dcn3d
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 4, 6, 10, generator=g)
+    w = torch.randn(16, 8, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(16, generator=g)
+    off = torch.randn(2, 81, 4, 6, 10, generator=g)
+    out = DCN.deform_conv_forward(x.to(DEV), w.to(DEV), b.to(DEV), off.to(DEV), 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 64)
+    close(out, dcn3d.deform_conv3d_forward(x, off, w, b), 1e-4, 'DCN.deform_conv_forward')
+    go = torch.randn(out.shape, generator=g)
+    grads = DCN.deform_conv_backward(x.to(DEV), w.to(DEV), b.to(DEV), off.to(DEV), go.to(DEV), 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 64)
+    assert len(grads) == 4
+    for a, r in zip(grads, dcn3d.deform_conv3d_backward(x, off, w, b, go)):
+        close(a, r, 2e-4, 'DCN.deform_conv_backward')
+    with pytest.raises(RuntimeError):
+        DCN.deform_conv_forward(x, w.to(DEV), b.to(DEV), off.to(DEV), 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 64)   # CPU tensor
