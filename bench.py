@@ -185,7 +185,9 @@ def main():
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+            # 16 threads: the oracle's small-tensor PyTorch-CPU ops scale badly beyond that (256 threads on the 128-core
+            # host took 740 s for the same sample that 8-16 threads finish in ~10-20 s)
+            line['cpu_baseline'] = cpu_baseline(min(16, os.cpu_count() or 1))
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -131,38 +131,41 @@ struct PsmP {
   int shift[16];
 };
 
-// vol [B, 2C + G, L, h, w]
-__global__ void psm_volume_kernel(const float* __restrict__ ref, const float* __restrict__ tar, float* __restrict__ vol, PsmP p) {
+// vol [B, 2C + G, L, h, w]; one workgroup row = one (b, channel, level, y) row, lanes along x with 16-byte accesses
+__global__ __launch_bounds__(256) void psm_volume_kernel(const float* __restrict__ ref, const float* __restrict__ tar, float* __restrict__ vol, PsmP p) {
   const int CV = 2 * p.C + p.G;
-  const long long hw = (long long)p.h * p.w;
-  const long long total = (long long)p.B * CV * p.L * hw;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % p.w);
-    const int y = (int)((i / p.w) % p.h);
-    const int l = (int)((i / hw) % p.L);
-    const int cv = (int)((i / (hw * p.L)) % CV);
-    const int b = (int)(i / (hw * p.L * CV));
-    const int d = p.shift[l];
-    // rows written by the reference: d >= 0 -> y < h - d ; d < 0 -> y >= -d
-    const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);
-    float v = 0.f;
-    if (rowok) {
-      if (cv < p.C) {
-        v = ref[(((long long)b * p.C + cv) * p.h + y) * p.w + x];
-      } else if (cv < 2 * p.C) {
-        v = tar[(((long long)b * p.C + (cv - p.C)) * p.h + (y + d)) * p.w + x];
-      } else {
-        const int gi = cv - 2 * p.C;
-        const int cpg = p.C / p.G;
-        float acc = 0.f;
-        for (int j = 0; j < cpg; ++j) {
-          const int c = gi * cpg + j;
-          acc += ref[(((long long)b * p.C + c) * p.h + y) * p.w + x] * tar[(((long long)b * p.C + c) * p.h + (y + d)) * p.w + x];
-        }
-        v = -(acc / (float)cpg);
-      }
+  long long row = blockIdx.x;
+  const int y = (int)(row % p.h); row /= p.h;
+  const int l = (int)(row % p.L); row /= p.L;
+  const int cv = (int)(row % CV);
+  const int b = (int)(row / CV);
+  const int d = p.shift[l];
+  const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);   // rows the reference writes (psmnet/modules.py:229-246)
+  float* dst = vol + (long long)blockIdx.x * p.w;
+  const bool vec = (p.w & 3) == 0;
+  if (!rowok) {
+    for (int x = threadIdx.x; x < p.w; x += 256) dst[x] = 0.f;
+    return;
+  }
+  if (cv < 2 * p.C) {
+    const float* src = cv < p.C ? ref + (((long long)b * p.C + cv) * p.h + y) * p.w
+                                : tar + (((long long)b * p.C + (cv - p.C)) * p.h + (y + d)) * p.w;
+    if (vec) {
+      for (int x = 4 * threadIdx.x; x < p.w; x += 1024) *reinterpret_cast<float4*>(dst + x) = *reinterpret_cast<const float4*>(src + x);
+    } else {
+      for (int x = threadIdx.x; x < p.w; x += 256) dst[x] = src[x];
     }
-    vol[i] = v;
+  } else {
+    const int gi = cv - 2 * p.C;
+    const int cpg = p.C / p.G;
+    for (int x = threadIdx.x; x < p.w; x += 256) {
+      float acc = 0.f;
+      for (int j = 0; j < cpg; ++j) {
+        const int c = gi * cpg + j;
+        acc += ref[(((long long)b * p.C + c) * p.h + y) * p.w + x] * tar[(((long long)b * p.C + c) * p.h + (y + d)) * p.w + x];
+      }
+      dst[x] = -(acc / (float)cpg);
+    }
   }
 }
 
@@ -217,8 +220,9 @@ int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const
   PsmP p;
   p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.G = groups;
   for (int i = 0; i < 16; ++i) p.shift[i] = i < L ? shifts_host[i] : 0;
-  const long long total = (long long)B * (2 * C + groups) * L * h * w;
-  hipLaunchKernelGGL(psm_volume_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, (hipStream_t)stream, ref, tar, vol, p);
+  const long long rows = (long long)B * (2 * C + groups) * L * h;
+  if (rows > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(psm_volume_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, ref, tar, vol, p);
   return dpf_check_launch();
 }
 
