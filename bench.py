@@ -9,7 +9,7 @@ region.  Rank 0 prints ONE JSON line (contract in the task description) includin
   "roofline":     the dominant kernel (implicit-GEMM convolution on the fp32 matrix cores) -- algorithmic FLOPs per
                   launch / average launch duration, measured live with HIP events on the launch stream;
   "cpu_baseline": the CPU oracle (oracle/, a PyTorch-CPU restatement of the reference) timed on this host's cores on a
-                  bounded sample (one 1x256x256 train step), scaled to 1024x1536 samples/s by pixel count.
+                  bounded sample (one 1x384x512 train step, 16 threads), scaled to 1024x1536 samples/s by pixel count.
 """
 import argparse
 import json
@@ -31,7 +31,7 @@ def cpu_baseline(threads):
     from oracle import recipe_state
     from oracle.stereodpnet import StereoDPNetOracle
     torch.set_num_threads(threads)
-    H = W = 256
+    H, W = 384, 512
     batch = synthetic_batch(1, H, W, seed=7)
     st = recipe_state()
     orc = StereoDPNetOracle(st, training=True)
@@ -40,7 +40,7 @@ def cpu_baseline(threads):
     res['final_loss'].backward()
     dt = time.time() - t0
     return {'value': (1.0 / dt) * (H * W) / (1024.0 * 1536.0), 'unit': 'samples/s (1024x1536 equivalent)', 'cores': threads,
-            'kind': 'port', 'sample': 'one 1x256x256 forward+loss+backward of the CPU oracle (%.1f s), scaled by pixel count' % dt}
+            'kind': 'port', 'sample': 'one 1x%dx%d forward+loss+backward of the CPU oracle (%.1f s), scaled by pixel count' % (H, W, dt)}
 
 
 def stage_bench(args):

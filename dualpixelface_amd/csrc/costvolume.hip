@@ -131,40 +131,50 @@ struct PsmP {
   int shift[16];
 };
 
-// vol [B, 2C + G, L, h, w]; one workgroup row = one (b, channel, level, y) row, lanes along x with 16-byte accesses
+// vol [B, 2C + G, L, h, w]; one workgroup = PSM_RB consecutive rows of one (b, channel, level) plane (contiguous in vol and,
+// for the concat channels, in the source feature map too), lanes along x with 16-byte accesses
+constexpr int PSM_RB = 8;
 __global__ __launch_bounds__(256) void psm_volume_kernel(const float* __restrict__ ref, const float* __restrict__ tar, float* __restrict__ vol, PsmP p) {
   const int CV = 2 * p.C + p.G;
-  long long row = blockIdx.x;
-  const int y = (int)(row % p.h); row /= p.h;
-  const int l = (int)(row % p.L); row /= p.L;
-  const int cv = (int)(row % CV);
-  const int b = (int)(row / CV);
+  const int hb = (p.h + PSM_RB - 1) / PSM_RB;
+  long long blk = blockIdx.x;
+  const int y0 = (int)(blk % hb) * PSM_RB; blk /= hb;
+  const int l = (int)(blk % p.L); blk /= p.L;
+  const int cv = (int)(blk % CV);
+  const int b = (int)(blk / CV);
   const int d = p.shift[l];
-  const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);   // rows the reference writes (psmnet/modules.py:229-246)
-  float* dst = vol + (long long)blockIdx.x * p.w;
-  const bool vec = (p.w & 3) == 0;
-  if (!rowok) {
-    for (int x = threadIdx.x; x < p.w; x += 256) dst[x] = 0.f;
-    return;
-  }
+  const int nrow = min(PSM_RB, p.h - y0);
+  float* dst = vol + ((((long long)b * CV + cv) * p.L + l) * p.h + y0) * p.w;
+  const int n = nrow * p.w;
   if (cv < 2 * p.C) {
-    const float* src = cv < p.C ? ref + (((long long)b * p.C + cv) * p.h + y) * p.w
-                                : tar + (((long long)b * p.C + (cv - p.C)) * p.h + (y + d)) * p.w;
-    if (vec) {
-      for (int x = 4 * threadIdx.x; x < p.w; x += 1024) *reinterpret_cast<float4*>(dst + x) = *reinterpret_cast<const float4*>(src + x);
+    const float* src = cv < p.C ? ref + (((long long)b * p.C + cv) * p.h + y0) * p.w
+                                : tar + (((long long)b * p.C + (cv - p.C)) * p.h + (y0 + d)) * p.w;
+    if ((p.w & 3) == 0) {
+      for (int e = 4 * threadIdx.x; e < n; e += 1024) {
+        const int y = y0 + e / p.w;
+        const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);   // rows the reference writes (psmnet/modules.py:229-246)
+        *reinterpret_cast<float4*>(dst + e) = rowok ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     } else {
-      for (int x = threadIdx.x; x < p.w; x += 256) dst[x] = src[x];
+      for (int e = threadIdx.x; e < n; e += 256) {
+        const int y = y0 + e / p.w;
+        const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);
+        dst[e] = rowok ? src[e] : 0.f;
+      }
     }
   } else {
     const int gi = cv - 2 * p.C;
     const int cpg = p.C / p.G;
-    for (int x = threadIdx.x; x < p.w; x += 256) {
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int y = y0 + e / p.w, x = e % p.w;
+      const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);
       float acc = 0.f;
-      for (int j = 0; j < cpg; ++j) {
-        const int c = gi * cpg + j;
-        acc += ref[(((long long)b * p.C + c) * p.h + y) * p.w + x] * tar[(((long long)b * p.C + c) * p.h + (y + d)) * p.w + x];
-      }
-      dst[x] = -(acc / (float)cpg);
+      if (rowok)
+        for (int j = 0; j < cpg; ++j) {
+          const int c = gi * cpg + j;
+          acc += ref[(((long long)b * p.C + c) * p.h + y) * p.w + x] * tar[(((long long)b * p.C + c) * p.h + (y + d)) * p.w + x];
+        }
+      dst[e] = rowok ? -(acc / (float)cpg) : 0.f;
     }
   }
 }
@@ -220,7 +230,7 @@ int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const
   PsmP p;
   p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.G = groups;
   for (int i = 0; i < 16; ++i) p.shift[i] = i < L ? shifts_host[i] : 0;
-  const long long rows = (long long)B * (2 * C + groups) * L * h;
+  const long long rows = (long long)B * (2 * C + groups) * L * ((h + PSM_RB - 1) / PSM_RB);
   if (rows > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(psm_volume_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, ref, tar, vol, p);
   return dpf_check_launch();
