@@ -271,6 +271,7 @@ constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8, GI_CS = 9;   // 8 chan
 struct GiP {
   int TZ, RZmax, RY, RX;     // tile depth, region dims
   int tilesZ, tilesY, tilesX;
+  int CG;                    // grad_input is produced for channels [0, CG) only
 };
 
 // Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 sustains 0.33 lanes/clk/CU whatever the address pattern,
@@ -330,11 +331,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
     }
   }
 
-  for (int c0 = 0; c0 < p.C; c0 += GI_CH) {
+  for (int c0 = 0; c0 < q.CG; c0 += GI_CH) {      // only the channels whose gradient the caller needs
     __syncthreads();                                            // previous chunk flushed
     for (int i = tid; i < regvox * GI_CS + GI_CS; i += 256) s_reg[i] = 0.0;
     const int cc = c0 + lc;
-    const bool cok = cc < p.C;
+    const bool cok = cc < q.CG;
     Off3 onext = load_off(p, off_b, 0, ppos);
     float bnext[16];
 #pragma unroll
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       const int zy = row / GI_CH;
       const int ly = zy % q.RY, lz = zy / q.RY;
       const int gz = rz0 + lz, gy = ry0 + ly;
-      if (c0 + c >= p.C || gy < 0 || gy >= p.H) continue;
+      if (c0 + c >= q.CG || gy < 0 || gy >= p.H) continue;
       float* dst = dxb + (long long)(c0 + c) * chan + ((long long)gz * p.H + gy) * p.W;
       for (int lx = lane; lx < rowlen; lx += 64) {
         const int gx = rx0 + lx;
@@ -1052,10 +1053,26 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
 
 // Mirrors DCN.deform_conv_backward(...) -> [grad_input, grad_offset, grad_weight, grad_bias] (deform_conv.h:49-69).
 // grad_input / grad_weight / grad_bias are zero-initialised here, like the reference's at::zeros_like (cu:202-205).
+int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const float* bias, const float* offset, const float* grad_output,
+                                  float* grad_input, float* grad_offset, float* grad_weight, float* grad_bias, float* ws, int B, int C,
+                                  int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd,
+                                  int dh, int dw, int group, int deformable_group, int im2col_step, int grad_input_channels, void* stream);
+
 int dpf_deform_conv3d_backward(const float* input, const float* weight, const float* bias, const float* offset, const float* grad_output,
                                float* grad_input, float* grad_offset, float* grad_weight, float* grad_bias, float* ws, int B, int C,
                                int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd,
                                int dh, int dw, int group, int deformable_group, int im2col_step, void* stream) {
+  return dpf_deform_conv3d_backward_ex(input, weight, bias, offset, grad_output, grad_input, grad_offset, grad_weight, grad_bias, ws, B, C, D, H,
+                                       W, K, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw, group, deformable_group, im2col_step, C, stream);
+}
+
+// Same as dpf_deform_conv3d_backward, but grad_input is only produced for input channels [0, grad_input_channels) (the remaining
+// channels of the zero-initialised tensor stay 0): StereoDPNet's first deformable conv consumes 32 cost channels + 3 constant
+// XYZ channels (normal_module.py:166), whose gradient nobody reads.
+int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const float* bias, const float* offset, const float* grad_output,
+                                  float* grad_input, float* grad_offset, float* grad_weight, float* grad_bias, float* ws, int B, int C,
+                                  int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd,
+                                  int dh, int dw, int group, int deformable_group, int im2col_step, int grad_input_channels, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   (void)im2col_step; (void)bias;
   if (!input || !weight || !offset || !grad_output || !grad_input || !grad_offset || !grad_weight || !ws) return DPF_ERR_INVALID_ARG;
@@ -1083,6 +1100,7 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
     q.tilesZ = dpf_div_up(p.Do, q.TZ);
     q.tilesY = dpf_div_up(p.Ho, GI_TY);
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
+    q.CG = grad_input_channels < C ? (grad_input_channels < 0 ? 0 : grad_input_channels) : C;
     const int npos = 64 * q.TZ;
     const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 25 + 4);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;

@@ -487,7 +487,7 @@ def deform_conv_forward_raw(x, weight, bias, offset, stride, pad, dil, group=1, 
     return out
 
 
-def deform_conv_backward_raw(x, weight, bias, offset, go, stride, pad, dil, group=1, dgroup=1, step=64):
+def deform_conv_backward_raw(x, weight, bias, offset, go, stride, pad, dil, group=1, dgroup=1, step=64, gi_channels=None):
     B, C, D, H, W = x.shape
     K, _, kd, kh, kw = weight.shape
     L = lib()
@@ -496,8 +496,9 @@ def deform_conv_backward_raw(x, weight, bias, offset, go, stride, pad, dil, grou
     gw = torch.empty_like(weight)
     gb = torch.empty_like(bias)
     ws = scratch(L.call('dpf_deform_conv3d_workspace_floats', C, K, kd * kh * kw), x.device, 'convw')
-    L.call('dpf_deform_conv3d_backward', _ptr(x), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(go), _ptr(gi), _ptr(goff), _ptr(gw), _ptr(gb),
-           _ptr(ws), B, C, D, H, W, K, kd, kh, kw, *stride, *pad, *dil, group, dgroup, step, _stream())
+    L.call('dpf_deform_conv3d_backward_ex', _ptr(x), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(go), _ptr(gi), _ptr(goff), _ptr(gw), _ptr(gb),
+           _ptr(ws), B, C, D, H, W, K, kd, kh, kw, *stride, *pad, *dil, group, dgroup, step, C if gi_channels is None else int(gi_channels),
+           _stream())
     return gi, goff, gw, gb
 
 
@@ -505,22 +506,24 @@ class DeformConvFn(torch.autograd.Function):
     """Same contract as the reference's DeformConvFunction (src/module/dcn3d/functions/deform_conv_func.py:16-59)."""
 
     @staticmethod
-    def forward(ctx, x, offset, weight, bias, stride, pad, dil):
+    def forward(ctx, x, offset, weight, bias, stride, pad, dil, gi_channels=None):
         x, offset, weight, bias = _c(x), _c(offset), _c(weight), _c(bias)
         _need(x, offset, weight, bias)
         ctx.cfg = (stride, pad, dil)
+        ctx.gi_channels = gi_channels
         ctx.save_for_backward(x, offset, weight, bias)
         return deform_conv_forward_raw(x, weight, bias, offset, stride, pad, dil)
 
     @staticmethod
     def backward(ctx, go):
         x, offset, weight, bias = ctx.saved_tensors
-        gi, goff, gw, gb = deform_conv_backward_raw(x, weight, bias, offset, _c(go), *ctx.cfg)
-        return gi, goff, gw, gb, None, None, None
+        gi, goff, gw, gb = deform_conv_backward_raw(x, weight, bias, offset, _c(go), *ctx.cfg, gi_channels=ctx.gi_channels)
+        return gi, goff, gw, gb, None, None, None, None
 
 
-def deform_conv3d(x, offset, weight, bias, stride=1, pad=1, dil=1):
-    return DeformConvFn.apply(x, offset, weight, bias, _t3(stride), _t3(pad), _t3(dil))
+def deform_conv3d(x, offset, weight, bias, stride=1, pad=1, dil=1, gi_channels=None):
+    """gi_channels: only the first gi_channels input channels need a gradient (the others' grad_input stays zero)."""
+    return DeformConvFn.apply(x, offset, weight, bias, _t3(stride), _t3(pad), _t3(dil), gi_channels)
 
 
 # ----------------------------------------------------------------------------------------------- normal module glue

@@ -440,10 +440,10 @@ class StereoDPNetCore(_Base):
         return [k3], [o3]
 
     # ------------------------------------------------------------------ normal module (normal_module.py:140-194)
-    def _deform(self, x, p):
+    def _deform(self, x, p, gi_channels=None):
         P = self._P
         off = ops.conv3d(x, P[p + '.conv_offset.weight'], P[p + '.conv_offset.bias'], 1, 1, 1)
-        return ops.deform_conv3d(x, off, P[p + '.weight'], P[p + '.bias']), off
+        return ops.deform_conv3d(x, off, P[p + '.weight'], P[p + '.bias'], gi_channels=gi_channels), off
 
     def _normals(self, cost, disp_full, batch):
         P, p, m = self._P, 'normal_estimator', self.option.model
@@ -457,7 +457,8 @@ class StereoDPNetCore(_Base):
             raise NotImplementedError('use_sampling=false is not on the StereoDPNet hot path')
         vol, _ = ops.anm_volume(cost, disp_full, batch['K'].float(), batch['abvalue'].float(), self.costrange, int(m.dsample_num))
         if m.use_deform:
-            v1, off1 = self._deform(vol, p + '.deform_conv1')
+            # the 3 XYZ channels of `vol` are constants of the batch (no gradient consumer): skip their grad_input
+            v1, off1 = self._deform(vol, p + '.deform_conv1', gi_channels=C)
             v1 = self._bn(v1, p + '.act1.0', ACT_RELU)
             v2, off2 = self._deform(v1, p + '.deform_conv2')
             v2 = self._bn(v2, p + '.act2.0', ACT_RELU)

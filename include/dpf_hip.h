@@ -108,6 +108,12 @@ int dpf_deform_conv3d_backward(const float* input, const float* weight, const fl
                                int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd,
                                int dh, int dw, int group, int deformable_group, int im2col_step, void* stream);
 
+/* extension: grad_input only for input channels [0, grad_input_channels) (the rest of the zero-initialised tensor stays 0) */
+int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const float* bias, const float* offset, const float* grad_output,
+                                  float* grad_input, float* grad_offset, float* grad_weight, float* grad_bias, float* ws, int B, int C,
+                                  int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd,
+                                  int dh, int dw, int group, int deformable_group, int im2col_step, int grad_input_channels, void* stream);
+
 /* ---- Adaptive Normal Module glue (src/model/stereodpnet/normal_module.py:80-138,154-167,185-190) ------------------ */
 int dpf_anm_select(const float* disp_full, int* idx, float* sdisp, const float* costrange_host, int B, int H, int W, int h, int w, int L,
                    int K, void* stream);
