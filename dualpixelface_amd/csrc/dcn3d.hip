@@ -765,12 +765,18 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
   }
 }
 
+constexpr int WG_NREP = 8;   // replicas of the grad_weight scratch tensor (spreads same-address atomic contention)
+
 // ---------------------------------------------------------------------------------------------------- grad_offset
 // gcol[c][p] = sum_k W[k][c][t] go[k][p] on v_mfma_f32_16x16x4_f32 (D row = channel, col = voxel), then
 // grad_offset[3t+dir][p] = sum_c gcol[c][p] * d sample(c,p,t) / d coord_dir   (cuh:111-190, 336-405)
+// WG = true additionally produces grad_weight in the same pass (the corner values are already in registers): the sampled tile
+// S[16][256] replaces gcol in LDS and each wave contracts it against its 16 output channels of go (see dcn_wgrad_region_kernel)
+template <bool WG>
 __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                     const float* __restrict__ wt2 /*[T][K][CT]*/, const float* __restrict__ go,
-                                                                    float* __restrict__ doff, DcnP p, RegGeo g, int CT) {
+                                                                    float* __restrict__ doff, float* __restrict__ dwtmp, DcnP p, RegGeo g, int CT,
+                                                                    int nchunk) {
   extern __shared__ __align__(16) float smem[];
   float* s_reg = smem;                       // [RV][RG_VS]
   float* s_gc = s_reg + RG_VS * g.RV;        // [16][ST]
@@ -802,6 +808,22 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
     }
   }
 
+  // grad_weight: A fragments go[k = 16*wave + l15][voxel 4*ks + lg] (64 k-steps over the tile), replica of the scratch tensor
+  float wfrag[WG ? 64 : 1];
+  float* rep = nullptr;
+  if (WG) {
+    const int kk = 16 * wave + l15;
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) {
+      const int pl = 4 * ks + lg;
+      const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+      const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
+      const bool ok = kk < p.K && az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
+      wfrag[ks] = ok ? go[((long long)c.b * p.K + kk) * p.P + ((long long)gz * p.Ho + gy) * p.Wo + gx] : 0.f;
+    }
+    rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
+  }
+
   for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
     __syncthreads();
     stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
@@ -830,6 +852,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
       }
       __syncthreads();
       float gd = 0.f, gh = 0.f, gw = 0.f;
+      float sval[RG_CH];
+#pragma unroll
+      for (int ch = 0; ch < RG_CH; ++ch) sval[ch] = 0.f;
       if (sp.valid) {
         float gcv[RG_CH];
 #pragma unroll
@@ -846,6 +871,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
 #pragma unroll
             for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
             dots[j] = dot;
+            if (WG) {
+              const float wj = sp.wz[j >> 2] * sp.wy[(j >> 1) & 1] * sp.wx[j & 1];
+#pragma unroll
+              for (int ch = 0; ch < RG_CH; ++ch) sval[ch] = fmaf(wj, v[ch], sval[ch]);
+            }
           }
         } else {
 #pragma unroll
@@ -856,6 +886,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
 #pragma unroll
             for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
             dots[j] = dot;
+            if (WG) {
+              const float wj = sp.wz[j >> 2] * sp.wy[(j >> 1) & 1] * sp.wx[j & 1];
+#pragma unroll
+              for (int ch = 0; ch < RG_CH; ++ch) sval[ch] = fmaf(wj, v[ch], sval[ch]);
+            }
           }
         }
 #pragma unroll
@@ -874,6 +909,21 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
           q[0] += gd; q[p.P] += gh; q[2 * p.P] += gw;
         }
       }
+      if (WG) {
+        // this thread is the only reader of column `tid` of the gcol tile, so it can overwrite it with its samples right away
+#pragma unroll
+        for (int ch = 0; ch < RG_CH; ++ch) s_gc[ch * ST + tid] = sval[ch];
+        __syncthreads();
+        f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 64; ++ks) wacc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[ks], s_gc[l15 * ST + 4 * ks + lg], wacc, 0, 0, 0);
+        if (c0 + l15 < p.C) {
+          float* dst = rep + ((long long)(t * nchunk + c0 / RG_CH) * 64 + 16 * wave + 4 * lg) * 16 + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * wave + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], wacc[r]);
+        }
+      }
     }
   }
 }
@@ -883,8 +933,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
 // contracts it against its 16 output channels of go (kept in registers) with v_mfma_f32_16x16x4_f32 (D row = k, col = c);
 // the [64 x 16] partial is added into one of NREP replicas of a [T][chunk][64][16] scratch tensor (64-B contiguous atomics,
 // replicas spread the same-address contention of the 6144 workgroups) that a second kernel folds into dW[k][c][t].
-constexpr int WG_NREP = 8;
-
 __global__ __launch_bounds__(256) void dcn_wgrad_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                const float* __restrict__ go, float* __restrict__ dwtmp, DcnP p, RegGeo g,
                                                                int nchunk) {
@@ -1117,13 +1165,27 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     }
   }
   RegGeo rg{};
-  if (dx_done && K <= 64 && region_geo(rg, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
+  const bool region_ok = K <= 64 && region_geo(rg, p) == DPF_OK && !getenv("DPF_DCN_V1");
+  const bool fuse_wg = region_ok && dx_done && !getenv("DPF_DCN_NOFUSE");
+  const long long a_ = (long long)p.T * C * (((K + 31) / 32) * 32), b_ = (long long)p.T * K * (((C + 31) / 32) * 32);
+  float* dwtmp = ws + (((a_ > b_ ? a_ : b_) + 63) & ~63LL);
+  const int nchunk = (C + RG_CH - 1) / RG_CH;
+  if (region_ok) {
+    if (hipMemsetAsync(dwtmp, 0, sizeof(float) * (size_t)WG_NREP * p.T * nchunk * 64 * 16, st) != hipSuccess) return DPF_ERR_LAUNCH;
+  }
+  if (region_ok && dx_done) {
     const size_t lds = sizeof(float) * ((size_t)RG_VS * rg.RV + (size_t)RG_CH * ST);
     const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
-    if (set_lds(dcn_bwd_offset_region_kernel, lds) != DPF_OK) return DPF_ERR_LAUNCH;
-    hipLaunchKernelGGL(dcn_bwd_offset_region_kernel, grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, p, rg, CT);
-  } else
-  {
+    if (fuse_wg) {
+      if (set_lds(dcn_bwd_offset_region_kernel<true>, lds) != DPF_OK) return DPF_ERR_LAUNCH;
+      hipLaunchKernelGGL(dcn_bwd_offset_region_kernel<true>, grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, p, rg, CT,
+                         nchunk);
+    } else {
+      if (set_lds(dcn_bwd_offset_region_kernel<false>, lds) != DPF_OK) return DPF_ERR_LAUNCH;
+      hipLaunchKernelGGL(dcn_bwd_offset_region_kernel<false>, grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, p, rg, CT,
+                         nchunk);
+    }
+  } else {
     const size_t lds = sizeof(float) * ((size_t)K * SP + (size_t)CT * SP + 3 * 4 * TP);
     const dim3 grid((unsigned)(B * p.tiles_per_b));
 #define DPF_D(M)                                                                                                       \
@@ -1139,25 +1201,20 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     switch (MTC) { case 1: DPF_D(1); break; case 2: DPF_D(2); break; case 3: DPF_D(3); break; default: DPF_D(4); break; }
 #undef DPF_D
   }
-  RegGeo wg{};
-  if (K <= 64 && region_geo(wg, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
-    const long long a_ = (long long)p.T * C * (((K + 31) / 32) * 32), b_ = (long long)p.T * K * (((C + 31) / 32) * 32);
-    float* dwtmp = ws + (((a_ > b_ ? a_ : b_) + 63) & ~63LL);
-    const int nchunk = (C + RG_CH - 1) / RG_CH;
-    const size_t tmp_bytes = sizeof(float) * (size_t)WG_NREP * p.T * nchunk * 64 * 16;
-    if (hipMemsetAsync(dwtmp, 0, tmp_bytes, st) != hipSuccess) return DPF_ERR_LAUNCH;
-    const size_t lds = sizeof(float) * ((size_t)RG_VS * wg.RV + (size_t)RG_CH * ST);
-    const dim3 grid((unsigned)((long long)B * wg.tilesZ * wg.tilesY * wg.tilesX));
-    if (set_lds(dcn_wgrad_region_kernel, lds) != DPF_OK) return DPF_ERR_LAUNCH;
-    hipLaunchKernelGGL(dcn_wgrad_region_kernel, grid, dim3(256), lds, st, input, offset, grad_output, dwtmp, p, wg, nchunk);
+  if (region_ok) {
+    if (!fuse_wg) {
+      const size_t lds = sizeof(float) * ((size_t)RG_VS * rg.RV + (size_t)RG_CH * ST);
+      const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
+      if (set_lds(dcn_wgrad_region_kernel, lds) != DPF_OK) return DPF_ERR_LAUNCH;
+      hipLaunchKernelGGL(dcn_wgrad_region_kernel, grid, dim3(256), lds, st, input, offset, grad_output, dwtmp, p, rg, nchunk);
+    }
     hipLaunchKernelGGL(dcn_wgrad_fold_kernel, dim3(dpf_ew_grid((long long)K * C * p.T)), dim3(256), 0, st, dwtmp, grad_weight, K, C, p.T, nchunk);
-  } else
-  {
+  } else {
     const long long ntile = (long long)B * p.tiles_per_b;
-    long long nchunk = 2048 / p.T;
-    if (nchunk < 1) nchunk = 1;
-    if (nchunk > ntile) nchunk = ntile;
-    p.nchunk = (int)nchunk;
+    long long nchunkw = 2048 / p.T;
+    if (nchunkw < 1) nchunkw = 1;
+    if (nchunkw > ntile) nchunkw = ntile;
+    p.nchunk = (int)nchunkw;
     const size_t lds = sizeof(float) * ((size_t)32 * MTC * SP + (size_t)32 * MT * SP);
     const dim3 grid((unsigned)(p.T * p.nchunk));
 #define DPF_W(M, N)                                                                                           \
