@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sync-bn', action='store_true',
+                    help='BatchNorm statistics over the global batch (what the reference does under DDP); default per-rank statistics')
     ap.add_argument('--shapes', default=None, help='write a per-convolution-shape timing table to this file')
     ap.add_argument('--workload', default='train', choices=['train', 'psm_volume', 'cost_volume'],
                     help="'train' = the BASELINE metric; the other two time one HBM-bound stage in isolation (BASELINE configs[3], SURVEY a2-a4)")
@@ -114,6 +116,8 @@ def main():
     model.to(dev)
     broadcast_flat(model.flat_parameters(), 0)
     reducer = make_reducer(model) if world > 1 else None
+    if args.sync_bn and world > 1:
+        model.enable_sync_batchnorm()
     batch = {k: v.to(dev) for k, v in synthetic_batch(args.batch, args.height, args.width, seed=rank).items()}
 
     def sync():
@@ -179,7 +183,7 @@ def main():
             'config': {'workload': 'StereoDPNet train step (fwd+loss+bwd+grad all-reduce+Adam), %d x %dx%d synthetic DP pairs per GPU'
                                    % (args.batch, args.height, args.width),
                        'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,
-                       'batchnorm': 'per-rank statistics'},
+                       'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics'},
             'final_loss': loss,
             'flop_frac_of_f32_peak': value * FLOP_PER_PIXEL_FWD_BWD * pixels / (world * PEAK_F32_TFLOPS * 1e12),
             'roofline': roof,

@@ -65,6 +65,46 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+// cross-rank batch statistics (SyncBatchNorm): this rank's { mean, M2 = sum (x - mean)^2 } per channel from the shifted sums
+__global__ void bn_local_moments_kernel(const float* __restrict__ x, const float* __restrict__ sums, int C, long long S, double count,
+                                        float* __restrict__ moments) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double K = x[(long long)c * S];
+  const double m1 = sums[2 * c] / count;
+  double m2 = sums[2 * c + 1] - count * m1 * m1;
+  if (m2 < 0) m2 = 0;
+  moments[2 * c] = (float)(K + m1);
+  moments[2 * c + 1] = (float)m2;
+}
+
+// pairwise-merge (Chan et al.) of W ranks' { mean, M2 } with their element counts -> global mean / invstd, running statistics
+__global__ void bn_merge_moments_kernel(const float* __restrict__ moments /*[W][2C]*/, const float* __restrict__ counts /*[W]*/, int W, int C,
+                                        float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                        float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0, mu = 0;
+  for (int r = 0; r < W; ++r) {
+    n += (double)counts[r];
+    mu += (double)counts[r] * (double)moments[((long long)r * C + c) * 2];
+  }
+  mu /= n;
+  double m2 = 0;
+  for (int r = 0; r < W; ++r) {
+    const double d = (double)moments[((long long)r * C + c) * 2] - mu;
+    m2 += (double)moments[((long long)r * C + c) * 2 + 1] + (double)counts[r] * d * d;
+  }
+  const double var = m2 / n;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = n > 1 ? m2 / (n - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
 // eval mode: mean/invstd straight from the running statistics
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
                                      float* __restrict__ mean, float* __restrict__ invstd) {
@@ -135,14 +175,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
   const long long s1 = min(S, s0 + ROW_CHUNK);
   float a = 0.f, b = 0.f, sl = 0.f;
-  for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
-    const float xh = (x[base + s] - mu) * is;
-    const float z = fmaf(xh, g, be) + (res ? res[base + s] : 0.f);
-    const float d = dy[base + s];
+  auto one = [&](float xv, float rv, float d) {
+    const float xh = (xv - mu) * is;
+    const float z = fmaf(xh, g, be) + rv;
     const float dz = d * dpf_dact(z, act, slope);
     a += dz;
     b += dz * xh;
     if (act == DPF_ACT_PRELU && z <= 0.f) sl += z * d;
+  };
+  if ((S & 3) == 0) {
+    for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + base + s);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + base + s);
+      const float4 rv = res ? *reinterpret_cast<const float4*>(res + base + s) : make_float4(0, 0, 0, 0);
+      one(xv.x, rv.x, dv.x); one(xv.y, rv.y, dv.y); one(xv.z, rv.z, dv.z); one(xv.w, rv.w, dv.w);
+    }
+  } else {
+    for (long long s = s0 + threadIdx.x; s < s1; s += 256) one(x[base + s], res ? res[base + s] : 0.f, dy[base + s]);
   }
   a = dpf_block_sum_256(a, sm);
   b = dpf_block_sum_256(b, sm);
@@ -181,12 +230,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const long long base = (long long)row * S;
   const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
   const long long s1 = min(S, s0 + ROW_CHUNK);
-  for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
-    const float xh = (x[base + s] - mu) * is;
-    const float z = fmaf(xh, g, be) + (res ? res[base + s] : 0.f);
-    const float dz = dy[base + s] * dpf_dact(z, act, slope);
-    if (dres) dres[base + s] = dz;
-    if (dx) dx[base + s] = mean ? gi * (dz - m_dz - xh * m_dzx) : dz;
+  auto one = [&](float xv, float rv, float d, float& o_dz, float& o_dx) {
+    const float xh = (xv - mu) * is;
+    const float z = fmaf(xh, g, be) + rv;
+    o_dz = d * dpf_dact(z, act, slope);
+    o_dx = mean ? gi * (o_dz - m_dz - xh * m_dzx) : o_dz;
+  };
+  if ((S & 3) == 0) {
+    for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + base + s);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + base + s);
+      const float4 rv = res ? *reinterpret_cast<const float4*>(res + base + s) : make_float4(0, 0, 0, 0);
+      float4 oz, ox;
+      one(xv.x, rv.x, dv.x, oz.x, ox.x); one(xv.y, rv.y, dv.y, oz.y, ox.y);
+      one(xv.z, rv.z, dv.z, oz.z, ox.z); one(xv.w, rv.w, dv.w, oz.w, ox.w);
+      if (dres) *reinterpret_cast<float4*>(dres + base + s) = oz;
+      if (dx) *reinterpret_cast<float4*>(dx + base + s) = ox;
+    }
+  } else {
+    for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
+      float oz, ox;
+      one(x[base + s], res ? res[base + s] : 0.f, dy[base + s], oz, ox);
+      if (dres) dres[base + s] = oz;
+      if (dx) dx[base + s] = ox;
+    }
   }
 }
 
@@ -244,6 +311,30 @@ int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float mom
   return dpf_check_launch();
 }
 
+// SyncBatchNorm, step 1 of 2: this rank's per-channel { mean, M2 } of x[N,C,S] -> moments[2*C].  ws: >= 2*C floats.
+// The caller all-gathers moments (and N*S) over the ranks and hands the [W][2*C] stack to dpf_bn_merge_moments.
+// (torch.nn.SyncBatchNorm semantics, which the reference turns on under DDP: config_manager.py:57, main.py:55.)
+int dpf_bn_local_moments(const float* x, int N, int C, long long S, float* moments, float* ws, void* stream) {
+  dpf_clear_error();
+  if (!x || !moments || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
+  hipLaunchKernelGGL(bn_stats_kernel, row_grid(N * C, S), dim3(256), 0, st, x, ws, N, C, S);
+  hipLaunchKernelGGL(bn_local_moments_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, st, x, ws, C, S, (double)N * (double)S, moments);
+  return dpf_check_launch();
+}
+
+// SyncBatchNorm, step 2 of 2: merge W ranks' moments (device, [W][2*C]) and element counts (device, [W]) into the global
+// mean / invstd [C]; updates the running statistics with the global unbiased variance when running_mean != NULL.
+int dpf_bn_merge_moments(const float* moments, const float* counts, int W, int C, float eps, float momentum, float* running_mean,
+                         float* running_var, float* mean, float* invstd, void* stream) {
+  dpf_clear_error();
+  if (!moments || !counts || !mean || !invstd || W <= 0 || C <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bn_merge_moments_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, (hipStream_t)stream, moments, counts, W, C, eps,
+                     momentum, running_mean, running_var, mean, invstd);
+  return dpf_check_launch();
+}
+
 int dpf_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!running_mean || !running_var || !mean || !invstd || C <= 0) return DPF_ERR_INVALID_ARG;
@@ -267,28 +358,38 @@ int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd,
 
 // Backward of dpf_norm_act_forward w.r.t. x, res, w, b, slope (res2's gradient is dy itself).
 // ws: >= 3*C floats.  dweight/dbias [wmod], dslope [1] are ACCUMULATED into (+=); any may be NULL.
-int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
-                          int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
-                          float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, void* stream) {
+// phase 0: everything.  phase 1: only the per-channel reductions (ws[3c] = sum dz, ws[3c+1] = sum dz*xhat) and the parameter
+// gradients; phase 2: only dx / dres from a ws the caller has summed over the ranks, with count = global N*S (SyncBatchNorm).
+int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
+                             int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
+                             float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, int phase,
+                             double count, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
-  if (!x || !dy || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
+  if (!x || !dy || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535 || phase < 0 || phase > 2) return DPF_ERR_INVALID_ARG;
   if (wmod <= 0) wmod = C;
   hipStream_t st = (hipStream_t)stream;
   const bool need_reduce = (mean != nullptr) || (act == DPF_ACT_PRELU && dslope);
-  if (need_reduce) {
+  if (need_reduce && phase != 2) {
     if (hipMemsetAsync(ws, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope,
                        slope_const, ws, C, S);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpf_div_up(wmod, 64)), dim3(64), 0, st, ws, C, wmod, mean ? dweight : nullptr,
                        mean ? dbias : nullptr, act == DPF_ACT_PRELU ? dslope : nullptr);
   }
-  if (dx || dres) {
+  if ((dx || dres) && phase != 1) {
     // instance-norm view (wmod < C): statistics are per row, count = S; batch norm: count = N*S
-    const double count = (double)N * (double)S;
+    if (count <= 0) count = (double)N * (double)S;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope,
                        slope_const, ws, (float)(1.0 / count), training, dx, dres, C, S);
   }
   return dpf_check_launch();
+}
+
+int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
+                          int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
+                          float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, void* stream) {
+  return dpf_norm_act_backward_ex(x, dy, mean, invstd, w, b, wmod, res, act, slope, slope_const, training, dx, dres, dweight, dbias, dslope,
+                                  ws, N, C, S, 0, 0.0, stream);
 }
 
 // out[C] += sum over n, s of g[N,C,S]

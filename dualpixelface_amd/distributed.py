@@ -104,3 +104,38 @@ def make_reducer(model, nbuckets=3):
             if offs:
                 bounds.append(min(offs))
     return FlatGradReducer(flat_g, layout, bounds[:max(0, nbuckets - 1)])
+
+
+class StatExchange(object):
+    """Cross-rank exchange of BatchNorm statistics (SyncBatchNorm; SURVEY section 8e "second, optional exchange").
+
+    The reference turns torch's SyncBatchNorm on whenever accelerator == 'ddp' (config_manager.py:57, main.py:55).  Here the
+    statistics kernels stay local (ops.NormActFn) and only two tiny vectors per BatchNorm call cross the ranks: the packed
+    {mean, M2, count} [2C+1] in forward (all-gather) and {sum dz, sum dz*xhat, .} [3C] in backward (all-reduce).
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self._counts = {}
+
+    def all_gather(self, t):
+        out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
+        return out
+
+    def all_reduce_sum_(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def total_count(self, local_count):
+        """Global element count for a local count.  Cached per local count: ranks are assumed to change batch shape together
+        (DistributedSampler pads the last batch), which keeps the host out of the per-layer critical path."""
+        key = int(local_count)
+        if key not in self._counts:
+            t = torch.tensor([float(local_count)], dtype=torch.float64)
+            if dist.get_backend(self.group) == 'nccl':
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._counts[key] = float(t.item())
+        return self._counts[key]

@@ -248,8 +248,9 @@ class NormActFn(torch.autograd.Function):
     """y = act(norm(x) * w + b + res) + res2 with norm = batch norm (training/eval) or instance norm, or no norm."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const):
+    def forward(ctx, x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const, exchange=None):
         # mode: 0 none, 1 batch norm (training), 2 batch norm (eval), 3 instance norm
+        # exchange: distributed.StatExchange -> training batch norm uses the statistics of the global batch (SyncBatchNorm)
         x = _c(x)
         res = None if res is None else _c(res)
         res2 = None if res2 is None else _c(res2)
@@ -259,7 +260,21 @@ class NormActFn(torch.autograd.Function):
         L = lib()
         mean = invstd = None
         n_, c_, wmod = N, C, C
-        if mode == 1:
+        count_total = 0.0
+        if mode == 1 and exchange is not None:
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            ws = scratch(2 * C, x.device)
+            packed = torch.empty(2 * C + 1, dtype=torch.float32, device=x.device)
+            packed[2 * C] = float(N * S)
+            L.call('dpf_bn_local_moments', _ptr(x), N, C, S, _ptr(packed), _ptr(ws), _stream())
+            gathered = exchange.all_gather(packed)                       # [W, 2C+1]
+            moments = gathered[:, :2 * C].contiguous()
+            counts = gathered[:, 2 * C].contiguous()
+            L.call('dpf_bn_merge_moments', _ptr(moments), _ptr(counts), gathered.shape[0], C, BN_EPS, BN_MOMENTUM, _ptr(running_mean),
+                   _ptr(running_var), _ptr(mean), _ptr(invstd), _stream())
+            count_total = exchange.total_count(N * S)
+        elif mode == 1:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
             ws = scratch(2 * C, x.device)
@@ -280,6 +295,8 @@ class NormActFn(torch.autograd.Function):
                _ptr(slope), float(slope_const), _ptr(y), n_, c_, S, _stream())
         ctx.save_for_backward(x, weight, bias, slope, res, mean, invstd)
         ctx.cfg = (mode, act, float(slope_const), n_, c_, S, wmod, res2 is not None)
+        ctx.exchange = exchange if mode == 1 else None
+        ctx.count_total = count_total
         return y
 
     @staticmethod
@@ -294,18 +311,25 @@ class NormActFn(torch.autograd.Function):
         dweight = torch.zeros_like(weight) if (weight is not None and ctx.needs_input_grad[1]) else None
         dbias = torch.zeros_like(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
         dslope = torch.zeros_like(slope) if (slope is not None and ctx.needs_input_grad[3]) else None
-        ws = scratch(3 * c_, x.device)
         training = 1 if mode in (1, 3) else 0
-        L.call('dpf_norm_act_backward', _ptr(x), _ptr(gy), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), wmod, _ptr(res), act,
-               _ptr(slope), slope_const, training, _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), _ptr(dslope), _ptr(ws), n_, c_, S,
-               _stream())
+        args = (_ptr(x), _ptr(gy), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), wmod, _ptr(res), act, _ptr(slope), slope_const,
+                training, _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), _ptr(dslope))
+        if ctx.exchange is not None:
+            # SyncBatchNorm: local reductions, sum over the ranks, then dx with the global element count
+            ws = torch.empty(3 * c_, dtype=torch.float32, device=x.device)
+            L.call('dpf_norm_act_backward_ex', *args, _ptr(ws), n_, c_, S, 1, 0.0, _stream())
+            ctx.exchange.all_reduce_sum_(ws)
+            L.call('dpf_norm_act_backward_ex', *args, _ptr(ws), n_, c_, S, 2, float(ctx.count_total), _stream())
+        else:
+            ws = scratch(3 * c_, x.device)
+            L.call('dpf_norm_act_backward', *args, _ptr(ws), n_, c_, S, _stream())
         dres2 = gy if (has_res2 and ctx.needs_input_grad[5]) else None
-        return dx, dweight, dbias, dslope, dres, dres2, None, None, None, None, None
+        return dx, dweight, dbias, dslope, dres, dres2, None, None, None, None, None, None
 
 
 def norm_act(x, weight=None, bias=None, slope=None, res=None, res2=None, running_mean=None, running_var=None, mode=0, act=ACT_NONE,
-             slope_const=0.0):
-    return NormActFn.apply(x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const)
+             slope_const=0.0, exchange=None):
+    return NormActFn.apply(x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const, exchange)
 
 
 # ----------------------------------------------------------------------------------------------- resampling

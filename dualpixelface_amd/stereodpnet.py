@@ -192,7 +192,15 @@ class StereoDPNetCore(_Base):
         self.grid_cache_compat = bool(getattr(m, 'asm_grid_cache_compat', True))
         self._tables = {}
         self._pending_counts = {}
+        self.stat_exchange = None          # distributed.StatExchange -> SyncBatchNorm (see enable_sync_batchnorm)
         self._build_parameters(build_spec(option))
+
+    def enable_sync_batchnorm(self, group=None):
+        """Training BatchNorm statistics over the global batch, like torch.nn.SyncBatchNorm which the reference switches on for
+        accelerator == 'ddp' (config_manager.py:57, main.py:55).  ``group=False`` turns it off again."""
+        from .distributed import StatExchange
+        self.stat_exchange = None if group is False else StatExchange(group)
+        return self
 
     # ------------------------------------------------------------------ parameters
     def _build_parameters(self, spec):
@@ -291,7 +299,7 @@ class StereoDPNetCore(_Base):
             key = p + '.num_batches_tracked'
             self._pending_counts[key] = self._pending_counts.get(key, 0) + 1
         return ops.norm_act(x, P[p + '.weight'], P[p + '.bias'], slope, res, res2, B[p + '.running_mean'], B[p + '.running_var'],
-                            1 if self.training else 2, act, slope_const)
+                            1 if self.training else 2, act, slope_const, self.stat_exchange if self.training else None)
 
     def _convbn2(self, x, p, stride=1, pad=1, dil=1, act=ACT_NONE, slope=None, res=None):
         y = ops.conv2d(x, self._P[p + '.0.weight'], None, stride, dil if dil > 1 else pad, dil)   # basics.py:17-22
@@ -360,7 +368,7 @@ class StereoDPNetCore(_Base):
         q = p + '.mask_convs.1'
         if self.training:
             rm, rv = stat_sink if stat_sink is not None else (Bf[q + '.running_mean'], Bf[q + '.running_var'])
-            mk = ops.norm_act(mk, P[q + '.weight'], P[q + '.bias'], None, None, None, rm, rv, 1, ACT_RELU)
+            mk = ops.norm_act(mk, P[q + '.weight'], P[q + '.bias'], None, None, None, rm, rv, 1, ACT_RELU, exchange=self.stat_exchange)
         else:
             mk = ops.norm_act(mk, P[q + '.weight'], P[q + '.bias'], None, None, None, Bf[q + '.running_mean'], Bf[q + '.running_var'], 2,
                               ACT_RELU)

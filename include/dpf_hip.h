@@ -68,6 +68,17 @@ int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd,
 int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
                           int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
                           float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, void* stream);
+/* SyncBatchNorm (the reference enables torch SyncBatchNorm under DDP: config_manager.py:57, main.py:55).  Statistics: each rank
+ * computes dpf_bn_local_moments -> moments[2*C] = {mean, M2}; the host all-gathers them (RCCL) and dpf_bn_merge_moments produces
+ * the global mean / invstd and the running-statistics update.  Backward: dpf_norm_act_backward_ex phase 1 (local reductions
+ * into ws + parameter gradients), host all-reduce(sum) of ws[3*C], phase 2 (dx / dres) with count = global N*S. */
+int dpf_bn_local_moments(const float* x, int N, int C, long long S, float* moments, float* ws, void* stream);
+int dpf_bn_merge_moments(const float* moments, const float* counts, int W, int C, float eps, float momentum, float* running_mean,
+                         float* running_var, float* mean, float* invstd, void* stream);
+int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
+                             int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
+                             float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, int phase,
+                             double count, void* stream);
 int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void* stream);
 
 /* ---- resampling: F.interpolate(bilinear, align_corners=True) (modules.py:127-128, normal_module.py:22-29), FPN's

@@ -58,3 +58,46 @@ def test_flat_grad_reducer_world2():
     assert torch.allclose(g0[12:19], torch.full((7,), 4.0))
     assert torch.allclose(g0[19:29], 2 * 2 * p0[19:29])
     assert torch.equal(g0[29:], torch.zeros(6))
+
+
+def _stat_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from dualpixelface_amd.distributed import init_from_env, StatExchange
+    init_from_env('gloo')
+    ex = StatExchange()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(5, 6, 4, 3, generator=g) * 2 + 1          # same tensor everywhere; rank 0 owns 2 samples, rank 1 owns 3
+    mine = x[:2] if rank == 0 else x[2:]
+    C = x.shape[1]
+    count = mine.numel() // C
+    m = mine.mean((0, 2, 3))
+    M2 = ((mine - m.view(1, -1, 1, 1)) ** 2).sum((0, 2, 3))
+    packed = torch.cat([torch.stack([m, M2], 1).reshape(-1), torch.tensor([float(count)])])
+    gathered = ex.all_gather(packed)
+    total = ex.total_count(count)
+    ws = torch.full((3 * C,), float(rank + 1))
+    ex.all_reduce_sum_(ws)
+    out[rank] = (gathered.clone(), total, ws.clone())
+    dist.destroy_process_group()
+
+
+def test_stat_exchange_world2():
+    """The SyncBatchNorm exchange: all-gathered {mean, M2, count} merge to the full-batch moments (uneven per-rank batches)."""
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_stat_worker, args=(2, port, out), nprocs=2, join=True)
+    g0, t0, w0 = out[0]
+    g1, t1, w1 = out[1]
+    assert torch.equal(g0, g1) and g0.shape == (2, 13)
+    assert t0 == t1 == 5 * 4 * 3
+    assert torch.equal(w0, torch.full((18,), 3.0)) and torch.equal(w1, w0)
+    # the merge dpf_bn_merge_moments performs (Chan et al.), restated
+    x = torch.randn(5, 6, 4, 3, generator=torch.Generator().manual_seed(5)) * 2 + 1
+    n = g0[:, 12].double()
+    mean_r, M2_r = g0[:, 0:12:2].double(), g0[:, 1:12:2].double()
+    mu = (n[:, None] * mean_r).sum(0) / n.sum()
+    M2 = (M2_r + n[:, None] * (mean_r - mu) ** 2).sum(0)
+    assert torch.allclose(mu.float(), x.mean((0, 2, 3)), atol=1e-5)
+    assert torch.allclose((M2 / n.sum()).float(), x.var((0, 2, 3), unbiased=False), atol=1e-4)

@@ -134,6 +134,71 @@ def test_batchnorm_train(act, shape):
         close(g, gr, 2e-4, 'bn ' + nm)
 
 
+class _TwoRankExchange(object):
+    """Stands in for distributed.StatExchange on a one-GPU box: plays the other rank of a 2-rank SyncBatchNorm with plain
+    torch math, so the local kernels + merge / phase-2 kernels can be checked against full-batch batch norm."""
+    world_size = 2
+
+    def __init__(self, x1, dz1, mean_g, invstd_g):
+        self.x1, self.dz1, self.mean_g, self.invstd_g = x1, dz1, mean_g, invstd_g
+        C = x1.shape[1]
+        self.dims = [0] + list(range(2, x1.dim()))
+        self.count1 = x1.numel() // C
+
+    def all_gather(self, packed):
+        m1 = self.x1.mean(self.dims)
+        bshape = [1, -1] + [1] * (self.x1.dim() - 2)
+        M2 = ((self.x1 - m1.view(bshape)) ** 2).sum(self.dims)
+        other = torch.cat([torch.stack([m1, M2], 1).reshape(-1), torch.tensor([float(self.count1)], device=packed.device)])
+        return torch.stack([packed, other.to(packed.dtype)])
+
+    def total_count(self, local):
+        return float(local + self.count1)
+
+    def all_reduce_sum_(self, ws):
+        bshape = [1, -1] + [1] * (self.x1.dim() - 2)
+        xh = (self.x1 - self.mean_g.view(bshape)) * self.invstd_g.view(bshape)
+        v = ws.view(-1, 3)
+        v[:, 0] += self.dz1.sum(self.dims)
+        v[:, 1] += (self.dz1 * xh).sum(self.dims)
+        return ws
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 7, 9), (2, 16, 4, 6, 12)])
+def test_sync_batchnorm_matches_full_batch(shape):
+    """rank 0 holds the first 2 samples, the emulated rank 1 three more: outputs, running statistics and dx must equal batch norm
+    over all 5 samples (torch.nn.SyncBatchNorm semantics); dw/db are this rank's partial sums (DDP averages them afterwards)."""
+    ops = _ops()
+    C = shape[1]
+    full = (5,) + tuple(shape[1:])
+    x = (rnd(*full, seed=21) * 1.5 - 0.3).requires_grad_()
+    w = (torch.rand(C, generator=torch.Generator().manual_seed(22)) + 0.5).requires_grad_()
+    b = rnd(C, seed=23).requires_grad_()
+    rm, rv = rnd(C, seed=24) * 0.1, torch.rand(C, generator=torch.Generator().manual_seed(25)) + 0.5
+    rm_r, rv_r = rm.clone(), rv.clone()
+    z = F.batch_norm(x, rm_r, rv_r, w, b, True, 0.1, 1e-5)
+    y_ref = F.relu(z)
+    go = rnd(*full, seed=26)
+    gx_r, = torch.autograd.grad(y_ref, (x,), go)
+    dims = [0] + list(range(2, x.dim()))
+    bshape = [1, -1] + [1] * (x.dim() - 2)
+    mean_g = x.detach().mean(dims)
+    invstd_g = 1.0 / torch.sqrt(x.detach().var(dims, unbiased=False) + 1e-5)
+    dz = (go * (z.detach() > 0)).detach()
+    xh = (x.detach() - mean_g.view(bshape)) * invstd_g.view(bshape)
+    ex = _TwoRankExchange(x.detach()[2:].to(DEV), dz[2:].to(DEV), mean_g.to(DEV), invstd_g.to(DEV))
+    xg, wg, bg = [t.detach().to(DEV).requires_grad_() for t in (x[:2], w, b)]
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    y = ops.norm_act(xg, wg, bg, None, None, None, rmg, rvg, 1, ops.ACT_RELU, exchange=ex)
+    close(y, y_ref[:2], 1e-5, 'syncbn fwd')
+    close(rmg, rm_r, 1e-5, 'syncbn running_mean')
+    close(rvg, rv_r, 1e-5, 'syncbn running_var')
+    gx, gw, gb = torch.autograd.grad(y, (xg, wg, bg), go[:2].to(DEV))
+    close(gx, gx_r[:2], 2e-4, 'syncbn dx')
+    close(gw, (dz * xh)[:2].sum(dims), 2e-4, 'syncbn dw (local part)')
+    close(gb, dz[:2].sum(dims), 2e-4, 'syncbn db (local part)')
+
+
 def test_batchnorm_eval_and_instance_norm_and_leaky():
     ops = _ops()
     x = rnd(2, 32, 3, 6, 8, seed=20)
