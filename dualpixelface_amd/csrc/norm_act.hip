@@ -15,16 +15,18 @@ constexpr int ROW_CHUNK = 4096;   // elements of one row handled by one block
 
 // ---------------------------------------------------------------- statistics (training)
 // sums[c] = { sum(x - K_c), sum((x - K_c)^2) } with the shift K_c = x[0, c, 0] (single pass, cancellation-safe)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ sums, int N, int C, long long S) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ sums, int N, int C, long long S,
+                                                       int chunk) {
   __shared__ float sm[4];
   const int row = blockIdx.y;   // n*C + c
   const int c = row % C;
   const float K = x[(long long)c * S];
   const float* xr = x + (long long)row * S;
-  const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
-  const long long s1 = min(S, s0 + ROW_CHUNK);
+  const long long s0 = (long long)blockIdx.x * chunk;
+  const long long s1 = min(S, s0 + chunk);
   float a = 0.f, b = 0.f;
   if ((S & 3) == 0) {
+#pragma unroll 4
     for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
       const float4 v = *reinterpret_cast<const float4*>(xr + s);
       const float d0 = v.x - K, d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ w, const float* __restrict__ bsh, int wmod,
                                                             const float* __restrict__ res, int act, const float* __restrict__ slope_p,
-                                                            float slope_c, float* __restrict__ sums, int C, long long S) {
+                                                            float slope_c, float* __restrict__ sums, int C, long long S, int chunk) {
   __shared__ float sm[4];
   const int row = blockIdx.y;
   const int c = row % C;
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
   const float slope = slope_p ? slope_p[0] : slope_c;
   const long long base = (long long)row * S;
-  const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
-  const long long s1 = min(S, s0 + ROW_CHUNK);
+  const long long s0 = (long long)blockIdx.x * chunk;
+  const long long s1 = min(S, s0 + chunk);
   float a = 0.f, b = 0.f, sl = 0.f;
   auto one = [&](float xv, float rv, float d) {
     const float xh = (xv - mu) * is;
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (act == DPF_ACT_PRELU && z <= 0.f) sl += z * d;
   };
   if ((S & 3) == 0) {
+#pragma unroll 2
     for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
       const float4 xv = *reinterpret_cast<const float4*>(x + base + s);
       const float4 dv = *reinterpret_cast<const float4*>(dy + base + s);
@@ -293,6 +296,15 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 
 inline dim3 row_grid(int rows, long long S) { return dim3((unsigned)dpf_div_up(S, ROW_CHUNK), (unsigned)rows); }
 
+// reduction kernels end in a block reduction + atomics, so they take larger row chunks while the grid still fills the chip
+inline int reduce_chunk(int rows, long long S) {
+  long long chunk = ((S * rows / 4096 + 1023) / 1024) * 1024;
+  if (chunk < ROW_CHUNK) chunk = ROW_CHUNK;
+  if (chunk > 65536) chunk = 65536;
+  return (int)chunk;
+}
+inline dim3 reduce_grid(int rows, long long S, int chunk) { return dim3((unsigned)dpf_div_up(S, chunk), (unsigned)rows); }
+
 }  // namespace
 
 extern "C" {
@@ -305,7 +317,8 @@ int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float mom
   if (!x || !mean || !invstd || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
-  hipLaunchKernelGGL(bn_stats_kernel, row_grid(N * C, S), dim3(256), 0, st, x, ws, N, C, S);
+  const int chunk = reduce_chunk(N * C, S);
+  hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, ws, N, C, S, chunk);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, st, x, ws, C, S, (double)N * (double)S, eps, momentum,
                      running_mean, running_var, mean, invstd);
   return dpf_check_launch();
@@ -319,7 +332,8 @@ int dpf_bn_local_moments(const float* x, int N, int C, long long S, float* momen
   if (!x || !moments || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
-  hipLaunchKernelGGL(bn_stats_kernel, row_grid(N * C, S), dim3(256), 0, st, x, ws, N, C, S);
+  const int chunk = reduce_chunk(N * C, S);
+  hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, ws, N, C, S, chunk);
   hipLaunchKernelGGL(bn_local_moments_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, st, x, ws, C, S, (double)N * (double)S, moments);
   return dpf_check_launch();
 }
@@ -371,8 +385,9 @@ int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean,
   const bool need_reduce = (mean != nullptr) || (act == DPF_ACT_PRELU && dslope);
   if (need_reduce && phase != 2) {
     if (hipMemsetAsync(ws, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope,
-                       slope_const, ws, C, S);
+    const int chunk = reduce_chunk(N * C, S);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act,
+                       slope, slope_const, ws, C, S, chunk);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpf_div_up(wmod, 64)), dim3(64), 0, st, ws, C, wmod, mean ? dweight : nullptr,
                        mean ? dbias : nullptr, act == DPF_ACT_PRELU ? dslope : nullptr);
   }
