@@ -286,8 +286,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   const int regvox = q.RZmax * q.RY * q.RX;
   int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + GI_CS + 1) & ~1));   // [npos][8] local voxel index or -1 (16-B aligned); GI_CS dummy doubles before it
   int* s_vox = s_lidx + npos * 8;                              // [npos][8] global voxel index or -1
-  float* s_w = (float*)(s_vox + npos * 8);                     // [npos][8]
-  int* s_far = (int*)(s_w + npos * 8);                         // [4] per-tap flag: some corner left the region
+  float* s_w = (float*)(s_vox + npos * 8);                     // [npos][8] corner weight, 0 outside the region
+  float* s_wfar = s_w + npos * 8;                              // [npos][8] corner weight (far pass)
+  int* s_far = (int*)(s_wfar + npos * 8);                         // [4] per-tap flag: some corner left the region
   int* s_farm = s_far + 4;                                      // [npos] per-voxel flag
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int lc = l15 & 7;            // channel within the chunk; lanes 8..15 of a group mirror lanes 0..7 ...
@@ -356,16 +357,23 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
         for (int j = 0; j < 8; ++j) {
           float wg;
           const long long v = corner_index(p, cn, j, wg);
-          int li = -1;
+          // element index of the corner's cell in the region; corners outside the region (or the volume) point at the dummy
+          // cell behind it with weight 0, so the scatter below needs no select
+          int li = regvox * GI_CS;
+          bool in = false;
           if (v >= 0) {
             const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
             const int lz = cn.d0 + jd - rz0, ly = cn.h0 + jh - ry0, lx = cn.w0 + jw - rx0;
-            if (lz >= 0 && lz < RZ && ly >= 0 && ly < q.RY && lx >= 0 && lx < q.RX) li = (lz * q.RY + ly) * q.RX + lx;
+            if (lz >= 0 && lz < RZ && ly >= 0 && ly < q.RY && lx >= 0 && lx < q.RX) {
+              li = ((lz * q.RY + ly) * q.RX + lx) * GI_CS;
+              in = true;
+            }
           }
           s_lidx[tid * 8 + j] = li;
-          s_vox[tid * 8 + j] = (int)v;
-          s_w[tid * 8 + j] = wg;
-          if (li < 0 && v >= 0) anyfar = 1;
+          s_vox[tid * 8 + j] = (in || v < 0) ? -1 : (int)v;      // >= 0 only for far corners (second pass)
+          s_w[tid * 8 + j] = in ? wg : 0.f;
+          s_wfar[tid * 8 + j] = wg;
+          if (!in && v >= 0) anyfar = 1;
         }
         s_farm[tid] = anyfar;
         if (anyfar) s_far[0] = 1;
@@ -400,12 +408,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
             const int li[4] = {la.x, la.y, la.z, la.w};
             const float wv[4] = {wa.x, wa.y, wa.z, wa.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const bool in = li[j] >= 0;
-              const int a = in ? li[j] * GI_CS + lc : regvox * GI_CS + lc;
-              const double val = in ? (double)(wv[j] * g) : 0.0;
-              atomicAdd(&s_reg[a], val);
-            }
+            for (int j = 0; j < 4; ++j) atomicAdd(&s_reg[li[j] + lc], (double)(wv[j] * g));
           }
           if (s_far[0] != 0) {                                     // block-uniform: some corner of this tap left the region
 #pragma unroll
@@ -415,8 +418,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
               const float g = acc[r];
               for (int j = 0; j < 4; ++j) {
                 const int v = s_vox[pl * 8 + jb + j];
-                if (s_lidx[pl * 8 + jb + j] < 0 && v >= 0)
-                  atomicAdd(&dxb[(long long)cc * chan + v], s_w[pl * 8 + jb + j] * g);   // direct scatter
+                if (v >= 0) atomicAdd(&dxb[(long long)cc * chan + v], s_wfar[pl * 8 + jb + j] * g);   // direct scatter
               }
             }
           }
@@ -1150,7 +1152,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
     q.CG = grad_input_channels < C ? (grad_input_channels < 0 ? 0 : grad_input_channels) : C;
     const int npos = 64 * q.TZ;
-    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 25 + 4);
+    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 33 + 4);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
     if (lds <= 150 * 1024 && blocks < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
