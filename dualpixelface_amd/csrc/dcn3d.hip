@@ -76,6 +76,70 @@ __device__ __forceinline__ Corner make_corner(const DcnP& p, const float* __rest
   return corner_from(p, t, pos, load_off(p, off_b, t, pos));
 }
 
+// ---- division-free variants for the region kernels: the thread knows its output voxel (zo, yo, xo), the tap loop keeps the
+// tap's (ti, tj, tk) in scalars, and the offsets are read through a pointer that advances by 3*P per tap
+struct TapIt {
+  int ti, tj, tk;
+};
+
+__device__ __forceinline__ void tap_next(const DcnP& p, TapIt& it) {
+  if (++it.tk == p.kw) {
+    it.tk = 0;
+    if (++it.tj == p.kh) {
+      it.tj = 0;
+      ++it.ti;
+    }
+  }
+}
+
+__device__ __forceinline__ Off3 load_off_ptr(const float* __restrict__ offp, long long P, bool ok) {
+  Off3 o = {0.f, 0.f, 0.f};
+  if (ok) {
+    o.d = offp[0];
+    o.h = offp[P];
+    o.w = offp[2 * P];
+  }
+  return o;
+}
+
+// zb / yb / xb = output voxel * stride - pad
+__device__ __forceinline__ Corner corner_at(const DcnP& p, bool pvalid, int zb, int yb, int xb, const TapIt& it, const Off3& o) {
+  Corner c;
+  c.valid = 0;
+  c.d0 = c.h0 = c.w0 = 0;
+  c.ld = c.lh = c.lw = 0.f;
+  const float fd = (float)(zb + it.ti * p.dd) + o.d;
+  const float fh = (float)(yb + it.tj * p.dh) + o.h;
+  const float fw = (float)(xb + it.tk * p.dw) + o.w;
+  if (pvalid && fd > -1.f && fh > -1.f && fw > -1.f && fd < (float)p.D && fh < (float)p.H && fw < (float)p.W) {   // cuh:248
+    const float d0 = floorf(fd), h0 = floorf(fh), w0 = floorf(fw);
+    c.d0 = (int)d0; c.h0 = (int)h0; c.w0 = (int)w0;
+    c.ld = fd - d0; c.lh = fh - h0; c.lw = fw - w0;
+    c.valid = 1;
+  }
+  return c;
+}
+
+// w[A][B][T] -> wt[T][RP][KT] like repack_weights_kernel, with the reduce index zero-padded to RP rows as well, so that the
+// kernels can fetch their weight fragments without bounds checks
+__global__ void repack_weights_pad_kernel(const float* __restrict__ w, float* __restrict__ wt, int A, int B, int T, int KT, int mode, int RP) {
+  const int R = mode == 0 ? B : A;
+  const int O = mode == 0 ? A : B;
+  const long long total = (long long)T * RP * KT;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(i % KT);
+    const int r = (int)((i / KT) % RP);
+    const int t = (int)(i / ((long long)KT * RP));
+    float v = 0.f;
+    if (o < O && r < R) {
+      const int a = mode == 0 ? o : r;
+      const int b = mode == 0 ? r : o;
+      v = w[((long long)a * B + b) * T + t];
+    }
+    wt[i] = v;
+  }
+}
+
 // corner j = (jd, jh, jw) bits; returns flat voxel index or -1 (cuh:43-65), weight (cuh:67-68)
 __device__ __forceinline__ long long corner_index(const DcnP& p, const Corner& c, int j, float& wgt) {
   const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
@@ -83,6 +147,15 @@ __device__ __forceinline__ long long corner_index(const DcnP& p, const Corner& c
   wgt = (jd ? c.ld : 1.f - c.ld) * (jh ? c.lh : 1.f - c.lh) * (jw ? c.lw : 1.f - c.lw);
   if (!c.valid || d < 0 || d > p.D - 1 || h < 0 || h > p.H - 1 || w < 0 || w > p.W - 1) return -1;
   return ((long long)d * p.H + h) * p.W + w;
+}
+
+// 32-bit variant (the host checks D*H*W < 2^31)
+__device__ __forceinline__ int corner_index32(const DcnP& p, const Corner& c, int j, float& wgt) {
+  const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
+  const int d = c.d0 + jd, h = c.h0 + jh, w = c.w0 + jw;
+  wgt = (jd ? c.ld : 1.f - c.ld) * (jh ? c.lh : 1.f - c.lh) * (jw ? c.lw : 1.f - c.lw);
+  if (!c.valid || d < 0 || d > p.D - 1 || h < 0 || h > p.H - 1 || w < 0 || w > p.W - 1) return -1;
+  return (d * p.H + h) * p.W + w;
 }
 
 // S[c][pp] = trilinear sample of channel c at voxel pp of the tile, for tap t
@@ -278,7 +351,7 @@ struct GiP {
 // ds_add_f64 3.1 and ds_add_u64 4.8-5.4.  The region therefore accumulates in fp64 (also the more accurate sum); it is
 // converted to fp32 once, at the flush.
 template <int NST>   // position sub-tiles of 16 per wave (positions per block = 64 * NST)
-__global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][K][CT]*/,
+__global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
                                                             const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT) {
   extern __shared__ __align__(16) double smem_d[];
   const int npos = 64 * NST;
@@ -332,31 +405,36 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
     }
   }
 
+  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
+  const float* offp0 = off_b + (pvalid ? ppos : 0);
   for (int c0 = 0; c0 < q.CG; c0 += GI_CH) {      // only the channels whose gradient the caller needs
     __syncthreads();                                            // previous chunk flushed
     for (int i = tid; i < regvox * GI_CS + GI_CS; i += 256) s_reg[i] = 0.0;
     const int cc = c0 + lc;
     const bool cok = cc < q.CG;
-    Off3 onext = load_off(p, off_b, 0, ppos);
+    const float* offp = offp0;
+    Off3 onext = load_off_ptr(offp, p.P, pvalid);
+    TapIt it = {0, 0, 0};
     float bnext[16];
+    const float* wtn = wt2 + (long long)lg * CT + cc;      // rows k >= K of the repacked tensor are zero; cc < CT always
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int k = 4 * ks + lg;
-      bnext[ks] = (cok && k < p.K) ? wt2[(long long)k * CT + cc] : 0.f;
-    }
+    for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
     for (int t = 0; t < p.T; ++t) {
       __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
       if (tid == 0) s_far[0] = 0;
       __syncthreads();
       const Off3 ocur = onext;
-      onext = load_off(p, off_b, t + 1, ppos);                  // prefetch: consumed one barrier-to-barrier phase later
+      offp += 3 * p.P;
+      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch: consumed one barrier-to-barrier phase later
+      const TapIt itc = it;
+      tap_next(p, it);
       if (tid < npos) {
-        const Corner cn = corner_from(p, t, ppos, ocur);
+        const Corner cn = corner_at(p, pvalid, zb, yb, xbase, itc, ocur);
         int anyfar = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float wg;
-          const long long v = corner_index(p, cn, j, wg);
+          const int v = corner_index32(p, cn, j, wg);
           // element index of the corner's cell in the region; corners outside the region (or the volume) point at the dummy
           // cell behind it with weight 0, so the scatter below needs no select
           int li = regvox * GI_CS;
@@ -383,12 +461,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) bfrag[ks] = bnext[ks];
       if (t + 1 < p.T) {
-        const float* wtn = wt2 + (long long)(t + 1) * p.K * CT + cc;
+        wtn += 64 * CT;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const int k = 4 * ks + lg;
-          bnext[ks] = (cok && k < p.K) ? wtn[(long long)k * CT] : 0.f;
-        }
+        for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
       }
       __syncthreads();                                          // tables visible
 #pragma unroll
@@ -683,7 +758,7 @@ constexpr int ST = 256 + 4;   // padded row of the [16][256] sample / gcol tile
 // ---------------------------------------------------------------------------------------------------- forward
 template <int MT>
 __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                             const float* __restrict__ wt /*[T][C][KT]*/, const float* __restrict__ bias,
+                                                             const float* __restrict__ wt /*[T][C16][KT], zero rows beyond C*/, const float* __restrict__ bias,
                                                              float* __restrict__ out, DcnP p, RegGeo g) {
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32 * MT;
@@ -709,24 +784,29 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
 
+  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
+  const int C16 = (p.C + RG_CH - 1) / RG_CH * RG_CH;
+  const float* offp0 = off_b + (pvalid ? ppos : 0);
   for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
     __syncthreads();                                   // previous chunk's region / S tile consumed
     stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
-    Off3 onext = load_off(p, off_b, 0, ppos);
+    const float* offp = offp0;
+    Off3 onext = load_off_ptr(offp, p.P, pvalid);
+    TapIt it = {0, 0, 0};
     __syncthreads();
     for (int t = 0; t < p.T; ++t) {
       const Off3 ocur = onext;
-      onext = load_off(p, off_b, t + 1, ppos);         // prefetch the next tap's offsets
+      offp += 3 * p.P;
+      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch the next tap's offsets
       // weight fragments of this tap: issue early, consume after the sampling phase
       float a[RG_CH / 2][MT];
-      const float* wtt = wt + ((long long)t * p.C + c0) * KT + l31;
+      const float* wtt = wt + ((long long)t * C16 + c0 + hh) * KT + l31;
 #pragma unroll
-      for (int sx = 0; sx < RG_CH / 2; ++sx) {
-        const int cc = 2 * sx + hh;
+      for (int sx = 0; sx < RG_CH / 2; ++sx)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[sx][m] = (c0 + cc < p.C) ? wtt[(long long)cc * KT + m * 32] : 0.f;
-      }
-      const Corner cn = corner_from(p, t, ppos, ocur);
+        for (int m = 0; m < MT; ++m) a[sx][m] = wtt[(2 * sx) * KT + m * 32];
+      const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
+      tap_next(p, it);
       const Samp sp = make_samp(p, g, c, cn);
       if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
       {
@@ -776,7 +856,7 @@ constexpr int WG_NREP = 8;   // replicas of the grad_weight scratch tensor (spre
 // S[16][256] replaces gcol in LDS and each wave contracts it against its 16 output channels of go (see dcn_wgrad_region_kernel)
 template <bool WG>
 __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                                    const float* __restrict__ wt2 /*[T][K][CT]*/, const float* __restrict__ go,
+                                                                    const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/, const float* __restrict__ go,
                                                                     float* __restrict__ doff, float* __restrict__ dwtmp, DcnP p, RegGeo g, int CT,
                                                                     int nchunk) {
   extern __shared__ __align__(16) float smem[];
@@ -826,22 +906,25 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
     rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
   }
 
+  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
+  const float* offp0 = off_b + (pvalid ? ppos : 0);
   for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
     __syncthreads();
     stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
-    Off3 onext = load_off(p, off_b, 0, ppos);
+    const float* offp = offp0;
+    Off3 onext = load_off_ptr(offp, p.P, pvalid);
+    TapIt it = {0, 0, 0};
     for (int t = 0; t < p.T; ++t) {
       const Off3 ocur = onext;
-      onext = load_off(p, off_b, t + 1, ppos);         // prefetch the next tap's offsets
-      // A fragments: W[k][c0 + l15][t]
+      offp += 3 * p.P;
+      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch the next tap's offsets
+      // A fragments: W[k][c0 + l15][t] (rows k >= K and columns >= C of the repacked tensor are zero)
       float afrag[16];
-      const float* wtt = wt2 + (long long)t * p.K * CT + c0 + l15;
+      const float* wtt = wt2 + ((long long)t * 64 + lg) * CT + c0 + l15;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int k = 4 * ks + lg;
-        afrag[ks] = (c0 + l15 < p.C && k < p.K) ? wtt[(long long)k * CT] : 0.f;
-      }
-      const Corner cn = corner_from(p, t, ppos, ocur);
+      for (int ks = 0; ks < 16; ++ks) afrag[ks] = wtt[(4 * ks) * CT];
+      const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
+      tap_next(p, it);
       const Samp sp = make_samp(p, g, c, cn);
       __syncthreads();                                 // previous tap's s_gc consumed (and region staged)
 #pragma unroll
@@ -860,7 +943,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
       if (sp.valid) {
         float gcv[RG_CH];
 #pragma unroll
-        for (int ch = 0; ch < RG_CH; ++ch) gcv[ch] = (c0 + ch < p.C) ? s_gc[ch * ST + tid] : 0.f;
+        for (int ch = 0; ch < RG_CH; ++ch) gcv[ch] = s_gc[ch * ST + tid];   // zero for channels beyond C (zero weight columns)
         // dot_j = sum_ch gcol[ch] * x[corner j][ch]; the three coordinate derivatives weight it with the other two
         // trilinear factors and the signed in-volume mask of their own axis (cuh:131-187)
         float dots[8];
@@ -1055,9 +1138,7 @@ int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void*
 
 // workspace floats for dpf_deform_conv3d_forward / _backward (repacked weights)
 long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
-  const long long a = (long long)T * C * (((K + 31) / 32) * 32);
-  const long long b = (long long)T * K * (((C + 31) / 32) * 32);
-  const long long repack = ((a > b ? a : b) + 63) & ~63LL;
+  const long long repack = (long long)T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);   // either repack, reduce index padded
   return repack + (long long)WG_NREP * T * ((C + RG_CH - 1) / RG_CH) * 64 * 16;   // + grad_weight scratch replicas
 }
 
@@ -1075,9 +1156,11 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
   if (rc != DPF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int MT = (K + 31) / 32, KT = 32 * MT;
-  hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * C * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0);
   RegGeo g{};
   if (region_geo(g, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
+    const int C16 = (C + RG_CH - 1) / RG_CH * RG_CH;
+    hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * C16 * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0,
+                       C16);
     const size_t lds = sizeof(float) * ((size_t)RG_VS * g.RV + (size_t)RG_CH * ST);
     const dim3 grid((unsigned)((long long)B * g.tilesZ * g.tilesY * g.tilesX));
 #define DPF_FR(M)                                                                                                  \
@@ -1089,6 +1172,7 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
 #undef DPF_FR
     return dpf_check_launch();
   }
+  hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * C * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0);
   const size_t lds = sizeof(float) * (size_t)p.CP * SP;
   const dim3 grid((unsigned)(B * p.tiles_per_b));
 #define DPF_F(M)                                                                                   \
@@ -1135,8 +1219,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   const long long in_elems = (long long)B * C * D * H * W;
   if (hipMemsetAsync(grad_input, 0, sizeof(float) * in_elems, st) != hipSuccess) return DPF_ERR_LAUNCH;
   if (hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)K * C * p.T, st) != hipSuccess) return DPF_ERR_LAUNCH;
-  // wt2[T][K][CT]: reduce = K (A), out = C (B)
-  hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * K * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1);
+  // wt2[T][K][CT]: reduce = K (A), out = C (B); the region kernels read it with K zero-padded to 64 rows
   // grad_input: LDS-privatised scatter when the haloed region fits, else the reference-style global atomics
   bool dx_done = false;
   if (K <= 64) {
@@ -1154,8 +1237,10 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     const int npos = 64 * q.TZ;
     const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 33 + 4);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
-    if (lds <= 150 * 1024 && blocks < 0x7fffffffLL) {
+    if (lds <= 150 * 1024 && blocks < 0x7fffffffLL && (long long)D * H * W < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
+      hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * 64 * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1,
+                         64);
 #define DPF_GI(NS)                                                                                                   \
   {                                                                                                                  \
     if (set_lds(dcn_bwd_input_kernel<NS>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                     \
@@ -1169,8 +1254,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   RegGeo rg{};
   const bool region_ok = K <= 64 && region_geo(rg, p) == DPF_OK && !getenv("DPF_DCN_V1");
   const bool fuse_wg = region_ok && dx_done && !getenv("DPF_DCN_NOFUSE");
-  const long long a_ = (long long)p.T * C * (((K + 31) / 32) * 32), b_ = (long long)p.T * K * (((C + 31) / 32) * 32);
-  float* dwtmp = ws + (((a_ > b_ ? a_ : b_) + 63) & ~63LL);
+  float* dwtmp = ws + (long long)p.T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);
   const int nchunk = (C + RG_CH - 1) / RG_CH;
   if (region_ok) {
     if (hipMemsetAsync(dwtmp, 0, sizeof(float) * (size_t)WG_NREP * p.T * nchunk * 64 * 16, st) != hipSuccess) return DPF_ERR_LAUNCH;
@@ -1188,6 +1272,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
                          nchunk);
     }
   } else {
+    hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * K * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1);
     const size_t lds = sizeof(float) * ((size_t)K * SP + (size_t)CT * SP + 3 * 4 * TP);
     const dim3 grid((unsigned)(B * p.tiles_per_b));
 #define DPF_D(M)                                                                                                       \
