@@ -312,7 +312,7 @@ struct WgP {
 // WTH rows of 32 positions per tile (8-row tiles for K <= 32 measured slower: 49 vs 52 TFLOP/s)
 // WNT column tiles (of 32 (c,t) pairs) per wave (4 tiles for K <= 32 measured no faster: 48.5 vs 52 TFLOP/s)
 template <int MT, int WTH = 4, int WNT = 2>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+__global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 ? 3 : 2))) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                          float* __restrict__ dw, WgP p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32 * MT;
