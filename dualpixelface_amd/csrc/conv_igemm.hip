@@ -303,6 +303,7 @@ struct WgP {
   int sd, sh, sw, pd, ph, pw, dd, dh, dw;
   int Ktot, k0;     // g has Ktot channels; this launch covers [k0, k0 + K)
   int CCW;          // channels per block
+  int es;           // polyphase factor: > 1 = dilation handled as es*es interleaved dilation-1 problems (dh = dw = 1 here)
   int nchunk;       // position chunks
   int tilesH, tilesW;
   long long ntiles;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 ? 3 : 2))) void conv_w
     const int rem = rowid - cc * rows_per_chan;
     const int pl = rem / ext_h;
     const int rr = rem - pl * ext_h;
-    s_rowoff[rowid] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + rr) * p.IW);
+    s_rowoff[rowid] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + (long long)rr * p.es) * p.IW);
     s_rowpr[rowid] = (pl << 16) | rr;
   }
 
@@ -376,10 +377,16 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 ? 3 : 2))) void conv_w
     long long b = tile;
     const int tw = (int)(b % p.tilesW); b /= p.tilesW;
     const int th = (int)(b % p.tilesH); b /= p.tilesH;
+    int fh = 0, fw = 0;                        // phase of this tile (polyphase dilation: positions fh + es*i, fw + es*j)
+    if (p.es > 1) {
+      fw = (int)(b % p.es); b /= p.es;
+      fh = (int)(b % p.es); b /= p.es;
+    }
     const int qd = (int)(b % p.QD);
     const int n = (int)(b / p.QD);
-    const int q0h = th * WTH, q0w = tw * TW;
-    const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, i0w = q0w * p.sw - p.pw;
+    const int q0h = th * WTH, q0w = tw * TW;   // tile origin in phase coordinates
+    const int es = p.es;
+    const int i0d = qd * p.sd - p.pd, i0h = fh + es * q0h * p.sh - p.ph, i0w = fw + es * q0w * p.sw - p.pw;
     __syncthreads();
     // stage x patch (SU rows fetched back-to-back, then written)
     constexpr int SU = 8;
@@ -393,10 +400,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 ? 3 : 2))) void conv_w
         const int rsafe = rowid < xrows ? rowid : 0;
         const int pr = s_rowpr[rsafe];
         const int pl = pr >> 16, rr = pr & 0xffff;
-        const int id = i0d + pl, ih = i0h + rr;
+        const int id = i0d + pl, ih = i0h + es * rr;
         const bool rowok = (rowid < xrows) && (id >= 0) && (id < p.ID) && (ih >= 0) && (ih < p.IH);
         const float* src = xbase + s_rowoff[rsafe];
-        const int iw0 = i0w + lane, iw1 = iw0 + 64;
+        const int iw0 = i0w + es * lane, iw1 = iw0 + es * 64;
         v0[u] = (rowok && lane < ext_w && iw0 >= 0 && iw0 < p.IW) ? src[iw0] : 0.f;
         v1[u] = (rowok && lane + 64 < ext_w && iw1 >= 0 && iw1 < p.IW) ? src[iw1] : 0.f;
       }
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 ? 3 : 2))) void conv_w
         const int rowid = 2 * (r0 + u) + hh;
         const int k = rowid / WTH;
         const int r = rowid - k * WTH;
-        const int qh = q0h + r, qw = q0w + l31;
+        const int qh = fh + es * (q0h + r), qw = fw + es * (q0w + l31);
         gv[u] = (rowid < KT * WTH && k < p.K && qh < p.QH && qw < p.QW) ? gn[(long long)k * g_chan + (long long)qh * p.QW + qw] : 0.f;
       }
 #pragma unroll
@@ -615,6 +622,16 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw_;
   if (p.T > MAXT) return DPF_ERR_UNSUPPORTED;
   p.Ktot = K;
+  // Dilated stride-1 convolutions: output (y, x) only meets inputs of its own residue class mod d, so the problem splits into
+  // d*d interleaved dilation-1 problems.  Tiles then carry a (kh-1)-wide halo instead of (kh-1)*d, at the price of strided
+  // (every d-th element) staging loads, which L2 absorbs.
+  p.es = 1;
+  if (sh == 1 && sw == 1 && dh == dw_ && dh > 1 && !getenv("DPF_WGRAD_NO_POLYPHASE")) {
+    p.es = dh;
+    p.dh = p.dw = 1;
+    dh = dw_ = 1;
+  }
+  const int QHp = dpf_div_up(QH, p.es), QWp = dpf_div_up(QW, p.es);   // extent of one phase
   for (int k0 = 0; k0 < K; k0 += 128) {   // one launch covers up to 128 g-channels (4 MFMA row tiles)
   p.k0 = k0;
   p.K = K - k0 < 128 ? K - k0 : 128;
@@ -634,9 +651,9 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   while (CCW > 1 && lds_bytes(CCW) > 96 * 1024) --CCW;
   if (lds_bytes(CCW) > 160 * 1024) return DPF_ERR_UNSUPPORTED;
   p.CCW = CCW;
-  p.tilesH = dpf_div_up(QH, WTH);
-  p.tilesW = dpf_div_up(QW, TW);
-  p.ntiles = (long long)N * QD * p.tilesH * p.tilesW;
+  p.tilesH = dpf_div_up(QHp, WTH);
+  p.tilesW = dpf_div_up(QWp, TW);
+  p.ntiles = (long long)N * QD * p.es * p.es * p.tilesH * p.tilesW;
   const int cchunks = dpf_div_up(C, CCW);
   long long nchunk = 2048 / cchunks;
   if (nchunk < 1) nchunk = 1;

@@ -46,6 +46,8 @@ CONV_CASES = [
     (2, 32, 1, 16, 24, 64, (1, 3, 3), (1, 2, 2), (0, 2, 2), (1, 2, 2)),
     (1, 96, 1, 17, 35, 32, (1, 3, 3), (1, 1, 1), (0, 5, 5), (1, 5, 5)),
     (3, 64, 1, 12, 20, 96, (1, 3, 3), (1, 1, 1), (0, 8, 8), (1, 8, 8)),
+    (2, 32, 1, 19, 41, 32, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 3, 3)),      # dilation 3, padding 2: polyphase wgrad, ragged phases
+    (1, 32, 2, 40, 70, 32, (1, 3, 3), (1, 1, 1), (0, 4, 4), (1, 4, 4)),      # several tiles per phase
     (2, 128, 1, 6, 9, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
     (2, 32, 1, 16, 24, 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),
     (4, 32, 1, 8, 12, 3, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
