@@ -200,6 +200,98 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restri
   }
 }
 
+// Weight gradient, 3x3 (x KD) stride-1 windows: no LDS.  One wave owns (n, od, channel, 64-column strip, row range) and marches
+// down the rows with lanes along W: per step it loads the newly entering input row of each kernel plane in its three column
+// shifts (9 coalesced loads for KD = 3, served by L1 after the first), keeps the other two rows of the window in registers, and
+// feeds KD*9 FMAs per output channel from them.  The KD*9*K per-lane partial sums are reduced across the wave once, at the end.
+template <int KK, int KD>
+__global__ __launch_bounds__(256) void smallk_wgrad_rows_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw,
+                                                                SkP p, int segs, int rsplit, int rows_per) {
+  const int lane = threadIdx.x & 63;
+  long long id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = (int)(id % p.C); id /= p.C;           // the 4 waves of a block share g rows (and x addresses modulo the channel)
+  const int seg = (int)(id % segs); id /= segs;
+  const int rs = (int)(id % rsplit); id /= rsplit;
+  const int od = (int)(id % p.OD);
+  const long long n = id / p.OD;
+  if (n >= p.N) return;
+  const int ow = seg * 64 + lane;
+  const int oh0 = rs * rows_per, oh1 = min(p.OH, oh0 + rows_per);
+  const long long iplane = (long long)p.IH * p.IW, ivol = iplane * p.ID, ovol = (long long)p.OD * p.OH * p.OW;
+  const float* xc = x + ((long long)n * p.C + c) * ivol;
+  const float* gn = g + (long long)n * p.K * ovol + (long long)od * p.OH * p.OW;
+  // per kernel plane: base pointer (or null when the plane is outside the volume)
+  const float* xpl[KD];
+#pragma unroll
+  for (int a = 0; a < KD; ++a) {
+    const int idp = od - p.pd + a * p.dd;
+    xpl[a] = (idp >= 0 && idp < p.ID) ? xc + (long long)idp * iplane : nullptr;
+  }
+  int iw[3];
+  bool cok[3];
+#pragma unroll
+  for (int sft = 0; sft < 3; ++sft) {
+    iw[sft] = ow - p.pw + sft;
+    cok[sft] = iw[sft] >= 0 && iw[sft] < p.IW;
+  }
+  auto load_row = [&](int ih, float (&dst)[KD][3]) {
+    const bool rok = ih >= 0 && ih < p.IH;
+#pragma unroll
+    for (int a = 0; a < KD; ++a)
+#pragma unroll
+      for (int sft = 0; sft < 3; ++sft) dst[a][sft] = (rok && cok[sft] && xpl[a]) ? xpl[a][(long long)ih * p.IW + iw[sft]] : 0.f;
+  };
+  float acc[KK][KD][3][3];
+#pragma unroll
+  for (int k = 0; k < KK; ++k)
+#pragma unroll
+    for (int a = 0; a < KD; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft) acc[k][a][b][sft] = 0.f;
+  float r0[KD][3], r1[KD][3], r2[KD][3];
+  load_row(oh0 - p.ph, r0);
+  load_row(oh0 - p.ph + 1, r1);
+  const bool gok = ow < p.OW;
+  for (int oh = oh0; oh < oh1; ++oh) {
+    load_row(oh - p.ph + 2, r2);
+    float gv[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) gv[k] = gok ? gn[(long long)k * ovol + (long long)oh * p.OW + ow] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+      for (int a = 0; a < KD; ++a)
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft) {
+          acc[k][a][0][sft] = fmaf(gv[k], r0[a][sft], acc[k][a][0][sft]);
+          acc[k][a][1][sft] = fmaf(gv[k], r1[a][sft], acc[k][a][1][sft]);
+          acc[k][a][2][sft] = fmaf(gv[k], r2[a][sft], acc[k][a][2][sft]);
+        }
+#pragma unroll
+    for (int a = 0; a < KD; ++a)
+#pragma unroll
+      for (int sft = 0; sft < 3; ++sft) {
+        r0[a][sft] = r1[a][sft];
+        r1[a][sft] = r2[a][sft];
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < KK; ++k)
+#pragma unroll
+    for (int a = 0; a < KD; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft) {
+          float v = acc[k][a][b][sft];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          if (lane == 0 && v != 0.f) atomicAdd(&dw[((long long)k * p.C + c) * p.T + (a * 3 + b) * 3 + sft], v);
+        }
+}
+
 int fill(SkP& p, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd,
          int dh, int dw) {
   if (N <= 0 || C <= 0 || K <= 0 || K > MAXK) return DPF_ERR_UNSUPPORTED;
@@ -239,6 +331,25 @@ int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int 
   SkP p{};
   int rc = fill(p, N, C, ID, IH, IW, K, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_);
   if (rc != DPF_OK) return rc;
+  if (kh == 3 && kw == 3 && (kd == 1 || kd == 3) && sd == 1 && sh == 1 && sw == 1 && dh == 1 && dw_ == 1 && !getenv("DPF_SMALLK_WGRAD_TILED")) {
+    // register-window kernel; split the rows of short strips so that the grid still fills the chip
+    const int segs = dpf_div_up(p.OW, 64);
+    const long long strips = (long long)N * p.OD * segs * C;
+    int rsplit = 1;
+    while (strips * rsplit < 8192 && rsplit * 32 < p.OH) rsplit *= 2;
+    const int rows_per = dpf_div_up(p.OH, rsplit);
+    const long long waves = strips * rsplit;
+    const dim3 grid((unsigned)dpf_div_up(waves, 4));
+    hipStream_t st = (hipStream_t)stream;
+#define DPF_SKW(KKv, KDv) hipLaunchKernelGGL((smallk_wgrad_rows_kernel<KKv, KDv>), grid, dim3(256), 0, st, g, x, dw, p, segs, rsplit, rows_per)
+    if (kd == 1) {
+      switch (K) { case 1: DPF_SKW(1, 1); break; case 2: DPF_SKW(2, 1); break; case 3: DPF_SKW(3, 1); break; default: DPF_SKW(4, 1); break; }
+    } else {
+      switch (K) { case 1: DPF_SKW(1, 3); break; case 2: DPF_SKW(2, 3); break; case 3: DPF_SKW(3, 3); break; default: DPF_SKW(4, 3); break; }
+    }
+#undef DPF_SKW
+    return dpf_check_launch();
+  }
   constexpr int CCH = 16;
   if (sw != 1 || dw_ != 1 || kw > 3 || CCH * kd * kh > 256) return DPF_ERR_UNSUPPORTED;
   const int ext_d = (kd - 1) * dd + 1, ext_h = (TH - 1) * sh + (kh - 1) * dh + 1, ext_w = TW + kw - 1;
