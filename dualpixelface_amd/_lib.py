@@ -13,7 +13,7 @@ import re
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdpf_hip.so')
+LIB_PATH = os.environ.get('DPF_LIB_PATH') or os.path.join(_HERE, 'libdpf_hip.so')   # override: A/B builds of the kernels
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dpf_hip.h')
 
 _CTYPES = {
