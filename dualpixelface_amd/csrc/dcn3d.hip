@@ -590,15 +590,23 @@ __global__ __launch_bounds__(256) void dcn_wgrad_kernel(const float* __restrict_
 
 // ==========================================================================================================
 // Region-staged kernels.  A workgroup owns TZ x 2 x 32 output voxels (TZ = min(Do, 4)); the haloed input region
-// [RZ][RY][RX] (halo RG_R on top of the kernel extent) of a 16-channel chunk is staged in LDS once and all 27 taps sample it
+// [RZ][RY][RX] (halo g.R on top of the kernel extent) of a 16-channel chunk is staged in LDS once and all 27 taps sample it
 // with ds_reads (8 per sample) instead of 8 scattered global loads; samples whose 2x2x2 corner block leaves the staged box
 // take a global-memory slow path.
-constexpr int RG_R = 3, RG_CH = 16, RG_TY = 2, RG_TX = 32;
-constexpr int RG_VS = 20;   // floats per voxel in the channel-last LDS image [RV][RG_VS]: 16 channels + 4 pad.  A lane reads the 16
-                            // channels of a corner as 4 ds_read_b128; 5*vox mod 16 is a permutation, so 16 consecutive voxels are
-                            // bank-conflict free
+constexpr int RG_TY = 2, RG_TX = 32;
+// Channels per chunk CH and floats per voxel VS of the channel-last LDS image [RV][VS]:
+//   CH = 16, VS = 20 (16 + 4 pad): a lane reads the channels of a corner as 4 ds_read_b128; 5*vox mod 16 is a permutation, so 16
+//            consecutive voxels are bank-conflict free.
+//   CH = 12, VS = 12: for channel counts that 16 divides badly (35 -> 36 instead of 48 padded channels); 3*vox mod 16 is a
+//            permutation too.  The smaller image leaves room for a halo of 4 instead of 3 (fewer samples on the slow path).
+template <int CH>
+struct RegCfg {
+  static_assert(CH == 16 || CH == 12, "chunk width");
+  static constexpr int VS = CH == 16 ? 20 : 12;
+};
 
 struct RegGeo {
+  int R;                   // halo on top of the kernel extent
   int TZ, RZmax, RY, RX, RV;
   int tilesZ, tilesY, tilesX;
 };
@@ -615,23 +623,24 @@ __device__ __forceinline__ RegCtx region_ctx(const DcnP& p, const RegGeo& g, int
   const int tz = blk % g.tilesZ;
   c.b = blk / g.tilesZ;
   c.z0 = tz * g.TZ; c.y0 = ty * RG_TY; c.x0 = tx * RG_TX;
-  const int rz0u = c.z0 * p.sd - p.pd - RG_R;
+  const int rz0u = c.z0 * p.sd - p.pd - g.R;
   c.rz0 = rz0u < 0 ? 0 : rz0u;
-  int rz1 = rz0u + (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * RG_R;
+  int rz1 = rz0u + (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * g.R;
   if (rz1 > p.D) rz1 = p.D;
   c.RZ = rz1 - c.rz0;
   if (c.RZ > g.RZmax) c.RZ = g.RZmax;
-  c.ry0 = c.y0 * p.sh - p.ph - RG_R;
-  c.rx0 = c.x0 * p.sw - p.pw - RG_R;
+  c.ry0 = c.y0 * p.sh - p.ph - g.R;
+  c.rx0 = c.x0 * p.sw - p.pw - g.R;
   return c;
 }
 
 // stage x[b, c0 .. c0+nch) over the region into s_reg[ch][RV] (zeros outside the volume / beyond C)
+template <int CH>
 __device__ __forceinline__ void stage_region(const DcnP& p, const RegGeo& g, const RegCtx& c, const float* __restrict__ xb, int c0, float* s_reg,
                                              int wave_u, int lane) {
   const long long chan = (long long)p.D * p.H * p.W;
   const int rows_per_ch = c.RZ * g.RY;
-  const int nrows = RG_CH * rows_per_ch;
+  const int nrows = CH * rows_per_ch;
   constexpr int SU = 8;
   for (int r0 = wave_u * SU; r0 < nrows; r0 += 4 * SU) {
     float v[SU];
@@ -651,7 +660,7 @@ __device__ __forceinline__ void stage_region(const DcnP& p, const RegGeo& g, con
       if (row < nrows && lane < g.RX) {
         const int ch = row / rows_per_ch;
         const int rem = row - ch * rows_per_ch;
-        s_reg[(rem * g.RX + lane) * RG_VS + ch] = v[u];
+        s_reg[(rem * g.RX + lane) * RegCfg<CH>::VS + ch] = v[u];
       }
     }
   }
@@ -694,10 +703,11 @@ __device__ __forceinline__ Samp make_samp(const DcnP& p, const RegGeo& g, const 
 }
 
 // 16 channels of corner (jd, jh, jw): 4 x ds_read_b128 from the channel-last image (fast path)
-__device__ __forceinline__ void corner_vec(const RegGeo& g, const Samp& s, const float* s_reg, int jd, int jh, int jw, float v[RG_CH]) {
-  const float4* r = reinterpret_cast<const float4*>(s_reg + (s.base + jd * s.dzs + jh * g.RX + jw) * RG_VS);
+template <int CH>
+__device__ __forceinline__ void corner_vec(const RegGeo& g, const Samp& s, const float* s_reg, int jd, int jh, int jw, float v[CH]) {
+  const float4* r = reinterpret_cast<const float4*>(s_reg + (s.base + jd * s.dzs + jh * g.RX + jw) * RegCfg<CH>::VS);
 #pragma unroll
-  for (int q = 0; q < RG_CH / 4; ++q) {
+  for (int q = 0; q < CH / 4; ++q) {
     const float4 f = r[q];
     v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
   }
@@ -711,13 +721,14 @@ __device__ __forceinline__ float corner_global(const DcnP& p, const Corner& cn, 
 }
 
 // slow path: the 16 channels of corner (jd, jh, jw) from global memory, issued as 16 independent loads
+template <int CH>
 __device__ __forceinline__ void corner_vec_global(const DcnP& p, const Corner& cn, const float* __restrict__ xb, int c0, long long chan, int jd,
-                                                  int jh, int jw, float v[RG_CH]) {
+                                                  int jh, int jw, float v[CH]) {
   const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
   const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
   const long long vox = in ? ((long long)d * p.H + h) * p.W + w : 0;
 #pragma unroll
-  for (int ch = 0; ch < RG_CH; ++ch) {
+  for (int ch = 0; ch < CH; ++ch) {
     const int c = c0 + ch < p.C ? c0 + ch : p.C - 1;
     const float x = xb[(long long)c * chan + vox];
     v[ch] = (in && c0 + ch < p.C) ? x : 0.f;
@@ -725,30 +736,31 @@ __device__ __forceinline__ void corner_vec_global(const DcnP& p, const Corner& c
 }
 
 // trilinear samples of the 16 channels of the staged chunk at one (voxel, tap)
+template <int CH>
 __device__ __forceinline__ void sample_chunk(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
-                                             const float* __restrict__ xb, int c0, long long chan, float val[RG_CH]) {
+                                             const float* __restrict__ xb, int c0, long long chan, float val[CH]) {
 #pragma unroll
-  for (int ch = 0; ch < RG_CH; ++ch) val[ch] = 0.f;
+  for (int ch = 0; ch < CH; ++ch) val[ch] = 0.f;
   if (!sp.valid) return;
   if (sp.fast) {       // straight-line: the 32 ds_read_b128 of the 8 corners can all be in flight
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
       const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
-      float v[RG_CH];
-      corner_vec(g, sp, s_reg, jd, jh, jw, v);
+      float v[CH];
+      corner_vec<CH>(g, sp, s_reg, jd, jh, jw, v);
 #pragma unroll
-      for (int ch = 0; ch < RG_CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+      for (int ch = 0; ch < CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
     }
   } else {
     for (int j = 0; j < 8; ++j) {
       const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
       const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
       if (wj == 0.f) continue;
-      float v[RG_CH];
-      corner_vec_global(p, cn, xb, c0, chan, jd, jh, jw, v);
+      float v[CH];
+      corner_vec_global<CH>(p, cn, xb, c0, chan, jd, jh, jw, v);
 #pragma unroll
-      for (int ch = 0; ch < RG_CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+      for (int ch = 0; ch < CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
     }
   }
 }
@@ -756,14 +768,14 @@ __device__ __forceinline__ void sample_chunk(const DcnP& p, const RegGeo& g, con
 constexpr int ST = 256 + 4;   // padded row of the [16][256] sample / gcol tile
 
 // ---------------------------------------------------------------------------------------------------- forward
-template <int MT>
+template <int MT, int CH>
 __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                             const float* __restrict__ wt /*[T][C16][KT], zero rows beyond C*/, const float* __restrict__ bias,
+                                                             const float* __restrict__ wt /*[T][Cpad][KT], zero rows beyond C*/, const float* __restrict__ bias,
                                                              float* __restrict__ out, DcnP p, RegGeo g) {
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32 * MT;
-  float* s_reg = smem;                       // [RV][RG_VS]
-  float* s_S = s_reg + RG_VS * g.RV;         // [16][ST]
+  float* s_reg = smem;                       // [RV][RegCfg<CH>::VS]
+  float* s_S = s_reg + RegCfg<CH>::VS * g.RV;         // [16][ST]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const RegCtx c = region_ctx(p, g, blockIdx.x);
@@ -785,11 +797,11 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
       for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
 
   const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
-  const int C16 = (p.C + RG_CH - 1) / RG_CH * RG_CH;
+  const int Cpad = (p.C + CH - 1) / CH * CH;
   const float* offp0 = off_b + (pvalid ? ppos : 0);
-  for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
+  for (int c0 = 0; c0 < p.C; c0 += CH) {
     __syncthreads();                                   // previous chunk's region / S tile consumed
-    stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
+    stage_region<CH>(p, g, c, xb, c0, s_reg, wave_u, lane);
     const float* offp = offp0;
     Off3 onext = load_off_ptr(offp, p.P, pvalid);
     TapIt it = {0, 0, 0};
@@ -799,10 +811,10 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
       offp += 3 * p.P;
       onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch the next tap's offsets
       // weight fragments of this tap: issue early, consume after the sampling phase
-      float a[RG_CH / 2][MT];
-      const float* wtt = wt + ((long long)t * C16 + c0 + hh) * KT + l31;
+      float a[CH / 2][MT];
+      const float* wtt = wt + ((long long)t * Cpad + c0 + hh) * KT + l31;
 #pragma unroll
-      for (int sx = 0; sx < RG_CH / 2; ++sx)
+      for (int sx = 0; sx < CH / 2; ++sx)
 #pragma unroll
         for (int m = 0; m < MT; ++m) a[sx][m] = wtt[(2 * sx) * KT + m * 32];
       const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
@@ -810,14 +822,14 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
       const Samp sp = make_samp(p, g, c, cn);
       if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
       {
-        float val[RG_CH];
-        sample_chunk(p, g, sp, cn, s_reg, xb, c0, chan, val);
+        float val[CH];
+        sample_chunk<CH>(p, g, sp, cn, s_reg, xb, c0, chan, val);
 #pragma unroll
-        for (int ch = 0; ch < RG_CH; ++ch) s_S[ch * ST + tid] = val[ch];
+        for (int ch = 0; ch < CH; ++ch) s_S[ch * ST + tid] = val[ch];
       }
       __syncthreads();
 #pragma unroll
-      for (int sx = 0; sx < RG_CH / 2; ++sx) {
+      for (int sx = 0; sx < CH / 2; ++sx) {
         float bv[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) bv[nt] = s_S[(2 * sx + hh) * ST + wave * 64 + nt * 32 + l31];
@@ -854,14 +866,14 @@ constexpr int WG_NREP = 8;   // replicas of the grad_weight scratch tensor (spre
 // grad_offset[3t+dir][p] = sum_c gcol[c][p] * d sample(c,p,t) / d coord_dir   (cuh:111-190, 336-405)
 // WG = true additionally produces grad_weight in the same pass (the corner values are already in registers): the sampled tile
 // S[16][256] replaces gcol in LDS and each wave contracts it against its 16 output channels of go (see dcn_wgrad_region_kernel)
-template <bool WG>
+template <bool WG, int CH>
 __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                     const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/, const float* __restrict__ go,
                                                                     float* __restrict__ doff, float* __restrict__ dwtmp, DcnP p, RegGeo g, int CT,
                                                                     int nchunk) {
   extern __shared__ __align__(16) float smem[];
-  float* s_reg = smem;                       // [RV][RG_VS]
-  float* s_gc = s_reg + RG_VS * g.RV;        // [16][ST]
+  float* s_reg = smem;                       // [RV][RegCfg<CH>::VS]
+  float* s_gc = s_reg + RegCfg<CH>::VS * g.RV;        // [16][ST]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const RegCtx c = region_ctx(p, g, blockIdx.x);
@@ -908,9 +920,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
 
   const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
   const float* offp0 = off_b + (pvalid ? ppos : 0);
-  for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
+  for (int c0 = 0; c0 < p.C; c0 += CH) {
     __syncthreads();
-    stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
+    stage_region<CH>(p, g, c, xb, c0, s_reg, wave_u, lane);
     const float* offp = offp0;
     Off3 onext = load_off_ptr(offp, p.P, pvalid);
     TapIt it = {0, 0, 0};
@@ -937,44 +949,44 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
       }
       __syncthreads();
       float gd = 0.f, gh = 0.f, gw = 0.f;
-      float sval[RG_CH];
+      float sval[CH];
 #pragma unroll
-      for (int ch = 0; ch < RG_CH; ++ch) sval[ch] = 0.f;
+      for (int ch = 0; ch < CH; ++ch) sval[ch] = 0.f;
       if (sp.valid) {
-        float gcv[RG_CH];
+        float gcv[CH];
 #pragma unroll
-        for (int ch = 0; ch < RG_CH; ++ch) gcv[ch] = s_gc[ch * ST + tid];   // zero for channels beyond C (zero weight columns)
+        for (int ch = 0; ch < CH; ++ch) gcv[ch] = s_gc[ch * ST + tid];   // zero for channels beyond C (zero weight columns)
         // dot_j = sum_ch gcol[ch] * x[corner j][ch]; the three coordinate derivatives weight it with the other two
         // trilinear factors and the signed in-volume mask of their own axis (cuh:131-187)
         float dots[8];
         if (sp.fast) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float v[RG_CH];
-            corner_vec(g, sp, s_reg, j >> 2, (j >> 1) & 1, j & 1, v);
+            float v[CH];
+            corner_vec<CH>(g, sp, s_reg, j >> 2, (j >> 1) & 1, j & 1, v);
             float dot = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
+            for (int ch = 0; ch < CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
             dots[j] = dot;
             if (WG) {
               const float wj = sp.wz[j >> 2] * sp.wy[(j >> 1) & 1] * sp.wx[j & 1];
 #pragma unroll
-              for (int ch = 0; ch < RG_CH; ++ch) sval[ch] = fmaf(wj, v[ch], sval[ch]);
+              for (int ch = 0; ch < CH; ++ch) sval[ch] = fmaf(wj, v[ch], sval[ch]);
             }
           }
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float v[RG_CH];
-            corner_vec_global(p, cn, xb, c0, chan, j >> 2, (j >> 1) & 1, j & 1, v);
+            float v[CH];
+            corner_vec_global<CH>(p, cn, xb, c0, chan, j >> 2, (j >> 1) & 1, j & 1, v);
             float dot = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < RG_CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
+            for (int ch = 0; ch < CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
             dots[j] = dot;
             if (WG) {
               const float wj = sp.wz[j >> 2] * sp.wy[(j >> 1) & 1] * sp.wx[j & 1];
 #pragma unroll
-              for (int ch = 0; ch < RG_CH; ++ch) sval[ch] = fmaf(wj, v[ch], sval[ch]);
+              for (int ch = 0; ch < CH; ++ch) sval[ch] = fmaf(wj, v[ch], sval[ch]);
             }
           }
         }
@@ -997,13 +1009,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
       if (WG) {
         // this thread is the only reader of column `tid` of the gcol tile, so it can overwrite it with its samples right away
 #pragma unroll
-        for (int ch = 0; ch < RG_CH; ++ch) s_gc[ch * ST + tid] = sval[ch];
+        for (int ch = 0; ch < CH; ++ch) s_gc[ch * ST + tid] = sval[ch];
         __syncthreads();
         f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 64; ++ks) wacc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[ks], s_gc[l15 * ST + 4 * ks + lg], wacc, 0, 0, 0);
-        if (c0 + l15 < p.C) {
-          float* dst = rep + ((long long)(t * nchunk + c0 / RG_CH) * 64 + 16 * wave + 4 * lg) * 16 + l15;
+        if (l15 < CH && c0 + l15 < p.C) {
+          float* dst = rep + ((long long)(t * nchunk + c0 / CH) * 64 + 16 * wave + 4 * lg) * 16 + l15;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (16 * wave + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], wacc[r]);
@@ -1022,8 +1034,8 @@ __global__ __launch_bounds__(256) void dcn_wgrad_region_kernel(const float* __re
                                                                const float* __restrict__ go, float* __restrict__ dwtmp, DcnP p, RegGeo g,
                                                                int nchunk) {
   extern __shared__ __align__(16) float smem[];
-  float* s_reg = smem;                       // [RV][RG_VS]
-  float* s_S = s_reg + RG_VS * g.RV;         // [16][ST]
+  float* s_reg = smem;                       // [RV][RegCfg<16>::VS]
+  float* s_S = s_reg + RegCfg<16>::VS * g.RV;         // [16][ST]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const RegCtx c = region_ctx(p, g, blockIdx.x);
@@ -1048,9 +1060,9 @@ __global__ __launch_bounds__(256) void dcn_wgrad_region_kernel(const float* __re
   }
   float* rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
 
-  for (int c0 = 0; c0 < p.C; c0 += RG_CH) {
+  for (int c0 = 0; c0 < p.C; c0 += 16) {
     __syncthreads();
-    stage_region(p, g, c, xb, c0, s_reg, wave_u, lane);
+    stage_region<16>(p, g, c, xb, c0, s_reg, wave_u, lane);
     Off3 onext = load_off(p, off_b, 0, ppos);
     for (int t = 0; t < p.T; ++t) {
       const Off3 ocur = onext;
@@ -1059,17 +1071,17 @@ __global__ __launch_bounds__(256) void dcn_wgrad_region_kernel(const float* __re
       const Samp sp = make_samp(p, g, c, cn);
       __syncthreads();                                 // region staged / previous tap's s_S consumed
       {
-        float val[RG_CH];
-        sample_chunk(p, g, sp, cn, s_reg, xb, c0, chan, val);
+        float val[16];
+        sample_chunk<16>(p, g, sp, cn, s_reg, xb, c0, chan, val);
 #pragma unroll
-        for (int ch = 0; ch < RG_CH; ++ch) s_S[ch * ST + tid] = val[ch];
+        for (int ch = 0; ch < 16; ++ch) s_S[ch * ST + tid] = val[ch];
       }
       __syncthreads();
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], s_S[l15 * ST + 4 * ks + lg], acc, 0, 0, 0);
       if (c0 + l15 < p.C) {
-        float* dst = rep + ((long long)(t * nchunk + c0 / RG_CH) * 64 + 16 * wave + 4 * lg) * 16 + l15;
+        float* dst = rep + ((long long)(t * nchunk + c0 / 16) * 64 + 16 * wave + 4 * lg) * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (16 * wave + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], acc[r]);
@@ -1078,32 +1090,43 @@ __global__ __launch_bounds__(256) void dcn_wgrad_region_kernel(const float* __re
   }
 }
 
-// dW[k][c][t] = sum_rep tmp[rep][t][c/16][k][c%16]
-__global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __restrict__ dw, int K, int C, int T, int nchunk) {
+// dW[k][c][t] = sum_rep tmp[rep][t][c/ch][k][c%ch]   (ch = channels per chunk of the producing kernel)
+__global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __restrict__ dw, int K, int C, int T, int nchunk, int ch) {
   const int total = K * C * T;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int t = i % T, cc = (i / T) % C, k = i / (T * C);
     float s = 0.f;
-    for (int r = 0; r < WG_NREP; ++r) s += dwtmp[(((long long)r * T + t) * nchunk + cc / RG_CH) * 64 * 16 + k * 16 + (cc % RG_CH)];
+    for (int r = 0; r < WG_NREP; ++r) s += dwtmp[(((long long)r * T + t) * nchunk + cc / ch) * 64 * 16 + k * 16 + (cc % ch)];
     dw[i] = s;
   }
 }
 
-int region_geo(RegGeo& g, const DcnP& p) {
+size_t region_lds(const RegGeo& g, int CH) { return sizeof(float) * ((size_t)(CH == 16 ? 20 : 12) * g.RV + (size_t)16 * ST); }
+
+int region_geo(RegGeo& g, const DcnP& p, int CH, int R) {
+  g.R = R;
   g.TZ = p.Do < 4 ? p.Do : 4;
-  int RZ = (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * RG_R;
+  int RZ = (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * R;
   if (RZ > p.D) RZ = p.D;
   g.RZmax = RZ;
-  g.RY = (RG_TY - 1) * p.sh + (p.kh - 1) * p.dh + 1 + 2 * RG_R;
-  g.RX = (RG_TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + 2 * RG_R;
+  g.RY = (RG_TY - 1) * p.sh + (p.kh - 1) * p.dh + 1 + 2 * R;
+  g.RX = (RG_TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + 2 * R;
   g.RV = g.RZmax * g.RY * g.RX;
   g.tilesZ = dpf_div_up(p.Do, g.TZ);
   g.tilesY = dpf_div_up(p.Ho, RG_TY);
   g.tilesX = dpf_div_up(p.Wo, RG_TX);
-  const size_t lds = sizeof(float) * ((size_t)RG_VS * g.RV + (size_t)RG_CH * ST);
   const long long blocks = (long long)p.B * g.tilesZ * g.tilesY * g.tilesX;
-  if (g.RX > 64 || lds > 150 * 1024 || blocks >= 0x7fffffffLL || p.K > 128) return DPF_ERR_UNSUPPORTED;
+  if (g.RX > 64 || region_lds(g, CH) > 150 * 1024 || blocks >= 0x7fffffffLL || p.K > 128) return DPF_ERR_UNSUPPORTED;
   return DPF_OK;
+}
+
+// chunk width: 12 where it pads the channel count less than 16 does (35 -> 36 vs 48)
+int region_chunk(int C) { return ((C + 11) / 12 * 12 < (C + 15) / 16 * 16) ? 12 : 16; }
+
+// widest halo (4, then 3) whose LDS image fits
+int region_pick(RegGeo& g, const DcnP& p, int CH) {
+  if (region_geo(g, p, CH, 4) == DPF_OK) return DPF_OK;
+  return region_geo(g, p, CH, 3);
 }
 
 int fill_params(DcnP& p, int B, int C, int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
@@ -1139,7 +1162,7 @@ int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void*
 // workspace floats for dpf_deform_conv3d_forward / _backward (repacked weights)
 long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
   const long long repack = (long long)T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);   // either repack, reduce index padded
-  return repack + (long long)WG_NREP * T * ((C + RG_CH - 1) / RG_CH) * 64 * 16;   // + grad_weight scratch replicas
+  return repack + (long long)WG_NREP * T * ((C + 11) / 12) * 64 * 16;   // + grad_weight scratch replicas (chunks of >= 12 channels)
 }
 
 // Mirrors DCN.deform_conv_forward(input, weight, bias, offset, kd,kh,kw, sd,sh,sw, pd,ph,pw, dd,dh,dw, group, deformable_group,
@@ -1157,18 +1180,24 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
   hipStream_t st = (hipStream_t)stream;
   const int MT = (K + 31) / 32, KT = 32 * MT;
   RegGeo g{};
-  if (region_geo(g, p) == DPF_OK && !getenv("DPF_DCN_V1")) {
-    const int C16 = (C + RG_CH - 1) / RG_CH * RG_CH;
-    hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * C16 * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0,
-                       C16);
-    const size_t lds = sizeof(float) * ((size_t)RG_VS * g.RV + (size_t)RG_CH * ST);
+  const int CH = region_chunk(C);
+  if (!getenv("DPF_DCN_V1") && region_pick(g, p, CH) == DPF_OK) {
+    const int Cpad = (C + CH - 1) / CH * CH;
+    hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * Cpad * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0,
+                       Cpad);
+    const size_t lds = region_lds(g, CH);
     const dim3 grid((unsigned)((long long)B * g.tilesZ * g.tilesY * g.tilesX));
-#define DPF_FR(M)                                                                                                  \
-  {                                                                                                                \
-    if (set_lds(dcn_fwd_region_kernel<M>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                   \
-    hipLaunchKernelGGL((dcn_fwd_region_kernel<M>), grid, dim3(256), lds, st, input, offset, ws, bias, output, p, g); \
+#define DPF_FR2(M, Cw)                                                                                                   \
+  {                                                                                                                      \
+    if (set_lds(dcn_fwd_region_kernel<M, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                     \
+    hipLaunchKernelGGL((dcn_fwd_region_kernel<M, Cw>), grid, dim3(256), lds, st, input, offset, ws, bias, output, p, g); \
+  }
+#define DPF_FR(M)            \
+  {                          \
+    if (CH == 16) DPF_FR2(M, 16) else DPF_FR2(M, 12) \
   }
     switch (MT) { case 1: DPF_FR(1); break; case 2: DPF_FR(2); break; case 3: DPF_FR(3); break; default: DPF_FR(4); break; }
+#undef DPF_FR2
 #undef DPF_FR
     return dpf_check_launch();
   }
@@ -1252,25 +1281,33 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     }
   }
   RegGeo rg{};
-  const bool region_ok = K <= 64 && region_geo(rg, p) == DPF_OK && !getenv("DPF_DCN_V1");
-  const bool fuse_wg = region_ok && dx_done && !getenv("DPF_DCN_NOFUSE");
+  // the fused offset + weight gradient kernel picks its chunk width / halo like the forward; the stand-alone weight-gradient
+  // fallback works on 16-channel chunks with a halo of 3
+  const bool want_fuse = dx_done && !getenv("DPF_DCN_NOFUSE");
+  const int CHb = want_fuse ? region_chunk(C) : 16;
+  const bool region_ok = K <= 64 && !getenv("DPF_DCN_V1") && (want_fuse ? region_pick(rg, p, CHb) : region_geo(rg, p, 16, 3)) == DPF_OK &&
+                         (CHb == 16 || (C + 11) / 12 * 12 + 4 <= CT);   // 16 weight columns are fetched from each chunk origin
+  const bool fuse_wg = region_ok && want_fuse;
   float* dwtmp = ws + (long long)p.T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);
-  const int nchunk = (C + RG_CH - 1) / RG_CH;
+  const int nchunk = (C + CHb - 1) / CHb;
   if (region_ok) {
     if (hipMemsetAsync(dwtmp, 0, sizeof(float) * (size_t)WG_NREP * p.T * nchunk * 64 * 16, st) != hipSuccess) return DPF_ERR_LAUNCH;
   }
   if (region_ok && dx_done) {
-    const size_t lds = sizeof(float) * ((size_t)RG_VS * rg.RV + (size_t)RG_CH * ST);
+    const size_t lds = region_lds(rg, CHb);
     const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
+#define DPF_OFF(WGv, Cw)                                                                                                        \
+  {                                                                                                                             \
+    if (set_lds(dcn_bwd_offset_region_kernel<WGv, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                   \
+    hipLaunchKernelGGL((dcn_bwd_offset_region_kernel<WGv, Cw>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, \
+                       p, rg, CT, nchunk);                                                                                      \
+  }
     if (fuse_wg) {
-      if (set_lds(dcn_bwd_offset_region_kernel<true>, lds) != DPF_OK) return DPF_ERR_LAUNCH;
-      hipLaunchKernelGGL(dcn_bwd_offset_region_kernel<true>, grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, p, rg, CT,
-                         nchunk);
+      if (CHb == 16) DPF_OFF(true, 16) else DPF_OFF(true, 12)
     } else {
-      if (set_lds(dcn_bwd_offset_region_kernel<false>, lds) != DPF_OK) return DPF_ERR_LAUNCH;
-      hipLaunchKernelGGL(dcn_bwd_offset_region_kernel<false>, grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, p, rg, CT,
-                         nchunk);
+      DPF_OFF(false, 16)
     }
+#undef DPF_OFF
   } else {
     hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * K * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1);
     const size_t lds = sizeof(float) * ((size_t)K * SP + (size_t)CT * SP + 3 * 4 * TP);
@@ -1290,12 +1327,12 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   }
   if (region_ok) {
     if (!fuse_wg) {
-      const size_t lds = sizeof(float) * ((size_t)RG_VS * rg.RV + (size_t)RG_CH * ST);
+      const size_t lds = region_lds(rg, 16);
       const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
       if (set_lds(dcn_wgrad_region_kernel, lds) != DPF_OK) return DPF_ERR_LAUNCH;
       hipLaunchKernelGGL(dcn_wgrad_region_kernel, grid, dim3(256), lds, st, input, offset, grad_output, dwtmp, p, rg, nchunk);
     }
-    hipLaunchKernelGGL(dcn_wgrad_fold_kernel, dim3(dpf_ew_grid((long long)K * C * p.T)), dim3(256), 0, st, dwtmp, grad_weight, K, C, p.T, nchunk);
+    hipLaunchKernelGGL(dcn_wgrad_fold_kernel, dim3(dpf_ew_grid((long long)K * C * p.T)), dim3(256), 0, st, dwtmp, grad_weight, K, C, p.T, nchunk, CHb);
   } else {
     const long long ntile = (long long)B * p.tiles_per_b;
     long long nchunkw = 2048 / p.T;

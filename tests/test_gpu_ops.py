@@ -311,13 +311,15 @@ def test_softargmin():
     close(gg, gr, 1e-4, 'softargmin bwd')
 
 
-@pytest.mark.parametrize('cfg', [(2, 35, 64, 4, 6, 9), (1, 64, 64, 4, 8, 12), (2, 5, 7, 3, 5, 6)])
+@pytest.mark.parametrize('cfg', [(2, 35, 64, 4, 6, 9), (1, 64, 64, 4, 8, 12), (2, 5, 7, 3, 5, 6),
+                                 # several tiles per axis and offsets reaching past the staged halo (slow paths), 12- and 16-wide chunks
+                                 (1, 20, 40, 5, 9, 70, 3.0), (1, 16, 24, 4, 7, 45, 4.0)])
 def test_deform_conv(cfg):
     from oracle import dcn3d
     ops = _ops()
-    B, C, K, D, H, W = cfg
+    B, C, K, D, H, W = cfg[:6]
     x = rnd(B, C, D, H, W, seed=70)
-    off = rnd(B, 81, D, H, W, seed=71, scale=1.5)
+    off = rnd(B, 81, D, H, W, seed=71, scale=cfg[6] if len(cfg) > 6 else 1.5)
     wt = rnd(K, C, 3, 3, 3, seed=72, scale=0.1)
     bs = rnd(K, seed=73)
     y_ref = dcn3d.deform_conv3d_forward(x, off, wt, bs)
