@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   for (int c0 = 0; c0 < q.CG; c0 += GI_CH) {      // only the channels whose gradient the caller needs
     __syncthreads();                                            // previous chunk flushed
     for (int i = tid; i < regvox * GI_CS + GI_CS; i += 256) s_reg[i] = 0.0;
+    if (tid == 0) s_far[0] = 0;
     const int cc = c0 + lc;
     const bool cok = cc < q.CG;
     const float* offp = offp0;
@@ -421,8 +422,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
     for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
     for (int t = 0; t < p.T; ++t) {
       __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
-      if (tid == 0) s_far[0] = 0;
-      __syncthreads();
+      if (tid == 0) s_far[(t + 1) & 1] = 0;                     // the flag alternates between two slots: no extra barrier to reset it
       const Off3 ocur = onext;
       offp += 3 * p.P;
       onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch: consumed one barrier-to-barrier phase later
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
           if (!in && v >= 0) anyfar = 1;
         }
         s_farm[tid] = anyfar;
-        if (anyfar) s_far[0] = 1;
+        if (anyfar) s_far[t & 1] = 1;
       }
       // B fragments: W[k][c0 + lc][t] (both lane halves of a group hold the same 8 channels); next tap's are prefetched
       float bfrag[16];
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(&s_reg[li[j] + lc], (double)(wv[j] * g));
           }
-          if (s_far[0] != 0) {                                     // block-uniform: some corner of this tap left the region
+          if (s_far[t & 1] != 0) {                                     // block-uniform: some corner of this tap left the region
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int pl = (wave * NST + st) * 16 + 4 * lg + r;
