@@ -350,11 +350,16 @@ struct GiP {
 // Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 sustains 0.33 lanes/clk/CU whatever the address pattern,
 // ds_add_f64 3.1 and ds_add_u64 4.8-5.4.  The region therefore accumulates in fp64 (also the more accurate sum); it is
 // converted to fp32 once, at the flush.
-template <int NST>   // position sub-tiles of 16 per wave (positions per block = 64 * NST)
-__global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
+// NW waves per workgroup, NST position sub-tiles of 16 per wave (positions per block = 16 * NST * NW).  NW = 8 runs two waves per
+// SIMD on the same LDS footprint: every phase has twice the threads (each voxel's eight table corners are split between a
+// thread pair), so the issue-bound table / scatter streams of the two waves interleave.
+template <int NST, int NW>
+__global__ __launch_bounds__(64 * NW) void dcn_bwd_input_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
                                                             const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT) {
   extern __shared__ __align__(16) double smem_d[];
-  const int npos = 64 * NST;
+  constexpr int NT = 64 * NW;
+  constexpr int npos = 16 * NST * NW;
+  constexpr bool HALVES = NW == 8;   // thread pair per voxel in the table phase
   double* s_reg = smem_d;                                      // [RZ*RY*RX][GI_CS]
   const int regvox = q.RZmax * q.RY * q.RX;
   int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + GI_CS + 1) & ~1));   // [npos][8] local voxel index or -1 (16-B aligned); GI_CS dummy doubles before it
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   float* s_w = (float*)(s_vox + npos * 8);                     // [npos][8] corner weight, 0 outside the region
   float* s_wfar = s_w + npos * 8;                              // [npos][8] corner weight (far pass)
   int* s_far = (int*)(s_wfar + npos * 8);                         // [4] per-tap flag: some corner left the region
-  int* s_farm = s_far + 4;                                      // [npos] per-voxel flag
+  int* s_farm = s_far + 4;                                      // [2][npos] per-voxel flag (one row per thread of a pair)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int lc = l15 & 7;            // channel within the chunk; lanes 8..15 of a group mirror lanes 0..7 ...
   const int jb = (l15 >> 3) * 4;     // ... and scatter corners 4..7 instead of 0..3
@@ -384,9 +389,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   const float* off_b = offset + (long long)b * 3 * p.T * p.P;
   float* dxb = dx + (long long)b * p.C * chan;
 
-  const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
+  const int vox = HALVES ? (tid & (npos - 1)) : tid;       // this thread's voxel in the table phase
+  const int half = HALVES ? tid / npos : 0;
+  const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
   const int zo = z0 + pdz, yo = y0 + pdy, xo = x0 + pdx;
-  const bool pvalid = tid < npos && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const bool pvalid = (HALVES || tid < npos) && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
   const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
 
   // A fragments: go[k][voxel] for this wave's NST sub-tiles, all k (K <= 64 -> 16 k-steps of 4), kept in registers
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
   const float* offp0 = off_b + (pvalid ? ppos : 0);
   for (int c0 = 0; c0 < q.CG; c0 += GI_CH) {      // only the channels whose gradient the caller needs
     __syncthreads();                                            // previous chunk flushed
-    for (int i = tid; i < regvox * GI_CS + GI_CS; i += 256) s_reg[i] = 0.0;
+    for (int i = tid; i < regvox * GI_CS + GI_CS; i += NT) s_reg[i] = 0.0;
     if (tid == 0) s_far[0] = 0;
     const int cc = c0 + lc;
     const bool cok = cc < q.CG;
@@ -428,11 +435,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
       onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch: consumed one barrier-to-barrier phase later
       const TapIt itc = it;
       tap_next(p, it);
-      if (tid < npos) {
+      if (HALVES || tid < npos) {
         const Corner cn = corner_at(p, pvalid, zb, yb, xbase, itc, ocur);
         int anyfar = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int jj = 0; jj < (HALVES ? 4 : 8); ++jj) {
+          const int j = HALVES ? 4 * half + jj : jj;
           float wg;
           const int v = corner_index32(p, cn, j, wg);
           // element index of the corner's cell in the region; corners outside the region (or the volume) point at the dummy
@@ -447,13 +455,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
               in = true;
             }
           }
-          s_lidx[tid * 8 + j] = li;
-          s_vox[tid * 8 + j] = (in || v < 0) ? -1 : (int)v;      // >= 0 only for far corners (second pass)
-          s_w[tid * 8 + j] = in ? wg : 0.f;
-          s_wfar[tid * 8 + j] = wg;
+          s_lidx[vox * 8 + j] = li;
+          s_vox[vox * 8 + j] = (in || v < 0) ? -1 : (int)v;      // >= 0 only for far corners (second pass)
+          s_w[vox * 8 + j] = in ? wg : 0.f;
+          s_wfar[vox * 8 + j] = wg;
           if (!in && v >= 0) anyfar = 1;
         }
-        s_farm[tid] = anyfar;
+        s_farm[half * npos + vox] = anyfar;
         if (anyfar) s_far[t & 1] = 1;
       }
       // B fragments: W[k][c0 + lc][t] (both lane halves of a group hold the same 8 channels); next tap's are prefetched
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int pl = (wave * NST + st) * 16 + 4 * lg + r;
-              if (s_farm[pl] == 0) continue;
+              if ((s_farm[pl] | (HALVES ? s_farm[npos + pl] : 0)) == 0) continue;
               const float g = acc[r];
               for (int j = 0; j < 4; ++j) {
                 const int v = s_vox[pl * 8 + jb + j];
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_kernel(const float* __restr
     // flush: lanes along x (row-contiguous global atomics); odd channel stride keeps the LDS reads conflict-light
     const int rowlen = q.RX;
     const int nrows = RZ * q.RY * GI_CH;
-    for (int row = wave; row < nrows; row += 4) {
+    for (int row = wave; row < nrows; row += NW) {
       const int c = row % GI_CH;
       const int zy = row / GI_CH;
       const int ly = zy % q.RY, lz = zy / q.RY;
@@ -1264,18 +1272,25 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
     q.CG = grad_input_channels < C ? (grad_input_channels < 0 ? 0 : grad_input_channels) : C;
     const int npos = 64 * q.TZ;
-    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 33 + 4);
+    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 34 + 4);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
     if (lds <= 150 * 1024 && blocks < 0x7fffffffLL && (long long)D * H * W < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
       hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * 64 * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1,
                          64);
-#define DPF_GI(NS)                                                                                                   \
-  {                                                                                                                  \
-    if (set_lds(dcn_bwd_input_kernel<NS>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                     \
-    hipLaunchKernelGGL((dcn_bwd_input_kernel<NS>), grid, dim3(256), lds, st, offset, ws, grad_output, grad_input, p, q, CT); \
+#define DPF_GI(NS, NWv)                                                                                                        \
+  {                                                                                                                            \
+    if (set_lds(dcn_bwd_input_kernel<NS, NWv>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                          \
+    hipLaunchKernelGGL((dcn_bwd_input_kernel<NS, NWv>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT); \
   }
-      switch (q.TZ) { case 1: DPF_GI(1); break; case 2: DPF_GI(2); break; case 3: DPF_GI(3); break; default: DPF_GI(4); break; }
+      switch (q.TZ) {
+        case 1: DPF_GI(1, 4); break;
+        case 2: DPF_GI(2, 4); break;
+        case 3: DPF_GI(3, 4); break;
+        default:
+          if (getenv("DPF_DCN_GI4")) DPF_GI(4, 4) else DPF_GI(2, 8)   // 256 voxels: 8 waves (two per SIMD)
+          break;
+      }
 #undef DPF_GI
       dx_done = true;
     }
