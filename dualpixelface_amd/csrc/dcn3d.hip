@@ -645,12 +645,12 @@ __device__ __forceinline__ RegCtx region_ctx(const DcnP& p, const RegGeo& g, int
 // stage x[b, c0 .. c0+nch) over the region into s_reg[ch][RV] (zeros outside the volume / beyond C)
 template <int CH>
 __device__ __forceinline__ void stage_region(const DcnP& p, const RegGeo& g, const RegCtx& c, const float* __restrict__ xb, int c0, float* s_reg,
-                                             int wave_u, int lane) {
+                                             int wave_u, int lane, int nwaves = 4) {
   const long long chan = (long long)p.D * p.H * p.W;
   const int rows_per_ch = c.RZ * g.RY;
   const int nrows = CH * rows_per_ch;
   constexpr int SU = 8;
-  for (int r0 = wave_u * SU; r0 < nrows; r0 += 4 * SU) {
+  for (int r0 = wave_u * SU; r0 < nrows; r0 += nwaves * SU) {
     float v[SU];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -862,6 +862,149 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
         for (int j = 0; j < 16; ++j) {
           const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
           if (k < p.K) out[((long long)c.b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
+        }
+    }
+  }
+}
+
+// ---- 8-wave forward (two waves per SIMD on the same LDS image): a thread pair per voxel, each thread sampling half of the
+// chunk's channels; each wave contracts 32 voxels.
+template <int CH, int H>
+__device__ __forceinline__ void corner_half(const RegGeo& g, const Samp& s, const float* s_reg, int jd, int jh, int jw, float v[CH / 2]) {
+  const float* r = s_reg + (s.base + jd * s.dzs + jh * g.RX + jw) * RegCfg<CH>::VS + H * (CH / 2);
+  if (CH == 16) {
+    const float4 a = *reinterpret_cast<const float4*>(r), b = *reinterpret_cast<const float4*>(r + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else if (H == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(r);
+    const float2 b = *reinterpret_cast<const float2*>(r + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y;
+  } else {
+    const float2 a = *reinterpret_cast<const float2*>(r);
+    const float4 b = *reinterpret_cast<const float4*>(r + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = b.z; v[5] = b.w;
+  }
+}
+
+template <int CH, int H>
+__device__ __forceinline__ void sample_half(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
+                                            const float* __restrict__ xb, int c0, long long chan, float val[CH / 2]) {
+  constexpr int NC = CH / 2;
+#pragma unroll
+  for (int ch = 0; ch < NC; ++ch) val[ch] = 0.f;
+  if (!sp.valid) return;
+  if (sp.fast) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+      const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+      float v[NC];
+      corner_half<CH, H>(g, sp, s_reg, jd, jh, jw, v);
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+    }
+  } else {
+    for (int j = 0; j < 8; ++j) {
+      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+      const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+      if (wj == 0.f) continue;
+      const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
+      const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
+      const long long vox = in ? ((long long)d * p.H + h) * p.W + w : 0;
+      float v[NC];
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch) {
+        const int cg = c0 + H * NC + ch;
+        const float x = xb[(long long)(cg < p.C ? cg : p.C - 1) * chan + vox];
+        v[ch] = (in && cg < p.C) ? x : 0.f;
+      }
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
+    }
+  }
+}
+
+template <int MT, int CH>
+__global__ __launch_bounds__(512) void dcn_fwd_region8_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                              const float* __restrict__ wt /*[T][Cpad][KT], zero rows beyond C*/,
+                                                              const float* __restrict__ bias, float* __restrict__ out, DcnP p, RegGeo g) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int KT = 32 * MT;
+  constexpr int NC = CH / 2;
+  float* s_reg = smem;                                // [RV][VS]
+  float* s_S = s_reg + RegCfg<CH>::VS * g.RV;         // [CH][ST]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int half = wave_u >> 2;                        // waves 0-3: channels [0, CH/2), waves 4-7: the rest
+  const int vox = tid & 255;
+  const RegCtx c = region_ctx(p, g, blockIdx.x);
+  const long long chan = (long long)p.D * p.H * p.W;
+  const float* xb = x + (long long)c.b * p.C * chan;
+  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
+  const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
+  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
+  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[m][j] = 0.f;
+
+  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
+  const int Cpad = (p.C + CH - 1) / CH * CH;
+  const float* offp0 = off_b + (pvalid ? ppos : 0);
+  for (int c0 = 0; c0 < p.C; c0 += CH) {
+    __syncthreads();                                   // previous chunk's region / S tile consumed
+    stage_region<CH>(p, g, c, xb, c0, s_reg, wave_u, lane, 8);
+    const float* offp = offp0;
+    Off3 onext = load_off_ptr(offp, p.P, pvalid);
+    TapIt it = {0, 0, 0};
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t) {
+      const Off3 ocur = onext;
+      offp += 3 * p.P;
+      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);
+      float a[CH / 2][MT];
+      const float* wtt = wt + ((long long)t * Cpad + c0 + hh) * KT + l31;
+#pragma unroll
+      for (int sx = 0; sx < CH / 2; ++sx)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[sx][m] = wtt[(2 * sx) * KT + m * 32];
+      const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
+      tap_next(p, it);
+      const Samp sp = make_samp(p, g, c, cn);
+      if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
+      {
+        float val[NC];
+        if (half == 0) sample_half<CH, 0>(p, g, sp, cn, s_reg, xb, c0, chan, val);
+        else sample_half<CH, 1>(p, g, sp, cn, s_reg, xb, c0, chan, val);
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) s_S[(half * NC + ch) * ST + vox] = val[ch];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sx = 0; sx < CH / 2; ++sx) {
+        const float bv = s_S[(2 * sx + hh) * ST + wave * 32 + l31];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sx][m], bv, acc[m], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: D row = out channel, col = voxel (wave*32 + l31)
+  {
+    const int pl = wave * 32 + l31;
+    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+    const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
+    if (az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo) {
+      const long long pos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (k < p.K) out[((long long)c.b * p.K + k) * p.P + pos] = acc[m][j] + (bias ? bias[k] : 0.f);
         }
     }
   }
@@ -1195,10 +1338,17 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
                        Cpad);
     const size_t lds = region_lds(g, CH);
     const dim3 grid((unsigned)((long long)B * g.tilesZ * g.tilesY * g.tilesX));
-#define DPF_FR2(M, Cw)                                                                                                   \
-  {                                                                                                                      \
-    if (set_lds(dcn_fwd_region_kernel<M, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                     \
-    hipLaunchKernelGGL((dcn_fwd_region_kernel<M, Cw>), grid, dim3(256), lds, st, input, offset, ws, bias, output, p, g); \
+    // 8-wave workgroups measured faster for 16-wide chunks (10.2 vs 10.8 ms, C = 64) and slower for 12-wide ones (8.4 vs 8.15 ms, C = 35)
+    const bool eight = getenv("DPF_DCN_FWD8") ? atoi(getenv("DPF_DCN_FWD8")) != 0 : CH == 16;
+#define DPF_FR2(M, Cw)                                                                                                      \
+  {                                                                                                                         \
+    if (eight) {                                                                                                            \
+      if (set_lds(dcn_fwd_region8_kernel<M, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                     \
+      hipLaunchKernelGGL((dcn_fwd_region8_kernel<M, Cw>), grid, dim3(512), lds, st, input, offset, ws, bias, output, p, g); \
+    } else {                                                                                                                \
+      if (set_lds(dcn_fwd_region_kernel<M, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                      \
+      hipLaunchKernelGGL((dcn_fwd_region_kernel<M, Cw>), grid, dim3(256), lds, st, input, offset, ws, bias, output, p, g);  \
+    }                                                                                                                       \
   }
 #define DPF_FR(M)            \
   {                          \
