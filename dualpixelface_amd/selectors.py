@@ -26,14 +26,25 @@ def scheduler_selector(optimizer, option):
 
 
 class metric_selector(object):
-    """Hook object only: the evaluation metrics (absolute_dp / affine_dp / normal_dp, CPU + TensorFlow in the
-    reference) are outside the training hot path."""
+    """The reference's metric hook (src/metric/metric_selector.py:7-39): one benchmark object per name in
+    ``option.model.metric_type``; ``forward`` returns {name: metric row} and logs it, ``viewer`` prints the running means."""
 
     def __init__(self, option):
-        self.names = list(getattr(option.model, 'metric_type', []))
+        from .metrics import BENCHMARKS
+        self.metric_func, self.metric_name = [], []
+        for name in list(getattr(option.model, 'metric_type', [])):
+            if name not in BENCHMARKS:
+                raise NotImplementedError('wrong metric type : %s' % name)
+            self.metric_func.append(BENCHMARKS[name](option))
+            self.metric_name.append(name)
 
-    def forward(self, results, batch):
-        return {}
+    def forward(self, pred, batch, log=True, target_type='disp'):
+        with torch.no_grad():
+            return {name: func.measure(pred, batch, log, target_type) for name, func in zip(self.metric_name, self.metric_func)}
 
     def viewer(self):
-        return None
+        for name, func in zip(self.metric_name, self.metric_func):
+            print('metric_type = %s' % name)
+            results, table = func.get_value(use_chart=True)
+            if table is not None:
+                print(table)

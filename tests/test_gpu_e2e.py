@@ -170,3 +170,24 @@ def test_dcn_compat_module_matches_reference_signature():
         close(a, r, 2e-4, 'DCN.deform_conv_backward')
     with pytest.raises(RuntimeError):
         DCN.deform_conv_forward(x, w.to(DEV), b.to(DEV), off.to(DEV), 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 64)   # CPU tensor
+
+
+def test_validation_step_runs_the_metric_hooks():
+    """validation_step -> metric_selector.forward(results, batch) like mainmodel.py:143-148; the metrics of the GPU forward equal
+    the metrics of the same prediction evaluated on the host."""
+    from dualpixelface_amd import metrics as M
+    from dualpixelface_amd.recipe import synthetic_batch
+    model = build_model(training=False)
+    batch = {k: v.to(DEV) for k, v in synthetic_batch(2, 32, 48, seed=3).items()}
+    with torch.no_grad():
+        results = model.validation_step(batch, 0)
+    sel = model.metric_model
+    assert sel.metric_name == ['absolute_dp', 'affine_dp', 'normal_dp'] and all(f.index == 1 for f in sel.metric_func)
+    rows = {n: f.get_value(0) for n, f in zip(sel.metric_name, sel.metric_func)}
+    assert all(np.isfinite(v) for r in rows.values() for v in r)
+    cpu_res = {k: v.cpu() for k, v in results.items() if torch.is_tensor(v)}
+    cpu_batch = {k: v.cpu() for k, v in batch.items()}
+    depth = M.disp2depth(cpu_res['pred_depth'], cpu_batch['abvalue'])
+    ref = M.depth_errors(cpu_batch['depth'], depth[:, 0], cpu_batch['mask'], 1.01)
+    np.testing.assert_allclose(rows['absolute_dp'], ref, rtol=1e-4, atol=1e-6)
+    model.validation_epoch_end([results])
