@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
+                    help="bf16 = BASELINE configs[4]: bf16-operand MFMA for the 2-D convs, fp32 everywhere else (default: exact fp32)")
     ap.add_argument('--sync-bn', action='store_true',
                     help='BatchNorm statistics over the global batch (what the reference does under DDP); default per-rank statistics')
     ap.add_argument('--shapes', default=None, help='write a per-convolution-shape timing table to this file')
@@ -112,7 +114,10 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(1)
-    model = STEREODPNET(load_option())          # reference initialisation scheme, random weights
+    opt = load_option()
+    if args.precision == 'bf16':
+        opt.precision = 'bf16'
+    model = STEREODPNET(opt)                    # reference initialisation scheme, random weights
     model.to(dev)
     broadcast_flat(model.flat_parameters(), 0)
     reducer = make_reducer(model) if world > 1 else None
@@ -179,7 +184,8 @@ def main():
         line = {
             'metric': 'train samples/sec, StereoDPNet 1024x1536 DP pair', 'value': value, 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16 2-D conv operands, f32 elsewhere',
+            'data': 'synthetic',
             'config': {'workload': 'StereoDPNet train step (fwd+loss+bwd+grad all-reduce+Adam), %d x %dx%d synthetic DP pairs per GPU'
                                    % (args.batch, args.height, args.width),
                        'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,

@@ -207,7 +207,56 @@ def conv3d(x, w, bias=None, stride=1, pad=0, dil=1):
     return ConvFn.apply(x, w, bias, _t3(stride), _t3(pad), _t3(dil))
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
+class ConvBf16Fn(torch.autograd.Function):
+    """nn.Conv2d with bf16 operands / fp32 accumulation (BASELINE config 5).  Forward and the stride-1 data gradient run on
+    the bf16 MFMA kernel; strided data gradients, all weight gradients and the bias gradient stay on the fp32 kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil):
+        x, w = _c(x), _c(w)
+        _need(x, w, bias)
+        N, C, IH, IW = x.shape
+        K, kh, kw = w.shape[0], w.shape[2], w.shape[3]
+        oh, ow = _out_dim(IH, kh, stride, pad, dil), _out_dim(IW, kw, stride, pad, dil)
+        out = torch.empty((N, K, oh, ow), dtype=torch.float32, device=x.device)
+        L = lib()
+        ws = scratch((L.call('dpf_conv2d_bf16_workspace_bytes', C, K, kh * kw) + 3) // 4, x.device, 'convw')
+        with _Timed('conv_bf16', 2.0 * N * K * C * kh * kw * oh * ow, 'b16 N%d C%d K%d in%dx%d k%d%d s%d d%d' % (N, C, K, IH, IW, kh, kw, stride, dil)):
+            L.call('dpf_conv2d_bf16_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, IH, IW, K, kh, kw, stride, stride, pad, pad,
+                   dil, dil, _stream())
+        ctx.cfg = (stride, pad, dil)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil = ctx.cfg
+        gy = _c(gy)
+        N, C, IH, IW = x.shape
+        K, kh, kw = w.shape[0], w.shape[2], w.shape[3]
+        gx = gw = gb = None
+        s3, p3, d3 = (1, stride, stride), (0, pad, pad), (1, dil, dil)
+        if ctx.needs_input_grad[0]:
+            if stride == 1 and dil * (kh - 1) >= pad and dil * (kw - 1) >= pad:
+                gx = torch.empty_like(x)
+                L = lib()
+                ws = scratch((L.call('dpf_conv2d_bf16_workspace_bytes', C, K, kh * kw) + 3) // 4, x.device, 'convw')
+                with _Timed('conv_bf16', 2.0 * N * K * C * kh * kw * IH * IW, 'b16t N%d C%d K%d in%dx%d k%d%d d%d' % (N, K, C, IH, IW, kh, kw, dil)):
+                    L.call('dpf_conv2d_bf16_dgrad', _ptr(gy), _ptr(w), _ptr(gx), _ptr(ws), N, C, IH, IW, K, kh, kw, pad, pad, dil, dil, _stream())
+            else:
+                gx = _conv_transpose_raw(gy.unsqueeze(2), w.unsqueeze(2), None, (1, IH, IW), (1, kh, kw), s3, p3, d3).squeeze(2)
+        if ctx.needs_input_grad[1]:
+            gw = _conv_wgrad_raw(gy.unsqueeze(2), x.unsqueeze(2), (K, C, 1, kh, kw), s3, p3, d3).squeeze(2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _channel_sum(gy)
+        return gx, gw, gb, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, bf16=False):
+    if bf16 and w.shape[0] > 4:          # the handful-of-channels heads keep their direct fp32 kernels
+        return ConvBf16Fn.apply(x, w, bias, int(stride), int(pad), int(dil))
     y = ConvFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride, stride), (0, pad, pad), (1, dil, dil))
     return y.squeeze(2)
 

@@ -193,6 +193,8 @@ class StereoDPNetCore(_Base):
         self._tables = {}
         self._pending_counts = {}
         self.stat_exchange = None          # distributed.StatExchange -> SyncBatchNorm (see enable_sync_batchnorm)
+        # mixed precision: the reference's `precision: 16` is PL autocast; here 16 / 'bf16' select bf16-operand 2-D convs
+        self.bf16_2d = str(getattr(option, 'precision', 32)) in ('16', 'bf16')
         self._build_parameters(build_spec(option))
 
     def enable_sync_batchnorm(self, group=None):
@@ -293,6 +295,10 @@ class StereoDPNetCore(_Base):
         self._pending_counts = {}
 
     # ------------------------------------------------------------------ primitives
+    def _conv2d(self, *args):
+        """nn.Conv2d; with option.precision 'bf16' / 16 on the bf16 MFMA kernel (BASELINE config 5), else exact fp32."""
+        return ops.conv2d(*args, bf16=self.bf16_2d)
+
     def _bn(self, x, p, act=ACT_NONE, slope=None, res=None, res2=None, slope_const=0.0):
         P, B = self._P, self._B
         if self.training:
@@ -302,7 +308,7 @@ class StereoDPNetCore(_Base):
                             1 if self.training else 2, act, slope_const, self.stat_exchange if self.training else None)
 
     def _convbn2(self, x, p, stride=1, pad=1, dil=1, act=ACT_NONE, slope=None, res=None):
-        y = ops.conv2d(x, self._P[p + '.0.weight'], None, stride, dil if dil > 1 else pad, dil)   # basics.py:17-22
+        y = self._conv2d(x, self._P[p + '.0.weight'], None, stride, dil if dil > 1 else pad, dil)   # basics.py:17-22
         return self._bn(y, p + '.1', act, slope, res)
 
     def _convbn3(self, x, p, stride=1, act=ACT_NONE, res=None):
@@ -318,8 +324,8 @@ class StereoDPNetCore(_Base):
         o = self._convbn2(o2, p + '.conv3', act=ACT_PRELU, slope=P[p + '.prelu.weight'], res=o1)       # prelu(conv3 + out1)
         o = self._convbn2(o, p + '.conv4.0', s, s, 2, act=ACT_PRELU, slope=P[p + '.conv4.1.weight'])
         d = ops.depthwise_conv3x3(o, P[p + '.conv5.depthwise.weight'])
-        d = ops.conv2d(d, P[p + '.conv5.pointwise.weight'])
-        skip = ops.conv2d(x, P[p + '.conv_skip.weight'], P[p + '.conv_skip.bias'], s)
+        d = self._conv2d(d, P[p + '.conv5.pointwise.weight'])
+        skip = self._conv2d(x, P[p + '.conv_skip.weight'], P[p + '.conv_skip.bias'], s)
         return self._bn(d, p + '.conv5.bn', ACT_PRELU, P[p + '.conv5.prelu.weight'], None, skip)       # prelu(bn) + skip
 
     def _features(self, img):
@@ -337,8 +343,8 @@ class StereoDPNetCore(_Base):
             o3 = self._dpblock(o3, p + '.interblock2.%d' % i, 1)
         o3 = self._dpblock(o3, p + '.block3', 2)
         # feature pyramid (torchvision FeaturePyramidNetwork semantics; call site modules.py:83-85,119)
-        lat = lambda i, t: ops.conv2d(t, P['%s.fpn.inner_blocks.%d.weight' % (p, i)], P['%s.fpn.inner_blocks.%d.bias' % (p, i)])
-        out = lambda i, t: ops.conv2d(t, P['%s.fpn.layer_blocks.%d.weight' % (p, i)], P['%s.fpn.layer_blocks.%d.bias' % (p, i)], 1, 1)
+        lat = lambda i, t: self._conv2d(t, P['%s.fpn.inner_blocks.%d.weight' % (p, i)], P['%s.fpn.inner_blocks.%d.bias' % (p, i)])
+        out = lambda i, t: self._conv2d(t, P['%s.fpn.layer_blocks.%d.weight' % (p, i)], P['%s.fpn.layer_blocks.%d.bias' % (p, i)], 1, 1)
         last = lat(2, o3)
         lo = out(2, last)
         last = ops.nearest_up_add(lat(1, o2), last)
@@ -477,7 +483,7 @@ class StereoDPNetCore(_Base):
         Dn = v2.shape[2]
         f = ops.swap_axes12(v2).view(B * Dn, v2.shape[1], h, w)
         for i, dil in enumerate((1, 2, 4, 8, 1, 1)):
-            f = ops.conv2d(f, P['%s.n_convs.%d.0.weight' % (p, i)], None, 1, dil, dil)
+            f = self._conv2d(f, P['%s.n_convs.%d.0.weight' % (p, i)], None, 1, dil, dil)
             f = ops.norm_act(f, act=ACT_LEAKY, slope_const=0.1)
         f = ops.upsample_bilinear(f, 4)
         return ops.sigmoid_mean(f, B, Dn), off1, off2

@@ -51,6 +51,16 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
 int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int sd,
                           int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
 
+/* ---- 2-D convolutions with bf16 operands, fp32 accumulation and storage (v_mfma_f32_32x32x16_bf16): the mixed-precision mode of
+ * BASELINE config 5 ("MFMA bf16 2D convs"); the reference's counterpart is PL precision 16 autocast over nn.Conv2d
+ * (config_/train_faceDP.json "precision", src/module/asm/basics.py:17-22).  x, w, outputs are fp32 tensors; operands are rounded
+ * to bf16 (RNE) inside the kernel.  ws: dpf_conv2d_bf16_workspace_bytes(C, K, kh*kw) bytes.  dgrad: stride-1 convs only. */
+long long dpf_conv2d_bf16_workspace_bytes(int C, int K, int T);
+int dpf_conv2d_bf16_forward(const float* x, const float* w, const float* bias, float* out, void* ws, int N, int C, int IH, int IW, int K, int kh,
+                            int kw, int sh, int sw, int ph, int pw, int dh, int dw, void* stream);
+int dpf_conv2d_bf16_dgrad(const float* go, const float* w, float* dx, void* ws, int N, int C, int IH, int IW, int K, int kh, int kw, int ph, int pw,
+                          int dh, int dw, void* stream);
+
 /* ---- depthwise 3x3: depthwise_separable_conv.depthwise (src/module/asm/basics.py:39-58) --------------------------- */
 int dpf_depthwise_conv2d_forward(const float* x, const float* w, float* y, int N, int C, int H, int W, int k, int pad, void* stream);
 int dpf_depthwise_conv2d_backward_data(const float* g, const float* w, float* dx, int N, int C, int H, int W, int k, int pad, void* stream);

@@ -434,3 +434,40 @@ def test_layout_kernels():
     rg = r.to(DEV)
     ops.bn_replay(rg, af.to(DEV), ab.to(DEV), 0.9 ** 16, 0.9 * 4.2, 4.2)
     close(rg, r * 0.9 ** 16 + af * (0.9 * 4.2) + ab * 4.2, 1e-6, 'bn replay')
+
+
+BF16_CASES = [
+    # N, C, H, W, K, k, stride, pad, dil
+    (2, 32, 20, 45, 32, 3, 1, 1, 1),
+    (1, 3, 33, 70, 32, 3, 2, 1, 1),       # first conv: 3 channels in one 16-wide chunk, stride 2
+    (2, 96, 17, 35, 32, 3, 1, 5, 5),      # dilated
+    (1, 64, 12, 40, 192, 1, 1, 0, 1),     # 1x1, > 128 output channels (two launches)
+    (2, 40, 16, 24, 64, 3, 2, 2, 2),      # stride 2 + dilation: data gradient falls back to the fp32 kernel
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_conv2d_bf16_operands(case):
+    """bf16-operand conv == fp32 conv of the bf16-rounded operands (products are exact in fp32; only the summation order
+    differs): 1e-5 of the tensor scale.  The weight gradient runs on the fp32 kernel with unrounded operands."""
+    ops = _ops()
+    N, C, H, W, K, k, st, pd, dl = case
+    x = rnd(N, C, H, W, seed=90).requires_grad_()
+    w = rnd(K, C, k, k, seed=91, scale=0.1).requires_grad_()
+    b = rnd(K, seed=92).requires_grad_()
+    xr, wr = x.detach().bfloat16().float().requires_grad_(), w.detach().bfloat16().float().requires_grad_()
+    y_ref = F.conv2d(xr, wr, b, st, pd, dl)
+    go = rnd(*y_ref.shape, seed=93)
+    xg, wg, bg = [t.detach().to(DEV).requires_grad_() for t in (x, w, b)]
+    y = ops.conv2d(xg, wg, bg, st, pd, dl, bf16=True)
+    close(y, y_ref, 1e-5, 'bf16 conv fwd')
+    gx, gw, gb = torch.autograd.grad(y, (xg, wg, bg), go.to(DEV))
+    if st == 1:
+        (gx_r,) = torch.autograd.grad(F.conv2d(xr, wr, None, st, pd, dl), xr, go.bfloat16().float())   # bf16(go) * bf16(w)
+        close(gx, gx_r, 1e-5, 'bf16 conv dgrad')
+    else:
+        (gx_r,) = torch.autograd.grad(F.conv2d(x, w, None, st, pd, dl), x, go)
+        close(gx, gx_r, 1e-4, 'fp32 fallback dgrad')
+    (gw_r,) = torch.autograd.grad(F.conv2d(x, w, None, st, pd, dl), w, go)
+    close(gw, gw_r, 2e-4, 'fp32 wgrad')
+    close(gb, go.sum((0, 2, 3)), 1e-4, 'bgrad')
