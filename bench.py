@@ -140,7 +140,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    loss = float(res['final_loss'])
+    loss = float(res['final_loss'].detach())
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

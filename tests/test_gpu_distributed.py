@@ -1,0 +1,98 @@
+"""Data-parallel path on a GPU (``-m gpu``): two ranks share the one GPU of the test box over the gloo backend (RCCL refuses two
+ranks on one device), which still exercises everything that is ours: parameter broadcast, the bucketed flat-gradient reducer
+driven by autograd hooks, the fused Adam with the 1/world scale, and the SyncBatchNorm statistic exchange.
+
+With SyncBatchNorm, 2 ranks x 2 samples must reproduce the single-process step on the 4-sample batch (the loss terms are means
+over equally sized, fully masked batches, so the rank-mean of the gradients is the global-batch gradient)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H, W = 32, 48
+
+
+def _model():
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.plugin import STEREODPNET
+    from dualpixelface_amd.recipe import fill_by_recipe
+    m = STEREODPNET(load_option())
+    fill_by_recipe(m)
+    return m.to('cuda').train()
+
+
+def _full_batch():
+    from dualpixelface_amd.recipe import synthetic_batch
+    return synthetic_batch(4, H, W, seed=11)
+
+
+def _worker(rank, world, port, sync_bn, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch.distributed as dist
+    from dualpixelface_amd.distributed import init_from_env, make_reducer, broadcast_flat
+    torch.cuda.set_device(0)
+    init_from_env('gloo')
+    model = _model()
+    if rank == 1:                                  # broadcast must repair this
+        with torch.no_grad():
+            model.flat_parameters().mul_(1.5)
+    broadcast_flat(model.flat_parameters(), 0)
+    reducer = make_reducer(model)
+    if sync_bn:
+        model.enable_sync_batchnorm()
+    full = _full_batch()
+    batch = {k: v[2 * rank:2 * rank + 2].cuda() for k, v in full.items()}
+    res = model.train_step(batch, reducer, lr=1e-3)
+    torch.cuda.synchronize()
+    out[rank] = (model.flat_parameters().detach().cpu(), model.flat_gradients(zero=False).detach().cpu(), float(res['final_loss']),
+                 model.state_dict()['feature_extraction.firstconv.0.1.running_mean'].cpu())
+    dist.destroy_process_group()
+
+
+def _run(sync_bn):
+    port = 33500 + (os.getpid() % 2000) + (7 if sync_bn else 0)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, sync_bn, out), nprocs=2, join=True)
+    return out[0], out[1]
+
+
+def test_two_ranks_per_rank_batchnorm():
+    (p0, g0, l0, _), (p1, g1, l1, _) = _run(False)
+    assert torch.equal(g0, g1), 'both ranks must hold the same summed gradient'
+    assert torch.equal(p0, p1), 'parameters must stay replicated after the fused Adam step'
+    assert l0 != l1                                 # different samples
+    # the summed gradient is the sum of the two local gradients (computed here without any exchange)
+    full = _full_batch()
+    ref = torch.zeros_like(g0)
+    for r in range(2):
+        m = _model()
+        m.flat_gradients(zero=True)
+        res = m.forward({k: v[2 * r:2 * r + 2].cuda() for k, v in full.items()})
+        res['final_loss'].backward()
+        ref += m.flat_gradients(zero=False).detach().cpu()
+    scale = ref.abs().max().item()
+    assert (g0 - ref).abs().max().item() <= 2e-3 * scale
+
+
+def test_two_ranks_sync_batchnorm_equals_single_process_full_batch():
+    (p0, g0, l0, rm0), (p1, g1, l1, rm1) = _run(True)
+    assert torch.equal(p0, p1) and torch.equal(g0, g1)
+    assert torch.allclose(rm0, rm1, rtol=0, atol=1e-7), 'running statistics follow the global batch on every rank'
+    m = _model()
+    res = m.train_step({k: v.cuda() for k, v in _full_batch().items()}, None, lr=1e-3)
+    ref_p = m.flat_parameters().detach().cpu()
+    ref_g = m.flat_gradients(zero=False).detach().cpu()
+    assert abs(0.5 * (l0 + l1) - float(res['final_loss'])) <= 1e-4 * abs(float(res['final_loss']))
+    assert torch.allclose(rm0, m.state_dict()['feature_extraction.firstconv.0.1.running_mean'].cpu(), rtol=1e-4, atol=1e-6)
+    # summed over 2 ranks = 2 x the full-batch gradient (each rank's loss is a mean over its half); fp32 + BatchNorm conditioning
+    # of this tiny fixture: relative L2
+    rel = ((0.5 * g0 - ref_g).norm() / ref_g.norm()).item()
+    assert rel <= 5e-2, rel
+    # Adam normalises the step: parameters move by <= lr, identically up to that tolerance
+    assert (p0 - ref_p).abs().max().item() <= 2.5e-3
