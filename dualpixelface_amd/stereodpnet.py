@@ -289,6 +289,19 @@ class StereoDPNetCore(_Base):
         self._flush_counts()
         return super(StereoDPNetCore, self).state_dict(*a, **k)
 
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """As nn.Module.load_state_dict; a checkpoint written after the first forward also carries the lazily registered,
+        resolution-specific ``normal_estimator.grid`` -- it is materialised here so that resuming into a fresh model
+        works under strict=True (the reference's own strict load trips over that key)."""
+        key = 'normal_estimator.grid'
+        if key in state_dict and 'grid' not in self._modules['normal_estimator']._parameters:
+            ref = self._flat
+            grid = torch.as_tensor(state_dict[key]).detach().clone().to(device=ref.device, dtype=torch.float32)
+            self._modules['normal_estimator'].register_parameter('grid', nn.Parameter(grid, False))
+            self._index()
+        self._pending_counts = {}
+        return super(StereoDPNetCore, self).load_state_dict(state_dict, strict=strict, **kw)
+
     def _flush_counts(self):
         for name, n in self._pending_counts.items():
             self._B[name] += n

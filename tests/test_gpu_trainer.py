@@ -1,0 +1,66 @@
+"""Native trainer on the GPU (``-m gpu``): checkpoint -> resume continues exactly like the uninterrupted run, the entry point
+runs a synthetic smoke epoch, validation uses the metric hooks."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(opt):
+    from dualpixelface_amd.plugin import STEREODPNET
+    from dualpixelface_amd.recipe import fill_by_recipe
+    m = STEREODPNET(opt)
+    fill_by_recipe(m)
+    return m.to('cuda').train()
+
+
+def test_resume_matches_uninterrupted_training(tmp_path):
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.synthetic_data import synthetic_loader
+    from dualpixelface_amd.trainer import Trainer
+    opt = load_option()
+    opt.epoch, opt.init_lr, opt.scheduler = 2, 1e-3, 'explr'
+    loader = synthetic_loader(4, 32, 48, batch_size=2, seed=3)
+    val = synthetic_loader(1, 32, 48, batch_size=1, seed=4)
+    a = _model(opt)
+    ta = Trainer(opt, str(tmp_path / 'a'), rank=0, world_size=1)
+    hist = ta.fit(a, loader, val)
+    assert ta.global_step == 4 and os.path.exists(ta.checkpoint_path(0)) and os.path.exists(ta.checkpoint_path(1))
+    assert any('metrics' in h and set(h['metrics']) == {'absolute_dp', 'affine_dp', 'normal_dp'} for h in hist)
+    # a second model resumes after epoch 0 and must land on the same parameters, moments and running statistics
+    opt.load_model = ta.checkpoint_path(0)
+    b = _model(opt)
+    with torch.no_grad():
+        b.flat_parameters().mul_(0.5)                      # the checkpoint must overwrite this
+    tb = Trainer(opt, str(tmp_path / 'b'), rank=0, world_size=1)
+    tb.fit(b, loader, None)
+    assert tb.epoch == 2 and tb.global_step == 4
+    pa, pb = a.flat_parameters().cpu(), b.flat_parameters().cpu()
+    # not bit-identical: the atomics of the weight / input gradients reorder fp32 sums, and Adam turns a changed last bit of a
+    # tiny gradient into a step of up to lr (5e-4 in epoch 1) -- two uninterrupted runs differ the same way.  Almost every
+    # parameter must agree to 1e-5 and none may be off by more than the two steps taken since the checkpoint.
+    diff = (pa - pb).abs()
+    assert (diff > 1e-5).float().mean().item() <= 1e-3 and diff.max().item() <= 1.1e-3, ((diff > 1e-5).float().mean().item(), diff.max().item())
+    assert a._adam['step'] == b._adam['step'] == 4
+    sa, sb = a.state_dict(), b.state_dict()
+    k = 'feature_extraction.firstconv.0.1.running_var'
+    assert torch.allclose(sa[k].cpu(), sb[k].cpu(), rtol=1e-4)
+    assert int(sa['feature_extraction.firstconv.0.1.num_batches_tracked']) == int(sb['feature_extraction.firstconv.0.1.num_batches_tracked'])
+
+
+def test_entry_point_smoke():
+    """python main.py --config train_faceDP --workspace <name> with synthetic samples: two optimizer steps, a checkpoint and a log."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, 'main.py', '--config', 'train_faceDP', '--workspace', 'pytest_smoke', '--synthetic', '8', '--height', '64',
+           '--width', '96', '--max_steps', '2']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ws = os.path.join(ROOT, 'workspace', 'stereodpnet', 'pytest_smoke')
+    assert os.path.exists(os.path.join(ws, 'checkpoint_epoch=00.ckpt')) and os.path.exists(os.path.join(ws, 'log.jsonl'))
+    ck = torch.load(os.path.join(ws, 'checkpoint_epoch=00.ckpt'), map_location='cpu', weights_only=False)
+    assert ck['global_step'] == 2 and len(ck['state_dict']) == 512      # the reference's 511 keys + the lazy normal_estimator.grid (Q9)
