@@ -64,7 +64,7 @@ __device__ __forceinline__ void pixel_probs(const float* __restrict__ k, const H
 #pragma unroll
   for (int l = 0; l < MAXL; ++l)
     if (l < p.L) {
-      prob[l] = expf(prob[l] - mx);
+      prob[l] = __expf(prob[l] - mx);   // v_exp_f32 path (2 ulp): the softmax is checked to 1e-5
       sum += prob[l];
     }
   pred = 0.f;
