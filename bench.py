@@ -46,7 +46,7 @@ def cpu_baseline(threads):
 def stage_bench(args):
     """HBM-bound stages in isolation: achieved = algorithmic bytes / HIP-event time, peak = 8 TB/s."""
     from dualpixelface_amd import load_option, ops
-    from dualpixelface_amd.plugin import STEREODPNET
+    from dualpixelface_amd.plugin import PSMNET, STEREODPNET
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     B, h, w, C, L = args.batch, args.height // 4, args.width // 4, 32, 8
@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--model', default='stereodpnet', choices=['stereodpnet', 'psmnet'],
+                    help='psmnet = BASELINE configs[3] (cross-model plugin check): the PSMNet plugin on the same kernels')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
                     help="bf16 = BASELINE configs[4]: bf16-operand MFMA for the 2-D convs, fp32 everywhere else (default: exact fp32)")
     ap.add_argument('--sync-bn', action='store_true',
@@ -102,7 +104,7 @@ def main():
 
     from dualpixelface_amd import load_option, ops
     from dualpixelface_amd.distributed import init_from_env, make_reducer, broadcast_flat
-    from dualpixelface_amd.plugin import STEREODPNET
+    from dualpixelface_amd.plugin import PSMNET, STEREODPNET
     from dualpixelface_amd.recipe import synthetic_batch
     import torch.distributed as dist
 
@@ -114,10 +116,10 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(1)
-    opt = load_option()
+    opt = load_option('train_faceDP_psmnet' if args.model == 'psmnet' else 'train_faceDP')
     if args.precision == 'bf16':
         opt.precision = 'bf16'
-    model = STEREODPNET(opt)                    # reference initialisation scheme, random weights
+    model = (PSMNET if args.model == 'psmnet' else STEREODPNET)(opt)     # reference initialisation scheme, random weights
     model.to(dev)
     broadcast_flat(model.flat_parameters(), 0)
     reducer = make_reducer(model) if world > 1 else None
@@ -182,16 +184,16 @@ def main():
                     'families': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3} for k, v in fam.items()}}
         pixels = args.height * args.width
         line = {
-            'metric': 'train samples/sec, StereoDPNet 1024x1536 DP pair', 'value': value, 'unit': 'samples/s', 'n_gpus': world,
+            'metric': 'train samples/sec, %s 1024x1536 DP pair' % ('PSMNet' if args.model == 'psmnet' else 'StereoDPNet'), 'value': value, 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16 2-D conv operands, f32 elsewhere',
             'data': 'synthetic',
-            'config': {'workload': 'StereoDPNet train step (fwd+loss+bwd+grad all-reduce+Adam), %d x %dx%d synthetic DP pairs per GPU'
-                                   % (args.batch, args.height, args.width),
+            'config': {'workload': '%s train step (fwd+loss+bwd+grad all-reduce+Adam), %d x %dx%d synthetic DP pairs per GPU'
+                                   % ('PSMNet' if args.model == 'psmnet' else 'StereoDPNet', args.batch, args.height, args.width),
                        'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,
                        'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics'},
             'final_loss': loss,
-            'flop_frac_of_f32_peak': value * FLOP_PER_PIXEL_FWD_BWD * pixels / (world * PEAK_F32_TFLOPS * 1e12),
+            'flop_frac_of_f32_peak': (value * FLOP_PER_PIXEL_FWD_BWD * pixels / (world * PEAK_F32_TFLOPS * 1e12)) if args.model == 'stereodpnet' else None,
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

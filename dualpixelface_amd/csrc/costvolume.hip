@@ -179,6 +179,47 @@ __global__ __launch_bounds__(256) void psm_volume_kernel(const float* __restrict
   }
 }
 
+// gradient of the PSMNet volume w.r.t. both feature maps, gather form (one thread per feature element, no atomics):
+//   dref[c][y]  = sum_l [row y written at level l] ( dvol[c][l][y]     - corr_l(tar[c][y + d_l]) )
+//   dtar[c][y'] = sum_l [y = y' - d_l written]     ( dvol[C + c][l][y] - corr_l(ref[c][y]) ),   corr_l(v) = dvol[2C + g(c)][l][y] * v / cpg
+__global__ __launch_bounds__(256) void psm_volume_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ tar,
+                                                             const float* __restrict__ dvol, float* __restrict__ dref, float* __restrict__ dtar,
+                                                             PsmP p) {
+  const int CV = 2 * p.C + p.G;
+  const long long plane = (long long)p.h * p.w;
+  const long long total = (long long)p.B * p.C * plane;
+  const int cpg = p.G > 0 ? p.C / p.G : 1;
+  const float inv = 1.f / (float)cpg;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % p.w);
+    const int y = (int)((i / p.w) % p.h);
+    const int c = (int)((i / plane) % p.C);
+    const int b = (int)(i / (plane * p.C));
+    const float* dv = dvol + (long long)b * CV * p.L * plane;
+    const float* refc = ref + ((long long)b * p.C + c) * plane;
+    const float* tarc = tar + ((long long)b * p.C + c) * plane;
+    const int g = p.G > 0 ? c / cpg : 0;
+    float gr = 0.f, gt = 0.f;
+    for (int l = 0; l < p.L; ++l) {
+      const int d = p.shift[l];
+      const long long lo = ((long long)l * p.h) * p.w + x;
+      // reference side: this row itself
+      if (d >= 0 ? (y < p.h - d) : (y >= -d)) {
+        gr += dv[(long long)c * p.L * plane + lo + (long long)y * p.w];
+        if (p.G > 0) gr -= dv[(long long)(2 * p.C + g) * p.L * plane + lo + (long long)y * p.w] * tarc[(long long)(y + d) * p.w + x] * inv;
+      }
+      // target side: the volume row ys = y - d reads target row y
+      const int ys = y - d;
+      if (ys >= 0 && ys < p.h && (d >= 0 ? (ys < p.h - d) : (ys >= -d))) {
+        gt += dv[(long long)(p.C + c) * p.L * plane + lo + (long long)ys * p.w];
+        if (p.G > 0) gt -= dv[(long long)(2 * p.C + g) * p.L * plane + lo + (long long)ys * p.w] * refc[(long long)ys * p.w + x] * inv;
+      }
+    }
+    dref[i] = gr;
+    dtar[i] = gt;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -233,6 +274,19 @@ int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const
   const long long rows = (long long)B * (2 * C + groups) * L * ((h + PSM_RB - 1) / PSM_RB);
   if (rows > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(psm_volume_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, ref, tar, vol, p);
+  return dpf_check_launch();
+}
+
+int dpf_psm_volume_backward(const float* ref, const float* tar, const float* dvol, float* dref, float* dtar, const int* shifts_host, int B, int C,
+                            int h, int w, int L, int groups, void* stream) {
+  dpf_clear_error();
+  if (!ref || !tar || !dvol || !dref || !dtar || !shifts_host || B <= 0 || C <= 0 || L <= 0 || L > 16 || groups < 0 || (groups > 0 && C % groups))
+    return DPF_ERR_INVALID_ARG;
+  PsmP p;
+  p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.G = groups;
+  for (int i = 0; i < 16; ++i) p.shift[i] = i < L ? shifts_host[i] : 0;
+  hipLaunchKernelGGL(psm_volume_bwd_kernel, dim3(dpf_ew_grid((long long)B * C * h * w)), dim3(256), 0, (hipStream_t)stream, ref, tar, dvol, dref, dtar,
+                     p);
   return dpf_check_launch();
 }
 

@@ -121,6 +121,36 @@ __global__ void nearest_bwd_kernel(const float* __restrict__ g, float* __restric
   }
 }
 
+// nn.AvgPool2d(k, stride = k): one wave per output element, lanes stride over the k x k window (PSMNet's SPP branches pool
+// 64 / 32 / 16 / 8 windows of the quarter-resolution feature map, psmnet/modules.py:84-102)
+__global__ __launch_bounds__(256) void avg_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long NC, int H, int W, int k, int OH,
+                                                           int OW) {
+  const int lane = threadIdx.x & 63;
+  const long long total = NC * OH * OW;
+  for (long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); o < total; o += (long long)gridDim.x * 4) {
+    const int ox = (int)(o % OW), oy = (int)((o / OW) % OH);
+    const long long nc = o / ((long long)OW * OH);
+    const float* src = x + (nc * H + (long long)oy * k) * W + (long long)ox * k;
+    float a = 0.f;
+    for (int e = lane; e < k * k; e += 64) a += src[(long long)(e / k) * W + (e % k)];
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) a += __shfl_xor(a, s);
+    if (lane == 0) y[o] = a / (float)(k * k);
+  }
+}
+
+__global__ __launch_bounds__(256) void avg_pool_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, long long NC, int H, int W, int k, int OH,
+                                                           int OW) {
+  const long long total = NC * H * W;
+  const float inv = 1.f / (float)(k * k);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int xx = (int)(i % W), yy = (int)((i / W) % H);
+    const long long nc = i / ((long long)W * H);
+    const int oy = yy / k, ox = xx / k;
+    dx[i] = (oy < OH && ox < OW) ? g[(nc * OH + oy) * OW + ox] * inv : 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -152,6 +182,23 @@ int dpf_upsample_nearest_backward(const float* g, float* dtop, long long NC, int
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !dtop || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(nearest_bwd_kernel, dim3(dpf_ew_grid(NC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dtop, NC, h, w, H, W);
+  return dpf_check_launch();
+}
+
+// y[NC, H/k, W/k] = AvgPool2d(k, stride k)(x[NC, H, W]) (floor mode, no padding)
+int dpf_avg_pool2d_forward(const float* x, float* y, long long NC, int H, int W, int k, void* stream) {
+  dpf_clear_error();
+  if (!x || !y || NC <= 0 || k <= 0 || H < k || W < k) return DPF_ERR_INVALID_ARG;
+  const int OH = H / k, OW = W / k;
+  const long long total = NC * OH * OW;
+  hipLaunchKernelGGL(avg_pool_fwd_kernel, dim3(dpf_ew_grid(total, 4)), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, k, OH, OW);
+  return dpf_check_launch();
+}
+
+int dpf_avg_pool2d_backward(const float* g, float* dx, long long NC, int H, int W, int k, void* stream) {
+  dpf_clear_error();
+  if (!g || !dx || NC <= 0 || k <= 0 || H < k || W < k) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(avg_pool_bwd_kernel, dim3(dpf_ew_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, g, dx, NC, H, W, k, H / k, W / k);
   return dpf_check_launch();
 }
 

@@ -501,15 +501,64 @@ def cv_select(L, masks, tensors):
     return CvSelectFn.apply(L, list(masks), *tensors)
 
 
+class PsmVolumeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref, tar, shifts, groups):
+        ref, tar = _c(ref), _c(tar)
+        _need(ref, tar)
+        B, C, h, w = ref.shape
+        L = len(shifts)
+        vol = torch.empty((B, 2 * C + groups, L, h, w), dtype=torch.float32, device=ref.device)
+        lib().call('dpf_psm_volume_forward', _ptr(ref), _ptr(tar), _ptr(vol), _host_ints(shifts), B, C, h, w, L, groups, _stream())
+        ctx.save_for_backward(ref, tar)
+        ctx.cfg = (tuple(int(v) for v in shifts), int(groups))
+        return vol
+
+    @staticmethod
+    def backward(ctx, gv):
+        ref, tar = ctx.saved_tensors
+        shifts, groups = ctx.cfg
+        gv = _c(gv)
+        B, C, h, w = ref.shape
+        dref, dtar = torch.empty_like(ref), torch.empty_like(tar)
+        lib().call('dpf_psm_volume_backward', _ptr(ref), _ptr(tar), _ptr(gv), _ptr(dref), _ptr(dtar), _host_ints(shifts), B, C, h, w, len(shifts),
+                   groups, _stream())
+        return dref, dtar, None, None
+
+
 def psm_volume(ref, tar, shifts, groups=0):
-    """PSMNet concat (groups=0) or concat + group-wise correlation volume; forward only (cross-model check)."""
-    ref, tar = _c(ref), _c(tar)
-    _need(ref, tar)
-    B, C, h, w = ref.shape
-    L = len(shifts)
-    vol = torch.empty((B, 2 * C + groups, L, h, w), dtype=torch.float32, device=ref.device)
-    lib().call('dpf_psm_volume_forward', _ptr(ref), _ptr(tar), _ptr(vol), _host_ints(shifts), B, C, h, w, L, groups, _stream())
-    return vol
+    """PSMNet concat (groups=0) or concat + group-wise correlation volume (psmnet/modules.py:215-262)."""
+    return PsmVolumeFn.apply(ref, tar, [int(v) for v in shifts], int(groups))
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        x = _c(x)
+        _need(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // k, W // k), dtype=torch.float32, device=x.device)
+        lib().call('dpf_avg_pool2d_forward', _ptr(x), _ptr(y), N * C, H, W, int(k), _stream())
+        ctx.cfg = (N, C, H, W, int(k))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W, k = ctx.cfg
+        gy = _c(gy)
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=gy.device)
+        lib().call('dpf_avg_pool2d_backward', _ptr(gy), _ptr(dx), N * C, H, W, k, _stream())
+        return dx, None
+
+
+def avg_pool2d(x, k):
+    """nn.AvgPool2d((k, k), stride=(k, k))."""
+    return AvgPoolFn.apply(x, int(k))
+
+
+def resize_bilinear(x, H, W):
+    """F.interpolate(x, size=(H, W), mode='bilinear', align_corners=True)."""
+    return BilinearFn.apply(x, int(H), int(W))
 
 
 # ----------------------------------------------------------------------------------------------- disparity head

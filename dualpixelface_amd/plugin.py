@@ -7,12 +7,14 @@ import torch
 from . import ops
 from .losses import loss_selector
 from .selectors import metric_selector, optimizer_selector, scheduler_selector
+from .psmnet import PSMNetCore
 from .stereodpnet import StereoDPNetCore
 
 
-class STEREODPNET(StereoDPNetCore):
-    def __init__(self, option):
-        super(STEREODPNET, self).__init__(option)
+class _PluginHooks(object):
+    """The methods PL / main.py call on a model plugin (mainmodel.py:67-177), shared by every model family of the build."""
+
+    def _init_hooks(self, option):
         self.loss_model = loss_selector(option)
         self.metric_model = metric_selector(option)
         self._adam = None
@@ -92,3 +94,23 @@ class STEREODPNET(StereoDPNetCore):
         ops.adam_step(self.flat_parameters(), flat_g, st['m'], st['v'], st['step'], float(lr if lr is not None else self.option.init_lr),
                       0.9, 0.999, 1e-5, gscale)
         return results
+
+
+class STEREODPNET(_PluginHooks, StereoDPNetCore):
+    def __init__(self, option):
+        StereoDPNetCore.__init__(self, option)
+        self._init_hooks(option)
+
+
+class PSMNET(_PluginHooks, PSMNetCore):
+    """src/model/psmnet/mainmodel.py::PSMNET; its validation hooks are no-ops in the reference (mainmodel.py:143-149)."""
+
+    def __init__(self, option):
+        PSMNetCore.__init__(self, option)
+        self._init_hooks(option)
+
+    def validation_step(self, batch, batch_idx):
+        return None
+
+    def validation_epoch_end(self, outputs):
+        return None

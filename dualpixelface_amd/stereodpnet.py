@@ -195,7 +195,11 @@ class StereoDPNetCore(_Base):
         self.stat_exchange = None          # distributed.StatExchange -> SyncBatchNorm (see enable_sync_batchnorm)
         # mixed precision: the reference's `precision: 16` is PL autocast; here 16 / 'bf16' select bf16-operand 2-D convs
         self.bf16_2d = str(getattr(option, 'precision', 32)) in ('16', 'bf16')
-        self._build_parameters(build_spec(option))
+        self._build_parameters(self._spec(option))
+
+    @staticmethod
+    def _spec(option):
+        return build_spec(option)
 
     def enable_sync_batchnorm(self, group=None):
         """Training BatchNorm statistics over the global batch, like torch.nn.SyncBatchNorm which the reference switches on for

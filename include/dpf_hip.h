@@ -112,6 +112,13 @@ int dpf_cv_select_backward(const float* x3, const float* s, const float* dvol, f
 int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const int* shifts_host, int B, int C, int h, int w, int L,
                            int groups, void* stream);
 
+int dpf_psm_volume_backward(const float* ref, const float* tar, const float* dvol, float* dref, float* dtar, const int* shifts_host, int B, int C,
+                            int h, int w, int L, int groups, void* stream);
+
+/* ---- nn.AvgPool2d(k, stride k) of PSMNet's SPP branches (src/model/psmnet/modules.py:84-102) ---------------------- */
+int dpf_avg_pool2d_forward(const float* x, float* y, long long NC, int H, int W, int k, void* stream);
+int dpf_avg_pool2d_backward(const float* g, float* dx, long long NC, int H, int W, int k, void* stream);
+
 /* ---- disparity head: trilinear x4 + softmax + soft-argmin (modules.py:327-334,341-362) ---------------------------- */
 int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
                            int H, int W, void* stream);

@@ -11,10 +11,11 @@ import torch
 _KEYS = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'state_dict_keys.json')
 
 
-def recipe_state(requires_grad=True, dtype=torch.float32):
-    """Oracle ``state`` dict filled by the shared recipe (dualpixelface_amd/recipe.py)."""
+def recipe_state(requires_grad=True, dtype=torch.float32, keys_file=None):
+    """Oracle ``state`` dict filled by the shared recipe (dualpixelface_amd/recipe.py); ``keys_file``: another model's
+    {state_dict key: shape} fixture (default: StereoDPNet's)."""
     from dualpixelface_amd.recipe import recipe_tensor, SKIP_SUFFIXES
-    shapes = json.load(open(_KEYS))
+    shapes = json.load(open(keys_file or _KEYS))
     st = {}
     for k, shp in shapes.items():
         if k.endswith('num_batches_tracked'):

@@ -218,3 +218,43 @@ def test_bf16_mixed_precision_mode_tracks_fp32(golden_dir):
     res['final_loss'].backward()
     gsum = sum(float(p.grad.abs().sum()) for p in model.parameters() if p.grad is not None)
     assert np.isfinite(gsum) and gsum > 0
+
+
+def test_psmnet_plugin_against_reference_golden(golden_dir):
+    """BASELINE configs[3]: the PSMNet plugin (own feature extractor + integer-shift volume, shared aggregation / head kernels)
+    against vectors produced by importing the reference's src/model/psmnet (tests/golden/make_golden_psmnet.py)."""
+    import json
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.plugin import PSMNET
+    from dualpixelface_amd.recipe import fill_by_recipe, synthetic_batch
+    g = np.load(golden_dir + '/psmnet_256x256_b2.npz')
+    keys = json.load(open(golden_dir + '/psmnet_state_dict_keys.json'))
+    opt = load_option('train_faceDP_psmnet')
+    model = PSMNET(opt)
+    assert list(model.state_dict().keys()) == list(keys) or set(model.state_dict().keys()) == set(keys)
+    fill_by_recipe(model)
+    model.to(DEV).train()
+    batch = {k: v.to(DEV) for k, v in synthetic_batch(2, 256, 256, seed=7).items()}
+    model.flat_gradients(zero=True)
+    res = model(batch)
+    close(res['pred_depth'][:, :, ::2, ::2], g['train_pred_depth_s2'], None, 'psmnet pred_depth', atol=2e-3)
+    close(res['ref_feature'], g['train_ref_feature'], 2e-4, 'psmnet ref_feature')
+    close(res['final_loss'], g['final_loss'], 1e-4, 'psmnet loss')
+    res['final_loss'].backward()
+    pd = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith('grad::'):
+            ref = torch.from_numpy(g[k]).double()
+            rel = ((pd[k[6:]].grad.detach().cpu().double() - ref).norm() / ref.norm()).item()
+            assert rel <= 5e-2, (k, rel)      # as for StereoDPNet: BatchNorm-ill-conditioned fixture (branch1 normalises 2 values per channel)
+    close(model.state_dict()['feature_extraction.branch1.1.1.running_mean'], g['post::feature_extraction.branch1.1.1.running_mean'], 1e-4,
+          'branch1 running_mean')
+    fill_by_recipe(model)
+    model.eval()
+    with torch.no_grad():
+        ev = model(batch)
+    close(ev['pred_depth'][:, :, ::2, ::2], g['eval_pred_depth_s2'], None, 'psmnet eval pred_depth', atol=5e-3)
+    # the fused train step (flat arena, Adam) works for this model family too
+    model.train()
+    r2 = model.train_step(batch, None, lr=1e-4)
+    assert torch.isfinite(r2['final_loss'])

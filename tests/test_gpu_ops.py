@@ -471,3 +471,43 @@ def test_conv2d_bf16_operands(case):
     (gw_r,) = torch.autograd.grad(F.conv2d(x, w, None, st, pd, dl), w, go)
     close(gw, gw_r, 2e-4, 'fp32 wgrad')
     close(gb, go.sum((0, 2, 3)), 1e-4, 'bgrad')
+
+
+def test_avg_pool_and_resize_and_psm_volume_backward():
+    """PSMNet-specific operators: AvgPool2d(k, k), bilinear resize to an arbitrary size (align_corners=True, incl. from 1x1), and the
+    gradient of the integer-shift volume (concat and group-wise correlation) against autograd through the oracle."""
+    from oracle.psmnet_volume import psm_volume
+    ops = _ops()
+    x = rnd(2, 8, 19, 33, seed=100).requires_grad_()
+    for k in (8, 4, 16):
+        y_ref = F.avg_pool2d(x, (k, k), (k, k))
+        go = rnd(*y_ref.shape, seed=101)
+        (gx_r,) = torch.autograd.grad(y_ref, x, go)
+        xg = x.detach().to(DEV).requires_grad_()
+        y = ops.avg_pool2d(xg, k)
+        close(y, y_ref, 1e-6, 'avg_pool fwd k=%d' % k)
+        (gx,) = torch.autograd.grad(y, xg, go.to(DEV))
+        close(gx, gx_r, 1e-6, 'avg_pool bwd k=%d' % k)
+    for shape in ((1, 1), (2, 3), (8, 5)):
+        s = rnd(2, 8, *shape, seed=102).requires_grad_()
+        y_ref = F.interpolate(s, size=(16, 24), mode='bilinear', align_corners=True)
+        go = rnd(*y_ref.shape, seed=103)
+        (gs_r,) = torch.autograd.grad(y_ref, s, go)
+        sg = s.detach().to(DEV).requires_grad_()
+        y = ops.resize_bilinear(sg, 16, 24)
+        close(y, y_ref, 1e-6, 'resize fwd %s' % (shape,))
+        (gs,) = torch.autograd.grad(y, sg, go.to(DEV))
+        close(gs, gs_r, 1e-5, 'resize bwd %s' % (shape,))
+    ref, tar = rnd(2, 40, 12, 9, seed=104).requires_grad_(), rnd(2, 40, 12, 9, seed=105).requires_grad_()
+    costrange = [i * 0.5 - 1.0 for i in range(8)]                 # int() -> -1, 0, 0, 0, 0, 1, 1, 1 ... mixed signs
+    costrange[0], costrange[7] = -2.0, 3.0
+    for groups in (0, 40, 8):
+        v_ref = psm_volume(ref, tar, costrange, groups)
+        go = rnd(*v_ref.shape, seed=106)
+        gr_r, gt_r = torch.autograd.grad(v_ref, (ref, tar), go)
+        rg, tg = ref.detach().to(DEV).requires_grad_(), tar.detach().to(DEV).requires_grad_()
+        v = ops.psm_volume(rg, tg, [int(d) for d in costrange], groups)
+        close(v, v_ref, 1e-6, 'psm volume g=%d' % groups)
+        gr, gt = torch.autograd.grad(v, (rg, tg), go.to(DEV))
+        close(gr, gr_r, 1e-5, 'psm dref g=%d' % groups)
+        close(gt, gt_r, 1e-5, 'psm dtar g=%d' % groups)
