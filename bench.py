@@ -110,8 +110,11 @@ def main():
 
     if args.workload != 'train':
         return stage_bench(args)
-    rank, world, local = init_from_env()
+    # test hooks (tests/test_gpu_distributed.py): DPF_DIST_BACKEND=gloo and DPF_ONE_DEVICE=1 let two ranks share the one GPU of a test box
+    rank, world, local = init_from_env(os.environ.get('DPF_DIST_BACKEND'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if os.environ.get('DPF_ONE_DEVICE'):
+        local = 0
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 

@@ -96,3 +96,23 @@ def test_two_ranks_sync_batchnorm_equals_single_process_full_batch():
     assert rel <= 5e-2, rel
     # Adam normalises the step: parameters move by <= lr, identically up to that tolerance
     assert (p0 - ref_p).abs().max().item() <= 2.5e-3
+
+
+def test_bench_under_torchrun_two_ranks():
+    """The driver's multi-GPU invocation of bench.py (torch.distributed.run, one rank per GPU) with two ranks folded onto the test
+    box's single GPU over gloo: barrier / MAX-over-ranks timing, reducer, one JSON line from rank 0 with the whole-job rate."""
+    import json
+    import subprocess
+    env = dict(os.environ, DPF_DIST_BACKEND='gloo', DPF_ONE_DEVICE='1', PYTHONPATH=ROOT)
+    port = 35500 + (os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '1', '--height', '128',
+           '--width', '192', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 2 and d['config']['parallelism'] == 'dp2'
+    assert d['value'] > 0 and abs(d['value'] - 2 * 2 / (d['ms_per_step'] * 2 / 1e3)) < 1e-6 * d['value'] + 1e-9
