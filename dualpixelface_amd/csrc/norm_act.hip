@@ -270,13 +270,13 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, in
       a += sums[3 * c];
       b += sums[3 * c + 1];
     }
-    if (dbias) atomicAdd(&dbias[cp], a);
-    if (dweight) atomicAdd(&dweight[cp], b);
+    if (dbias) dbias[cp] = a;        // one thread owns channel cp: plain stores, the outputs need no zero-initialisation
+    if (dweight) dweight[cp] = b;
   }
   if (dslope && cp == 0) {
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += sums[3 * c + 2];
-    atomicAdd(dslope, s);
+    dslope[0] = s;
   }
 }
 
@@ -371,7 +371,7 @@ int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd,
 }
 
 // Backward of dpf_norm_act_forward w.r.t. x, res, w, b, slope (res2's gradient is dy itself).
-// ws: >= 3*C floats.  dweight/dbias [wmod], dslope [1] are ACCUMULATED into (+=); any may be NULL.
+// ws: >= 3*C floats.  dweight/dbias [wmod], dslope [1] are WRITTEN (=); any may be NULL.
 // phase 0: everything.  phase 1: only the per-channel reductions (ws[3c] = sum dz, ws[3c+1] = sum dz*xhat) and the parameter
 // gradients; phase 2: only dx / dres from a ws the caller has summed over the ranks, with count = global N*S (SyncBatchNorm).
 int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       int d0, d1;
       float ld;
       ac_src(l, rd, p.D, d0, d1, ld);
-      const float e = expf((1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid] - mx);
+      const float e = __expf((1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid] - mx);
       sum += e;
       num += e * p.disp[l];
     }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       int d0, d1;
       float ld;
       ac_src(l, rd, p.D, d0, d1, ld);
-      const float pr = expf((1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid] - mx) / sum;
+      const float pr = __expf((1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid] - mx) / sum;
       const float dl = pr * (p.disp[l] - pred) * g;
       s_db[d0][tid] += (1.f - ld) * dl;
       s_db[d1][tid] += ld * dl;

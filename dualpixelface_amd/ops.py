@@ -357,9 +357,10 @@ class NormActFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[4]) else None
-        dweight = torch.zeros_like(weight) if (weight is not None and ctx.needs_input_grad[1]) else None
-        dbias = torch.zeros_like(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
-        dslope = torch.zeros_like(slope) if (slope is not None and ctx.needs_input_grad[3]) else None
+        # written (not accumulated) by the finalize kernel: no zero fill
+        dweight = torch.empty_like(weight) if (weight is not None and ctx.needs_input_grad[1]) else None
+        dbias = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
+        dslope = torch.empty_like(slope) if (slope is not None and ctx.needs_input_grad[3]) else None
         training = 1 if mode in (1, 3) else 0
         args = (_ptr(x), _ptr(gy), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), wmod, _ptr(res), act, _ptr(slope), slope_const,
                 training, _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), _ptr(dslope))
