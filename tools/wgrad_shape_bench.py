@@ -1,0 +1,20 @@
+"""Time the weight-gradient kernel alone on a few shapes."""
+import sys, time, torch
+sys.path.insert(0, '.')
+from dualpixelface_amd import ops
+SHAPES = {'hg32': (4, 32, 8, 256, 384, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+          'fe32': (4, 32, 1, 512, 768, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+          'off81': (4, 64, 4, 256, 384, 81, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+          'hg_s2': (4, 32, 8, 256, 384, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))}
+for nm in sys.argv[1:] or list(SHAPES):
+    N, C, D, H, W, K, ks, st, pd, dl = SHAPES[nm]
+    x = torch.randn(N, C, D, H, W, device='cuda')
+    od = [(i + 2 * p - (d * (k - 1) + 1)) // s + 1 for i, k, s, p, d in zip((D, H, W), ks, st, pd, dl)]
+    g = torch.randn(N, K, *od, device='cuda')
+    ts = []
+    for it in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ops._conv_wgrad_raw(g, x, (K, C) + ks, st, pd, dl)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    t = min(ts[1:]); fl = 2.0 * g.numel() * C * ks[0] * ks[1] * ks[2]
+    print('%s wgrad %.3f ms %.1f TF' % (nm, t * 1e3, fl / t * 1e-12), flush=True)
