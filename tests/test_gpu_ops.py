@@ -511,3 +511,64 @@ def test_avg_pool_and_resize_and_psm_volume_backward():
         gr, gt = torch.autograd.grad(v, (rg, tg), go.to(DEV))
         close(gr, gr_r, 1e-5, 'psm dref g=%d' % groups)
         close(gt, gt_r, 1e-5, 'psm dtar g=%d' % groups)
+
+
+def test_full_size_properties():
+    """BASELINE-size tensors (4 x 32 x 8 x 256 x 384 aggregation conv, 4 x 35 x 4 x 256 x 384 deformable conv) through properties that
+    need no CPU reference: linearity of the forward, the adjoint identities <conv(x), g> = <x, dgrad(g)> = <w, wgrad(x, g)> that tie the
+    three conv kernels together, and the deformable conv's known answer (zero offsets == plain conv3d) plus its adjoints."""
+    ops = _ops()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    # fp32 outputs carry ~1e-6 relative noise per element, so inner products agree to ~1e-6 of ||out|| * ||g|| (Cauchy-Schwarz
+    # scale), not of their (cancelling) value
+    scale = lambda a, b: (dot(a, a) * dot(b, b)) ** 0.5
+    # ---- dense 3-D conv at the hourglass shape
+    x, y = r(4, 32, 8, 256, 384), r(4, 32, 8, 256, 384)
+    w = (r(32, 32, 3, 3, 3) * 0.05).requires_grad_()
+    xg = x.clone().requires_grad_()
+    out = ops.conv3d(xg, w, None, 1, 1, 1)
+    lin = ops.conv3d(0.5 * x - 2.0 * y, w, None, 1, 1, 1) - (0.5 * out.detach() - 2.0 * ops.conv3d(y, w, None, 1, 1, 1).detach())
+    assert float(lin.abs().max()) <= 2e-4 * float(out.detach().abs().max())
+    g = r(*out.shape)
+    gx, gw = torch.autograd.grad(out, (xg, w), g)
+    a0, a1, a2 = dot(out.detach(), g), dot(x, gx), dot(w.detach(), gw)
+    tol = 2e-6 * scale(out.detach(), g)
+    assert abs(a0 - a1) <= tol and abs(a0 - a2) <= tol, (a0, a1, a2, tol)
+    del x, y, out, lin, g, gx, xg
+    # ---- stride-2 conv and its transposed data gradient
+    x2 = r(4, 32, 8, 256, 384).requires_grad_()
+    w2 = (r(64, 32, 3, 3, 3) * 0.05).requires_grad_()
+    o2 = ops.conv3d(x2, w2, None, 2, 1, 1)
+    g2 = r(*o2.shape)
+    gx2, gw2 = torch.autograd.grad(o2, (x2, w2), g2)
+    b0, tol = dot(o2.detach(), g2), 2e-6 * scale(o2.detach(), g2)
+    assert abs(b0 - dot(x2.detach(), gx2)) <= tol and abs(b0 - dot(w2.detach(), gw2)) <= tol
+    del x2, o2, g2, gx2
+    # ---- deformable conv at the ANM shape: zero offsets == conv3d; adjoints with random offsets (beyond the halo too)
+    xd = r(4, 35, 4, 256, 384).requires_grad_()
+    wd = (r(64, 35, 3, 3, 3) * 0.05).requires_grad_()
+    bd = r(64).requires_grad_()
+    z = torch.zeros(4, 81, 4, 256, 384, device=DEV)
+    y0 = ops.deform_conv3d(xd, z, wd, bd)
+    yc = ops.conv3d(xd, wd, bd, 1, 1, 1)
+    assert float((y0 - yc).abs().max()) <= 1e-4 * float(yc.abs().max())
+    off = (r(4, 81, 4, 256, 384) * 1.5).requires_grad_()
+    yd = ops.deform_conv3d(xd, off, wd, bd)
+    gd = r(*yd.shape)
+    gxd, god, gwd, gbd = torch.autograd.grad(yd, (xd, off, wd, bd), gd)
+    c0, tol = dot(yd.detach(), gd), 2e-6 * scale(yd.detach(), gd)
+    # y is linear in (x), in (w, b) jointly: <y, g> = <x, dx> + <b, db> = <w, dw> + <b, db>
+    cb = dot(bd.detach(), gbd)
+    assert abs(c0 - (dot(xd.detach(), gxd) + cb)) <= tol, (c0, dot(xd.detach(), gxd), cb, tol)
+    assert abs(c0 - (dot(wd.detach(), gwd) + cb)) <= tol, (c0, dot(wd.detach(), gwd), cb, tol)
+    # grad_offset: directional derivative along a random direction by central differences (in float32: coarse tolerance)
+    d = r(*off.shape)
+    eps = 1e-2
+    with torch.no_grad():
+        yp = ops.deform_conv3d(xd.detach(), off.detach() + eps * d, wd.detach(), bd.detach())
+        ym = ops.deform_conv3d(xd.detach(), off.detach() - eps * d, wd.detach(), bd.detach())
+    fd = dot(yp - ym, gd) / (2 * eps)
+    an = dot(god, d)
+    assert abs(fd - an) <= 5e-2 * abs(an) + 50 * tol, (fd, an, tol)
