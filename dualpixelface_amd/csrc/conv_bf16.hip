@@ -24,6 +24,7 @@ struct CbP {
   int IH, IW, OH, OW;
   int kh, kw, sh, sw, ph, pw, dh, dw;
   int nchunk;           // ceil(C / 16)
+  int group;            // chunks staged per barrier pair
   int Ktot, k0;         // the output tensor has Ktot channels; this launch writes [k0, k0 + K)
   int tilesH, tilesW;
 };
@@ -55,7 +56,7 @@ template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv2d_bf16_kernel(const float* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
                                                           float* __restrict__ out, CbP p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  __bf16* s_in = reinterpret_cast<__bf16*>(smem_raw);      // [ext_h * ext_w][16]
+  __bf16* s_in = reinterpret_cast<__bf16*>(smem_raw);      // [group][ext_h * ext_w][16]
   constexpr int TH = 4 * NT, KT = 32 * MT;
   const int ext_h = (TH - 1) * p.sh + (p.kh - 1) * p.dh + 1;
   const int ext_w = (TW - 1) * p.sw + (p.kw - 1) * p.dw + 1;
@@ -83,13 +84,15 @@ __global__ __launch_bounds__(256) void conv2d_bf16_kernel(const float* __restric
 #pragma unroll
   for (int t = 0; t < NT; ++t) bbase[t] = (((wave * NT + t) * p.sh) * ext_w + l31 * p.sw) * 16 + 8 * hh;
 
-  const int T = p.kh * p.kw;
-  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-    __syncthreads();                                  // previous chunk consumed
+  // channel chunks are staged G at a time (one barrier pair and one burst of loads per G * 16 channels)
+  const int G = p.group;
+  for (int chunk0 = 0; chunk0 < p.nchunk; chunk0 += G) {
+    const int ng = min(G, p.nchunk - chunk0);
+    __syncthreads();                                  // previous group consumed
     // ---- stage: item = (channel octet, position); 8 coalesced row loads (one per channel), one 16-B LDS write
-    const int c0 = chunk * 16;
-    for (int i = tid; i < 2 * npos; i += 256) {
-      const int o = i >= npos ? 1 : 0;
+    const int c0 = chunk0 * 16;
+    for (int i = tid; i < 2 * ng * npos; i += 256) {
+      const int o = i / npos;                          // channel octet within the group
       const int pos = i - o * npos;
       const int r = pos / ext_w, cc = pos - r * ext_w;
       const int ih = i0h + r, iw = i0w + cc;
@@ -101,30 +104,32 @@ __global__ __launch_bounds__(256) void conv2d_bf16_kernel(const float* __restric
       bf16x8 pk;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pk[j] = (__bf16)v[j];
-      *reinterpret_cast<bf16x8*>(s_in + pos * 16 + 8 * o) = pk;
+      *reinterpret_cast<bf16x8*>(s_in + ((o >> 1) * npos + pos) * 16 + 8 * (o & 1)) = pk;
     }
     __syncthreads();
-    // ---- MFMA over the taps of this chunk
-    const __bf16* wc = wt + ((long long)chunk * KT + l31) * 16 + 8 * hh;
-    for (int a = 0; a < p.kh; ++a) {
-      for (int c = 0; c < p.kw; ++c) {
-        const int tap = a * p.kw + c;
-        const __bf16* wa = wc + (long long)tap * p.nchunk * KT * 16;
-        bf16x8 af[MT];
+    // ---- MFMA over the chunks of the group and their taps
+    for (int cg = 0; cg < ng; ++cg) {
+      const __bf16* wc = wt + ((long long)(chunk0 + cg) * KT + l31) * 16 + 8 * hh;
+      const __bf16* sc = s_in + cg * npos * 16;
+      for (int a = 0; a < p.kh; ++a) {
+        for (int c = 0; c < p.kw; ++c) {
+          const int tap = a * p.kw + c;
+          const __bf16* wa = wc + (long long)tap * p.nchunk * KT * 16;
+          bf16x8 af[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const bf16x8*>(wa + m * 32 * 16);
-        const int toff = (a * p.dh * ext_w + c * p.dw) * 16;
-        bf16x8 bf[NT];
+          for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const bf16x8*>(wa + m * 32 * 16);
+          const int toff = (a * p.dh * ext_w + c * p.dw) * 16;
+          bf16x8 bf[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(s_in + bbase[t] + toff);
+          for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(sc + bbase[t] + toff);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[t], acc[m][t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[t], acc[m][t], 0, 0, 0);
+        }
       }
     }
   }
-  (void)T;
   // ---- epilogue: D row = (j&3) + 8*(j>>2) + 4*(lane>>5), col = lane&31
   const int ow = q0w + l31;
   const long long oplane = (long long)p.OH * p.OW;
@@ -166,7 +171,10 @@ int launch(const float* x, const float* w, const float* bias, float* out, void* 
     const int NT = MT == 1 ? 4 : 2;
     const int TH = 4 * NT;
     const int ext_h = (TH - 1) * sh + (kh - 1) * dh + 1, ext_w = (TW - 1) * sw + (kw - 1) * dw + 1;
-    const size_t lds = (size_t)ext_h * ext_w * 32;
+    int group = p.nchunk < 4 ? p.nchunk : 4;
+    while (group > 1 && (size_t)group * ext_h * ext_w * 32 > 40 * 1024) --group;     // keep >= 3 workgroups per CU
+    p.group = group;
+    const size_t lds = (size_t)group * ext_h * ext_w * 32;
     if (lds > 150 * 1024) return DPF_ERR_UNSUPPORTED;
     p.tilesH = dpf_div_up(OH, TH);
     p.tilesW = dpf_div_up(OW, TW);
