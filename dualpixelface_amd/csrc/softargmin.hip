@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ k, const float* __restrict__ gpred, float* __restrict__ dk, HeadP p) {
-  __shared__ float tile[MAXD][TY + 2][TX + 2];
+  // fp64 cells: on MI355X ds_add_f32 sustains 0.33 lanes/clk/CU, ds_add_f64 3.1 (profiles/r01_lds_atomic_microbench.txt)
+  __shared__ double tile[MAXD][TY + 2][TX + 2];
   __shared__ float s_bl[MAXD][256];   // per-thread bilinear values / gradients, thread index fastest (conflict-free)
   __shared__ float s_db[MAXD][256];
   const float rd = p.L > 1 ? (float)(p.D - 1) / (float)(p.L - 1) : 0.f;
@@ -117,8 +118,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   float tl;
   ac_src(Y0, ry, p.h, ybase, t1, tl);
   ac_src(X0, rx, p.w, xbase, t1, tl);
-  float* flat = &tile[0][0][0];
-  for (int i = threadIdx.x; i < MAXD * (TY + 2) * (TX + 2); i += 256) flat[i] = 0.f;
+  double* flat = &tile[0][0][0];
+  for (int i = threadIdx.x; i < MAXD * (TY + 2) * (TX + 2); i += 256) flat[i] = 0.0;
   __syncthreads();
   const int tid = threadIdx.x;
   const int Y = Y0 + (tid >> 5), X = X0 + (tid & 31);
@@ -164,10 +165,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int ya = y0 - ybase, yb = y1 - ybase, xa = x0 - xbase, xb = x1 - xbase;
     for (int d = 0; d < p.D; ++d) {
       const float v = s_db[d][tid];
-      atomicAdd(&tile[d][ya][xa], hy * hx * v);
-      atomicAdd(&tile[d][ya][xb], hy * lx * v);
-      atomicAdd(&tile[d][yb][xa], ly * hx * v);
-      atomicAdd(&tile[d][yb][xb], ly * lx * v);
+      atomicAdd(&tile[d][ya][xa], (double)(hy * hx * v));
+      atomicAdd(&tile[d][ya][xb], (double)(hy * lx * v));
+      atomicAdd(&tile[d][yb][xa], (double)(ly * hx * v));
+      atomicAdd(&tile[d][yb][xb], (double)(ly * lx * v));
     }
   }
   __syncthreads();
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int xx = i % (TX + 2);
     const int yy = (i / (TX + 2)) % (TY + 2);
     const int d = i / ((TX + 2) * (TY + 2));
-    const float v = tile[d][yy][xx];
+    const float v = (float)tile[d][yy][xx];
     const int y = ybase + yy, x = xbase + xx;
     if (v != 0.f && y < p.h && x < p.w) atomicAdd(&dk[(((long long)b * p.D + d) * p.h + y) * p.w + x], v);
   }
