@@ -100,6 +100,64 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   }
 }
 
+// The shipped geometry (8 cost levels -> 32 hypotheses): with D and L compile-time constants the level interpolation
+// (d0, d1, lambda of every hypothesis) folds to constants, i.e. 32 FMAs on registers instead of 512 register-select instructions
+__global__ __launch_bounds__(256) void head_fwd_8x32_kernel(const float* __restrict__ k, float* __restrict__ pred, float* __restrict__ prob, HeadP p) {
+  constexpr int D = 8, L = 32;
+  constexpr float rd = (float)(D - 1) / (float)(L - 1);
+  const float ry = p.H > 1 ? (float)(p.h - 1) / (float)(p.H - 1) : 0.f;
+  const float rx = p.W > 1 ? (float)(p.w - 1) / (float)(p.W - 1) : 0.f;
+  const long long total = (long long)p.B * p.H * p.W;
+  const long long plane = (long long)p.H * p.W, lplane = (long long)p.h * p.w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % p.W);
+    const int Y = (int)((i / p.W) % p.H);
+    const int b = (int)(i / plane);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    ac_src(Y, ry, p.h, y0, y1, ly);
+    ac_src(X, rx, p.w, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* kb = k + (long long)b * D * lplane;
+    float bl[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float* q = kb + (long long)d * lplane;
+      bl[d] = hy * (hx * q[y0 * p.w + x0] + lx * q[y0 * p.w + x1]) + ly * (hx * q[y1 * p.w + x0] + lx * q[y1 * p.w + x1]);
+    }
+    float pr[L];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float src = rd * (float)l;                      // same expression as ac_src: folded at compile time
+      int d0 = (int)src;
+      if (d0 > D - 1) d0 = D - 1;
+      const int d1 = d0 + (d0 < D - 1 ? 1 : 0);
+      const float ld = src - (float)d0;
+      pr[l] = (1.f - ld) * bl[d0] + ld * bl[d1];
+      mx = fmaxf(mx, pr[l]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      pr[l] = __expf(pr[l] - mx);
+      sum += pr[l];
+    }
+    float e = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      pr[l] = pr[l] / sum;
+      e += pr[l] * p.disp[l];
+    }
+    pred[i] = e;
+    if (prob) {
+      float* q = prob + (long long)b * L * plane + (long long)Y * p.W + X;
+#pragma unroll
+      for (int l = 0; l < L; ++l) q[(long long)l * plane] = pr[l];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ k, const float* __restrict__ gpred, float* __restrict__ dk, HeadP p) {
   // fp64 cells: on MI355X ds_add_f32 sustains 0.33 lanes/clk/CU, ds_add_f64 3.1 (profiles/r01_lds_atomic_microbench.txt)
   __shared__ double tile[MAXD][TY + 2][TX + 2];
@@ -194,7 +252,10 @@ int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const 
   HeadP p;
   p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W;
   for (int i = 0; i < MAXL; ++i) p.disp[i] = i < L ? disp_host[i] : 0.f;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, logits, pred, prob, p);
+  if (D == 8 && L == 32)
+    hipLaunchKernelGGL(head_fwd_8x32_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, logits, pred, prob, p);
+  else
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, logits, pred, prob, p);
   return dpf_check_launch();
 }
 
