@@ -240,6 +240,96 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
+// backward for the shipped geometry: level interpolation folded at compile time, per-thread values in registers (no LDS arrays)
+__global__ __launch_bounds__(256) void head_bwd_8x32_kernel(const float* __restrict__ k, const float* __restrict__ gpred, float* __restrict__ dk, HeadP p) {
+  constexpr int D = 8, L = 32;
+  constexpr float rd = (float)(D - 1) / (float)(L - 1);
+  __shared__ double tile[D][TY + 2][TX + 2];      // fp64 cells: ds_add_f64 (3.1 lanes/clk/CU) instead of ds_add_f32 (0.33)
+  const float ry = p.H > 1 ? (float)(p.h - 1) / (float)(p.H - 1) : 0.f;
+  const float rx = p.W > 1 ? (float)(p.w - 1) / (float)(p.W - 1) : 0.f;
+  const int tilesX = (p.W + TX - 1) / TX, tilesY = (p.H + TY - 1) / TY;
+  int bb = blockIdx.x;
+  const int tx = bb % tilesX; bb /= tilesX;
+  const int ty = bb % tilesY;
+  const int b = bb / tilesY;
+  const int Y0 = ty * TY, X0 = tx * TX;
+  int ybase, xbase, t1;
+  float tl;
+  ac_src(Y0, ry, p.h, ybase, t1, tl);
+  ac_src(X0, rx, p.w, xbase, t1, tl);
+  double* flat = &tile[0][0][0];
+  for (int i = threadIdx.x; i < D * (TY + 2) * (TX + 2); i += 256) flat[i] = 0.0;
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int Y = Y0 + (tid >> 5), X = X0 + (tid & 31);
+  if (Y < p.H && X < p.W) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    ac_src(Y, ry, p.h, y0, y1, ly);
+    ac_src(X, rx, p.w, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const long long lplane = (long long)p.h * p.w;
+    const float* kb = k + (long long)b * D * lplane;
+    float bl[D], db[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float* q = kb + (long long)d * lplane;
+      bl[d] = hy * (hx * q[y0 * p.w + x0] + lx * q[y0 * p.w + x1]) + ly * (hx * q[y1 * p.w + x0] + lx * q[y1 * p.w + x1]);
+      db[d] = 0.f;
+    }
+    float pr[L];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float src = rd * (float)l;
+      int d0 = (int)src;
+      if (d0 > D - 1) d0 = D - 1;
+      const int d1 = d0 + (d0 < D - 1 ? 1 : 0);
+      const float ld = src - (float)d0;
+      pr[l] = (1.f - ld) * bl[d0] + ld * bl[d1];
+      mx = fmaxf(mx, pr[l]);
+    }
+    float sum = 0.f, num = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      pr[l] = __expf(pr[l] - mx);
+      sum += pr[l];
+      num += pr[l] * p.disp[l];
+    }
+    const float pred = num / sum;
+    const float g = gpred[((long long)b * p.H + Y) * p.W + X] / sum;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float src = rd * (float)l;
+      int d0 = (int)src;
+      if (d0 > D - 1) d0 = D - 1;
+      const int d1 = d0 + (d0 < D - 1 ? 1 : 0);
+      const float ld = src - (float)d0;
+      const float dl = pr[l] * (p.disp[l] - pred) * g;      // softmax-expectation gradient w.r.t. logit l
+      db[d0] += (1.f - ld) * dl;
+      db[d1] += ld * dl;
+    }
+    const int ya = y0 - ybase, yb = y1 - ybase, xa = x0 - xbase, xb = x1 - xbase;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float v = db[d];
+      atomicAdd(&tile[d][ya][xa], (double)(hy * hx * v));
+      atomicAdd(&tile[d][ya][xb], (double)(hy * lx * v));
+      atomicAdd(&tile[d][yb][xa], (double)(ly * hx * v));
+      atomicAdd(&tile[d][yb][xb], (double)(ly * lx * v));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D * (TY + 2) * (TX + 2); i += 256) {
+    const int xx = i % (TX + 2);
+    const int yy = (i / (TX + 2)) % (TY + 2);
+    const int d = i / ((TX + 2) * (TY + 2));
+    const float v = (float)tile[d][yy][xx];
+    const int y = ybase + yy, x = xbase + xx;
+    if (v != 0.f && y < p.h && x < p.w) atomicAdd(&dk[(((long long)b * D + d) * p.h + y) * p.w + x], v);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -270,7 +360,10 @@ int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlog
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dlogits, 0, sizeof(float) * (size_t)B * D * h * w, st) != hipSuccess) return DPF_ERR_LAUNCH;
   const long long blocks = (long long)B * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p);
+  if (D == 8 && L == 32)
+    hipLaunchKernelGGL(head_bwd_8x32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p);
+  else
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p);
   return dpf_check_launch();
 }
 
