@@ -200,6 +200,72 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restri
   }
 }
 
+// Forward specialised for 3x3 (x KD) stride-1 / dilation-1 windows and KK output channels: all loops unrolled, the 27 * KK weights
+// of a channel are wave-uniform scalar loads, every input row is loaded once as XB + 2 values and feeds 3 taps x XB outputs.
+template <int KK, int KD, bool VEC>
+__global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, SkP p) {
+  const long long oplane = (long long)p.OH * p.OW, ovol = oplane * p.OD;
+  const long long iplane = (long long)p.IH * p.IW, ivol = iplane * p.ID;
+  const int wq = (p.OW + XB - 1) / XB;
+  const long long total = (long long)p.N * p.OD * p.OH * wq;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ow0 = (int)(i % wq) * XB;
+    const int oh = (int)((i / wq) % p.OH);
+    const int od = (int)((i / ((long long)wq * p.OH)) % p.OD);
+    const int n = (int)(i / ((long long)wq * p.OH * p.OD));
+    float acc[KK][XB];
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+      for (int j = 0; j < XB; ++j) acc[k][j] = bias ? bias[k] : 0.f;
+    const float* xn = x + (long long)n * p.C * ivol;
+    const int iw0 = ow0 - p.pw;
+    bool cok[XB + 2];
+#pragma unroll
+    for (int u = 0; u < XB + 2; ++u) cok[u] = iw0 + u >= 0 && iw0 + u < p.IW;
+    for (int c = 0; c < p.C; ++c) {
+      const float* xc = xn + (long long)c * ivol;
+      const float* wc = w + (long long)c * (KD * 9);
+#pragma unroll
+      for (int a = 0; a < KD; ++a) {
+        const int id = od - p.pd + a * p.dd;
+        const bool dok = id >= 0 && id < p.ID;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const int ih = oh - p.ph + b;
+          const bool rok = dok && ih >= 0 && ih < p.IH;
+          const float* row = xc + (long long)id * iplane + (long long)ih * p.IW + iw0;
+          float v[XB + 2];
+          if (VEC) {
+            // pw == 1 and IW % 4 == 0: the four centre values are one aligned 16-byte load (consecutive lanes: 1 KiB contiguous)
+            const float4 mid = rok ? *reinterpret_cast<const float4*>(row + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[0] = (rok && cok[0]) ? row[0] : 0.f;
+            v[1] = mid.x; v[2] = mid.y; v[3] = mid.z; v[4] = mid.w;
+            v[5] = (rok && cok[5]) ? row[5] : 0.f;
+          } else {
+#pragma unroll
+            for (int u = 0; u < XB + 2; ++u) v[u] = (rok && cok[u]) ? row[u] : 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < KK; ++k) {
+            const float* wk = wc + (long long)k * p.C * (KD * 9) + (a * 3 + b) * 3;
+            const float w0 = wk[0], w1 = wk[1], w2 = wk[2];
+#pragma unroll
+            for (int j = 0; j < XB; ++j) acc[k][j] = fmaf(w0, v[j], fmaf(w1, v[j + 1], fmaf(w2, v[j + 2], acc[k][j])));
+          }
+        }
+      }
+    }
+    const long long obase = ((long long)od * p.OH + oh) * p.OW + ow0;
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+      for (int j = 0; j < XB; ++j)
+        if (ow0 + j < p.OW) out[((long long)n * p.K + k) * ovol + obase + j] = acc[k][j];
+  }
+}
+
 // Weight gradient, 3x3 (x KD) stride-1 windows: no LDS.  One wave owns (n, od, channel, 64-column strip, row range) and marches
 // down the rows with lanes along W: per step it loads the newly entering input row of each kernel plane in its three column
 // shifts (9 coalesced loads for KD = 3, served by L1 after the first), keeps the other two rows of the window in registers, and
@@ -319,6 +385,23 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
   if (rc != DPF_OK) return rc;
   if (sw != 1 || dw != 1 || kw > 3) return DPF_ERR_UNSUPPORTED;
   const long long total = (long long)N * p.OD * p.OH * ((p.OW + XB - 1) / XB);
+  if (kh == 3 && kw == 3 && (kd == 1 || kd == 3) && sd == 1 && sh == 1 && dh == 1 && !getenv("DPF_SMALLK_FWD_GENERIC")) {
+    const dim3 grid(dpf_ew_grid(total));
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = pw == 1 && (IW & 3) == 0 && (p.OW & 3) == 0 && XB == 4;
+#define DPF_SKF(KKv, KDv)                                                                                         \
+  {                                                                                                               \
+    if (vec) hipLaunchKernelGGL((smallk_fwd3_kernel<KKv, KDv, true>), grid, dim3(256), 0, st, x, w, bias, out, p); \
+    else hipLaunchKernelGGL((smallk_fwd3_kernel<KKv, KDv, false>), grid, dim3(256), 0, st, x, w, bias, out, p);   \
+  }
+    if (kd == 1) {
+      switch (K) { case 1: DPF_SKF(1, 1); break; case 2: DPF_SKF(2, 1); break; case 3: DPF_SKF(3, 1); break; default: DPF_SKF(4, 1); break; }
+    } else {
+      switch (K) { case 1: DPF_SKF(1, 3); break; case 2: DPF_SKF(2, 3); break; case 3: DPF_SKF(3, 3); break; default: DPF_SKF(4, 3); break; }
+    }
+#undef DPF_SKF
+    return dpf_check_launch();
+  }
   hipLaunchKernelGGL(smallk_fwd_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, p);
   return dpf_check_launch();
 }
