@@ -7,18 +7,19 @@
 
 namespace {
 
-// dst[n, cd0 + c, s] = src[n, cs0 + c, s]   for c < ncopy;  src has Cs channels, dst has Cd
+// dst[n, cd0 + c, s] = src[n, cs0 + c, s]   for c < ncopy;  src has Cs channels, dst has Cd.
+// grid.y = sample n (the ncopy * S elements of a sample are contiguous on both sides): no integer division per element
 __global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Cs, int cs0, int Cd, int cd0, int ncopy,
                                      long long S, int accumulate) {
   const long long per = (long long)ncopy * S;
-  const long long total = (long long)N * per;
+  const int n = blockIdx.y;
+  const float* sp = src + ((long long)n * Cs + cs0) * S;
+  float* dp = dst + ((long long)n * Cd + cd0) * S;
   if ((S & 3) == 0) {
-    const long long total4 = total >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-      const long long e = i << 2;
-      const long long n = e / per, r = e - n * per;
-      const float4 v = *reinterpret_cast<const float4*>(src + ((long long)n * Cs + cs0) * S + r);
-      float4* d = reinterpret_cast<float4*>(dst + ((long long)n * Cd + cd0) * S + r);
+    const long long per4 = per >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per4; i += (long long)gridDim.x * blockDim.x) {
+      const float4 v = reinterpret_cast<const float4*>(sp)[i];
+      float4* d = reinterpret_cast<float4*>(dp) + i;
       if (accumulate) {
         float4 o = *d;
         o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
@@ -28,24 +29,27 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, float* __res
       }
     }
   } else {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-      const long long n = e / per, r = e - n * per;
-      const float v = src[((long long)n * Cs + cs0) * S + r];
-      float* d = dst + ((long long)n * Cd + cd0) * S + r;
-      *d = accumulate ? *d + v : v;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long long)gridDim.x * blockDim.x) {
+      const float v = sp[e];
+      dp[e] = accumulate ? dp[e] + v : v;
     }
   }
 }
 
-// dst[b, d, c, s] = src[b, c, d, s]   (A = C, Bd = D)  -- the same kernel inverts itself with A and Bd swapped
+// dst[b, d, c, s] = src[b, c, d, s]   (A = C, Bd = D)  -- the same kernel inverts itself with A and Bd swapped.
+// grid.y = (b, d, c) row of S contiguous elements on both sides
 __global__ void swap_axes_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int A, int Bd, long long S) {
-  const long long total = (long long)B * A * Bd * S;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long s = i % S;
-    const int c = (int)((i / S) % A);          // dst index order: [b][d][c][s]
-    const int d = (int)((i / (S * A)) % Bd);
-    const long long b = i / (S * A * Bd);
-    dst[i] = src[((b * A + c) * Bd + d) * S + s];
+  const int row = blockIdx.y;                 // dst order [b][d][c]
+  const int c = row % A;
+  const int d = (row / A) % Bd;
+  const long long b = row / (A * Bd);
+  const float* sp = src + ((b * A + c) * Bd + d) * S;
+  float* dp = dst + (long long)row * S;
+  if ((S & 3) == 0) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (S >> 2); i += (long long)gridDim.x * blockDim.x)
+      reinterpret_cast<float4*>(dp)[i] = reinterpret_cast<const float4*>(sp)[i];
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (long long)gridDim.x * blockDim.x) dp[i] = sp[i];
   }
 }
 
@@ -74,8 +78,10 @@ int dpf_copy_channels(const float* src, float* dst, int N, int Cs, int cs0, int 
                       void* stream) {
   dpf_clear_error();
   if (!src || !dst || N <= 0 || ncopy <= 0 || cs0 < 0 || cd0 < 0 || cs0 + ncopy > Cs || cd0 + ncopy > Cd || S <= 0) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(copy_channels_kernel, dim3(dpf_ew_grid((long long)N * ncopy * S / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, dst, N,
-                     Cs, cs0, Cd, cd0, ncopy, S, accumulate);
+  if (N > 65535) return DPF_ERR_UNSUPPORTED;
+  int gx = dpf_ew_grid((long long)ncopy * S / 4 + 1);
+  if (gx > 2048 / N + 1) gx = 2048 / N + 1;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, src, dst, N, Cs, cs0, Cd, cd0, ncopy, S, accumulate);
   return dpf_check_launch();
 }
 
@@ -83,7 +89,11 @@ int dpf_copy_channels(const float* src, float* dst, int N, int Cs, int cs0, int 
 int dpf_swap_axes(const float* src, float* dst, int B, int A, int Bd, long long S, void* stream) {
   dpf_clear_error();
   if (!src || !dst || B <= 0 || A <= 0 || Bd <= 0 || S <= 0) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(swap_axes_kernel, dim3(dpf_ew_grid((long long)B * A * Bd * S)), dim3(256), 0, (hipStream_t)stream, src, dst, B, A, Bd, S);
+  if ((long long)B * A * Bd > 65535) return DPF_ERR_UNSUPPORTED;
+  const int rows = B * A * Bd;
+  int gx = dpf_ew_grid(S / 4 + 1);
+  if (gx > 4096 / rows + 1) gx = 4096 / rows + 1;
+  hipLaunchKernelGGL(swap_axes_kernel, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, src, dst, B, A, Bd, S);
   return dpf_check_launch();
 }
 
