@@ -7,53 +7,62 @@
 
 namespace {
 
-// y[n,c,y,x] = sum_t w[c][t] * x[n,c,y+ty-pad,x+tx-pad]  (flip = 1: taps mirrored -> data gradient)
-__global__ void dw_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, long long NC, int C, int H,
-                               int W, int k, int pad, int flip) {
-  const long long total = NC * H * W;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int xx = (int)(i % W);
-    const int yy = (int)((i / W) % H);
-    const long long nc = i / ((long long)W * H);
-    const int c = (int)(nc % C);
-    const float* xp = x + nc * H * W;
-    const float* wp = w + (long long)c * k * k;
+// y[n,c,y,x] = sum_t w[c][t] * x[n,c,y+ty-1,x+tx-1]  (flip = 1: taps mirrored -> data gradient).  k = 3, pad = 1.
+// grid.y = (n, c) plane, grid.x strides over row blocks; lanes along x: no integer division per element, the 9 weights of the
+// plane are wave-uniform, every output reads 3 rows x 3 shifted (L1-resident) values.
+__global__ __launch_bounds__(256) void dw_conv3_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H,
+                                                       int W, int flip) {
+  const int nc = blockIdx.y;
+  const int c = nc % C;
+  const float* xp = x + (long long)nc * H * W;
+  float* yp = y + (long long)nc * H * W;
+  float wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = w[(long long)c * 9 + (flip ? 8 - t : t)];
+  const int lanes_per_row = (W + 255) / 256;             // 256-thread segments per row
+  const int nseg = H * lanes_per_row;
+  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const int yy = seg / lanes_per_row;
+    const int xx = (seg - yy * lanes_per_row) * 256 + threadIdx.x;
+    if (xx >= W) continue;
     float acc = 0.f;
-    for (int ty = 0; ty < k; ++ty) {
-      const int sy = yy + ty - pad;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int sy = yy + ty - 1;
       if (sy < 0 || sy >= H) continue;
-      for (int tx = 0; tx < k; ++tx) {
-        const int sx = xx + tx - pad;
-        if (sx < 0 || sx >= W) continue;
-        const float wv = flip ? wp[(k - 1 - ty) * k + (k - 1 - tx)] : wp[ty * k + tx];
-        acc += wv * xp[(long long)sy * W + sx];
-      }
+      const float* row = xp + (long long)sy * W;
+      const float l = xx > 0 ? row[xx - 1] : 0.f, m = row[xx], r = xx + 1 < W ? row[xx + 1] : 0.f;
+      acc = fmaf(wv[ty * 3], l, fmaf(wv[ty * 3 + 1], m, fmaf(wv[ty * 3 + 2], r, acc)));
     }
-    y[i] = acc;
+    yp[(long long)yy * W + xx] = acc;
   }
 }
 
-// dw[c][t] += sum_{n,y,x} g[n,c,y,x] * x[n,c,y+ty-pad,x+tx-pad];  grid = (chunks, N*C)
+// dw[c][t] += sum_{n,y,x} g[n,c,y,x] * x[n,c,y+ty-1,x+tx-1];  grid = (row blocks, N*C): a block walks whole rows, lanes along x
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw,
-                                                       int C, int H, int W, int pad) {
+                                                       int C, int H, int W, int rows_per_block) {
   __shared__ float sm[4];
   const int row = blockIdx.y;
   const int c = row % C;
   const long long S = (long long)H * W;
   const float* gp = g + (long long)row * S;
   const float* xp = x + (long long)row * S;
-  const long long s0 = (long long)blockIdx.x * 4096;
-  const long long s1 = min(S, s0 + 4096);
+  const int y0 = blockIdx.x * rows_per_block, y1 = min(H, y0 + rows_per_block);
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
-    const int xx = (int)(s % W), yy = (int)(s / W);
-    const float gv = gp[s];
+  for (int yy = y0; yy < y1; ++yy) {
+    for (int xx = threadIdx.x; xx < W; xx += 256) {
+      const float gv = gp[(long long)yy * W + xx];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int sy = yy + t / 3 - pad, sx = xx + t % 3 - pad;
-      if (sy >= 0 && sy < H && sx >= 0 && sx < W) acc[t] += gv * xp[(long long)sy * W + sx];
+      for (int ty = 0; ty < 3; ++ty) {
+        const int sy = yy + ty - 1;
+        if (sy < 0 || sy >= H) continue;
+        const float* r = xp + (long long)sy * W;
+        acc[ty * 3] += gv * (xx > 0 ? r[xx - 1] : 0.f);
+        acc[ty * 3 + 1] += gv * r[xx];
+        acc[ty * 3 + 2] += gv * (xx + 1 < W ? r[xx + 1] : 0.f);
+      }
     }
   }
 #pragma unroll
@@ -71,16 +80,26 @@ extern "C" {
 int dpf_depthwise_conv2d_forward(const float* x, const float* w, float* y, int N, int C, int H, int W, int k, int pad, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !w || !y || N <= 0 || C <= 0 || 2 * pad != k - 1) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(dw_conv_kernel, dim3(dpf_ew_grid((long long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, w, y,
-                     (long long)N * C, C, H, W, k, pad, 0);
+  if (k != 3 || (long long)N * C > 65535) return DPF_ERR_UNSUPPORTED;
+  {
+    const int nseg = H * ((W + 255) / 256);
+    int gx = 4096 / (N * C) + 1;
+    if (gx > nseg) gx = nseg;
+    hipLaunchKernelGGL(dw_conv3_kernel, dim3(gx, N * C), dim3(256), 0, (hipStream_t)stream, x, w, y, C, H, W, 0);
+  }
   return dpf_check_launch();
 }
 
 int dpf_depthwise_conv2d_backward_data(const float* g, const float* w, float* dx, int N, int C, int H, int W, int k, int pad, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !w || !dx || N <= 0 || C <= 0 || 2 * pad != k - 1) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(dw_conv_kernel, dim3(dpf_ew_grid((long long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, g, w, dx,
-                     (long long)N * C, C, H, W, k, pad, 1);
+  if (k != 3 || (long long)N * C > 65535) return DPF_ERR_UNSUPPORTED;
+  {
+    const int nseg = H * ((W + 255) / 256);
+    int gx = 4096 / (N * C) + 1;
+    if (gx > nseg) gx = nseg;
+    hipLaunchKernelGGL(dw_conv3_kernel, dim3(gx, N * C), dim3(256), 0, (hipStream_t)stream, g, w, dx, C, H, W, 1);
+  }
   return dpf_check_launch();
 }
 
@@ -88,8 +107,12 @@ int dpf_depthwise_conv2d_backward_data(const float* g, const float* w, float* dx
 int dpf_depthwise_conv2d_backward_weight(const float* g, const float* x, float* dw, int N, int C, int H, int W, int k, int pad, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !x || !dw || N <= 0 || C <= 0 || k != 3 || pad != 1 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(dw_wgrad_kernel, dim3((unsigned)dpf_div_up((long long)H * W, 4096), (unsigned)(N * C)), dim3(256), 0,
-                     (hipStream_t)stream, g, x, dw, C, H, W, pad);
+  {
+    int rpb = dpf_div_up(4096, W);                 // ~4096 elements per block
+    if (rpb < 1) rpb = 1;
+    hipLaunchKernelGGL(dw_wgrad_kernel, dim3((unsigned)dpf_div_up(H, rpb), (unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, g, x, dw, C, H, W,
+                       rpb);
+  }
   return dpf_check_launch();
 }
 
