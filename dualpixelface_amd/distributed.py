@@ -82,6 +82,13 @@ class FlatGradReducer(object):
         self._work = []
         self._count = None
 
+    def reduce_all(self):
+        """One all-reduce(SUM) per bucket over the (already complete) arena; no hooks involved."""
+        if self.world_size > 1:
+            work = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in self.buckets]
+            for w in work:
+                w.wait()
+
     def remove(self):
         for h in self._hooks:
             h.remove()

@@ -73,20 +73,55 @@ class _PluginHooks(object):
         return [optimizer], ([scheduler] if scheduler is not None else [])
 
     # ---- MI355X-native step ------------------------------------------------------------------------------
+    def _grad_pairs(self):
+        """[(parameter, its view in the flat gradient arena)] in layout order (cached per arena)."""
+        fg = self.flat_gradients(zero=False)
+        cache = getattr(self, '_pairs_cache', None)
+        if cache is None or cache[0] is not fg:
+            pd = dict(self.named_parameters())
+            cache = (fg, [(pd[name], fg[off:off + numel].view(shape)) for name, off, numel, shape in self._layout])
+            self._pairs_cache = cache
+        return cache[1]
+
     def train_step(self, batch, reducer=None, lr=None):
         """forward + loss + backward + (gradient all-reduce) + fused Adam; returns the results dict."""
         if self.option.optim != 'adam':
             raise NotImplementedError('the fused step implements the shipped Adam configuration')
         self.train()
-        flat_g = self.flat_gradients(zero=True)
-        if reducer is not None:
-            reducer.begin()
-        results = self.forward(batch)
-        results['final_loss'].backward()
         gscale = 1.0
-        if reducer is not None:
-            reducer.finish()
-            gscale = 1.0 / reducer.world_size
+        if getattr(self, 'gather_grads', True):
+            # Gradients are produced as fresh tensors (autograd hands them over without an accumulate kernel when .grad is None) and
+            # gathered into the flat arena by one multi-tensor copy; the 14.7 MB all-reduce then runs once over the arena.  The
+            # alternative below accumulates into arena views (one add kernel per parameter, ~300 per step) and overlaps bucketed
+            # all-reduces with the backward pass through hooks -- an overlap worth < 0.1 % of a 400 ms step.
+            flat_g = self.flat_gradients(zero=False)
+            pairs = self._grad_pairs()
+            for p, _ in pairs:
+                p.grad = None
+            results = self.forward(batch)
+            results['final_loss'].backward()
+            views, grads = [], []
+            for p, v in pairs:
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    views.append(v)
+                    grads.append(p.grad)
+            torch._foreach_copy_(views, grads)
+            for p, v in pairs:
+                p.grad = v
+            if reducer is not None:
+                reducer.reduce_all()
+                gscale = 1.0 / reducer.world_size
+        else:
+            flat_g = self.flat_gradients(zero=True)
+            if reducer is not None:
+                reducer.begin()
+            results = self.forward(batch)
+            results['final_loss'].backward()
+            if reducer is not None:
+                reducer.finish()
+                gscale = 1.0 / reducer.world_size
         if self._adam is None or self._adam['m'].device != flat_g.device:
             self._adam = {'m': torch.zeros_like(flat_g), 'v': torch.zeros_like(flat_g), 'step': 0}
         st = self._adam
