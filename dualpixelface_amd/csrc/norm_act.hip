@@ -281,15 +281,23 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, in
 }
 
 // per-channel sum of g[N,C,S] -> out[C] (+=): conv bias gradients
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int C, long long S) {
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int C, long long S, int chunk) {
   __shared__ float sm[4];
   const int row = blockIdx.y;
   const int c = row % C;
   const long long base = (long long)row * S;
-  const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
-  const long long s1 = min(S, s0 + ROW_CHUNK);
+  const long long s0 = (long long)blockIdx.x * chunk;
+  const long long s1 = min(S, s0 + chunk);
   float a = 0.f;
-  for (long long s = s0 + threadIdx.x; s < s1; s += 256) a += g[base + s];
+  if ((S & 3) == 0) {
+#pragma unroll 4
+    for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
+      const float4 v = *reinterpret_cast<const float4*>(g + base + s);
+      a += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long long s = s0 + threadIdx.x; s < s1; s += 256) a += g[base + s];
+  }
   a = dpf_block_sum_256(a, sm);
   if (threadIdx.x == 0) atomicAdd(&out[c], a);
 }
@@ -411,7 +419,8 @@ int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, co
 int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !out || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(channel_sum_kernel, row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, g, out, C, S);
+  const int chunk = reduce_chunk(N * C, S);
+  hipLaunchKernelGGL(channel_sum_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, (hipStream_t)stream, g, out, C, S, chunk);
   return dpf_check_launch();
 }
 
