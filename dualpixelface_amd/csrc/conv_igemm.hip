@@ -19,6 +19,7 @@
 // each a dense stride-1 gather over the valid tap subset (no zero-insertion, no wasted MACs).
 #include "dpf_common.h"
 #include "dpf_repack.h"
+#include "conv_internal.h"
 #include <cstdlib>
 
 namespace {
@@ -498,6 +499,13 @@ int conv_common(const float* x, const float* w, const float* bias, float* out, f
   p.Ktot = Kfull;
   for (int k0 = 0; k0 < Kfull; k0 += 128) {
     const int Kc = Kfull - k0 < 128 ? Kfull - k0 : 128;
+    {   // LDS-DMA double-buffered kernel where the shape is eligible (conv_igemm2.hip)
+      DpfConvDesc d{p.N, p.C, Kc, Kfull, k0, p.ID, p.IH, p.IW, p.OD, p.OH, p.OW, p.kd, p.kh, p.kw, p.sd, p.sh, p.sw,
+                    p.pd, p.ph, p.pw, p.dd, p.dh, p.dw, p.transposed, wA, wB, repack_mode};
+      const int rc2 = dpf_igemm2_conv(x, w, bias, out, wt_ws, d, st);
+      if (rc2 == DPF_OK) continue;
+      if (rc2 != DPF_ERR_UNSUPPORTED) return rc2;
+    }
     const int KT = 32 * ((Kc + 31) / 32);
     const long long total = (long long)T * p.C * KT;
     hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wt_ws, wA, wB, T, KT, repack_mode, k0, Kc);
@@ -572,7 +580,10 @@ extern "C" {
 
 // workspace (floats) needed for the repacked weights of a conv with `T` taps, `reduce` reduction channels
 // and `outc` output channels
-long long dpf_conv_workspace_floats(int T, int reduce, int outc) { return (long long)T * reduce * (((outc + 31) / 32) * 32); }
+long long dpf_conv_workspace_floats(int T, int reduce, int outc) {
+  const long long a = (long long)T * reduce * (((outc + 31) / 32) * 32), b = dpf_igemm2_workspace_floats(T, reduce, outc);
+  return a > b ? a : b;
+}
 
 // x [N,C,ID,IH,IW], w [K,C,kd,kh,kw], bias [K] or NULL, out [N,K,OD,OH,OW]
 int dpf_conv_forward(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,

@@ -1,0 +1,368 @@
+// Dense convolution as implicit GEMM on the fp32 matrix cores, second generation: LDS-DMA double buffering.
+//
+// Same math and MFMA mapping as conv_igemm.hip (D[row = out channel][col = 32 consecutive W positions], exact-f32
+// v_mfma_f32_32x32x2_f32, one 256-thread workgroup owns ALL output channels of a (4*NT) x 32 position tile), but the
+// operand traffic is re-designed around what bounds that kernel on MI355X (profiles/r01_mfma_probe.txt: the matrix pipe
+// idles ~50 % behind the stage -> barrier -> MFMA -> barrier rhythm and the in-order vmcnt queue shared by weight and
+// patch loads):
+//   * every chunk of CC input channels is fetched by `global_load_lds_dwordx4` (LDS-DMA, 16 B per lane, no VGPR round trip,
+//     no ds_write): the haloed input patch as whole 16-byte-aligned row segments (per-lane SOURCE addresses; out-of-bounds
+//     segments read a zero page, so padding needs no predication in the MFMA loop), and the chunk's weights, which the
+//     repack lays out [chunk][tap][cc][k] so a chunk is one contiguous block;
+//   * two LDS buffers: the DMA of chunk i+1 is issued before the MFMA loop of chunk i and retired by the one
+//     vmcnt(0) + barrier at the end of that loop -- no global load result is ever waited for inside the MFMA stream, and
+//     both MFMA operands come from LDS (the weight fragments no longer share the vmcnt queue with the patch);
+//   * descriptors (per-lane source offsets) are computed once per workgroup with multiply-shift divisions.
+// Eligibility (host): IW % 4 == 0, 16-byte aligned x, forward convs of any stride / dilation and stride-1 transposed
+// convs (data gradients); everything else stays on conv_igemm.hip.
+#include "conv_internal.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int MAXT = 27;
+constexpr int NLD = 8;          // patch DMA instructions per thread and chunk (upper bound; 2048 x 16 B = 32 KB per chunk)
+constexpr int ZPAGE = 16;       // floats of zeros in front of the packed weights (source of out-of-bounds segments)
+
+struct G2P {
+  int N, C, K, Ktot, k0;
+  int ID, IH, IW, OD, OH, OW;
+  int sxd, sxh, sxw;            // input step per output step
+  int e0d, e0h, e0w;            // input coordinate of output 0 at the minimal tap: i = q * sx + e0
+  int ext_d, ext_h;             // patch planes, rows per plane
+  int RS, SR;                   // patch row stride in floats (multiple of 4), 16-byte segments per row
+  int colshift;                 // patch column of the first needed input column (alignment slack, 0..3)
+  int rpc, chanStride;          // rows per channel, floats per channel
+  int nseg;                     // 16-byte segments of one chunk's patch  (CC * rpc * SR)
+  int nwseg;                    // 16-byte segments of one chunk's weights (T * CC * KT / 4)
+  int T;
+  int tilesH, tilesW;
+  int nchunks;
+  unsigned mSR, mRPC, mEH;      // ceil(2^20 / d) for d = SR, rpc, ext_h
+  unsigned long long steps;     // 2-bit step code per tap (see the kernel's tap walk)
+  int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
+};
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+// resident workgroups per CU the register budget is declared for: accumulators + two operand sets + ~40 of bookkeeping
+template <int MT, int NT, int CC>
+constexpr int g2_occ() {
+  constexpr int est = MT * NT * 16 + CC * (MT + NT) + 40;
+  return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
+}
+
+template <int MT, int NT, int CC>
+__global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                                         const float* __restrict__ bias, float* __restrict__ out, G2P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KT = 32 * MT;
+  constexpr int TH = 4 * NT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int hh = lane >> 5;
+
+  int b = blockIdx.x;
+  const int tw = b % p.tilesW; b /= p.tilesW;
+  const int th = b % p.tilesH; b /= p.tilesH;
+  const int qd = b % p.OD;
+  const int n = b / p.OD;
+  const int q0h = th * TH, q0w = tw * 32;
+  const int i0d = qd * p.sxd + p.e0d, i0h = q0h * p.sxh + p.e0h;
+  const int a0 = q0w * p.sxw + p.e0w - p.colshift;     // 16-byte aligned first staged column
+
+  const int patchFloats = CC * p.chanStride;
+  const int bufFloats = patchFloats + p.T * CC * KT;
+  const long long x_chan = (long long)p.ID * p.IH * p.IW;
+  const float* xn = x + (long long)n * p.C * x_chan;
+
+  // ---- per-lane DMA descriptors: segment f = tid + 256 j of the flat [row][SR] patch image
+  int goff[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const unsigned f = tid + 256 * j;
+    const unsigned row = (f * p.mSR) >> 20;
+    const int seg = f - row * p.SR;
+    const unsigned cc = (row * p.mRPC) >> 20;
+    const unsigned rem = row - cc * p.rpc;
+    const unsigned pl = (rem * p.mEH) >> 20;
+    const int rr = rem - pl * p.ext_h;
+    const int id = i0d + (int)pl, ih = i0h + rr, iw = a0 + 4 * seg;
+    const bool ok = (int)f < p.nseg && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+    goff[j] = ok ? (int)((long long)cc * x_chan + ((long long)id * p.IH + ih) * p.IW + iw) : -1;
+  }
+
+  auto issue = [&](int chunk, int buf) {
+    float* dbase = smem + buf * bufFloats;
+    const float* xc = xn + (long long)chunk * CC * x_chan;
+    const int crem = p.C - chunk * CC;
+    const int flimit = (crem < CC ? crem : CC) * p.rpc * p.SR;    // segments of channels beyond C read the zero page
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      if (j * 256 < p.nseg) {                                     // wave-uniform
+        const int f = tid + 256 * j;
+        if (f < p.nseg) {
+          const float* src = (goff[j] >= 0 && f < flimit) ? xc + goff[j] : wpk;
+          glds16(src, dbase + (j * 256 + wave * 64) * 4);
+        }
+      }
+    }
+    const float* wc = wpk + ZPAGE + (long long)chunk * p.nwseg * 4;
+    float* wbase = dbase + patchFloats;
+    for (int f0 = wave * 64; f0 < p.nwseg; f0 += 256) {
+      const int f = f0 + lane;
+      if (f < p.nwseg) glds16(wc + f * 4, wbase + f0 * 4);
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
+
+  int lanebase[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) lanebase[t] = ((wave * NT + t) * p.sxh) * p.RS + l31 * p.sxw + p.colshift + hh * p.chanStride;
+  const int abase = hh * KT + l31;
+
+  issue(0, 0);
+  __syncthreads();                                               // vmcnt(0) + barrier: chunk 0 landed
+  const int nv = p.T;
+  const int tap0 = p.tap0, stepC = p.stepC, dB = p.incB - p.stepC, dA = p.incA - p.incB, chanStride = p.chanStride;
+  const unsigned long long steps = p.steps;
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < p.nchunks) issue(chunk + 1, buf ^ 1);
+    const float* s_in = smem + buf * bufFloats;
+    const float* s_w = s_in + patchFloats;
+    // Two operand register sets (A, B), taps two at a time: the LDS reads of tap s+1 are issued before the MFMAs of tap s, so
+    // the matrix pipe never waits for an operand fetch.  Tap offsets advance incrementally on the scalar unit
+    // (tap (a, b, c) -> base + a*stepA + b*stepB + c*stepC; weights are packed in the same order).
+    float aA[CC / 2][MT], bA[CC / 2][NT], aB[CC / 2][MT], bB[CC / 2][NT];
+    int slotn = 0, toff = tap0, woff = 0;
+    auto load_ops = [&](float (&a)[CC / 2][MT], float (&bb)[CC / 2][NT]) {
+      const float* wrow = s_w + abase + woff;
+#pragma unroll
+      for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[cp][m] = wrow[(2 * cp) * KT + m * 32];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bb[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
+      }
+      // advance to the next tap on the scalar unit: 2-bit step codes, one per tap (0: next column, 1: next row, 2: next plane,
+      // 3: wrap to tap 0 -- the wrapped fetch of the final iteration is a valid address whose data is not used)
+      const unsigned code = (unsigned)(steps >> (2 * slotn)) & 3u;
+      const int inc = stepC + (code > 0 ? dB : 0) + (code > 1 ? dA : 0);     // arithmetic, not a select of kernel-argument loads
+      toff = code == 3 ? tap0 : toff + inc;
+      woff = code == 3 ? 0 : woff + CC * KT;
+      slotn = code == 3 ? 0 : slotn + 1;
+    };
+    auto mfmas = [&](const float (&a)[CC / 2][MT], const float (&bb)[CC / 2][NT]) {
+#pragma unroll
+      for (int cp = 0; cp < CC / 2; ++cp)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp][m], bb[cp][t], acc[m][t], 0, 0, 0);
+    };
+    // `touch` = an empty asm that reads a whole operand set: hipcc retires LDS reads with lgkmcnt(0) at the first use, so the
+    // use is placed BEFORE the other set's fetch is issued -- each wait then only covers reads issued a full MFMA group earlier.
+    auto touch = [&](const float (&a)[CC / 2][MT], const float (&bb)[CC / 2][NT]) {
+#pragma unroll
+      for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a[cp][m]));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(bb[cp][t]));
+      }
+      asm volatile("" ::: "memory");
+    };
+    load_ops(aA, bA);
+    for (int slot = 0; slot + 1 < nv; slot += 2) {
+      touch(aA, bA);
+      load_ops(aB, bB);       // tap slot+1
+      __builtin_amdgcn_sched_barrier(6);   // VALU / SALU may cross, LDS reads and MFMAs may not
+      mfmas(aA, bA);          // tap slot
+      __builtin_amdgcn_sched_barrier(0);
+      touch(aB, bB);
+      load_ops(aA, bA);       // tap slot+2 (wrapped, unused, when slot+2 == nv)
+      __builtin_amdgcn_sched_barrier(6);
+      mfmas(aB, bB);          // tap slot+1
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nv & 1) mfmas(aA, bA);
+    __builtin_amdgcn_sched_barrier(0);                           // keep the MFMAs of this chunk in front of the DMA wait
+    __syncthreads();                                             // vmcnt(0): chunk+1 landed; barrier: this buffer is free
+  }
+
+  // ---- epilogue: D row = (j&3) + 8*(j>>2) + 4*(lane>>5), col = lane&31
+  const int ow = q0w + l31;
+  const long long out_plane = (long long)p.OH * p.OW;
+  const long long kstride = (long long)p.OD * out_plane;
+  const int oh0 = q0h + wave * NT;
+  float* op = out + ((long long)n * p.Ktot + p.k0) * kstride + ((long long)qd * p.OH + oh0) * p.OW + ow;
+  if (ow < p.OW) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (k < p.K) {
+          const float bv = bias ? bias[p.k0 + k] : 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (oh0 + t < p.OH) op[(long long)k * kstride + t * p.OW] = acc[m][t][j] + bv;
+        }
+      }
+    }
+  }
+}
+
+// wpk[0, ZPAGE) = 0;  wpk[ZPAGE + ((chunk*T + t)*CC + cc)*KT + k] = w(out = k0 + k, reduce = chunk*CC + cc, tap = t), zero padded
+__global__ void igemm2_pack_kernel(const float* __restrict__ w, float* __restrict__ wpk, int wA, int wB, int T, int KT, int CC, int nchunks,
+                                   int mode, int k0, int K, int C) {
+  const long long total = (long long)nchunks * T * CC * KT + ZPAGE;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (i >= ZPAGE) {
+      const long long e = i - ZPAGE;
+      const int k = (int)(e % KT);
+      const int cc = (int)((e / KT) % CC);
+      const int t = (int)((e / ((long long)KT * CC)) % T);
+      const int chunk = (int)(e / ((long long)KT * CC * T));
+      const int c = chunk * CC + cc;
+      if (k < K && c < C) {
+        const int a = mode == 0 ? k0 + k : c;
+        const int bb = mode == 0 ? c : k0 + k;
+        v = w[((long long)a * wB + bb) * T + t];
+      }
+    }
+    wpk[i] = v;
+  }
+}
+
+unsigned magic20(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+template <int MT, int NT, int CC>
+int launch_g2(const float* x, const float* wpk, const float* bias, float* out, const G2P& p, size_t lds, long long blocks, hipStream_t st) {
+  if (lds > 48 * 1024) {
+    static bool done = false;   // per instantiation
+    if (!done) {
+      if (hipFuncSetAttribute((const void*)igemm2_kernel<MT, NT, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return DPF_ERR_LAUNCH;
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL((igemm2_kernel<MT, NT, CC>), dim3((unsigned)blocks), dim3(256), lds, st, x, wpk, bias, out, p);
+  return dpf_check_launch();
+}
+
+}  // namespace
+
+long long dpf_igemm2_workspace_floats(int T, int reduce, int outc) {
+  const int KT = 32 * (((outc < 128 ? outc : 128) + 31) / 32);
+  return (long long)T * (reduce + 8) * KT + ZPAGE;
+}
+
+int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st) {
+  static const int enabled = env_int("DPF_IGEMM2", 1);
+  if (!enabled) return DPF_ERR_UNSUPPORTED;
+  const int T = d.kd * d.kh * d.kw;
+  if (T > MAXT || d.K > 128) return DPF_ERR_UNSUPPORTED;
+  if (d.transposed && (d.sd != 1 || d.sh != 1 || d.sw != 1)) return DPF_ERR_UNSUPPORTED;
+  if ((d.IW & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15)) return DPF_ERR_UNSUPPORTED;
+  const long long x_chan = (long long)d.ID * d.IH * d.IW;
+  if (9 * x_chan >= (1LL << 30)) return DPF_ERR_UNSUPPORTED;      // per-lane 32-bit source offsets within a chunk
+  if (T == 1 && !env_int("DPF_IGEMM2_1x1", 0)) return DPF_ERR_UNSUPPORTED;   // pointwise convs are HBM-bound: generic kernel
+
+  const int MT = (d.K + 31) / 32, KT = 32 * MT;
+  static const int nt_over = env_int("DPF_G2_NT", 0), cc_over = env_int("DPF_G2_CC", 0), lds_target = env_int("DPF_G2_LDS", 53 * 1024);
+  int NT = MT == 1 ? 4 : 2;
+  if (nt_over == 2 || (nt_over == 4 && MT <= 2)) NT = nt_over;
+  const int TH = 4 * NT;
+
+  G2P p{};
+  p.N = d.N; p.C = d.C; p.K = d.K; p.Ktot = d.Ktot; p.k0 = d.k0;
+  p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.OD = d.OD; p.OH = d.OH; p.OW = d.OW;
+  p.T = T;
+  int ext_w;
+  if (!d.transposed) {
+    p.sxd = d.sd; p.sxh = d.sh; p.sxw = d.sw;
+    p.e0d = -d.pd; p.e0h = -d.ph; p.e0w = -d.pw;
+  } else {
+    p.sxd = p.sxh = p.sxw = 1;
+    p.e0d = d.pd - (d.kd - 1) * d.dd; p.e0h = d.ph - (d.kh - 1) * d.dh; p.e0w = d.pw - (d.kw - 1) * d.dw;
+  }
+  p.ext_d = (d.kd - 1) * d.dd + 1;
+  p.ext_h = (TH - 1) * p.sxh + (d.kh - 1) * d.dh + 1;
+  ext_w = 31 * p.sxw + (d.kw - 1) * d.dw + 1;
+  p.colshift = ((p.e0w % 4) + 4) % 4;
+  p.RS = ((p.colshift + ext_w + 3) / 4) * 4;
+  p.SR = p.RS / 4;
+  p.rpc = p.ext_d * p.ext_h;
+  p.chanStride = p.rpc * p.RS;
+  {
+    const int sgn = d.transposed ? -1 : 1;
+    const int stepA = sgn * d.dd * p.ext_h * p.RS, stepB = sgn * d.dh * p.RS;
+    p.stepC = sgn * d.dw;
+    p.incB = stepB - (d.kw - 1) * p.stepC;
+    p.incA = stepA - (d.kh - 1) * stepB - (d.kw - 1) * p.stepC;
+    p.steps = 0;
+    for (int t = 0; t < T; ++t) {
+      const int c = t % d.kw, b = (t / d.kw) % d.kh;
+      const unsigned long long code = t == T - 1 ? 3 : (c + 1 < d.kw ? 0 : (b + 1 < d.kh ? 1 : 2));
+      p.steps |= code << (2 * t);
+    }
+    p.tap0 = d.transposed ? ((d.kd - 1) * d.dd * p.ext_h + (d.kh - 1) * d.dh) * p.RS + (d.kw - 1) * d.dw : 0;
+  }
+  // channels per chunk: the largest of {8, 4, 2} whose two buffers leave room for >= 3 resident workgroups
+  auto buf_bytes = [&](int cc) { return (size_t)(cc * p.chanStride + T * cc * KT) * sizeof(float); };
+  auto nseg_of = [&](int cc) { return cc * p.rpc * p.SR; };
+  int CC = 0;
+  for (int cc : {8, 4, 2})
+    if (2 * buf_bytes(cc) <= (size_t)lds_target && nseg_of(cc) <= NLD * 256) { CC = cc; break; }
+  if (cc_over == 2 || cc_over == 4 || cc_over == 8) CC = cc_over;
+  if (!CC) CC = 2;
+  if (nseg_of(CC) > NLD * 256 || 2 * buf_bytes(CC) > 160 * 1024) return DPF_ERR_UNSUPPORTED;
+  p.nseg = nseg_of(CC);
+  p.nwseg = T * CC * KT / 4;
+  p.nchunks = (d.C + CC - 1) / CC;
+  p.tilesH = dpf_div_up(d.OH, TH);
+  p.tilesW = dpf_div_up(d.OW, 32);
+  p.mSR = magic20(p.SR); p.mRPC = magic20(p.rpc); p.mEH = magic20(p.ext_h);
+  if ((long long)NLD * 256 * (p.SR > p.rpc ? p.SR : p.rpc) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
+  const long long blocks = (long long)d.N * d.OD * p.tilesH * p.tilesW;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
+
+  const long long total = (long long)p.nchunks * T * CC * KT + ZPAGE;
+  hipLaunchKernelGGL(igemm2_pack_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, ws, d.wA, d.wB, T, KT, CC, p.nchunks, d.mode, d.k0, d.K, d.C);
+  if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
+
+  const size_t lds = 2 * buf_bytes(CC);
+#define G2(M, N_, C_) return launch_g2<M, N_, C_>(x, ws, bias, out, p, lds, blocks, st)
+#define G2CC(M, N_)                                                                                                         \
+  switch (CC) { case 8: G2(M, N_, 8); case 4: G2(M, N_, 4); default: G2(M, N_, 2); }
+  if (NT == 4) {
+    if (MT == 1) { G2CC(1, 4) } else { G2CC(2, 4) }
+  }
+  switch (MT) {
+    case 1: G2CC(1, 2)
+    case 2: G2CC(2, 2)
+    case 3: G2CC(3, 2)
+    default: G2CC(4, 2)
+  }
+#undef G2CC
+#undef G2
+}

@@ -1,0 +1,20 @@
+// Internal (non-ABI) interface between the dense-convolution translation units.
+#pragma once
+#include "dpf_common.h"
+
+// One dense convolution launch (forward, or transposed = data gradient / ConvTranspose3d) covering the output channels
+// [k0, k0 + K) of a tensor with Ktot channels.  `w` is the caller's weight tensor w[wA][wB][T]; mode 0: reduce = wB, out = wA
+// (forward conv layout), mode 1: reduce = wA, out = wB (transposed layout).
+struct DpfConvDesc {
+  int N, C, K, Ktot, k0;
+  int ID, IH, IW, OD, OH, OW;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int transposed;
+  int wA, wB, mode;
+};
+
+// LDS-DMA double-buffered implicit GEMM (conv_igemm2.hip).  Returns DPF_OK when it launched, DPF_ERR_UNSUPPORTED when the
+// shape is not eligible (the caller then uses the generic kernel), another error code on failure.
+int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st);
+// floats of workspace dpf_igemm2_conv may use for (T taps, `reduce` reduction channels, `outc` output channels)
+long long dpf_igemm2_workspace_floats(int T, int reduce, int outc);

@@ -53,6 +53,18 @@ CONV_CASES = [
     (4, 32, 1, 8, 12, 3, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
     (1, 192, 1, 6, 9, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),      # data gradient has 192 channels (> one launch)
     (1, 40, 2, 5, 7, 160, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    # 16-byte-aligned rows (W % 4 == 0): the LDS-DMA double-buffered kernel (conv_igemm2.hip) -- ragged tiles, channel tails, strides,
+    # dilations, two launches over the output channels
+    (1, 35, 4, 9, 36, 81, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (2, 32, 3, 37, 72, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (1, 64, 5, 21, 44, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (1, 32, 6, 22, 68, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),
+    (1, 96, 1, 17, 36, 32, (1, 3, 3), (1, 1, 1), (0, 5, 5), (1, 5, 5)),
+    (1, 32, 2, 40, 72, 32, (1, 3, 3), (1, 1, 1), (0, 4, 4), (1, 4, 4)),
+    (2, 32, 1, 19, 40, 32, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 3, 3)),
+    (1, 40, 2, 5, 8, 160, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (2, 33, 1, 20, 36, 96, (1, 3, 3), (1, 1, 1), (0, 0, 0), (1, 1, 1)),      # no padding: the data gradient's patch starts outside the tensor
+    (1, 192, 1, 9, 12, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
 ]
 
 
