@@ -576,6 +576,10 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
 
 }  // namespace
 
+int dpf_conv_wgrad_slice(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int kbeg, int kcount, int QD,
+                         int QH, int QW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_,
+                         void* stream);
+
 extern "C" {
 
 // workspace (floats) needed for the repacked weights of a conv with `T` taps, `reduce` reduction channels
@@ -623,9 +627,46 @@ int dpf_conv_transpose(const float* x, const float* w, const float* bias, float*
 
 // dW[K][C][T] += ...   (dw must be zero-initialised or hold the running gradient)
 // g [N,K,QD,QH,QW] on the small grid, x [N,C,ID,IH,IW] on the dense grid.
+long long dpf_conv_wgrad_workspace_floats(int T, int C, int K) { return dpf_wgrad2_workspace_floats(T, C, K); }
+
+// as dpf_conv_wgrad below, with caller scratch (dpf_conv_wgrad_workspace_floats floats): eligible shapes run the LDS-DMA kernel
+// with a deterministic slab reduction (conv_wgrad2.hip) instead of float atomics
+int dpf_conv_wgrad_ws(const float* g, const float* x, float* dw, float* ws, long long ws_floats, int N, int C, int ID, int IH, int IW, int K,
+                      int QD, int QH, int QW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_,
+                      void* stream) {
+  dpf_clear_error();
+  if (!g || !x || !dw || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
+  const int T = kd * kh * kw;
+  for (int k0 = 0; k0 < K; k0 += 128) {
+    const int Kc = K - k0 < 128 ? K - k0 : 128;
+    float* dwk = dw + (long long)k0 * C * T;
+    int rc = DPF_ERR_UNSUPPORTED;
+    if (ws) {
+      DpfWgradDesc d{N, C, Kc, K, k0, ID, IH, IW, QD, QH, QW, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_};
+      rc = dpf_wgrad2(g, x, dwk, ws, ws_floats, d, (hipStream_t)stream);
+    }
+    if (rc == DPF_ERR_UNSUPPORTED) {
+      // generic kernel on this channel slice: g viewed with Ktot = K channels, slice [k0, k0 + Kc)
+      rc = dpf_conv_wgrad_slice(g, x, dwk, N, C, ID, IH, IW, K, k0, Kc, QD, QH, QW, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_, stream);
+    }
+    if (rc != DPF_OK) return rc;
+  }
+  return DPF_OK;
+}
+
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream) {
-  dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
+  dpf_clear_error();
+  return dpf_conv_wgrad_slice(g, x, dw, N, C, ID, IH, IW, K, 0, K, QD, QH, QW, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_, stream);
+}
+
+}  // extern "C"
+
+// generic (first-generation) weight gradient of the g-channel slice [kbeg, kbeg + kcount) of a g tensor with K channels; dw points at
+// row kbeg of dW
+int dpf_conv_wgrad_slice(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int kbeg, int kcount, int QD,
+                         int QH, int QW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_,
+                         void* stream) {   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !x || !dw || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
   WgP p{};
   p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW; p.QD = QD; p.QH = QH; p.QW = QW;
@@ -633,6 +674,7 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw_;
   if (p.T > MAXT) return DPF_ERR_UNSUPPORTED;
   p.Ktot = K;
+  const int Kend = kbeg + kcount;
   // Dilated stride-1 convolutions: output (y, x) only meets inputs of its own residue class mod d, so the problem splits into
   // d*d interleaved dilation-1 problems.  Tiles then carry a (kh-1)-wide halo instead of (kh-1)*d, at the price of strided
   // (every d-th element) staging loads, which L2 absorbs.
@@ -643,10 +685,10 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
     dh = dw_ = 1;
   }
   const int QHp = dpf_div_up(QH, p.es), QWp = dpf_div_up(QW, p.es);   // extent of one phase
-  for (int k0 = 0; k0 < K; k0 += 128) {   // one launch covers up to 128 g-channels (4 MFMA row tiles)
+  for (int k0 = kbeg; k0 < Kend; k0 += 128) {   // one launch covers up to 128 g-channels (4 MFMA row tiles)
   p.k0 = k0;
-  p.K = K - k0 < 128 ? K - k0 : 128;
-  float* dwk = dw + (long long)k0 * C * p.T;
+  p.K = Kend - k0 < 128 ? Kend - k0 : 128;
+  float* dwk = dw + (long long)(k0 - kbeg) * C * p.T;
   const int MT = (p.K + 31) / 32;
   const int KT = 32 * MT;
   const int WNT = 2;
@@ -685,5 +727,3 @@ int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int 
   }
   return dpf_check_launch();
 }
-
-}  // extern "C"

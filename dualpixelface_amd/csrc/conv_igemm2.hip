@@ -37,6 +37,7 @@ struct G2P {
   int nwseg;                    // 16-byte segments of one chunk's weights (T * CC * KT / 4)
   int T;
   int tilesH, tilesW;
+  int ntiles, cpx;              // tiles; tiles per XCD label
   int nchunks;
   unsigned mSR, mRPC, mEH;      // ceil(2^20 / d) for d = SR, rpc, ext_h
   unsigned long long steps;     // 2-bit step code per tap (see the kernel's tap walk)
@@ -66,11 +67,14 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
   const int l31 = lane & 31;
   const int hh = lane >> 5;
 
-  int b = blockIdx.x;
+  // L2-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (b % 8 labels the XCD), so each label walks a
+  // contiguous tile range ordered depth-fastest -- the workgroups that share input planes and halo rows run together behind one L2
+  int b = (blockIdx.x & 7) * p.cpx + (blockIdx.x >> 3);
+  if (b >= p.ntiles) return;
+  const int qd = b % p.OD; b /= p.OD;
   const int tw = b % p.tilesW; b /= p.tilesW;
-  const int th = b % p.tilesH; b /= p.tilesH;
-  const int qd = b % p.OD;
-  const int n = b / p.OD;
+  const int th = b % p.tilesH;
+  const int n = b / p.tilesH;
   const int q0h = th * TH, q0w = tw * 32;
   const int i0d = qd * p.sxd + p.e0d, i0h = q0h * p.sxh + p.e0h;
   const int a0 = q0w * p.sxw + p.e0w - p.colshift;     // 16-byte aligned first staged column
@@ -343,8 +347,11 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   p.tilesW = dpf_div_up(d.OW, 32);
   p.mSR = magic20(p.SR); p.mRPC = magic20(p.rpc); p.mEH = magic20(p.ext_h);
   if ((long long)NLD * 256 * (p.SR > p.rpc ? p.SR : p.rpc) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
-  const long long blocks = (long long)d.N * d.OD * p.tilesH * p.tilesW;
-  if (blocks <= 0 || blocks > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
+  const long long ntiles = (long long)d.N * d.OD * p.tilesH * p.tilesW;
+  if (ntiles <= 0 || ntiles > 0x3fffffffLL) return DPF_ERR_INVALID_ARG;
+  p.ntiles = (int)ntiles;
+  p.cpx = (int)((ntiles + 7) / 8);
+  const long long blocks = 8LL * p.cpx;
 
   const long long total = (long long)p.nchunks * T * CC * KT + ZPAGE;
   hipLaunchKernelGGL(igemm2_pack_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, ws, d.wA, d.wB, T, KT, CC, p.nchunks, d.mode, d.k0, d.K, d.C);

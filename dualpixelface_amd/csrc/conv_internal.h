@@ -18,3 +18,13 @@ struct DpfConvDesc {
 int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st);
 // floats of workspace dpf_igemm2_conv may use for (T taps, `reduce` reduction channels, `outc` output channels)
 long long dpf_igemm2_workspace_floats(int T, int reduce, int outc);
+
+// One weight-gradient launch for the g-channels [k0, k0 + K) of a g tensor with Ktot channels; dw points at row k0 of dW[Ktot][C][T].
+struct DpfWgradDesc {
+  int N, C, K, Ktot, k0;
+  int ID, IH, IW, QD, QH, QW;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+};
+// LDS-DMA double-buffered, slab-reduced (deterministic) weight gradient (conv_wgrad2.hip); DPF_ERR_UNSUPPORTED -> caller falls back.
+int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, hipStream_t st);
+long long dpf_wgrad2_workspace_floats(int T, int C, int K);

@@ -1,0 +1,422 @@
+// Weight gradient of the dense convolutions, second generation: LDS-DMA double buffering, position-split waves,
+// deterministic slab reduction.
+//
+//   dW[k][c][t] += sum_{n,q} g[n,k,q] * x[n,c, q*s - p + t*dil]          (replaces cuDNN's wgrad behind nn.Conv2d / nn.Conv3d;
+//   reference call sites as in conv_igemm.hip)
+//
+// D[row = k][col = (c, t)], reduction over positions on v_mfma_f32_32x32x2_f32 (exact f32).  A 256-thread workgroup owns a
+// 32-row slice of K and NCT column tiles (a whole number of input channels x all taps, <= 7 tiles) and walks position tiles
+// of 4 rows x 32.  Inside the workgroup the four waves split the POSITIONS (wave w = tile row w), not the columns: every wave
+// accumulates all NCT tiles over its own row, so the matrix pipes are evenly loaded for any column count (the first-generation
+// kernel and the column-split variant of this one idled 16 % of their MFMAs on ragged column chunks), and the four partial
+// results are summed once, through LDS, after the last tile.
+//   * both operands of a tile arrive by `global_load_lds_dwordx4` into one of two LDS buffers while the MFMAs of the previous
+//     tile run; one vmcnt(0) + barrier per tile;
+//   * the g tile keeps its global [k][position] order but its 16-byte slots are XOR-swizzled with (k & 15) through the DMA's
+//     per-lane SOURCE address: a lane (= row k) fetches 4 consecutive positions with ONE conflict-free ds_read_b128 that feeds
+//     4 x NCT MFMAs (the pairing of reduction indices inside an MFMA is free: lane half h takes positions 8j+4h .. 8j+4h+3);
+//   * the x patch is the forward kernel's aligned 16-byte-segment image; plane / channel strides are padded (host search) so
+//     the per-lane tap gather of the B operand spreads over the LDS banks;
+//   * a workgroup's tiles are a CONTIGUOUS range ordered depth-fastest, so the planes / halo rows it re-reads and the g tiles
+//     shared by the column chunks of the same positions are L2 hits (the strided assignment measured 4.8x the algorithmic bytes);
+//   * no float atomics: every workgroup stores its partial dW to a slab, a second kernel adds the slabs in a fixed order ->
+//     bitwise reproducible gradients.
+#include "conv_internal.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int NLX = 8;      // x-patch DMA instructions per thread and tile (upper bound: 32 KB)
+constexpr int WTH = 4;      // tile rows = waves
+constexpr int SPR = WTH * 8;   // 16-byte slots per g row
+constexpr int GFLOATS = 32 * SPR * 4;
+
+__device__ float4 dpf_wg2_zero_page[4];   // zero-initialised at module load: source of out-of-bounds segments
+
+struct W2P {
+  int N, C, K, Ktot, k0;
+  int ID, IH, IW, QD, QH, QW;
+  int sd, sh, sw, pd, ph, pw;
+  int kd, kh, kw, T;
+  int ext_d, ext_h, RS, SR, PS, CS, PSseg, CSseg, colshift;   // x image: row / plane / channel strides (floats, segments)
+  int CCW, cchunks, kslices, nxseg;
+  int tilesH, tilesW, nchunk;
+  long long ntiles, per;       // tiles per position chunk (contiguous range)
+  unsigned mCS, mPS, mSR;
+  long long slab_stride;       // floats between position-chunk slabs  (K * C * T)
+};
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+template <int NCT>
+constexpr int w2_occ() {
+  constexpr int est = NCT * 17 + 2 * NLX + 64;
+  return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
+}
+
+template <int NCT>
+__global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                     float* __restrict__ slab, W2P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int pchunk = b % p.nchunk; b /= p.nchunk;
+  const int cchunk = b % p.cchunks;
+  const int kslice = b / p.cchunks;
+  const int c0 = cchunk * p.CCW;
+  const int ncc = min(p.CCW, p.C - c0);
+  const int ncol = ncc * p.T;
+  const int kbase = kslice * 32;                 // first g channel of this workgroup (relative to k0)
+  const int krows = min(32, p.K - kbase);
+  const int xFloats = p.CCW * p.CS;
+  const int bufFloats = xFloats + GFLOATS;
+  const float* zero = reinterpret_cast<const float*>(dpf_wg2_zero_page);
+
+  // ---- column descriptors (B operand): lane -> (channel, tap) -> LDS offset of that tap for position 4*hh of this wave's row
+  int colbase[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t) {
+    const int coln = t * 32 + l31;
+    const int cn = coln < ncol ? coln : 0;
+    const int cc = cn / p.T;
+    const int tap = cn - cc * p.T;
+    const int tw_ = tap % p.kw, th_ = (tap / p.kw) % p.kh, td_ = tap / (p.kw * p.kh);
+    colbase[t] = cc * p.CS + td_ * p.PS + (th_ + wave * p.sh) * p.RS + tw_ + p.colshift + 4 * hh * p.sw;
+  }
+
+  // ---- x-patch DMA descriptors: flat segment f -> (cc, plane, row, seg); tile independent
+  const long long x_chan = (long long)p.ID * p.IH * p.IW;
+  const long long g_chan = (long long)p.QD * p.QH * p.QW;
+  int xoff[NLX], xmeta[NLX];      // source offset relative to the tile origin; (plane << 16) | (row << 8) | seg, or -1 (no DMA)
+#pragma unroll
+  for (int j = 0; j < NLX; ++j) {
+    const unsigned f = tid + 256 * j;
+    const unsigned cc = (f * p.mCS) >> 20;
+    const unsigned r1 = f - cc * p.CSseg;
+    const unsigned pl = (r1 * p.mPS) >> 20;
+    const unsigned r2 = r1 - pl * p.PSseg;
+    const unsigned rr = (r2 * p.mSR) >> 20;
+    const unsigned seg = r2 - rr * p.SR;
+    const bool ok = (int)f < p.nxseg && (int)cc < ncc && (int)pl < p.ext_d && (int)rr < p.ext_h;
+    xmeta[j] = ok ? (int)((pl << 16) | (rr << 8) | seg) : -1;
+    xoff[j] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + rr) * p.IW + 4 * seg);
+  }
+  // ---- g-tile DMA descriptors: physical slot P = k*SPR + sp (P = tid + 256 j) holds the logical slot sp ^ (k & 15) of row k;
+  //      k = tid/SPR + 8 j, so the permutation depends on j only through its parity (two variants), the row advances by a scalar
+  constexpr int KSTEP = 256 / SPR, NG = 32 / KSTEP;
+  const int gk0 = tid / SPR;
+  int glg[2], goff[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int lg = (tid % SPR) ^ ((gk0 + v * KSTEP) & 15);
+    glg[v] = lg;
+    goff[v] = (int)((long long)gk0 * g_chan + (long long)(lg >> 3) * p.QW + 4 * (lg & 7));
+  }
+
+  auto decode = [&](long long tile, int& n, int& qd, int& q0h, int& q0w) {     // depth fastest
+    long long r = tile;
+    qd = (int)(r % p.QD); r /= p.QD;
+    const int tw = (int)(r % p.tilesW); r /= p.tilesW;
+    const int th = (int)(r % p.tilesH);
+    n = (int)(r / p.tilesH);
+    q0h = th * WTH; q0w = tw * 32;
+  };
+
+  auto issue = [&](long long tile, int buf) {
+    int n, qd, q0h, q0w;
+    decode(tile, n, qd, q0h, q0w);
+    float* dbase = smem + buf * bufFloats;
+    const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, a0 = q0w * p.sw - p.pw - p.colshift;
+    const float* xt = x + ((long long)n * p.C + c0) * x_chan + ((long long)i0d * p.IH + i0h) * p.IW + a0;
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) {
+      if (j * 256 < p.nxseg) {                                   // wave-uniform
+        const int m = xmeta[j];
+        if (m >= 0) {
+          const int id = i0d + (m >> 16), ih = i0h + ((m >> 8) & 0xff), iw = a0 + 4 * (m & 0xff);
+          const bool ok = id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+          glds16(ok ? xt + xoff[j] : zero, dbase + (j * 256 + wave * 64) * 4);
+        }
+      }
+    }
+    const float* gt = g + ((long long)n * p.Ktot + p.k0 + kbase) * g_chan + ((long long)qd * p.QH + q0h) * p.QW + q0w;
+    float* gbase = dbase + xFloats;
+    bool gok[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) gok[v] = q0h + (glg[v] >> 3) < p.QH && q0w + 4 * (glg[v] & 7) < p.QW;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const bool ok = gk0 + j * KSTEP < krows && gok[j & 1];
+      glds16(ok ? gt + (long long)j * KSTEP * g_chan + goff[j & 1] : zero, gbase + (j * 256 + wave * 64) * 4);
+    }
+  };
+
+  f32x16 acc[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  const int sw = p.sw;
+  const int aslot = wave * 8 + hh;               // logical g slot of this lane's half, group 0
+  const int arow = l31 * SPR, axor = l31 & 15;
+  const long long tbeg = (long long)pchunk * p.per;
+  long long tend = tbeg + p.per;
+  if (tend > p.ntiles) tend = p.ntiles;
+  if (tbeg < tend) issue(tbeg, 0);
+  __syncthreads();
+  int buf = 0;
+  for (long long tile = tbeg; tile < tend; ++tile, buf ^= 1) {
+    if (tile + 1 < tend) issue(tile + 1, buf ^ 1);
+    const float* s_x = smem + buf * bufFloats;
+    const float* s_g = s_x + xFloats;
+    // group j = positions 8j .. 8j+7 of this wave's row: lane half h takes 8j+4h .. 8j+4h+3; element i of both halves is one
+    // MFMA k-step.  Units of (group, column-tile pair) are software pipelined over two B register sets; the A fragment of a
+    // group is fetched one group ahead.
+    constexpr int NP = (NCT + 1) / 2;            // column-tile pairs per group
+    f32x4 aC, aN;
+    float bA[2][4], bB[2][4];
+    auto load_a = [&](int j, f32x4& a) { a = *reinterpret_cast<const f32x4*>(s_g + (arow + ((aslot + 2 * j) ^ axor)) * 4); };
+    auto load_b = [&](int j, int pr, float (&bb)[2][4]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * pr + u;
+        if (t < NCT) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bb[u][i] = s_x[colbase[t] + (8 * j + i) * sw];
+        }
+      }
+    };
+    auto mfmas = [&](int pr, const f32x4& a, const float (&bb)[2][4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * pr + u;
+          if (t < NCT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[u][i], acc[t], 0, 0, 0);
+        }
+    };
+    auto touch = [&](const f32x4& a, const float (&bb)[2][4], int pr) {
+      asm volatile("" ::"v"(a));
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (2 * pr + u < NCT) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(bb[u][i]));
+        }
+      asm volatile("" ::: "memory");
+    };
+    load_a(0, aC);
+    load_b(0, 0, bA);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < 3) load_a(j + 1, aN);
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) {
+        // unit (j, pr) lives in set A when (j*NP + pr) is even, else in set B; fetch the next unit into the other set first
+        const int u0 = j * NP + pr;
+        const int nj = pr + 1 < NP ? j : j + 1, npr = pr + 1 < NP ? pr + 1 : 0;
+        if ((u0 & 1) == 0) {
+          touch(aC, bA, pr);
+          if (nj < 4) load_b(nj, npr, bB);
+          __builtin_amdgcn_sched_barrier(6);
+          mfmas(pr, aC, bA);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          touch(aC, bB, pr);
+          if (nj < 4) load_b(nj, npr, bA);
+          __builtin_amdgcn_sched_barrier(6);
+          mfmas(pr, aC, bB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      aC = aN;
+    }
+    __syncthreads();     // vmcnt(0): next tile landed; barrier: this buffer is free
+  }
+
+  // ---- sum the four waves' partial tiles through LDS (two rounds: 2,3 -> 0,1 then 1 -> 0); image [tile][reg][lane], conflict free
+  float* red = smem;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const int src_lo = round == 0 ? 2 : 1;       // waves in [src_lo, 2*src_lo) write, waves < src_lo (partner = wave + src_lo) add
+    if (wave >= src_lo && wave < 2 * src_lo) {
+      float* dst = red + (wave - src_lo) * (NCT * 16 * 64) + lane;
+#pragma unroll
+      for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dst[(t * 16 + j) * 64] = acc[t][j];
+    }
+    __syncthreads();
+    if (wave < src_lo) {
+      const float* src = red + wave * (NCT * 16 * 64) + lane;
+#pragma unroll
+      for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] += src[(t * 16 + j) * 64];
+    }
+    __syncthreads();
+  }
+  // ---- wave 0: partial dW -> slab[pchunk][kbase + k][c0*T + coln]   (plain stores; summed by wgrad2_reduce_kernel)
+  if (wave == 0) {
+    float* sl = slab + (long long)pchunk * p.slab_stride + (long long)kbase * p.C * p.T + (long long)c0 * p.T;
+    const long long rowlen = (long long)p.C * p.T;
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+      const int coln = t * 32 + l31;
+      if (coln < ncol) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (k < krows) sl[(long long)k * rowlen + coln] = acc[t][j];
+        }
+      }
+    }
+  }
+}
+
+// dw[i] += sum_{chunk} slab[chunk][i]  in chunk order (deterministic)
+__global__ void wgrad2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nchunk) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += slab[(long long)c * n + i];
+    dw[i] += s;
+  }
+}
+
+unsigned magic20(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+// bank conflicts of the B-operand gather for one candidate (PS, CS): sum over the 32-lane column windows of the extra LDS cycles
+int gather_conflicts(const DpfWgradDesc& d, int T, int ncolmax, int RS, int PS, int CS) {
+  int total = 0;
+  for (int c0 = 0; c0 < ncolmax; c0 += 32) {
+    int cnt[32] = {0};
+    for (int l = 0; l < 32 && c0 + l < ncolmax; ++l) {
+      const int col = c0 + l, cc = col / T, tap = col % T;
+      const int tw = tap % d.kw, th = (tap / d.kw) % d.kh, td = tap / (d.kw * d.kh);
+      ++cnt[(cc * CS + td * PS + th * RS + tw) & 31];
+    }
+    int worst = 0;
+    for (int b = 0; b < 32; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
+    total += worst - 1;
+  }
+  return total;
+}
+
+template <int NCT>
+int launch_w2(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
+  static bool done = false;
+  if (lds > 48 * 1024 && !done) {
+    if (hipFuncSetAttribute((const void*)wgrad2_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return DPF_ERR_LAUNCH;
+    done = true;
+  }
+  hipLaunchKernelGGL((wgrad2_kernel<NCT>), dim3(blocks), dim3(256), lds, st, g, x, slab, p);
+  return dpf_check_launch();
+}
+
+int w2_maxblocks() {
+  static const int v = env_int("DPF_W2_BLOCKS", 512);
+  return v;
+}
+
+}  // namespace
+
+long long dpf_wgrad2_workspace_floats(int T, int C, int K) {
+  // position chunks <= maxblocks / (column chunks * k slices), column chunks >= ceil(C*T / 224): slabs <= maxblocks * 224 * 32 floats (+ rounding)
+  const int Kc = K < 128 ? K : 128;
+  const long long cols = (long long)C * T;
+  const long long groups = ((cols + 223) / 224) * ((Kc + 31) / 32);
+  const long long nchunk = w2_maxblocks() / groups + 8;
+  return nchunk * Kc * cols + 64;
+}
+
+int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, hipStream_t st) {
+  static const int enabled = env_int("DPF_WGRAD2", 1);
+  if (!enabled || !ws) return DPF_ERR_UNSUPPORTED;
+  const int T = d.kd * d.kh * d.kw;
+  if (T > 27 || T < 9 || d.K > 128) return DPF_ERR_UNSUPPORTED;
+  if ((d.IW & 3) || (d.QW & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(g) & 15)) return DPF_ERR_UNSUPPORTED;
+  if (d.dh != 1 || d.dw != 1 || d.dd != 1) return DPF_ERR_UNSUPPORTED;        // dilated: polyphase kernel (conv_igemm.hip)
+  if (d.sw > 2 || d.sh > 2) return DPF_ERR_UNSUPPORTED;
+  const long long x_chan = (long long)d.ID * d.IH * d.IW;
+  static const int nct_max = env_int("DPF_W2_NCT", 7), lds_max = env_int("DPF_W2_LDS", 80 * 1024);
+
+  W2P p{};
+  p.N = d.N; p.C = d.C; p.K = d.K; p.Ktot = d.Ktot; p.k0 = d.k0;
+  p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.QD = d.QD; p.QH = d.QH; p.QW = d.QW;
+  p.sd = d.sd; p.sh = d.sh; p.sw = d.sw; p.pd = d.pd; p.ph = d.ph; p.pw = d.pw;
+  p.kd = d.kd; p.kh = d.kh; p.kw = d.kw; p.T = T;
+  p.ext_d = d.kd; p.ext_h = (WTH - 1) * d.sh + d.kh;
+  const int ext_w = 31 * d.sw + d.kw;
+  p.colshift = (((-d.pw) % 4) + 4) % 4;
+  p.RS = ((p.colshift + ext_w + 3) / 4) * 4;
+  p.SR = p.RS / 4;
+  // column chunks: whole channels, balanced, at most nct_max tiles of 32 columns; shrink until the two LDS buffers fit
+  int NCT = 0, CCW = 0;
+  for (int nmax = nct_max; nmax >= 1; --nmax) {
+    int ccw_cap = (nmax * 32) / T;
+    if (ccw_cap < 1) continue;
+    const int cchunks = dpf_div_up(d.C, ccw_cap);
+    CCW = dpf_div_up(d.C, cchunks);
+    NCT = dpf_div_up(CCW * T, 32);
+    // pad the plane / channel strides (multiples of 4 floats) for the fewest gather conflicts
+    int bestc = 1 << 30;
+    for (int pp = 0; pp < 8; ++pp)
+      for (int cp = 0; cp < 8; ++cp) {
+        const int PS = p.ext_h * p.RS + 4 * pp, CS = p.ext_d * PS + 4 * cp;
+        const int c = gather_conflicts(d, T, CCW * T, p.RS, PS, CS) * 64 + pp * p.ext_d + cp;
+        if (c < bestc) { bestc = c; p.PS = PS; p.CS = CS; }
+      }
+    const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
+    const size_t red = (size_t)2 * NCT * 16 * 64 * sizeof(float);
+    const size_t lds = 2 * buf > red ? 2 * buf : red;
+    if (CCW * p.CS / 4 > NLX * 256 || lds > (size_t)lds_max) { NCT = 0; continue; }
+    break;
+  }
+  if (NCT == 0) return DPF_ERR_UNSUPPORTED;
+  if (9LL * (CCW + 1) * x_chan >= (1LL << 30) || 33LL * (long long)d.QD * d.QH * d.QW >= (1LL << 31)) return DPF_ERR_UNSUPPORTED;
+  if ((long long)NLX * 256 * (p.CS / 4) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;
+  p.PSseg = p.PS / 4; p.CSseg = p.CS / 4;
+  p.CCW = CCW; p.nxseg = CCW * p.CS / 4;
+  p.cchunks = dpf_div_up(d.C, CCW);
+  p.kslices = dpf_div_up(d.K, 32);
+  p.tilesH = dpf_div_up(d.QH, WTH); p.tilesW = dpf_div_up(d.QW, 32);
+  p.ntiles = (long long)d.N * d.QD * p.tilesH * p.tilesW;
+  p.mCS = magic20(p.CSseg); p.mPS = magic20(p.PSseg); p.mSR = magic20(p.SR);
+  long long nchunk = w2_maxblocks() / (p.cchunks * p.kslices);
+  nchunk = (nchunk / 8) * 8;                       // same position chunk of every column chunk / k slice on one XCD (b % 8)
+  if (nchunk < 8) nchunk = 8;
+  if (nchunk > p.ntiles) nchunk = p.ntiles;
+  p.per = (p.ntiles + nchunk - 1) / nchunk;
+  nchunk = (p.ntiles + p.per - 1) / p.per;
+  p.nchunk = (int)nchunk;
+  p.slab_stride = (long long)d.K * d.C * T;
+  if (nchunk * p.slab_stride > ws_floats) return DPF_ERR_UNSUPPORTED;
+
+  const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
+  const size_t red = (size_t)2 * NCT * 16 * 64 * sizeof(float);
+  const size_t lds = 2 * buf > red ? 2 * buf : red;
+  const unsigned blocks = (unsigned)(p.kslices * p.cchunks * p.nchunk);
+  int rc;
+  switch (NCT) {
+    case 1: rc = launch_w2<1>(g, x, ws, p, lds, blocks, st); break;
+    case 2: rc = launch_w2<2>(g, x, ws, p, lds, blocks, st); break;
+    case 3: rc = launch_w2<3>(g, x, ws, p, lds, blocks, st); break;
+    case 4: rc = launch_w2<4>(g, x, ws, p, lds, blocks, st); break;
+    case 5: rc = launch_w2<5>(g, x, ws, p, lds, blocks, st); break;
+    case 6: rc = launch_w2<6>(g, x, ws, p, lds, blocks, st); break;
+    default: rc = launch_w2<7>(g, x, ws, p, lds, blocks, st); break;
+  }
+  if (rc != DPF_OK) return rc;
+  const long long n = p.slab_stride;
+  hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, st, ws, dw, n, p.nchunk);
+  return dpf_check_launch();
+}

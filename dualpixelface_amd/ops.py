@@ -137,7 +137,11 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
         return dw
     with _Timed('conv_wgrad', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW,
                 'wg  N%d C%d K%d x%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2])):
-        lib().call('dpf_conv_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, QD, QH, QW, kd, kh, kw, *stride, *pad, *dil, _stream())
+        L = lib()
+        nws = L.call('dpf_conv_wgrad_workspace_floats', kd * kh * kw, C, K)
+        ws = scratch(nws, x.device, 'wgradws')
+        L.call('dpf_conv_wgrad_ws', _ptr(g), _ptr(x), _ptr(dw), _ptr(ws), nws, N, C, ID, IH, IW, K, QD, QH, QW, kd, kh, kw, *stride, *pad, *dil,
+               _stream())
     return dw
 
 

@@ -50,9 +50,9 @@ for nm in names:
             if what == 'fwd':
                 ops.ConvFn.apply(x.detach(), w.detach(), None, st, pd, dl)
             elif what == 'dgrad':
-                torch.autograd.grad(y, x, go, retain_graph=True)
+                ops._conv_transpose_raw(go, w.detach(), None, x.shape[2:], w.shape[2:], st, pd, dl)
             else:
-                torch.autograd.grad(y, w, go, retain_graph=True)
+                ops._conv_wgrad_raw(go, x.detach(), w.shape, st, pd, dl)
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         t = min(ts[1:])
         res.append('%s %.3f ms %.1f TF' % (what, t * 1e3, flops / t * 1e-12))
