@@ -82,6 +82,25 @@ def stage_bench(args):
                                    'algorithmic_bytes_per_step': alg_bytes}}))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks (one process per GPU, torch.distributed.run on 127.0.0.1) as
+    CHILD processes -- this process has not touched the GPU and never execs -- and relay rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in r.stdout.splitlines():
+        if line.startswith('{'):
+            print(line)
+    sys.stdout.flush()
+    sys.exit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -102,6 +121,9 @@ def main():
                     help="'train' = the BASELINE metric; the other two time one HBM-bound stage in isolation (BASELINE configs[3], SURVEY a2-a4)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ and args.workload == 'train':
+        return self_launch(args.gpus)
+
     from dualpixelface_amd import load_option, ops
     from dualpixelface_amd.distributed import init_from_env, make_reducer, broadcast_flat
     from dualpixelface_amd.plugin import PSMNET, STEREODPNET
@@ -112,7 +134,7 @@ def main():
         return stage_bench(args)
     # test hooks (tests/test_gpu_distributed.py): DPF_DIST_BACKEND=gloo and DPF_ONE_DEVICE=1 let two ranks share the one GPU of a test box
     rank, world, local = init_from_env(os.environ.get('DPF_DIST_BACKEND'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or without RANK set)' % (args.gpus, world, args.gpus)
     if os.environ.get('DPF_ONE_DEVICE'):
         local = 0
     dev = torch.device('cuda', local)
@@ -187,7 +209,7 @@ def main():
                     'families': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3} for k, v in fam.items()}}
         pixels = args.height * args.width
         line = {
-            'metric': 'train samples/sec, %s 1024x1536 DP pair' % ('PSMNet' if args.model == 'psmnet' else 'StereoDPNet'), 'value': value, 'unit': 'samples/s', 'n_gpus': world,
+            'metric': 'train samples/sec, %s %dx%d DP pair' % ('PSMNet' if args.model == 'psmnet' else 'StereoDPNet', args.height, args.width), 'value': value, 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16 2-D conv operands, f32 elsewhere',
             'data': 'synthetic',

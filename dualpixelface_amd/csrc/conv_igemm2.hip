@@ -229,6 +229,214 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 transposed 3x3x3 convolution (pad 1, dilation 1): data gradient of the hourglass' stride-2 convs and the forward of
+// its nn.ConvTranspose3d layers (src/model/stereodpnet/modules.py:215-227).  out[n,k,2q+r] = sum_{c,t} W'[c,k,t] x[n,c,q+e(r,t)]:
+// per dimension the output parity r = 0 meets one tap (t = 1, e = 0) and r = 1 meets two (t = 0, e = 1; t = 2, e = 0).  The
+// first-generation kernel ran the 8 parity classes as 8 workgroups that each re-staged the same input patch (36.7 TFLOP/s);
+// here ONE workgroup stages the patch of a 4 x 32 q-tile once per channel chunk and keeps the accumulators of all 8 classes
+// (8 x 16 registers per wave, one q-row per wave): 27 (class, tap) MFMAs per channel pair, their B operands being just the 8
+// shifted views e in {0,1}^3 of the patch.  Same LDS-DMA double buffering and zero-page padding as igemm2_kernel.
+struct T2P {
+  int N, C, K, Ktot, k0;
+  int ID, IH, IW, OD, OH, OW;
+  int RS, SR, rpc, chanStride, nseg, nwseg, nchunks;
+  int tilesH, tilesW, ntiles, cpx, QD;
+  unsigned mSR, mRPC, mEH;
+};
+
+struct T2Combo { int cls, tap; };
+struct T2Unit { int e, n; T2Combo c[8]; };
+struct T2Table { T2Unit u[8]; };
+
+// units in issue order (sizes 8,4,4,2,2,2,1,4): shift e = (ed, eh, ew); per dimension shift 0 serves (r=0, t=1) and (r=1, t=2),
+// shift 1 serves (r=1, t=0)
+constexpr T2Table t2_table() {
+  T2Table tb{};
+  const int order[8] = {0, 1, 2, 3, 5, 6, 7, 4};
+  for (int ui = 0; ui < 8; ++ui) {
+    const int e = order[ui];
+    const int es[3] = {e >> 2, (e >> 1) & 1, e & 1};
+    T2Unit& u = tb.u[ui];
+    u.e = e;
+    u.n = 0;
+    for (int a = 0; a < 2; ++a) {
+      if (es[0] == 1 && a == 1) continue;
+      for (int b = 0; b < 2; ++b) {
+        if (es[1] == 1 && b == 1) continue;
+        for (int c = 0; c < 2; ++c) {
+          if (es[2] == 1 && c == 1) continue;
+          // option index 0: (shift 0 -> r=0,t=1 | shift 1 -> r=1,t=0); option 1 (shift 0 only): r=1,t=2
+          const int rd = es[0] == 1 ? 1 : a, td = es[0] == 1 ? 0 : (a ? 2 : 1);
+          const int rh = es[1] == 1 ? 1 : b, th = es[1] == 1 ? 0 : (b ? 2 : 1);
+          const int rw = es[2] == 1 ? 1 : c, tw = es[2] == 1 ? 0 : (c ? 2 : 1);
+          u.c[u.n].cls = rd * 4 + rh * 2 + rw;
+          u.c[u.n].tap = (td * 3 + th) * 3 + tw;
+          ++u.n;
+        }
+      }
+    }
+  }
+  return tb;
+}
+
+template <int CC>
+__global__ __launch_bounds__(256, 2) void igemm2_tr2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                            const float* __restrict__ bias, float* __restrict__ out, T2P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KT = 32;
+  constexpr T2Table TB = t2_table();
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = (blockIdx.x & 7) * p.cpx + (blockIdx.x >> 3);
+  if (b >= p.ntiles) return;
+  const int qd = b % p.QD; b /= p.QD;
+  const int tw = b % p.tilesW; b /= p.tilesW;
+  const int th = b % p.tilesH;
+  const int n = b / p.tilesH;
+  const int q0h = th * 4, q0w = tw * 32;
+
+  const int patchFloats = CC * p.chanStride;
+  const int bufFloats = patchFloats + 27 * CC * KT;
+  const long long x_chan = (long long)p.ID * p.IH * p.IW;
+  const float* xn = x + (long long)n * p.C * x_chan;
+
+  int goff[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const unsigned f = tid + 256 * j;
+    const unsigned row = (f * p.mSR) >> 20;
+    const int seg = f - row * p.SR;
+    const unsigned cc = (row * p.mRPC) >> 20;
+    const unsigned rem = row - cc * p.rpc;
+    const unsigned pl = (rem * p.mEH) >> 20;            // ext_h = 5 rows per plane
+    const int rr = rem - pl * 5;
+    const int id = qd + (int)pl, ih = q0h + rr, iw = q0w + 4 * seg;
+    const bool ok = (int)f < p.nseg && id < p.ID && ih < p.IH && iw < p.IW;
+    goff[j] = ok ? (int)((long long)cc * x_chan + ((long long)id * p.IH + ih) * p.IW + iw) : -1;
+  }
+  auto issue = [&](int chunk, int buf) {
+    float* dbase = smem + buf * bufFloats;
+    const float* xc = xn + (long long)chunk * CC * x_chan;
+    const int crem = p.C - chunk * CC;
+    const int flimit = (crem < CC ? crem : CC) * p.rpc * p.SR;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      if (j * 256 < p.nseg) {
+        const int f = tid + 256 * j;
+        if (f < p.nseg) {
+          const float* src = (goff[j] >= 0 && f < flimit) ? xc + goff[j] : wpk;
+          glds16(src, dbase + (j * 256 + wave * 64) * 4);
+        }
+      }
+    }
+    const float* wc = wpk + ZPAGE + (long long)chunk * p.nwseg * 4;
+    float* wbase = dbase + patchFloats;
+    for (int f0 = wave * 64; f0 < p.nwseg; f0 += 256) {
+      const int f = f0 + lane;
+      if (f < p.nwseg) glds16(wc + f * 4, wbase + f0 * 4);
+    }
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[c][j] = 0.f;
+
+  // B operand of shift e for this lane: patch[(2cp+hh)][ed][wave + eh][l31 + ew]
+  const int planeStride = 5 * p.RS;
+  int shoff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) shoff[e] = (e >> 2) * planeStride + (wave + ((e >> 1) & 1)) * p.RS + l31 + (e & 1) + hh * p.chanStride;
+  const int abase = hh * KT + l31;
+  const int chanStride = p.chanStride;
+
+  issue(0, 0);
+  __syncthreads();
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < p.nchunks) issue(chunk + 1, buf ^ 1);
+    const float* s_in = smem + buf * bufFloats;
+    const float* s_w = s_in + patchFloats + abase;
+    // units of (channel pair, shift) software pipelined over two register sets
+    float aA[8], aB[8], bA, bB;
+    auto load_unit = [&](int cp, int ui, float (&a)[8], float& bv) {
+      const T2Unit& u = TB.u[ui];
+      bv = s_in[shoff[u.e] + (2 * cp) * chanStride];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < u.n) a[i] = s_w[(u.c[i].tap * CC + 2 * cp) * KT];
+    };
+    auto mfma_unit = [&](int ui, const float (&a)[8], float bv) {
+      const T2Unit& u = TB.u[ui];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < u.n) acc[u.c[i].cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv, acc[u.c[i].cls], 0, 0, 0);
+    };
+    auto touch = [&](int ui, const float (&a)[8], float bv) {
+      asm volatile("" ::"v"(bv));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < TB.u[ui].n) asm volatile("" ::"v"(a[i]));
+      asm volatile("" ::: "memory");
+    };
+    load_unit(0, 0, aA, bA);
+#pragma unroll
+    for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+      for (int ui = 0; ui < 8; ++ui) {
+        const int ncp = ui + 1 < 8 ? cp : cp + 1, nui = ui + 1 < 8 ? ui + 1 : 0;
+        if ((ui & 1) == 0) {
+          touch(ui, aA, bA);
+          if (ncp < CC / 2) load_unit(ncp, nui, aB, bB);
+          __builtin_amdgcn_sched_barrier(6);
+          mfma_unit(ui, aA, bA);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          touch(ui, aB, bB);
+          if (ncp < CC / 2) load_unit(ncp, nui, aA, bA);
+          __builtin_amdgcn_sched_barrier(6);
+          mfma_unit(ui, aB, bB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: classes (rd, rh, 0) and (rd, rh, 1) interleave along W: one 8-byte store per lane covers ow = 2q, 2q+1
+  const int qh = q0h + wave, qw = q0w + l31;
+  const long long out_plane = (long long)p.OH * p.OW;
+  const long long kstride = (long long)p.OD * out_plane;
+  float* on = out + ((long long)n * p.Ktot + p.k0) * kstride;
+  const bool pair_ok = ((p.OW & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+      const int od = 2 * qd + rd, oh = 2 * qh + rh, ow = 2 * qw;
+      if (od >= p.OD || oh >= p.OH || ow >= p.OW) continue;
+      float* op = on + ((long long)od * p.OH + oh) * p.OW + ow;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (k < p.K) {
+          const float bv = bias ? bias[p.k0 + k] : 0.f;
+          const float v0 = acc[rd * 4 + rh * 2][j] + bv, v1 = acc[rd * 4 + rh * 2 + 1][j] + bv;
+          float* o = op + (long long)k * kstride;
+          if (pair_ok) {
+            *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+          } else {
+            o[0] = v0;
+            if (ow + 1 < p.OW) o[1] = v1;
+          }
+        }
+      }
+    }
+}
+
 // wpk[0, ZPAGE) = 0;  wpk[ZPAGE + ((chunk*T + t)*CC + cc)*KT + k] = w(out = k0 + k, reduce = chunk*CC + cc, tap = t), zero padded
 __global__ void igemm2_pack_kernel(const float* __restrict__ w, float* __restrict__ wpk, int wA, int wB, int T, int KT, int CC, int nchunks,
                                    int mode, int k0, int K, int C) {
@@ -275,6 +483,62 @@ int launch_g2(const float* x, const float* wpk, const float* bias, float* out, c
 
 }  // namespace
 
+
+namespace {
+template <int CC>
+int launch_t2(const float* x, const float* wpk, const float* bias, float* out, const T2P& p, size_t lds, hipStream_t st) {
+  static bool done = false;
+  if (lds > 48 * 1024 && !done) {
+    if (hipFuncSetAttribute((const void*)igemm2_tr2_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DPF_ERR_LAUNCH;
+    done = true;
+  }
+  hipLaunchKernelGGL((igemm2_tr2_kernel<CC>), dim3(8u * p.cpx), dim3(256), lds, st, x, wpk, bias, out, p);
+  return dpf_check_launch();
+}
+
+// stride-2 transposed 3x3x3 (pad 1): loops over 32-channel output slices
+int igemm2_tr2(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st) {
+  static const int enabled = env_int("DPF_IGEMM2_TR2", 1), cc_over = env_int("DPF_T2_CC", 0);
+  if (!enabled) return DPF_ERR_UNSUPPORTED;
+  if (d.kd != 3 || d.kh != 3 || d.kw != 3 || d.sd != 2 || d.sh != 2 || d.sw != 2 || d.pd != 1 || d.ph != 1 || d.pw != 1 || d.dd != 1 ||
+      d.dh != 1 || d.dw != 1)
+    return DPF_ERR_UNSUPPORTED;
+  // output extents an input of (ID, IH, IW) can reach: o = 2q + r <= 2*(I-1) + 1; larger outputs (not produced by these layers) -> generic kernel
+  if (d.OD > 2 * d.ID || d.OH > 2 * d.IH || d.OW > 2 * d.IW) return DPF_ERR_UNSUPPORTED;
+  const long long x_chan = (long long)d.ID * d.IH * d.IW;
+  if (9 * x_chan >= (1LL << 30)) return DPF_ERR_UNSUPPORTED;
+  const int CC = (cc_over == 4 || cc_over == 8 || cc_over == 2) ? cc_over : 8;
+  T2P p{};
+  p.N = d.N; p.C = d.C; p.Ktot = d.Ktot;
+  p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.OD = d.OD; p.OH = d.OH; p.OW = d.OW;
+  p.RS = 36; p.SR = 9; p.rpc = 2 * 5; p.chanStride = p.rpc * p.RS;
+  p.nseg = CC * p.rpc * p.SR;
+  p.nwseg = 27 * CC * 32 / 4;
+  p.nchunks = (d.C + CC - 1) / CC;
+  p.QD = dpf_div_up(d.OD, 2);
+  p.tilesH = dpf_div_up(dpf_div_up(d.OH, 2), 4);
+  p.tilesW = dpf_div_up(dpf_div_up(d.OW, 2), 32);
+  const long long ntiles = (long long)d.N * p.QD * p.tilesH * p.tilesW;
+  if (ntiles <= 0 || ntiles > 0x3fffffffLL) return DPF_ERR_INVALID_ARG;
+  p.ntiles = (int)ntiles;
+  p.cpx = (int)((ntiles + 7) / 8);
+  p.mSR = magic20(p.SR); p.mRPC = magic20(p.rpc); p.mEH = magic20(5);
+  const size_t lds = 2 * (size_t)(CC * p.chanStride + 27 * CC * 32) * sizeof(float);
+  for (int k0 = 0; k0 < d.K; k0 += 32) {
+    const int Kc = d.K - k0 < 32 ? d.K - k0 : 32;
+    p.K = Kc; p.k0 = d.k0 + k0;
+    const long long total = (long long)p.nchunks * 27 * CC * 32 + ZPAGE;
+    hipLaunchKernelGGL(igemm2_pack_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, ws, d.wA, d.wB, 27, 32, CC, p.nchunks, d.mode, p.k0, Kc, d.C);
+    if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
+    int rc;
+    switch (CC) { case 2: rc = launch_t2<2>(x, ws, bias, out, p, lds, st); break; case 4: rc = launch_t2<4>(x, ws, bias, out, p, lds, st); break;
+                  default: rc = launch_t2<8>(x, ws, bias, out, p, lds, st); break; }
+    if (rc != DPF_OK) return rc;
+  }
+  return DPF_OK;
+}
+}  // namespace
+
 long long dpf_igemm2_workspace_floats(int T, int reduce, int outc) {
   const int KT = 32 * (((outc < 128 ? outc : 128) + 31) / 32);
   return (long long)T * (reduce + 8) * KT + ZPAGE;
@@ -285,11 +549,11 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   if (!enabled) return DPF_ERR_UNSUPPORTED;
   const int T = d.kd * d.kh * d.kw;
   if (T > MAXT || d.K > 128) return DPF_ERR_UNSUPPORTED;
-  if (d.transposed && (d.sd != 1 || d.sh != 1 || d.sw != 1)) return DPF_ERR_UNSUPPORTED;
   if ((d.IW & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15)) return DPF_ERR_UNSUPPORTED;
   const long long x_chan = (long long)d.ID * d.IH * d.IW;
   if (9 * x_chan >= (1LL << 30)) return DPF_ERR_UNSUPPORTED;      // per-lane 32-bit source offsets within a chunk
   if (T == 1 && !env_int("DPF_IGEMM2_1x1", 0)) return DPF_ERR_UNSUPPORTED;   // pointwise convs are HBM-bound: generic kernel
+  if (d.transposed && (d.sd != 1 || d.sh != 1 || d.sw != 1)) return igemm2_tr2(x, w, bias, out, ws, d, st);
 
   const int MT = (d.K + 31) / 32, KT = 32 * MT;
   static const int nt_over = env_int("DPF_G2_NT", 0), cc_over = env_int("DPF_G2_CC", 0), lds_target = env_int("DPF_G2_LDS", 53 * 1024);

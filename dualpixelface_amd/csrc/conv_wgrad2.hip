@@ -37,7 +37,7 @@ struct W2P {
   int N, C, K, Ktot, k0;
   int ID, IH, IW, QD, QH, QW;
   int sd, sh, sw, pd, ph, pw;
-  int kd, kh, kw, T;
+  int kd, kh, kw, dd, dh, dw, T;
   int ext_d, ext_h, RS, SR, PS, CS, PSseg, CSseg, colshift;   // x image: row / plane / channel strides (floats, segments)
   int CCW, cchunks, kslices, nxseg;
   int tilesH, tilesW, nchunk;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
     const int cc = cn / p.T;
     const int tap = cn - cc * p.T;
     const int tw_ = tap % p.kw, th_ = (tap / p.kw) % p.kh, td_ = tap / (p.kw * p.kh);
-    colbase[t] = cc * p.CS + td_ * p.PS + (th_ + wave * p.sh) * p.RS + tw_ + p.colshift + 4 * hh * p.sw;
+    colbase[t] = cc * p.CS + td_ * p.dd * p.PS + (th_ * p.dh + wave * p.sh) * p.RS + tw_ * p.dw + p.colshift + 4 * hh * p.sw;
   }
 
   // ---- x-patch DMA descriptors: flat segment f -> (cc, plane, row, seg); tile independent
@@ -301,7 +301,7 @@ int gather_conflicts(const DpfWgradDesc& d, int T, int ncolmax, int RS, int PS, 
     for (int l = 0; l < 32 && c0 + l < ncolmax; ++l) {
       const int col = c0 + l, cc = col / T, tap = col % T;
       const int tw = tap % d.kw, th = (tap / d.kw) % d.kh, td = tap / (d.kw * d.kh);
-      ++cnt[(cc * CS + td * PS + th * RS + tw) & 31];
+      ++cnt[(cc * CS + td * d.dd * PS + th * d.dh * RS + tw * d.dw) & 31];
     }
     int worst = 0;
     for (int b = 0; b < 32; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
@@ -344,7 +344,8 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   const int T = d.kd * d.kh * d.kw;
   if (T > 27 || T < 9 || d.K > 128) return DPF_ERR_UNSUPPORTED;
   if ((d.IW & 3) || (d.QW & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(g) & 15)) return DPF_ERR_UNSUPPORTED;
-  if (d.dh != 1 || d.dw != 1 || d.dd != 1) return DPF_ERR_UNSUPPORTED;        // dilated: polyphase kernel (conv_igemm.hip)
+  static const int maxdil = env_int("DPF_W2_MAXDIL", 8);
+  if (d.dh > maxdil || d.dw > maxdil || d.dd > maxdil) return DPF_ERR_UNSUPPORTED;   // widely dilated: polyphase kernel (conv_igemm.hip)
   if (d.sw > 2 || d.sh > 2) return DPF_ERR_UNSUPPORTED;
   const long long x_chan = (long long)d.ID * d.IH * d.IW;
   static const int nct_max = env_int("DPF_W2_NCT", 7), lds_max = env_int("DPF_W2_LDS", 80 * 1024);
@@ -353,9 +354,9 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   p.N = d.N; p.C = d.C; p.K = d.K; p.Ktot = d.Ktot; p.k0 = d.k0;
   p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.QD = d.QD; p.QH = d.QH; p.QW = d.QW;
   p.sd = d.sd; p.sh = d.sh; p.sw = d.sw; p.pd = d.pd; p.ph = d.ph; p.pw = d.pw;
-  p.kd = d.kd; p.kh = d.kh; p.kw = d.kw; p.T = T;
-  p.ext_d = d.kd; p.ext_h = (WTH - 1) * d.sh + d.kh;
-  const int ext_w = 31 * d.sw + d.kw;
+  p.kd = d.kd; p.kh = d.kh; p.kw = d.kw; p.dd = d.dd; p.dh = d.dh; p.dw = d.dw; p.T = T;
+  p.ext_d = (d.kd - 1) * d.dd + 1; p.ext_h = (WTH - 1) * d.sh + (d.kh - 1) * d.dh + 1;
+  const int ext_w = 31 * d.sw + (d.kw - 1) * d.dw + 1;
   p.colshift = (((-d.pw) % 4) + 4) % 4;
   p.RS = ((p.colshift + ext_w + 3) / 4) * 4;
   p.SR = p.RS / 4;

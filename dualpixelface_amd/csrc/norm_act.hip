@@ -214,8 +214,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ res, int act, const float* __restrict__ slope_p,
                                                            float slope_c, const float* __restrict__ sums, float inv_count,
                                                            int training, float* __restrict__ dx, float* __restrict__ dres, int C,
-                                                           long long S) {
+                                                           long long S, const float* __restrict__ count_dev) {
   const int row = blockIdx.y;
+  if (count_dev) inv_count = 1.f / count_dev[0];     // SyncBatchNorm: the global element count, summed over the ranks on the device
   const int c = row % C;
   float mu = 0.f, is = 1.f, g = 1.f, be = 0.f, m_dz = 0.f, m_dzx = 0.f;
   if (mean) {
@@ -381,7 +382,8 @@ int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd,
 // Backward of dpf_norm_act_forward w.r.t. x, res, w, b, slope (res2's gradient is dy itself).
 // ws: >= 3*C floats.  dweight/dbias [wmod], dslope [1] are WRITTEN (=); any may be NULL.
 // phase 0: everything.  phase 1: only the per-channel reductions (ws[3c] = sum dz, ws[3c+1] = sum dz*xhat) and the parameter
-// gradients; phase 2: only dx / dres from a ws the caller has summed over the ranks, with count = global N*S (SyncBatchNorm).
+// gradients; phase 2: only dx / dres from a ws the caller has summed over the ranks, with count = global N*S (SyncBatchNorm), or
+// count < 0: the global count is read from ws[3*C] (the caller put its local count there before the all-reduce: no host sync).
 int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
                              int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
                              float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, int phase,
@@ -401,9 +403,11 @@ int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean,
   }
   if ((dx || dres) && phase != 1) {
     // instance-norm view (wmod < C): statistics are per row, count = S; batch norm: count = N*S
+    // phase 2 with count < 0: ws[3*C] holds the global element count (the caller all-reduced its local count with the sums)
+    const float* count_dev = (phase == 2 && count < 0) ? ws + 3 * (long long)C : nullptr;
     if (count <= 0) count = (double)N * (double)S;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope,
-                       slope_const, ws, (float)(1.0 / count), training, dx, dres, C, S);
+                       slope_const, ws, (float)(1.0 / count), training, dx, dres, C, S, count_dev);
   }
   return dpf_check_launch();
 }

@@ -23,7 +23,9 @@ def init_from_env(backend=None):
     if backend == 'nccl':
         torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # long timeout: ranks wait in a barrier while rank 0 validates (trainer.py)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(hours=4))
     return rank, world, local
 
 
@@ -124,7 +126,6 @@ class StatExchange(object):
     def __init__(self, group=None):
         self.group = group
         self.world_size = dist.get_world_size(group)
-        self._counts = {}
 
     def all_gather(self, t):
         out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
@@ -135,14 +136,3 @@ class StatExchange(object):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def total_count(self, local_count):
-        """Global element count for a local count.  Cached per local count: ranks are assumed to change batch shape together
-        (DistributedSampler pads the last batch), which keeps the host out of the per-layer critical path."""
-        key = int(local_count)
-        if key not in self._counts:
-            t = torch.tensor([float(local_count)], dtype=torch.float64)
-            if dist.get_backend(self.group) == 'nccl':
-                t = t.cuda()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            self._counts[key] = float(t.item())
-        return self._counts[key]

@@ -22,6 +22,8 @@ class SMOOTHL1Loss(object):
     def forward(self, preds, batch, target_type='disp'):
         if target_type != 'disp':
             raise NotImplementedError('only the disparity target is on the hot path')
+        if 'conf' in batch:
+            raise NotImplementedError("confidence-weighted smooth-L1 (use_conf, smoothL1.py:33-36) is off the MI355X hot path")
         pd = preds['pred_depth']
         mask = batch['mask'] if 'mask' in batch else torch.ones_like(batch['disp'])
         out = ops.stereo_losses(pd, None, batch['disp'], None, mask, self.head_weights(pd.shape[1]), 1.0, 0.0)

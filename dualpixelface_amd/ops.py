@@ -313,7 +313,6 @@ class NormActFn(torch.autograd.Function):
         L = lib()
         mean = invstd = None
         n_, c_, wmod = N, C, C
-        count_total = 0.0
         if mode == 1 and exchange is not None:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
@@ -326,7 +325,6 @@ class NormActFn(torch.autograd.Function):
             counts = gathered[:, 2 * C].contiguous()
             L.call('dpf_bn_merge_moments', _ptr(moments), _ptr(counts), gathered.shape[0], C, BN_EPS, BN_MOMENTUM, _ptr(running_mean),
                    _ptr(running_var), _ptr(mean), _ptr(invstd), _stream())
-            count_total = exchange.total_count(N * S)
         elif mode == 1:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
@@ -349,7 +347,6 @@ class NormActFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, bias, slope, res, mean, invstd)
         ctx.cfg = (mode, act, float(slope_const), n_, c_, S, wmod, res2 is not None)
         ctx.exchange = exchange if mode == 1 else None
-        ctx.count_total = count_total
         return y
 
     @staticmethod
@@ -370,10 +367,13 @@ class NormActFn(torch.autograd.Function):
                 training, _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), _ptr(dslope))
         if ctx.exchange is not None:
             # SyncBatchNorm: local reductions, sum over the ranks, then dx with the global element count
-            ws = torch.empty(3 * c_, dtype=torch.float32, device=x.device)
+            # ws[3C] carries this rank's element count through the same all-reduce: uneven per-rank batches need no extra
+            # collective and no host synchronisation
+            ws = torch.empty(3 * c_ + 1, dtype=torch.float32, device=x.device)
             L.call('dpf_norm_act_backward_ex', *args, _ptr(ws), n_, c_, S, 1, 0.0, _stream())
+            ws[3 * c_:].fill_(float(n_) * float(S))
             ctx.exchange.all_reduce_sum_(ws)
-            L.call('dpf_norm_act_backward_ex', *args, _ptr(ws), n_, c_, S, 2, float(ctx.count_total), _stream())
+            L.call('dpf_norm_act_backward_ex', *args, _ptr(ws), n_, c_, S, 2, -1.0, _stream())
         else:
             ws = scratch(3 * c_, x.device)
             L.call('dpf_norm_act_backward', *args, _ptr(ws), n_, c_, S, _stream())
@@ -809,15 +809,21 @@ class LossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred_depth, pred_normal, disp, normal, mask, head_weights, lam_d, lam_n):
-        pred_depth, disp, mask = _c(pred_depth), _c(disp), _c(mask)
+        # either prediction may be None (a loss used on its own: losses.SMOOTHL1Loss / COSINELoss)
+        pred_depth = None if pred_depth is None else _c(pred_depth)
+        disp = None if disp is None else _c(disp)
+        mask = _c(mask)
         pred_normal = None if pred_normal is None else _c(pred_normal)
         normal = None if normal is None else _c(normal)
         _need(pred_depth, pred_normal, disp, normal, mask)
-        B, n, H, W = pred_depth.shape
-        acc = torch.empty(n + 2, dtype=torch.float32, device=pred_depth.device)
-        out = torch.empty(3, dtype=torch.float32, device=pred_depth.device)
+        if pred_depth is not None:
+            B, n, H, W = pred_depth.shape
+        else:
+            (B, _, H, W), n = pred_normal.shape, 0
+        acc = torch.empty(n + 2, dtype=torch.float32, device=mask.device)
+        out = torch.empty(3, dtype=torch.float32, device=mask.device)
         lib().call('dpf_loss_forward', _ptr(pred_depth), _ptr(pred_normal), _ptr(disp), _ptr(normal), _ptr(mask), _ptr(acc), _ptr(out), B, n,
-                   H, W, _host_floats(head_weights), float(lam_d), float(lam_n), _stream())
+                   H, W, _host_floats(head_weights if n else [0.0]), float(lam_d), float(lam_n), _stream())
         ctx.save_for_backward(pred_depth, pred_normal, disp, normal, mask, acc)
         ctx.cfg = (tuple(head_weights), float(lam_d), float(lam_n), B, n, H, W)
         return out
@@ -827,10 +833,10 @@ class LossFn(torch.autograd.Function):
         pred_depth, pred_normal, disp, normal, mask, acc = ctx.saved_tensors
         head_weights, lam_d, lam_n, B, n, H, W = ctx.cfg
         gout = _c(gout)
-        dpd = torch.empty_like(pred_depth)
+        dpd = torch.empty_like(pred_depth) if pred_depth is not None else None
         dpn = torch.empty_like(pred_normal) if pred_normal is not None else None
         lib().call('dpf_loss_backward', _ptr(pred_depth), _ptr(pred_normal), _ptr(disp), _ptr(normal), _ptr(mask), _ptr(acc), _ptr(gout),
-                   _ptr(dpd), _ptr(dpn), B, n, H, W, _host_floats(head_weights), lam_d, lam_n, _stream())
+                   _ptr(dpd), _ptr(dpn), B, n, H, W, _host_floats(head_weights if n else [0.0]), lam_d, lam_n, _stream())
         return dpd, dpn, None, None, None, None, None, None
 
 

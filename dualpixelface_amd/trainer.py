@@ -11,7 +11,8 @@ flat arenas that a generic trainer would not know how to checkpoint, so this mod
     with the metric hooks every epoch, one checkpoint per epoch ``checkpoint_epoch=XX.ckpt``.
   * checkpoints hold ``state_dict`` under the reference's parameter names (a PL checkpoint of the reference loads into this
     model, and the other way round), the flat Adam moments, the step / epoch counters and the learning rate.
-  * one process per GPU under torchrun: rank-strided sampling of the training set, gradient all-reduce through
+  * one process per GPU under torchrun: the training set is sharded by SAMPLE with torch's DistributedSampler (own generator
+    seeded by (seed, epoch), padded so every rank runs the same number of equal-shape steps -- what PL does for the reference), gradient all-reduce through
     ``distributed.make_reducer``, SyncBatchNorm when ``option.sync_batch``; rank 0 writes checkpoints and logs.
 """
 import json
@@ -60,7 +61,7 @@ class Trainer(object):
         path = path or self.checkpoint_path(self.epoch)
         adam = model._adam or {}
         ckpt = {
-            'epoch': self.epoch, 'global_step': self.global_step,
+            'epoch': self.epoch + 1, 'global_step': self.global_step,      # PL 1.4.9 dump_checkpoint: the NEXT epoch to run
             'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
             'optimizer_states': [{'kind': 'flat_adam', 'step': int(adam.get('step', 0)),
                                   'm': adam['m'].detach().cpu() if 'm' in adam else None,
@@ -81,7 +82,7 @@ class Trainer(object):
         weights = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt['model']
         model.load_state_dict(weights, strict=bool(getattr(self.option, 'load_strict', True)))
         if resume:
-            self.epoch = int(ckpt.get('epoch', -1)) + 1                       # PL stores the finished epoch
+            self.epoch = int(ckpt.get('epoch', 0))                            # PL restores current_epoch = ckpt['epoch']
             self.global_step = int(ckpt.get('global_step', 0))
             states = ckpt.get('optimizer_states') or []
             if states and states[0].get('kind') == 'flat_adam' and states[0].get('m') is not None:
@@ -90,11 +91,24 @@ class Trainer(object):
         return ckpt
 
     # ------------------------------------------------------------------ loops
-    def _shard(self, loader):
-        """Rank-strided view of a loader's batches (DistributedSampler semantics without reshuffling the dataset object)."""
-        for i, batch in enumerate(loader):
-            if i % self.world_size == self.rank:
-                yield batch
+    def _shard(self, loader, epoch):
+        """This rank's batches of one epoch.  world_size 1: the loader as it is.  Otherwise the loader is rebuilt over the same
+        dataset with a DistributedSampler (shuffled by its own generator seeded with (seed, epoch), padded to a multiple of the
+        world size): every rank sees the same number of batches with the same shapes, so the per-step collectives always pair up."""
+        if self.world_size == 1:
+            return loader
+        key = id(loader)
+        if getattr(self, '_dist_key', None) != key:
+            from torch.utils.data import DataLoader
+            from torch.utils.data.distributed import DistributedSampler
+            self._dist_sampler = DistributedSampler(loader.dataset, num_replicas=self.world_size, rank=self.rank, shuffle=True,
+                                                    seed=int(getattr(self.option, 'seed', 1)), drop_last=False)
+            self._dist_loader = DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=self._dist_sampler,
+                                           num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
+                                           drop_last=loader.drop_last)
+            self._dist_key = key
+        self._dist_sampler.set_epoch(epoch)
+        return self._dist_loader
 
     def _to_device(self, batch, device):
         return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -141,7 +155,7 @@ class Trainer(object):
         while self.epoch < int(opt.epoch) and not done:
             lr = epoch_lr(opt, self.epoch)
             t0, n = time.time(), 0
-            for batch in self._shard(train_loader):
+            for batch in self._shard(train_loader, self.epoch):
                 batch = self._to_device(batch, device)
                 res = model.train_step(batch, reducer, lr=lr)
                 self.global_step += 1
@@ -159,6 +173,9 @@ class Trainer(object):
             if val_loader is not None and self.rank == 0 and not done:
                 rows = self.validate(model, val_loader)
                 self._log({'epoch': self.epoch, 'metrics': rows})
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.barrier()                 # the other ranks wait here, not inside the next epoch's first all-reduce
             self.save_checkpoint(model)
             self.epoch += 1
         if reducer is not None:

@@ -75,9 +75,10 @@ def _stat_worker(rank, world, port, out):
     M2 = ((mine - m.view(1, -1, 1, 1)) ** 2).sum((0, 2, 3))
     packed = torch.cat([torch.stack([m, M2], 1).reshape(-1), torch.tensor([float(count)])])
     gathered = ex.all_gather(packed)
-    total = ex.total_count(count)
-    ws = torch.full((3 * C,), float(rank + 1))
+    # the backward exchange: [3C] sums + this rank's element count in the last slot, one all-reduce (ops.NormActFn.backward)
+    ws = torch.cat([torch.full((3 * C,), float(rank + 1)), torch.tensor([float(count)])])
     ex.all_reduce_sum_(ws)
+    total, ws = float(ws[3 * C]), ws[:3 * C]
     out[rank] = (gathered.clone(), total, ws.clone())
     dist.destroy_process_group()
 

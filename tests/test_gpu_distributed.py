@@ -116,3 +116,20 @@ def test_bench_under_torchrun_two_ranks():
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak'
     assert d['config']['global_batch'] == 2 and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and abs(d['value'] - 2 * 2 / (d['ms_per_step'] * 2 / 1e3)) < 1e-6 * d['value'] + 1e-9
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2 ...` exactly as the driver may call it from a bare shell (no torchrun wrapper, no RANK in the
+    environment): bench.py spawns its own ranks as child processes before touching the GPU and relays rank 0's JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(DPF_DIST_BACKEND='gloo', DPF_ONE_DEVICE='1', PYTHONPATH=ROOT)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '1', '--height', '128', '--width', '192',
+           '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 and d['value'] > 0

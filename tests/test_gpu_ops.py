@@ -59,6 +59,8 @@ CONV_CASES = [
     (2, 32, 3, 37, 72, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     (1, 64, 5, 21, 44, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     (1, 32, 6, 22, 68, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),
+    (1, 32, 6, 22, 72, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),      # class-fused stride-2 data gradient (g rows 16-byte aligned)
+    (2, 48, 7, 13, 24, 33, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),      # odd extents: the data gradient's last plane / row / column has one parity only
     (1, 96, 1, 17, 36, 32, (1, 3, 3), (1, 1, 1), (0, 5, 5), (1, 5, 5)),
     (1, 32, 2, 40, 72, 32, (1, 3, 3), (1, 1, 1), (0, 4, 4), (1, 4, 4)),
     (2, 32, 1, 19, 40, 32, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 3, 3)),
@@ -87,7 +89,8 @@ def test_conv_forward_backward(case):
     close(gb, gb_r, 1e-4, 'conv bgrad')
 
 
-@pytest.mark.parametrize('shape', [(2, 64, 2, 4, 6, 64), (1, 64, 4, 8, 12, 32), (2, 64, 1, 3, 5, 32)])
+@pytest.mark.parametrize('shape', [(2, 64, 2, 4, 6, 64), (1, 64, 4, 8, 12, 32), (2, 64, 1, 3, 5, 32), (1, 64, 3, 5, 8, 32), (2, 35, 2, 6, 36, 64),
+                                   (1, 32, 5, 9, 40, 96)])
 def test_conv_transpose3d(shape):
     ops = _ops()
     N, Ci, D, H, W, Co = shape
@@ -166,15 +169,14 @@ class _TwoRankExchange(object):
         other = torch.cat([torch.stack([m1, M2], 1).reshape(-1), torch.tensor([float(self.count1)], device=packed.device)])
         return torch.stack([packed, other.to(packed.dtype)])
 
-    def total_count(self, local):
-        return float(local + self.count1)
-
     def all_reduce_sum_(self, ws):
         bshape = [1, -1] + [1] * (self.x1.dim() - 2)
         xh = (self.x1 - self.mean_g.view(bshape)) * self.invstd_g.view(bshape)
-        v = ws.view(-1, 3)
+        C = self.x1.shape[1]
+        v = ws[:3 * C].view(-1, 3)
         v[:, 0] += self.dz1.sum(self.dims)
         v[:, 1] += (self.dz1 * xh).sum(self.dims)
+        ws[3 * C] += float(self.count1)           # the other rank's element count rides in the last slot
         return ws
 
 

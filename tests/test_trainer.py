@@ -65,8 +65,70 @@ def test_checkpoint_every_epoch_and_resume(tmp_path):
     assert set(ck['state_dict']) == {'w', 'running'} and ck['optimizer_states'][0]['kind'] == 'flat_adam'
 
 
-def test_rank_strided_sharding():
+def test_sample_sharding_equal_steps_on_every_rank():
+    """world_size 3 over 7 samples, batch 2 (neither divides): every rank must see the same number of batches with the same shapes
+    (DistributedSampler padding), a different permutation per epoch that does not depend on the global RNG, and all samples covered."""
+    from torch.utils.data import DataLoader, Dataset
+
+    class DS(Dataset):
+        def __len__(self):
+            return 7
+
+        def __getitem__(self, i):
+            return {'x': torch.tensor([float(i)])}
+
     opt = load_option()
-    batches = list(range(7))
-    seen = [list(Trainer(opt, '.', rank=r, world_size=3)._shard(batches)) for r in range(3)]
-    assert seen == [[0, 3, 6], [1, 4], [2, 5]]
+    loader = DataLoader(DS(), batch_size=2, shuffle=True)
+    per_epoch = []
+    for epoch in range(2):
+        torch.manual_seed(epoch * 17)          # the global RNG state must not matter
+        seen = []
+        for r in range(3):
+            tr = Trainer(opt, '.', rank=r, world_size=3)
+            seen.append([b['x'].flatten().tolist() for b in tr._shard(loader, epoch)])
+        shapes = [[len(b) for b in s] for s in seen]
+        assert shapes[0] == shapes[1] == shapes[2] and len(shapes[0]) == 2, shapes
+        flat = sorted(int(v) for s in seen for b in s for v in b)
+        assert set(flat) == set(range(7)) and len(flat) == 9          # padded to 3 x 3 samples
+        per_epoch.append(seen)
+    assert per_epoch[0] != per_epoch[1]
+    assert list(Trainer(opt, '.', rank=0, world_size=1)._shard([1, 2, 3], 0)) == [1, 2, 3]
+
+
+def test_two_rank_trainer_gloo(tmp_path):
+    """Two gloo ranks through Trainer.fit on a batch count that is not divisible by the world size, with a short last batch and a
+    rank-0-only validation pass: both ranks must finish every epoch with the same number of steps (no hang, no mixed epochs)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_two_rank_worker, args=(2, str(tmp_path), 29500 + os.getpid() % 2000), nprocs=2, join=True)
+    steps = [int(open(os.path.join(str(tmp_path), 'steps%d.txt' % r)).read()) for r in range(2)]
+    assert steps[0] == steps[1] == 2 * 2, steps            # ceil(ceil(5/2)/2) = 2 batches per rank and epoch, 2 epochs
+
+
+def _two_rank_worker(rank, world, out, port):
+    import torch.distributed as dist
+    from torch.utils.data import DataLoader, Dataset
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    class DS(Dataset):
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return {'x': torch.tensor([float(i)])}
+
+    class Stub(_Stub):
+        def train_step(self, batch, reducer=None, lr=None):
+            t = batch['x'].sum().reshape(1).clone()
+            dist.all_reduce(t)                               # the per-step collective of the real model
+            return super().train_step(batch, reducer, lr)
+
+    opt = load_option()
+    opt.epoch, opt.scheduler, opt.sync_batch = 2, 'none', False
+    m = Stub()
+    import dualpixelface_amd.distributed as dd
+    dd.make_reducer = lambda model: None                     # the stub has no flat gradient arena
+    tr = Trainer(opt, out, rank=rank, world_size=world)
+    tr.fit(m, DataLoader(DS(), batch_size=2, shuffle=True), None)
+    open(os.path.join(out, 'steps%d.txt' % rank), 'w').write(str(len(m.steps)))
+    dist.destroy_process_group()
