@@ -615,6 +615,8 @@ struct RegCfg {
 
 struct RegGeo {
   int R;                   // halo on top of the kernel extent
+  int RYH;                 // halo along y (>= R: rows are cheap, the global-memory slow path of a sample that leaves the region is not)
+  int RXL;                 // left halo along x (>= R; chosen so that the region's first column is 16-byte aligned in global memory)
   int TZ, RZmax, RY, RX, RV;
   int tilesZ, tilesY, tilesX;
 };
@@ -637,8 +639,8 @@ __device__ __forceinline__ RegCtx region_ctx(const DcnP& p, const RegGeo& g, int
   if (rz1 > p.D) rz1 = p.D;
   c.RZ = rz1 - c.rz0;
   if (c.RZ > g.RZmax) c.RZ = g.RZmax;
-  c.ry0 = c.y0 * p.sh - p.ph - g.R;
-  c.rx0 = c.x0 * p.sw - p.pw - g.R;
+  c.ry0 = c.y0 * p.sh - p.ph - g.RYH;
+  c.rx0 = c.x0 * p.sw - p.pw - g.RXL;
   return c;
 }
 
@@ -671,6 +673,48 @@ __device__ __forceinline__ void stage_region(const DcnP& p, const RegGeo& g, con
         s_reg[(rem * g.RX + lane) * RegCfg<CH>::VS + ch] = v[u];
       }
     }
+  }
+}
+
+// Vectorised staging (needs W % 4 == 0, rx0 % 4 == 0, RX % 4 == 0, 16-byte aligned x): a unit = 4 channels x 4 consecutive x of
+// one region row, fetched as 4 float4 loads (one per channel), transposed in registers and written as 4 ds_write_b128 (one
+// per voxel of the channel-last image) -- 6x fewer load and 16x fewer LDS-write instructions than stage_region, all loads of
+// a thread in flight together.
+template <int CH>
+__device__ __forceinline__ void stage_region4(const DcnP& p, const RegGeo& g, const RegCtx& c, const float* __restrict__ xb, int c0, float* s_reg,
+                                              int tid, int nthreads) {
+  constexpr int VS = RegCfg<CH>::VS, NCG = CH / 4;
+  const long long chan = (long long)p.D * p.H * p.W;
+  const int SR = g.RX >> 2;
+  const int units = c.RZ * g.RY * NCG * SR;
+  for (int u = tid; u < units; u += nthreads) {
+    const int seg = u % SR;
+    const int it = u / SR;
+    const int cg = it % NCG;
+    const int row = it / NCG;
+    const int lz = row / g.RY, ly = row - lz * g.RY;
+    const int gz = c.rz0 + lz, gy = c.ry0 + ly, gx = c.rx0 + 4 * seg;
+    const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    const float* src = xb + (long long)(c0 + 4 * cg) * chan + ((long long)gz * p.H + gy) * p.W + gx;
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (ok && c0 + 4 * cg + q < p.C) ? *reinterpret_cast<const float4*>(src + q * chan) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* dst = s_reg + ((long long)(row * g.RX + 4 * seg)) * VS + 4 * cg;
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+    *reinterpret_cast<float4*>(dst + VS) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+    *reinterpret_cast<float4*>(dst + 2 * VS) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+    *reinterpret_cast<float4*>(dst + 3 * VS) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+  }
+}
+
+// picks the vectorised staging when the geometry allows it
+template <int CH>
+__device__ __forceinline__ void stage_region_any(const DcnP& p, const RegGeo& g, const RegCtx& c, const float* __restrict__ xb, int c0, float* s_reg,
+                                                 int tid, int nthreads, bool vec) {
+  if (vec) {
+    stage_region4<CH>(p, g, c, xb, c0, s_reg, tid, nthreads);
+  } else {
+    stage_region<CH>(p, g, c, xb, c0, s_reg, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, nthreads >> 6);
   }
 }
 
@@ -1010,6 +1054,140 @@ __global__ __launch_bounds__(512) void dcn_fwd_region8_kernel(const float* __res
   }
 }
 
+// ---- role-split forward: waves 0-3 SAMPLE (one output voxel per thread, all CH channels of the staged chunk: VALU + LDS reads),
+// waves 4-7 CONTRACT (64 voxels per wave on the fp32 matrix cores).  The sampled tile S[CH][256] is double buffered, so the
+// samplers build tap t+1 while the MFMA waves consume tap t: one barrier per tap instead of two, and the vector / LDS pipes and the
+// matrix pipe of every SIMD (which hosts one wave of each role) run concurrently.  The 4- and 8-wave kernels above alternate the
+// two phases with every wave in lockstep at one workgroup per CU (LDS), which leaves each pipe idle for the other's phase.
+constexpr int STR = 256;   // row of the [CH][256] sample tile (lane-consecutive writes and reads: no padding needed)
+// NW = 8: 4 sampler waves (a voxel per thread, all CH channels) + 4 MFMA waves (64 voxels each).
+// NW = 16: 8 sampler waves (a thread PAIR per voxel, half the channels each) + 8 MFMA waves (32 voxels each): four waves per SIMD --
+//          the kernel is latency bound at one LDS-limited workgroup per CU (measured: MFMA 25 %, VALU 17 %, LDS 20 % busy with 8 waves).
+template <int MT, int CH, int NW>
+__global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                             const float* __restrict__ wt /*[T][Cpad][KT], zero rows beyond C*/,
+                                                             const float* __restrict__ bias, float* __restrict__ out, DcnP p, RegGeo g, int vec) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int KT = 32 * MT;
+  constexpr int NS = NW / 2;                          // sampler waves = MFMA waves
+  constexpr int NTW = 8 / NS;                         // 32-voxel column tiles per MFMA wave (2 or 1)
+  constexpr int NC = CH / 2;
+  float* s_reg = smem;                                // [RV][VS]
+  float* s_S = s_reg + RegCfg<CH>::VS * g.RV;         // [2][CH][STR]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool sampler = wave_u < NS;
+  const int mw = wave_u - NS;                          // MFMA wave index
+  const int half = wave_u >> 2;                        // NW = 16: sampler waves 0-3 take channels [0, CH/2), 4-7 the rest
+  const int vox = tid & 255;
+  const RegCtx c = region_ctx(p, g, blockIdx.x);
+  const long long chan = (long long)p.D * p.H * p.W;
+  const float* xb = x + (long long)c.b * p.C * chan;
+  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
+  const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
+  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
+  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
+
+  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
+  const int Cpad = (p.C + CH - 1) / CH * CH;
+  const float* offp0 = off_b + (pvalid ? ppos : 0);
+  for (int c0 = 0; c0 < p.C; c0 += CH) {
+    __syncthreads();                                   // samplers are done with the previous chunk's region
+    stage_region_any<CH>(p, g, c, xb, c0, s_reg, tid, 64 * NW, vec != 0);
+    __syncthreads();
+    if (sampler) {
+      const float* offp = offp0;
+      Off3 onext = load_off_ptr(offp, p.P, pvalid);
+      TapIt it = {0, 0, 0};
+      for (int t = 0; t < p.T; ++t) {
+        const Off3 ocur = onext;
+        offp += 3 * p.P;
+        onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);
+        const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
+        tap_next(p, it);
+        const Samp sp = make_samp(p, g, c, cn);
+        float* dst = s_S + (t & 1) * (CH * STR) + vox;
+        if (NW == 8) {
+          float val[CH];
+          sample_chunk<CH>(p, g, sp, cn, s_reg, xb, c0, chan, val);
+#pragma unroll
+          for (int ch = 0; ch < CH; ++ch) dst[ch * STR] = val[ch];
+        } else {
+          float val[NC];
+          if (half == 0) sample_half<CH, 0>(p, g, sp, cn, s_reg, xb, c0, chan, val);
+          else sample_half<CH, 1>(p, g, sp, cn, s_reg, xb, c0, chan, val);
+#pragma unroll
+          for (int ch = 0; ch < NC; ++ch) dst[(half * NC + ch) * STR] = val[ch];
+        }
+        __syncthreads();                               // barrier t: S[t&1] is complete; the MFMA waves have finished reading S[(t-1)&1]
+      }
+    } else {
+      // weight fragments of tap t are fetched (L2) one tap ahead
+      float aN[CH / 2][MT];
+      {
+        const float* wtt = wt + ((long long)c0 + hh) * KT + l31;
+#pragma unroll
+        for (int sx = 0; sx < CH / 2; ++sx)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) aN[sx][m] = wtt[(2 * sx) * KT + m * 32];
+      }
+      for (int t = 0; t < p.T; ++t) {
+        float a[CH / 2][MT];
+#pragma unroll
+        for (int sx = 0; sx < CH / 2; ++sx)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a[sx][m] = aN[sx][m];
+        if (t + 1 < p.T) {
+          const float* wtt = wt + ((long long)(t + 1) * Cpad + c0 + hh) * KT + l31;
+#pragma unroll
+          for (int sx = 0; sx < CH / 2; ++sx)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) aN[sx][m] = wtt[(2 * sx) * KT + m * 32];
+        }
+        __syncthreads();                               // barrier t
+        const float* src = s_S + (t & 1) * (CH * STR) + mw * (32 * NTW) + l31;
+#pragma unroll
+        for (int sx = 0; sx < CH / 2; ++sx) {
+          float bv[NTW];
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) bv[nt] = src[(2 * sx + hh) * STR + nt * 32];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sx][m], bv[nt], acc[m][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!sampler) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int pl = mw * (32 * NTW) + nt * 32 + l31;
+      const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+      const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
+      if (az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo) {
+        const long long pos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            if (k < p.K) out[((long long)c.b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
+          }
+      }
+    }
+  }
+}
+
 constexpr int WG_NREP = 8;   // replicas of the grad_weight scratch tensor (spreads same-address atomic contention)
 
 // ---------------------------------------------------------------------------------------------------- grad_offset
@@ -1021,7 +1199,7 @@ template <bool WG, int CH>
 __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                     const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/, const float* __restrict__ go,
                                                                     float* __restrict__ doff, float* __restrict__ dwtmp, DcnP p, RegGeo g, int CT,
-                                                                    int nchunk) {
+                                                                    int nchunk, int vec) {
   extern __shared__ __align__(16) float smem[];
   float* s_reg = smem;                       // [RV][RegCfg<CH>::VS]
   float* s_gc = s_reg + RegCfg<CH>::VS * g.RV;        // [16][ST]
@@ -1073,7 +1251,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
   const float* offp0 = off_b + (pvalid ? ppos : 0);
   for (int c0 = 0; c0 < p.C; c0 += CH) {
     __syncthreads();
-    stage_region<CH>(p, g, c, xb, c0, s_reg, wave_u, lane);
+    stage_region_any<CH>(p, g, c, xb, c0, s_reg, tid, 256, vec != 0);
     const float* offp = offp0;
     Off3 onext = load_off_ptr(offp, p.P, pvalid);
     TapIt it = {0, 0, 0};
@@ -1081,6 +1259,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
       const Off3 ocur = onext;
       offp += 3 * p.P;
       onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch the next tap's offsets
+      // running grad_offset of this (tap, voxel) from the previous channel chunks: fetched now, added after the sampling phase
+      float* dq = doff_b + (long long)(3 * t) * p.P + ppos;
+      float dprev[3] = {0.f, 0.f, 0.f};
+      if (pvalid && c0 > 0) { dprev[0] = dq[0]; dprev[1] = dq[p.P]; dprev[2] = dq[2 * p.P]; }
       // A fragments: W[k][c0 + l15][t] (rows k >= K and columns >= C of the repacked tensor are zero)
       float afrag[16];
       const float* wtt = wt2 + ((long long)t * 64 + lg) * CT + c0 + l15;
@@ -1149,13 +1331,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
           gw += (jw ? sp.mx[1] : -sp.mx[0]) * sp.wz[jd] * sp.wy[jh] * dots[j];
         }
       }
-      if (pvalid) {   // this thread owns (t, voxel): accumulate over channel chunks with plain read-modify-write
-        float* q = doff_b + (long long)(3 * t) * p.P + ppos;
-        if (c0 == 0) {
-          q[0] = gd; q[p.P] = gh; q[2 * p.P] = gw;
-        } else {
-          q[0] += gd; q[p.P] += gh; q[2 * p.P] += gw;
-        }
+      if (pvalid) {   // this thread owns (t, voxel): accumulate over the channel chunks
+        dq[0] = dprev[0] + gd; dq[p.P] = dprev[1] + gh; dq[2 * p.P] = dprev[2] + gw;
       }
       if (WG) {
         // this thread is the only reader of column `tid` of the gcol tile, so it can overwrite it with its samples right away
@@ -1254,20 +1431,26 @@ __global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __
 
 size_t region_lds(const RegGeo& g, int CH) { return sizeof(float) * ((size_t)(CH == 16 ? 20 : 12) * g.RV + (size_t)16 * ST); }
 
-int region_geo(RegGeo& g, const DcnP& p, int CH, int R) {
+int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, int RYH = -1) {
   g.R = R;
+  g.RXL = R;
+  g.RYH = RYH < R ? R : RYH;
   g.TZ = p.Do < 4 ? p.Do : 4;
   int RZ = (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * R;
   if (RZ > p.D) RZ = p.D;
   g.RZmax = RZ;
-  g.RY = (RG_TY - 1) * p.sh + (p.kh - 1) * p.dh + 1 + 2 * R;
+  g.RY = (RG_TY - 1) * p.sh + (p.kh - 1) * p.dh + 1 + 2 * g.RYH;
   g.RX = (RG_TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + 2 * R;
+  if (aligned) {   // first region column = x0*sw - pw - RXL on a 16-byte boundary (x0*sw is a multiple of 32), RX a multiple of 4
+    while ((p.pw + g.RXL) & 3) ++g.RXL;
+    g.RX = ((g.RXL + (RG_TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + R + 3) / 4) * 4;
+  }
   g.RV = g.RZmax * g.RY * g.RX;
   g.tilesZ = dpf_div_up(p.Do, g.TZ);
   g.tilesY = dpf_div_up(p.Ho, RG_TY);
   g.tilesX = dpf_div_up(p.Wo, RG_TX);
   const long long blocks = (long long)p.B * g.tilesZ * g.tilesY * g.tilesX;
-  if (g.RX > 64 || region_lds(g, CH) > 150 * 1024 || blocks >= 0x7fffffffLL || p.K > 128) return DPF_ERR_UNSUPPORTED;
+  if (g.RX > 64 || region_lds(g, CH) > 160 * 1024 || blocks >= 0x7fffffffLL || p.K > 128) return DPF_ERR_UNSUPPORTED;
   return DPF_OK;
 }
 
@@ -1275,9 +1458,9 @@ int region_geo(RegGeo& g, const DcnP& p, int CH, int R) {
 int region_chunk(int C) { return ((C + 11) / 12 * 12 < (C + 15) / 16 * 16) ? 12 : 16; }
 
 // widest halo (4, then 3) whose LDS image fits
-int region_pick(RegGeo& g, const DcnP& p, int CH) {
-  if (region_geo(g, p, CH, 4) == DPF_OK) return DPF_OK;
-  return region_geo(g, p, CH, 3);
+int region_pick(RegGeo& g, const DcnP& p, int CH, bool aligned = false) {
+  if (region_geo(g, p, CH, 4, aligned) == DPF_OK) return DPF_OK;
+  return region_geo(g, p, CH, 3, aligned);
 }
 
 int fill_params(DcnP& p, int B, int C, int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
@@ -1336,8 +1519,40 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
     const int Cpad = (C + CH - 1) / CH * CH;
     hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * Cpad * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0,
                        Cpad);
-    const size_t lds = region_lds(g, CH);
     const dim3 grid((unsigned)((long long)B * g.tilesZ * g.tilesY * g.tilesX));
+    // role-split pipeline (sampler waves + MFMA waves, double-buffered sample tile) where its LDS image fits; with 16-byte aligned
+    // rows the region gets an aligned x-origin and is staged with float4 loads
+    static const int use_rs = getenv("DPF_DCN_FWD_RS") ? atoi(getenv("DPF_DCN_FWD_RS")) : 8;   // 0 off, 8 or 16 waves (8 measured faster: 12.3 vs 13.2 ms)
+    if (use_rs && MT <= 2) {
+      RegGeo ga{};
+      const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2 && !getenv("DPF_DCN_NOVEC");
+      auto lds_of = [&](const RegGeo& q) { return sizeof(float) * ((size_t)(CH == 16 ? 20 : 12) * q.RV + (size_t)2 * CH * STR); };
+      int vec = 0;
+      bool ok = false;
+      if (can_vec) {
+        static const int rs_default = 8;
+        (void)rs_default;
+        const int cand[4][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 3}};     // (x/z halo, y halo), widest first
+        for (int i = 0; i < 4 && !ok; ++i)
+          if (region_geo(ga, p, CH, cand[i][0], true, cand[i][1]) == DPF_OK && lds_of(ga) <= 160 * 1024) { ok = true; vec = 1; }
+      }
+      if (!ok) { ga = g; ok = lds_of(ga) <= 160 * 1024; }
+      if (ok) {
+        const size_t lds_rs = lds_of(ga);
+        const dim3 grid_rs((unsigned)((long long)B * ga.tilesZ * ga.tilesY * ga.tilesX));
+#define DPF_RS(M, Cw, Nw)                                                                                                  \
+  {                                                                                                                        \
+    if (set_lds(dcn_fwd_rs_kernel<M, Cw, Nw>, lds_rs) != DPF_OK) return DPF_ERR_LAUNCH;                                    \
+    hipLaunchKernelGGL((dcn_fwd_rs_kernel<M, Cw, Nw>), grid_rs, dim3(64 * Nw), lds_rs, st, input, offset, ws, bias, output, p, ga, vec); \
+  }
+#define DPF_RSN(M, Cw) { if (use_rs == 8) DPF_RS(M, Cw, 8) else DPF_RS(M, Cw, 16) }
+        if (MT == 1) { if (CH == 16) DPF_RSN(1, 16) else DPF_RSN(1, 12) } else { if (CH == 16) DPF_RSN(2, 16) else DPF_RSN(2, 12) }
+#undef DPF_RSN
+#undef DPF_RS
+        return dpf_check_launch();
+      }
+    }
+    const size_t lds = region_lds(g, CH);
     // 8-wave workgroups measured faster for 16-wide chunks (10.2 vs 10.8 ms, C = 64) and slower for 12-wide ones (8.4 vs 8.15 ms, C = 35)
     const bool eight = getenv("DPF_DCN_FWD8") ? atoi(getenv("DPF_DCN_FWD8")) != 0 : CH == 16;
 #define DPF_FR2(M, Cw)                                                                                                      \
@@ -1450,7 +1665,17 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   // fallback works on 16-channel chunks with a halo of 3
   const bool want_fuse = dx_done && !getenv("DPF_DCN_NOFUSE");
   const int CHb = want_fuse ? region_chunk(C) : 16;
-  const bool region_ok = K <= 64 && !getenv("DPF_DCN_V1") && (want_fuse ? region_pick(rg, p, CHb) : region_geo(rg, p, 16, 3)) == DPF_OK &&
+  // aligned x-origin + float4 staging when the rows are 16-byte aligned; widest halo whose LDS image fits
+  const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2 && !getenv("DPF_DCN_NOVEC");
+  int vec_off = 0;
+  bool geo_ok = false;
+  if (want_fuse && can_vec) {
+    const int cand[4][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 3}};
+    for (int i = 0; i < 4 && !geo_ok; ++i)
+      if (region_geo(rg, p, CHb, cand[i][0], true, cand[i][1]) == DPF_OK) { geo_ok = true; vec_off = 1; }
+  }
+  if (!geo_ok) geo_ok = (want_fuse ? region_pick(rg, p, CHb) : region_geo(rg, p, 16, 3)) == DPF_OK;
+  const bool region_ok = K <= 64 && !getenv("DPF_DCN_V1") && geo_ok &&
                          (CHb == 16 || (C + 11) / 12 * 12 + 4 <= CT);   // 16 weight columns are fetched from each chunk origin
   const bool fuse_wg = region_ok && want_fuse;
   float* dwtmp = ws + (long long)p.T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);
@@ -1465,7 +1690,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   {                                                                                                                             \
     if (set_lds(dcn_bwd_offset_region_kernel<WGv, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                   \
     hipLaunchKernelGGL((dcn_bwd_offset_region_kernel<WGv, Cw>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, \
-                       p, rg, CT, nchunk);                                                                                      \
+                       p, rg, CT, nchunk, vec_off);                                                                             \
   }
     if (fuse_wg) {
       if (CHb == 16) DPF_OFF(true, 16) else DPF_OFF(true, 12)

@@ -10,5 +10,5 @@ out=gpurun_out/pmc_$tag
 rm -rf $out
 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $out -o p -- python3 "$@" > gpurun_out/pmc_$tag.log 2>&1
 f=$(find $out -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_summary.py $f igemm2_kernel wgrad2_kernel conv_wgrad_kernel conv_igemm_kernel > gpurun_out/pmc_$tag.txt
+python3 tools/pmc_summary.py $f ${PMC_FILTER:-igemm2_kernel wgrad2_kernel conv_wgrad_kernel conv_igemm_kernel} > gpurun_out/pmc_$tag.txt
 cat gpurun_out/pmc_$tag.txt
