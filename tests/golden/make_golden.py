@@ -320,3 +320,4 @@ if __name__ == '__main__':
     gen_e2e('train_32x48_b2', 2, 32, 48, True, 'bern', stages=True)
     gen_e2e('eval_32x48_b2', 2, 32, 48, False, 'ones', stages=False)
     gen_e2e('train_64x96_b1', 1, 64, 96, True, 'ones', stages=False)
+    gen_e2e('train_128x128_b2', 2, 128, 128, True, 'bern', stages=False)      # better conditioned BatchNorm: gradient / Adam-step pin

@@ -56,3 +56,50 @@ def test_gradcheck_small():
     b = torch.randn(2, generator=g, dtype=torch.float64, requires_grad=True)
     off = (torch.rand(1, 81, 2, 3, 3, generator=g, dtype=torch.float64) * 0.8 + 0.1).requires_grad_()   # away from the floor() kinks
     assert torch.autograd.gradcheck(lambda *a: DeformConv3dFn.apply(*a, (1, 1, 1), (1, 1, 1), (1, 1, 1)), (x, off, w, b), eps=1e-6, atol=1e-5)
+
+
+def _adversarial_offsets(B, D, H, W, seed):
+    """Offsets that put the sample coordinate of every (tap, voxel) on an edge case in at least one dimension: exactly -1, inside
+    (-1, 0), just below 0, on integers (0, 1, size-1), inside (size-1, size), exactly size, far outside -- mixed with plain
+    fractional positions."""
+    g = torch.Generator().manual_seed(seed)
+    T = 27
+    off = torch.zeros(B, 3 * T, D, H, W, dtype=torch.float64)
+    dims = (D, H, W)
+    for t in range(T):
+        tap = (t // 9 - 1, (t // 3) % 3 - 1, t % 3 - 1)
+        for ax in range(3):
+            n = dims[ax]
+            base = torch.arange(n, dtype=torch.float64) + tap[ax]                 # stride 1, pad 1
+            shape = [1, 1, 1]
+            shape[ax] = n
+            base = base.view(shape).expand(D, H, W)
+            special = torch.tensor([-1.0, -0.5, -1e-9, 0.0, 0.25, 1.0, n - 1.0, n - 0.5, float(n), n + 3.0, -3.0, 0.999999999, 1.5])
+            pick = torch.randint(0, len(special), (B, D, H, W), generator=g)
+            target = special[pick]
+            plain = torch.rand(B, D, H, W, generator=g, dtype=torch.float64) < 0.35
+            target = torch.where(plain, base + torch.randn(B, D, H, W, generator=g, dtype=torch.float64) * 0.8, target)
+            off[:, 3 * t + ax] = target - base
+    return off
+
+
+def test_literal_restatement_matches_vectorised_oracle_on_edge_samples():
+    """oracle/dcn3d_literal.py (the CUDA kernels walked index by index: (int) truncation, 5x5x5 window, 24-branch coordinate
+    weight) and oracle/dcn3d.py (vectorised) are two independent readings of the reference; they must agree to rounding on
+    adversarial sample positions -- the strongest pin available for an op whose reference binary cannot be built here."""
+    from oracle import dcn3d_literal as lit
+    g = torch.Generator().manual_seed(3)
+    B, C, K, D, H, W = 1, 2, 3, 2, 3, 4
+    x = torch.randn(B, C, D, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(K, C, 3, 3, 3, generator=g, dtype=torch.float64)
+    b = torch.randn(K, generator=g, dtype=torch.float64)
+    for seed in (0, 1):
+        off = _adversarial_offsets(B, D, H, W, seed)
+        out = deform_conv3d_forward(x, off, w, b)
+        go = torch.randn(out.shape, generator=g, dtype=torch.float64)
+        out_l = lit.forward(x.numpy(), off.numpy(), w.numpy(), b.numpy())
+        assert abs(out.numpy() - out_l).max() < 1e-12
+        vec = deform_conv3d_backward(x, off, w, b, go)
+        ref = lit.backward(x.numpy(), off.numpy(), w.numpy(), b.numpy(), go.numpy())
+        for name, a, e in zip(('grad_input', 'grad_offset', 'grad_weight', 'grad_bias'), vec, ref):
+            assert abs(a.numpy() - e).max() < 1e-12, name
