@@ -603,14 +603,17 @@ __global__ __launch_bounds__(256) void dcn_wgrad_kernel(const float* __restrict_
 // take a global-memory slow path.
 constexpr int RG_TY = 2, RG_TX = 32;
 // Channels per chunk CH and floats per voxel VS of the channel-last LDS image [RV][VS]:
-//   CH = 16, VS = 20 (16 + 4 pad): a lane reads the channels of a corner as 4 ds_read_b128; 5*vox mod 16 is a permutation, so 16
-//            consecutive voxels are bank-conflict free.
+//   CH = 16, VS = 16: a lane reads the channels of a corner as 4 ds_read_b128; the four 16-byte quads of voxel v are stored at
+//            quad position q ^ ((v >> 2) & 3) (XOR swizzle), so 16 consecutive voxels reading the same quad hit 16 different
+//            16-byte slots of the 256-byte bank row (conflict free) without the 25 % padding a 20-float stride would cost.
 //   CH = 12, VS = 12: for channel counts that 16 divides badly (35 -> 36 instead of 48 padded channels); 3*vox mod 16 is a
 //            permutation too.  The smaller image leaves room for a halo of 4 instead of 3 (fewer samples on the slow path).
 template <int CH>
 struct RegCfg {
   static_assert(CH == 16 || CH == 12, "chunk width");
-  static constexpr int VS = CH == 16 ? 20 : 12;
+  static constexpr int VS = CH;
+  // float offset of 16-byte quad q of region voxel v
+  static __device__ __forceinline__ int quad(int v, int q) { return CH == 16 ? v * 16 + 4 * (q ^ ((v >> 2) & 3)) : v * 12 + 4 * q; }
 };
 
 struct RegGeo {
@@ -670,7 +673,7 @@ __device__ __forceinline__ void stage_region(const DcnP& p, const RegGeo& g, con
       if (row < nrows && lane < g.RX) {
         const int ch = row / rows_per_ch;
         const int rem = row - ch * rows_per_ch;
-        s_reg[(rem * g.RX + lane) * RegCfg<CH>::VS + ch] = v[u];
+        s_reg[RegCfg<CH>::quad(rem * g.RX + lane, ch >> 2) + (ch & 3)] = v[u];
       }
     }
   }
@@ -683,7 +686,7 @@ __device__ __forceinline__ void stage_region(const DcnP& p, const RegGeo& g, con
 template <int CH>
 __device__ __forceinline__ void stage_region4(const DcnP& p, const RegGeo& g, const RegCtx& c, const float* __restrict__ xb, int c0, float* s_reg,
                                               int tid, int nthreads) {
-  constexpr int VS = RegCfg<CH>::VS, NCG = CH / 4;
+  constexpr int NCG = CH / 4;
   const long long chan = (long long)p.D * p.H * p.W;
   const int SR = g.RX >> 2;
   const int units = c.RZ * g.RY * NCG * SR;
@@ -699,11 +702,11 @@ __device__ __forceinline__ void stage_region4(const DcnP& p, const RegGeo& g, co
     float4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = (ok && c0 + 4 * cg + q < p.C) ? *reinterpret_cast<const float4*>(src + q * chan) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float* dst = s_reg + ((long long)(row * g.RX + 4 * seg)) * VS + 4 * cg;
-    *reinterpret_cast<float4*>(dst) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-    *reinterpret_cast<float4*>(dst + VS) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-    *reinterpret_cast<float4*>(dst + 2 * VS) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-    *reinterpret_cast<float4*>(dst + 3 * VS) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+    const int v0 = row * g.RX + 4 * seg;            // a multiple of 4: the four voxels share one swizzle key
+    *reinterpret_cast<float4*>(s_reg + RegCfg<CH>::quad(v0, cg)) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+    *reinterpret_cast<float4*>(s_reg + RegCfg<CH>::quad(v0 + 1, cg)) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+    *reinterpret_cast<float4*>(s_reg + RegCfg<CH>::quad(v0 + 2, cg)) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+    *reinterpret_cast<float4*>(s_reg + RegCfg<CH>::quad(v0 + 3, cg)) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
   }
 }
 
@@ -757,10 +760,10 @@ __device__ __forceinline__ Samp make_samp(const DcnP& p, const RegGeo& g, const 
 // 16 channels of corner (jd, jh, jw): 4 x ds_read_b128 from the channel-last image (fast path)
 template <int CH>
 __device__ __forceinline__ void corner_vec(const RegGeo& g, const Samp& s, const float* s_reg, int jd, int jh, int jw, float v[CH]) {
-  const float4* r = reinterpret_cast<const float4*>(s_reg + (s.base + jd * s.dzs + jh * g.RX + jw) * RegCfg<CH>::VS);
+  const int vx = s.base + jd * s.dzs + jh * g.RX + jw;
 #pragma unroll
   for (int q = 0; q < CH / 4; ++q) {
-    const float4 f = r[q];
+    const float4 f = *reinterpret_cast<const float4*>(s_reg + RegCfg<CH>::quad(vx, q));
     v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
   }
 }
@@ -915,9 +918,11 @@ __global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __rest
 // chunk's channels; each wave contracts 32 voxels.
 template <int CH, int H>
 __device__ __forceinline__ void corner_half(const RegGeo& g, const Samp& s, const float* s_reg, int jd, int jh, int jw, float v[CH / 2]) {
-  const float* r = s_reg + (s.base + jd * s.dzs + jh * g.RX + jw) * RegCfg<CH>::VS + H * (CH / 2);
+  const int vx = s.base + jd * s.dzs + jh * g.RX + jw;
+  const float* r = s_reg + vx * RegCfg<CH>::VS + H * (CH / 2);      // CH = 12: linear image
   if (CH == 16) {
-    const float4 a = *reinterpret_cast<const float4*>(r), b = *reinterpret_cast<const float4*>(r + 4);
+    const float4 a = *reinterpret_cast<const float4*>(s_reg + RegCfg<CH>::quad(vx, 2 * H)),
+                 b = *reinterpret_cast<const float4*>(s_reg + RegCfg<CH>::quad(vx, 2 * H + 1));
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   } else if (H == 0) {
     const float4 a = *reinterpret_cast<const float4*>(r);
@@ -1353,6 +1358,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
   }
 }
 
+
 // ---------------------------------------------------------------------------------------------------- grad_weight
 // dW[k][c][t] = sum_{b,p} go[k][p] * S[c][p;t].  Per (chunk, tap) the sampled tile S[16][256] goes to LDS and each wave
 // contracts it against its 16 output channels of go (kept in registers) with v_mfma_f32_16x16x4_f32 (D row = k, col = c);
@@ -1429,7 +1435,7 @@ __global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __
   }
 }
 
-size_t region_lds(const RegGeo& g, int CH) { return sizeof(float) * ((size_t)(CH == 16 ? 20 : 12) * g.RV + (size_t)16 * ST); }
+size_t region_lds(const RegGeo& g, int CH) { return sizeof(float) * ((size_t)CH * g.RV + (size_t)16 * ST); }
 
 int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, int RYH = -1) {
   g.R = R;
@@ -1526,14 +1532,14 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
     if (use_rs && MT <= 2) {
       RegGeo ga{};
       const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2 && !getenv("DPF_DCN_NOVEC");
-      auto lds_of = [&](const RegGeo& q) { return sizeof(float) * ((size_t)(CH == 16 ? 20 : 12) * q.RV + (size_t)2 * CH * STR); };
+      auto lds_of = [&](const RegGeo& q) { return sizeof(float) * ((size_t)CH * q.RV + (size_t)2 * CH * STR); };
       int vec = 0;
       bool ok = false;
       if (can_vec) {
         static const int rs_default = 8;
         (void)rs_default;
-        const int cand[4][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 3}};     // (x/z halo, y halo), widest first
-        for (int i = 0; i < 4 && !ok; ++i)
+        const int cand[6][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}};     // (x/z halo, y halo), widest first
+        for (int i = 0; i < 6 && !ok; ++i)
           if (region_geo(ga, p, CH, cand[i][0], true, cand[i][1]) == DPF_OK && lds_of(ga) <= 160 * 1024) { ok = true; vec = 1; }
       }
       if (!ok) { ga = g; ok = lds_of(ga) <= 160 * 1024; }
@@ -1683,6 +1689,8 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   if (region_ok) {
     if (hipMemsetAsync(dwtmp, 0, sizeof(float) * (size_t)WG_NREP * p.T * nchunk * 64 * 16, st) != hipSuccess) return DPF_ERR_LAUNCH;
   }
+  // (A role-split variant of this kernel -- sampler waves + MFMA waves over three rotating tiles, like dcn_fwd_rs_kernel -- was built and
+  // measured slower, 17.9 vs 13.7 ms on the 64-channel layer: its MFMA waves carry both matrix products and the 256-register budget spills.)
   if (region_ok && dx_done) {
     const size_t lds = region_lds(rg, CHb);
     const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
