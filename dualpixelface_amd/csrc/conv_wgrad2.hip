@@ -39,7 +39,7 @@ struct W2P {
   int sd, sh, sw, pd, ph, pw;
   int kd, kh, kw, dd, dh, dw, T;
   int ext_d, ext_h, RS, SR, PS, CS, PSseg, CSseg, colshift;   // x image: row / plane / channel strides (floats, segments)
-  int CCW, cchunks, kslices, nxseg;
+  int CCW, cchunks, kslices, groups, nxseg;
   int tilesH, tilesW, nchunk;
   long long ntiles, per;       // tiles per position chunk (contiguous range)
   unsigned mCS, mPS, mSR;
@@ -50,11 +50,12 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
 
-template <int NCT>
-constexpr int w2_occ() {
-  constexpr int est = NCT * 17 + 2 * NLX + 64;
+constexpr int w2_occ_of(int nct) {
+  const int est = nct * 17 + 2 * NLX + 64;
   return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
 }
+template <int NCT>
+constexpr int w2_occ() { return w2_occ_of(NCT); }
 
 template <int NCT>
 __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
@@ -62,10 +63,14 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int b = blockIdx.x;
-  const int pchunk = b % p.nchunk; b /= p.nchunk;
-  const int cchunk = b % p.cchunks;
-  const int kslice = b / p.cchunks;
+  // workgroups that walk the SAME tiles (the column chunks / k slices of one position chunk) share the g tiles and x patches:
+  // they get the same blockIdx % 8 label, i.e. (observed round-robin dispatch) the same XCD and L2
+  const int jb = blockIdx.x >> 3;
+  const int pchunk = (jb / p.groups) * 8 + (blockIdx.x & 7);
+  if (pchunk >= p.nchunk) return;
+  const int gidx = jb % p.groups;
+  const int cchunk = gidx % p.cchunks;
+  const int kslice = gidx / p.cchunks;
   const int c0 = cchunk * p.CCW;
   const int ncc = min(p.CCW, p.C - c0);
   const int ncol = ncc * p.T;
@@ -116,18 +121,25 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
     goff[v] = (int)((long long)gk0 * g_chan + (long long)(lg >> 3) * p.QW + 4 * (lg & 7));
   }
 
-  auto decode = [&](long long tile, int& n, int& qd, int& q0h, int& q0w) {     // depth fastest
-    long long r = tile;
-    qd = (int)(r % p.QD); r /= p.QD;
-    const int tw = (int)(r % p.tilesW); r /= p.tilesW;
-    const int th = (int)(r % p.tilesH);
-    n = (int)(r / p.tilesH);
-    q0h = th * WTH; q0w = tw * 32;
-  };
+  // tile cursor (depth fastest): decoded once, then advanced by one per issued tile -- no integer division in the tile loop
+  int cur_qd, cur_tw, cur_th, cur_n;
+  {
+    long long r = (long long)pchunk * p.per;
+    cur_qd = (int)(r % p.QD); r /= p.QD;
+    cur_tw = (int)(r % p.tilesW); r /= p.tilesW;
+    cur_th = (int)(r % p.tilesH);
+    cur_n = (int)(r / p.tilesH);
+  }
 
-  auto issue = [&](long long tile, int buf) {
-    int n, qd, q0h, q0w;
-    decode(tile, n, qd, q0h, q0w);
+  auto issue = [&](int buf) {
+    const int n = cur_n, qd = cur_qd, q0h = cur_th * WTH, q0w = cur_tw * 32;
+    if (++cur_qd == p.QD) {
+      cur_qd = 0;
+      if (++cur_tw == p.tilesW) {
+        cur_tw = 0;
+        if (++cur_th == p.tilesH) { cur_th = 0; ++cur_n; }
+      }
+    }
     float* dbase = smem + buf * bufFloats;
     const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, a0 = q0w * p.sw - p.pw - p.colshift;
     const float* xt = x + ((long long)n * p.C + c0) * x_chan + ((long long)i0d * p.IH + i0h) * p.IW + a0;
@@ -166,11 +178,11 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
   const long long tbeg = (long long)pchunk * p.per;
   long long tend = tbeg + p.per;
   if (tend > p.ntiles) tend = p.ntiles;
-  if (tbeg < tend) issue(tbeg, 0);
+  if (tbeg < tend) issue(0);
   __syncthreads();
   int buf = 0;
   for (long long tile = tbeg; tile < tend; ++tile, buf ^= 1) {
-    if (tile + 1 < tend) issue(tile + 1, buf ^ 1);
+    if (tile + 1 < tend) issue(buf ^ 1);
     const float* s_x = smem + buf * bufFloats;
     const float* s_g = s_x + xFloats;
     // group j = positions 8j .. 8j+7 of this wave's row: lane half h takes 8j+4h .. 8j+4h+3; element i of both halves is one
@@ -322,10 +334,7 @@ int launch_w2(const float* g, const float* x, float* slab, const W2P& p, size_t 
   return dpf_check_launch();
 }
 
-int w2_maxblocks() {
-  static const int v = env_int("DPF_W2_BLOCKS", 512);
-  return v;
-}
+int w2_maxblocks() { return 1024; }     // upper bound of resident workgroups (4 per CU): sizes the slab workspace
 
 }  // namespace
 
@@ -392,9 +401,20 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   p.tilesH = dpf_div_up(d.QH, WTH); p.tilesW = dpf_div_up(d.QW, 32);
   p.ntiles = (long long)d.N * d.QD * p.tilesH * p.tilesW;
   p.mCS = magic20(p.CSseg); p.mPS = magic20(p.PSseg); p.mSR = magic20(p.SR);
-  long long nchunk = w2_maxblocks() / (p.cchunks * p.kslices);
-  nchunk = (nchunk / 8) * 8;                       // same position chunk of every column chunk / k slice on one XCD (b % 8)
-  if (nchunk < 8) nchunk = 8;
+  // as many position chunks as fit the chip at once: (workgroups resident per CU by registers and LDS) x 256 CUs / groups
+  p.groups = p.cchunks * p.kslices;
+  const size_t buf0 = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
+  const size_t red0 = (size_t)2 * NCT * 16 * 64 * sizeof(float);
+  const size_t lds0 = 2 * buf0 > red0 ? 2 * buf0 : red0;
+  int occ = w2_occ_of(NCT);
+  if ((size_t)occ * lds0 > 160 * 1024) occ = (int)((160 * 1024) / lds0);
+  if (occ < 1) occ = 1;
+  static const int cap_over = env_int("DPF_W2_CAPACITY", 0);
+  // one resident round of workgroups; with many (column chunk, k slice) groups the position chunks get coarse, and two rounds
+  // balance the CUs better (measured: K = 81 / 96 layers 58 -> 71-86 TFLOP/s, the 32-channel layers unchanged)
+  const int capacity = cap_over ? cap_over : occ * 256 * (p.groups >= 12 ? 2 : 1);
+  long long nchunk = capacity / p.groups;
+  if (nchunk < 1) nchunk = 1;
   if (nchunk > p.ntiles) nchunk = p.ntiles;
   p.per = (p.ntiles + nchunk - 1) / nchunk;
   nchunk = (p.ntiles + p.per - 1) / p.per;
@@ -405,7 +425,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
   const size_t red = (size_t)2 * NCT * 16 * 64 * sizeof(float);
   const size_t lds = 2 * buf > red ? 2 * buf : red;
-  const unsigned blocks = (unsigned)(p.kslices * p.cchunks * p.nchunk);
+  const unsigned blocks = (unsigned)(8 * ((p.nchunk + 7) / 8) * p.groups);
   int rc;
   switch (NCT) {
     case 1: rc = launch_w2<1>(g, x, ws, p, lds, blocks, st); break;
