@@ -9,7 +9,9 @@ region.  Rank 0 prints ONE JSON line (contract in the task description) includin
   "roofline":     the dominant kernel (implicit-GEMM convolution on the fp32 matrix cores) -- algorithmic FLOPs per
                   launch / average launch duration, measured live with HIP events on the launch stream;
   "cpu_baseline": the CPU oracle (oracle/, a PyTorch-CPU restatement of the reference) timed on this host's cores on a
-                  bounded sample (one 1x384x512 train step, 16 threads), scaled to 1024x1536 samples/s by pixel count.
+                  bounded sample (one 1x512x768 train step = BASELINE configs[1]'s shape, 16 threads), scaled to 1024x1536
+                  samples/s by pixel count (kind "port").
+`python bench.py --gpus N` without RANK in the environment starts its own N ranks (child processes) and relays rank 0's line.
 """
 import argparse
 import json
@@ -26,12 +28,13 @@ FLOP_PER_PIXEL_FWD_BWD = 2.708e6        # SURVEY.md section 8d (fwd 902 764 FLOP
 PEAK_F32_TFLOPS = 157.3                 # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 
 
-def cpu_baseline(threads):
+def cpu_baseline(threads, H=512, W=768):
+    """The CPU oracle (oracle/, a PyTorch-CPU restatement pinned to the reference's golden vectors) on a bounded sample: one
+    forward + loss + backward at BASELINE configs[1]'s shape (1 x 512 x 768), scaled to 1024 x 1536 samples/s by pixel count."""
     from dualpixelface_amd.recipe import synthetic_batch
     from oracle import recipe_state
     from oracle.stereodpnet import StereoDPNetOracle
     torch.set_num_threads(threads)
-    H, W = 384, 512
     batch = synthetic_batch(1, H, W, seed=7)
     st = recipe_state()
     orc = StereoDPNetOracle(st, training=True)
@@ -110,6 +113,8 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', default=None, metavar='HxW:threads[,threads...]',
+                    help='time only the CPU oracle at the given size for each thread count (e.g. 1024x1536:16,128) and exit')
     ap.add_argument('--model', default='stereodpnet', choices=['stereodpnet', 'psmnet'],
                     help='psmnet = BASELINE configs[3] (cross-model plugin check): the PSMNet plugin on the same kernels')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
@@ -123,6 +128,12 @@ def main():
 
     if args.gpus > 1 and 'RANK' not in os.environ and args.workload == 'train':
         return self_launch(args.gpus)
+    if args.cpu_baseline_only:
+        size, threads = args.cpu_baseline_only.split(':')
+        h, w = (int(v) for v in size.split('x'))
+        for t in threads.split(','):
+            print(json.dumps(cpu_baseline(int(t), h, w)))
+        return
 
     from dualpixelface_amd import load_option, ops
     from dualpixelface_amd.distributed import init_from_env, make_reducer, broadcast_flat
@@ -178,12 +189,13 @@ def main():
         value = global_batch * args.steps / elapsed
         fam = {}
         shapes = {}
-        for family, flops, e0, e1, tag in prof:
+        for family, flops, e0, e1, tag, nbytes in prof:
             secs = e0.elapsed_time(e1) * 1e-3
-            f = fam.setdefault(family, [0.0, 0.0, 0])
+            f = fam.setdefault(family, [0.0, 0.0, 0, 0.0])
             f[0] += flops
             f[1] += secs
             f[2] += 1
+            f[3] += nbytes
             g = shapes.setdefault(tag, [0.0, 0.0, 0])
             g[0] += flops
             g[1] += secs
@@ -195,17 +207,17 @@ def main():
         dom = max(fam, key=lambda k: fam[k][1]) if fam else None
         roof = None
         if dom:
-            flops, secs, n = fam[dom]
+            flops, secs, n, alg_bytes = fam[dom]
             ach = flops / secs / 1e12
             traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
             if os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                fam_key = {'conv_igemm': 'conv_igemm_kernel', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dom)
+                fam_key = {'conv_igemm': 'igemm2', 'conv_wgrad': 'wgrad2'}.get(dom)
                 rec = json.load(open(tpath)).get(fam_key)
                 if rec:
                     traffic = rec['hbm_bytes_per_launch']
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
-                    'traffic': traffic, 'launches': n, 'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed,
+                    'traffic': traffic, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n, 'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed,
                     'families': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3} for k, v in fam.items()}}
         pixels = args.height * args.width
         line = {

@@ -21,8 +21,8 @@ PROFILE = None
 
 
 class _Timed(object):
-    def __init__(self, family, flops, tag=''):
-        self.family, self.flops, self.tag = family, flops, tag
+    def __init__(self, family, flops, tag='', nbytes=0.0):
+        self.family, self.flops, self.tag, self.nbytes = family, flops, tag, nbytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -34,7 +34,7 @@ class _Timed(object):
     def __exit__(self, *a):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.family, self.flops, self.e0, self.e1, self.tag))
+            PROFILE.append((self.family, self.flops, self.e0, self.e1, self.tag, self.nbytes))
         return False
 
 
@@ -104,7 +104,8 @@ def _conv_fwd_raw(x, w, bias, stride, pad, dil):
         return out
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
     with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * od * oh * ow,
-                'fwd N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2])):
+                'fwd N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
+                4.0 * (x.numel() + out.numel() + w.numel())):
         L.call('dpf_conv_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, kd, kh, kw,
                *stride, *pad, *dil, _stream())
     return out
@@ -119,7 +120,8 @@ def _conv_transpose_raw(x, w, bias, out_dims, ksize, stride, pad, dil):
     L = lib()
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
     with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW,
-                'tr  N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2])):
+                'tr  N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
+                4.0 * (x.numel() + out.numel() + w.numel())):
         L.call('dpf_conv_transpose', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, *out_dims, kd, kh, kw,
                *stride, *pad, *dil, _stream())
     return out
@@ -136,7 +138,8 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
             lib().call('dpf_conv_smallk_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, kd, kh, kw, *stride, *pad, *dil, _stream())
         return dw
     with _Timed('conv_wgrad', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW,
-                'wg  N%d C%d K%d x%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2])):
+                'wg  N%d C%d K%d x%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
+                4.0 * (x.numel() + g.numel() + dw.numel())):
         L = lib()
         nws = L.call('dpf_conv_wgrad_workspace_floats', kd * kh * kw, C, K)
         ws = scratch(nws, x.device, 'wgradws')

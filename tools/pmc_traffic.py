@@ -11,7 +11,7 @@ import sys
 
 
 def family(name):
-    for key in ('conv_igemm_kernel', 'conv_wgrad_kernel', 'dcn_bwd_input', 'dcn_fwd_region', 'dcn_bwd_offset', 'dcn_wgrad_region',
+    for key in ('igemm2', 'wgrad2', 'conv_igemm_kernel', 'conv_wgrad_kernel', 'dcn_bwd_input', 'dcn_fwd', 'dcn_bwd_offset', 'dcn_wgrad_region',
                 'smallk', 'bn_', 'head_'):
         if key in name:
             return key
