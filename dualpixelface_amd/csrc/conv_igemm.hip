@@ -491,16 +491,16 @@ int launch_igemm(const float* x, const float* wt, const float* bias, float* out,
 int conv_launch(const float* x, const float* wt_ws, const float* bias, float* out, ConvP p, hipStream_t st);
 
 int conv_common(const float* x, const float* w, const float* bias, float* out, float* wt_ws, ConvP p, int repack_mode,
-                int wA, int wB, hipStream_t st) {
+                int wA, int wB, hipStream_t st, int Ktot = 0) {
   const int T = p.kd * p.kh * p.kw;
   if (T > MAXT || T < 1) return DPF_ERR_UNSUPPORTED;
   // one launch covers up to 128 output channels (4 MFMA row tiles); wider outputs are split
   const int Kfull = p.K;
-  p.Ktot = Kfull;
+  p.Ktot = Ktot > 0 ? Ktot : Kfull;          // channels of the output tensor (>= the Kfull channels this call computes)
   for (int k0 = 0; k0 < Kfull; k0 += 128) {
     const int Kc = Kfull - k0 < 128 ? Kfull - k0 : 128;
     {   // LDS-DMA double-buffered kernel where the shape is eligible (conv_igemm2.hip)
-      DpfConvDesc d{p.N, p.C, Kc, Kfull, k0, p.ID, p.IH, p.IW, p.OD, p.OH, p.OW, p.kd, p.kh, p.kw, p.sd, p.sh, p.sw,
+      DpfConvDesc d{p.N, p.C, Kc, p.Ktot, k0, p.ID, p.IH, p.IW, p.OD, p.OH, p.OW, p.kd, p.kh, p.kw, p.sd, p.sh, p.sw,
                     p.pd, p.ph, p.pw, p.dd, p.dh, p.dw, p.transposed, wA, wB, repack_mode};
       const int rc2 = dpf_igemm2_conv(x, w, bias, out, wt_ws, d, st);
       if (rc2 == DPF_OK) continue;
@@ -621,6 +621,20 @@ int dpf_conv_transpose(const float* x, const float* w, const float* bias, float*
   return conv_common(x, w, bias, out, ws, p, /*mode*/ 1, C, K, (hipStream_t)stream);
 }
 
+// As dpf_conv_transpose for an output tensor (and weight) of Ktot channels of which only the first K are computed (the others
+// are left untouched): data gradients whose trailing input channels have no consumer (the constant XYZ channels of the ANM volume).
+int dpf_conv_transpose_ex(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                          int K, int Ktot, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                          int dd, int dh, int dw, void* stream) {
+  dpf_clear_error();
+  if (!x || !w || !out || !ws || N <= 0 || C <= 0 || K <= 0 || Ktot < K) return DPF_ERR_INVALID_ARG;
+  ConvP p{};
+  p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW; p.OD = OD; p.OH = OH; p.OW = OW;
+  p.kd = kd; p.kh = kh; p.kw = kw; p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw;
+  p.transposed = 1;
+  return conv_common(x, w, bias, out, ws, p, /*mode*/ 1, C, Ktot, (hipStream_t)stream, Ktot);
+}
+
 // Forward conv with the weight stored transposed-conv style w[K_reduce=C? ...]:
 // data gradient of nn.ConvTranspose3d: out[n,ci,q] = sum_{co,t} w[ci][co][t] * g[n,co, q*s - p + t*dil]
 // i.e. a forward conv whose weight is indexed [out][reduce][t] -- identical to dpf_conv_forward (w[K][C][T]).
@@ -633,7 +647,7 @@ long long dpf_conv_wgrad_workspace_floats(int T, int C, int K) { return dpf_wgra
 // with a deterministic slab reduction (conv_wgrad2.hip) instead of float atomics
 int dpf_conv_wgrad_ws(const float* g, const float* x, float* dw, float* ws, long long ws_floats, int N, int C, int ID, int IH, int IW, int K,
                       int QD, int QH, int QW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_,
-                      void* stream) {
+                      int accumulate, void* stream) {
   dpf_clear_error();
   if (!g || !x || !dw || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
   const int T = kd * kh * kw;
@@ -643,9 +657,10 @@ int dpf_conv_wgrad_ws(const float* g, const float* x, float* dw, float* ws, long
     int rc = DPF_ERR_UNSUPPORTED;
     if (ws) {
       DpfWgradDesc d{N, C, Kc, K, k0, ID, IH, IW, QD, QH, QW, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_};
-      rc = dpf_wgrad2(g, x, dwk, ws, ws_floats, d, (hipStream_t)stream);
+      rc = dpf_wgrad2(g, x, dwk, ws, ws_floats, d, accumulate, (hipStream_t)stream);
     }
     if (rc == DPF_ERR_UNSUPPORTED) {
+      if (!accumulate && hipMemsetAsync(dwk, 0, sizeof(float) * (size_t)Kc * C * T, (hipStream_t)stream) != hipSuccess) return DPF_ERR_LAUNCH;
       // generic kernel on this channel slice: g viewed with Ktot = K channels, slice [k0, k0 + Kc)
       rc = dpf_conv_wgrad_slice(g, x, dwk, N, C, ID, IH, IW, K, k0, Kc, QD, QH, QW, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_, stream);
     }

@@ -26,5 +26,6 @@ struct DpfWgradDesc {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
 };
 // LDS-DMA double-buffered, slab-reduced (deterministic) weight gradient (conv_wgrad2.hip); DPF_ERR_UNSUPPORTED -> caller falls back.
-int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, hipStream_t st);
+// accumulate = 0: dw is overwritten (no zero-initialisation needed), 1: dw += ...
+int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, int accumulate, hipStream_t st);
 long long dpf_wgrad2_workspace_floats(int T, int C, int K);

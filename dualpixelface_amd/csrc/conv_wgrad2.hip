@@ -291,11 +291,11 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
 }
 
 // dw[i] += sum_{chunk} slab[chunk][i]  in chunk order (deterministic)
-__global__ void wgrad2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nchunk) {
+__global__ void wgrad2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nchunk, int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int c = 0; c < nchunk; ++c) s += slab[(long long)c * n + i];
-    dw[i] += s;
+    dw[i] = accumulate ? dw[i] + s : s;
   }
 }
 
@@ -347,7 +347,7 @@ long long dpf_wgrad2_workspace_floats(int T, int C, int K) {
   return nchunk * Kc * cols + 64;
 }
 
-int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, hipStream_t st) {
+int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, int accumulate, hipStream_t st) {
   static const int enabled = env_int("DPF_WGRAD2", 1);
   if (!enabled || !ws) return DPF_ERR_UNSUPPORTED;
   const int T = d.kd * d.kh * d.kw;
@@ -438,6 +438,6 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   }
   if (rc != DPF_OK) return rc;
   const long long n = p.slab_stride;
-  hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, st, ws, dw, n, p.nchunk);
+  hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, st, ws, dw, n, p.nchunk, accumulate);
   return dpf_check_launch();
 }

@@ -111,13 +111,23 @@ def _conv_fwd_raw(x, w, bias, stride, pad, dil):
     return out
 
 
-def _conv_transpose_raw(x, w, bias, out_dims, ksize, stride, pad, dil):
-    """x on the strided grid [N,C,...] -> out [N,K,*out_dims]; w is [C][K][T] in memory."""
+def _conv_transpose_raw(x, w, bias, out_dims, ksize, stride, pad, dil, k_needed=None):
+    """x on the strided grid [N,C,...] -> out [N,K,*out_dims]; w is [C][K][T] in memory.  ``k_needed`` < K: only the first k_needed
+    output channels are computed (the others are zero)."""
     N, C, ID, IH, IW = x.shape
     K = w.shape[1]
     kd, kh, kw = ksize
     out = torch.empty((N, K) + tuple(out_dims), dtype=torch.float32, device=x.device)
     L = lib()
+    if k_needed is not None and 0 < k_needed < K:
+        out[:, k_needed:].zero_()
+        ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
+        with _Timed('conv_igemm', 2.0 * N * k_needed * C * kd * kh * kw * ID * IH * IW,
+                    'tr  N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, k_needed, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
+                    4.0 * (x.numel() + out.numel() * k_needed // K + w.numel())):
+            L.call('dpf_conv_transpose_ex', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, k_needed, K, *out_dims,
+                   kd, kh, kw, *stride, *pad, *dil, _stream())
+        return out
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
     with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW,
                 'tr  N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
@@ -132,7 +142,8 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
     N, C, ID, IH, IW = x.shape
     K, QD, QH, QW = g.shape[1], g.shape[2], g.shape[3], g.shape[4]
     kd, kh, kw = wshape[2:]
-    dw = torch.zeros(wshape, dtype=torch.float32, device=x.device)
+    smallk = K <= 4 and stride[2] == 1 and dil[2] == 1 and kw <= 3 and 16 * kd * kh <= 256
+    dw = (torch.zeros if smallk else torch.empty)(wshape, dtype=torch.float32, device=x.device)
     if K <= 4 and stride[2] == 1 and dil[2] == 1 and kw <= 3 and 16 * kd * kh <= 256:
         with _Timed('conv_smallk', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW, 'skw N%d C%d K%d x%dx%dx%d' % (N, C, K, ID, IH, IW)):
             lib().call('dpf_conv_smallk_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, kd, kh, kw, *stride, *pad, *dil, _stream())
@@ -144,7 +155,7 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
         nws = L.call('dpf_conv_wgrad_workspace_floats', kd * kh * kw, C, K)
         ws = scratch(nws, x.device, 'wgradws')
         L.call('dpf_conv_wgrad_ws', _ptr(g), _ptr(x), _ptr(dw), _ptr(ws), nws, N, C, ID, IH, IW, K, QD, QH, QW, kd, kh, kw, *stride, *pad, *dil,
-               _stream())
+               0, _stream())
     return dw
 
 
@@ -160,10 +171,11 @@ class ConvFn(torch.autograd.Function):
     """nn.Conv3d semantics on [N,C,D,H,W] (2-D callers use depth 1)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil):
+    def forward(ctx, x, w, bias, stride, pad, dil, gi_channels=None):
         x, w = _c(x), _c(w)
         _need(x, w, bias)
         ctx.cfg = (stride, pad, dil)
+        ctx.gi_channels = gi_channels
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return _conv_fwd_raw(x, w, bias, stride, pad, dil)
@@ -175,12 +187,12 @@ class ConvFn(torch.autograd.Function):
         gy = _c(gy)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _conv_transpose_raw(gy, w, None, x.shape[2:], w.shape[2:], stride, pad, dil)
+            gx = _conv_transpose_raw(gy, w, None, x.shape[2:], w.shape[2:], stride, pad, dil, k_needed=ctx.gi_channels)
         if ctx.needs_input_grad[1]:
             gw = _conv_wgrad_raw(gy, x, w.shape, stride, pad, dil)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _channel_sum(gy)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 class ConvTransposeFn(torch.autograd.Function):
@@ -210,8 +222,9 @@ class ConvTransposeFn(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
-def conv3d(x, w, bias=None, stride=1, pad=0, dil=1):
-    return ConvFn.apply(x, w, bias, _t3(stride), _t3(pad), _t3(dil))
+def conv3d(x, w, bias=None, stride=1, pad=0, dil=1, gi_channels=None):
+    """gi_channels: only the first gi_channels input channels need a gradient (the others' data gradient is zero)."""
+    return ConvFn.apply(x, w, bias, _t3(stride), _t3(pad), _t3(dil), gi_channels)
 
 
 class ConvBf16Fn(torch.autograd.Function):

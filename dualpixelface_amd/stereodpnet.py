@@ -473,7 +473,7 @@ class StereoDPNetCore(_Base):
     # ------------------------------------------------------------------ normal module (normal_module.py:140-194)
     def _deform(self, x, p, gi_channels=None):
         P = self._P
-        off = ops.conv3d(x, P[p + '.conv_offset.weight'], P[p + '.conv_offset.bias'], 1, 1, 1)
+        off = ops.conv3d(x, P[p + '.conv_offset.weight'], P[p + '.conv_offset.bias'], 1, 1, 1, gi_channels=gi_channels)
         return ops.deform_conv3d(x, off, P[p + '.weight'], P[p + '.bias'], gi_channels=gi_channels), off
 
     def _normals(self, cost, disp_full, batch):

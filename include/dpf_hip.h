@@ -41,15 +41,19 @@ int dpf_conv_forward(const float* x, const float* w, const float* bias, float* o
 int dpf_conv_transpose(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
                        int K, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
                        int dd, int dh, int dw, void* stream);
+/* dpf_conv_transpose into an output tensor / weight of Ktot >= K channels, computing only channels [0, K) */
+int dpf_conv_transpose_ex(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                          int K, int Ktot, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                          int dd, int dh, int dw, void* stream);
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
 /* same, with caller scratch `ws` of dpf_conv_wgrad_workspace_floats(T, C, K) floats: eligible shapes (16-byte aligned rows, 3x3 /
  * 3x3x3 kernels, dilation 1) then run without float atomics -- partial tiles are reduced in a fixed order, so the gradient is
- * bitwise reproducible; other shapes use the same kernel as dpf_conv_wgrad */
+ * bitwise reproducible; other shapes use the same kernel as dpf_conv_wgrad.  accumulate = 0: dw is overwritten (any content), 1: dw += */
 long long dpf_conv_wgrad_workspace_floats(int T, int C, int K);
 int dpf_conv_wgrad_ws(const float* g, const float* x, float* dw, float* ws, long long ws_floats, int N, int C, int ID, int IH, int IW, int K,
                       int QD, int QH, int QW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_,
-                      void* stream);
+                      int accumulate, void* stream);
 
 /* narrow outputs (K <= 4): the 32 -> 1 cost heads (modules.py:286-296) and the 32 -> 3 normal conv (normal_module.py:65);
  * same conventions as dpf_conv_forward / dpf_conv_wgrad, direct (non-MFMA) HBM-bound kernels */

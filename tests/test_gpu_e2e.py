@@ -276,7 +276,12 @@ def test_c2_shape_forward_and_loss_vs_cpu_oracle():
     res = model.train_step({k: v.to(DEV) for k, v in batch.items()})          # forward + loss + backward + Adam at this size
     close(model.last_taps['volume'], orc.taps['volume'], 2e-4, 'volume')
     close(res['pred_depth'], ref['pred_depth'], None, 'pred_depth', atol=3e-3)
-    close(res['pred_normal'], ref['pred_normal'], None, 'pred_normal', atol=1e-3)
+    # The normal head samples the 4 cost levels nearest to the predicted disparity (normal_module.py:80-138): a discontinuous
+    # selection.  Over 98 304 quarter-resolution pixels a prediction that sits within fp32 rounding of a level boundary can pick
+    # the neighbouring level on one side only (observed: one run in five, a single pixel, |d normal| = 0.08), so this size is
+    # checked with an outlier budget instead of a hard maximum: <= 1e-4 of the values beyond 1e-3, mean error <= 1e-5.
+    err = (res['pred_normal'].detach().cpu().double() - ref['pred_normal'].double()).abs()
+    assert float((err > 1e-3).double().mean()) <= 1e-4 and float(err.mean()) <= 1e-5, (float(err.max()), float(err.mean()))
     for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
         close(res[k], ref[k], 2e-4, k)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)

@@ -89,6 +89,22 @@ def test_conv_forward_backward(case):
     close(gb, gb_r, 1e-4, 'conv bgrad')
 
 
+def test_conv_data_gradient_of_leading_channels_only():
+    """conv3d(gi_channels=n): the data gradient is computed for the first n input channels only (the rest is zero) -- the constant XYZ
+    channels of the ANM volume have no gradient consumer (normal_module.py:166)."""
+    ops = _ops()
+    x = rnd(2, 35, 3, 10, 24, seed=1)
+    w = rnd(81, 35, 3, 3, 3, seed=2, scale=0.1)
+    go = rnd(2, 81, 3, 10, 24, seed=3)
+    xr = x.clone().requires_grad_()
+    (gx_r,) = torch.autograd.grad(F.conv3d(xr, w, None, 1, 1, 1), xr, go)
+    xg, wg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    y = ops.conv3d(xg, wg, None, 1, 1, 1, gi_channels=32)
+    gx, gw = torch.autograd.grad(y, (xg, wg), go.to(DEV))
+    close(gx[:, :32], gx_r[:, :32], 1e-4, 'partial dgrad')
+    assert float(gx[:, 32:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 2, 4, 6, 64), (1, 64, 4, 8, 12, 32), (2, 64, 1, 3, 5, 32), (1, 64, 3, 5, 8, 32), (2, 35, 2, 6, 36, 64),
                                    (1, 32, 5, 9, 40, 96)])
 def test_conv_transpose3d(shape):
