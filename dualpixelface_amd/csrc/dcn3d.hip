@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
 // channel of 4 voxels (D row = voxel, col = channel), adds the 8 corner contributions with conflict-free LDS atomics
 // (16 consecutive channels per voxel) and flushes the region once with row-contiguous global atomics.  Samples that leave
 // the region (|offset| >~ 2) fall back to a direct global atomic.
-constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8, GI_CS = 9;   // 8 channels per pass, padded channel stride (doubles)
+constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8, GI_CS = 8;   // 8 channels per pass; cell stride 64 B: the cells of 4 x-adjacent voxels tile the 256-B bank row (GI_CS = 9 measured 59 % conflict cycles)
 
 struct GiP {
   int TZ, RZmax, RY, RX;     // tile depth, region dims
@@ -353,9 +353,16 @@ struct GiP {
 // NW waves per workgroup, NST position sub-tiles of 16 per wave (positions per block = 16 * NST * NW).  NW = 8 runs two waves per
 // SIMD on the same LDS footprint: every phase has twice the threads (each voxel's eight table corners are split between a
 // thread pair), so the issue-bound table / scatter streams of the two waves interleave.
-template <int NST, int NW>
+// FX: the region accumulates in 64-bit FIXED POINT with ds_add_u64 (4.8-5.4 lanes/clk/CU against 3.1 for ds_add_f64,
+// tools/lds_atomic_bench.hip).  The conversion that made an earlier fixed-point variant a net loss is moved out of the per-corner
+// path: a gcol value is quantised ONCE (27 bits against a per-workgroup bound max_p sum_k |go| * max |W|), the 8 corner weights of a
+// (voxel, tap) are quantised once in the table phase (23 bits, shared by all channels), and a contribution is one v_mad_i64_i32.
+// 2^26 * 2^23 * (6912 units of weight mass a tile can put into one cell) < 2^63: no overflow for ANY offsets; integer sums are order
+// independent, so this half of grad_input is also bitwise reproducible.
+template <int NST, int NW, bool FX>
 __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
-                                                            const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT) {
+                                                            const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT,
+                                                            const float* __restrict__ wmaxv /*[chunks of GI_CH] max |W|, FX only*/) {
   extern __shared__ __align__(16) double smem_d[];
   constexpr int NT = 64 * NW;
   constexpr int npos = 16 * NST * NW;
@@ -368,6 +375,9 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_kernel(const float* __r
   float* s_wfar = s_w + npos * 8;                              // [npos][8] corner weight (far pass)
   int* s_far = (int*)(s_wfar + npos * 8);                         // [4] per-tap flag: some corner left the region
   int* s_farm = s_far + 4;                                      // [2][npos] per-voxel flag (one row per thread of a pair)
+  float* s_gmax = (float*)(s_farm + 2 * npos);                  // [NW] per-wave max_p sum_k |go[k][p]|  (FX)
+  long long* s_regq = reinterpret_cast<long long*>(s_reg);      // the same region viewed as int64 (FX)
+  int* s_wq = reinterpret_cast<int*>(s_w);                      // table weights as 23-bit fixed point (FX)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int lc = l15 & 7;            // channel within the chunk; lanes 8..15 of a group mirror lanes 0..7 ...
   const int jb = (l15 >> 3) * 4;     // ... and scatter corners 4..7 instead of 0..3
@@ -412,10 +422,35 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_kernel(const float* __r
     }
   }
 
+  float gbound = 0.f;
+  if (FX) {   // max over this workgroup's voxels of sum_k |go[k][voxel]|
+    float m = 0.f;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      float sa = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) sa += fabsf(afrag[st][ks]);
+      sa += __shfl_xor(sa, 16, 64);
+      sa += __shfl_xor(sa, 32, 64);
+      m = fmaxf(m, sa);
+    }
+    m = dpf_wave_max(m);
+    if (lane == 0) s_gmax[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gbound = fmaxf(gbound, s_gmax[w]);
+  }
+
   const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
   const float* offp0 = off_b + (pvalid ? ppos : 0);
   for (int c0 = 0; c0 < q.CG; c0 += GI_CH) {      // only the channels whose gradient the caller needs
     __syncthreads();                                            // previous chunk flushed
+    // |gcol| <= gbound * max|W| of this channel chunk: quantisation step of the 27-bit gcol values, and its inverse for the flush
+    float qscale = 0.f, qinv = 0.f;
+    if (FX) {
+      const float B = gbound * wmaxv[c0 / GI_CH];
+      if (B > 0.f) { qscale = 67108864.f / B; qinv = B * (1.f / 67108864.f) * (1.f / 8388608.f); }
+    }
     for (int i = tid; i < regvox * GI_CS + GI_CS; i += NT) s_reg[i] = 0.0;
     if (tid == 0) s_far[0] = 0;
     const int cc = c0 + lc;
@@ -457,7 +492,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_kernel(const float* __r
           }
           s_lidx[vox * 8 + j] = li;
           s_vox[vox * 8 + j] = (in || v < 0) ? -1 : (int)v;      // >= 0 only for far corners (second pass)
-          s_w[vox * 8 + j] = in ? wg : 0.f;
+          if (FX) s_wq[vox * 8 + j] = in ? __float2int_rn(wg * 8388608.f) : 0;
+          else s_w[vox * 8 + j] = in ? wg : 0.f;
           s_wfar[vox * 8 + j] = wg;
           if (!in && v >= 0) anyfar = 1;
         }
@@ -487,11 +523,20 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_kernel(const float* __r
             const int pl = (wave * NST + st) * 16 + 4 * lg + r;   // D row = voxel
             const float g = acc[r];
             const int4 la = *reinterpret_cast<const int4*>(&s_lidx[pl * 8 + jb]);
-            const float4 wa = *reinterpret_cast<const float4*>(&s_w[pl * 8 + jb]);
             const int li[4] = {la.x, la.y, la.z, la.w};
-            const float wv[4] = {wa.x, wa.y, wa.z, wa.w};
+            if (FX) {
+              const int4 wa = *reinterpret_cast<const int4*>(&s_wq[pl * 8 + jb]);
+              const int wq[4] = {wa.x, wa.y, wa.z, wa.w};
+              const long long G = (long long)__float2int_rn(g * qscale);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(&s_reg[li[j] + lc], (double)(wv[j] * g));
+              for (int j = 0; j < 4; ++j)
+                atomicAdd(reinterpret_cast<unsigned long long*>(&s_regq[li[j] + lc]), (unsigned long long)(G * (long long)wq[j]));
+            } else {
+              const float4 wa = *reinterpret_cast<const float4*>(&s_w[pl * 8 + jb]);
+              const float wv[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) atomicAdd(&s_reg[li[j] + lc], (double)(wv[j] * g));
+            }
           }
           if (s_far[t & 1] != 0) {                                     // block-uniform: some corner of this tap left the region
 #pragma unroll
@@ -521,11 +566,27 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_kernel(const float* __r
       float* dst = dxb + (long long)(c0 + c) * chan + ((long long)gz * p.H + gy) * p.W;
       for (int lx = lane; lx < rowlen; lx += 64) {
         const int gx = rx0 + lx;
-        const float v = (float)s_reg[((lz * q.RY + ly) * q.RX + lx) * GI_CS + c];
+        const int cell = ((lz * q.RY + ly) * q.RX + lx) * GI_CS + c;
+        const float v = FX ? (float)((double)s_regq[cell] * (double)qinv) : (float)s_reg[cell];
         if (v != 0.f && gx >= 0 && gx < p.W) atomicAdd(&dst[gx], v);
       }
     }
   }
+}
+
+// wmax[ch] = max over taps, k and the GI_CH channels of chunk ch of |wt2[t][k][c]|   (one workgroup per chunk)
+__global__ __launch_bounds__(256) void dcn_wmax_kernel(const float* __restrict__ wt2, float* __restrict__ wmax, int T, int CT, int C) {
+  __shared__ float sm[4];
+  const int c0 = blockIdx.x * GI_CH;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < T * 64 * GI_CH; i += 256) {
+    const int cc = i % GI_CH, row = i / GI_CH;
+    if (c0 + cc < C) m = fmaxf(m, fabsf(wt2[(long long)row * CT + c0 + cc]));
+  }
+  m = dpf_wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) wmax[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
 // ------------------------------------------------------------------------------------------ backward: weight
@@ -1502,7 +1563,7 @@ int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void*
 // workspace floats for dpf_deform_conv3d_forward / _backward (repacked weights)
 long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
   const long long repack = (long long)T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);   // either repack, reduce index padded
-  return repack + (long long)WG_NREP * T * ((C + 11) / 12) * 64 * 16;   // + grad_weight scratch replicas (chunks of >= 12 channels)
+  return repack + (long long)WG_NREP * T * ((C + 11) / 12) * 64 * 16 + 64;   // + grad_weight scratch replicas (chunks of >= 12 channels) + max|W| per channel chunk
 }
 
 // Mirrors DCN.deform_conv_forward(input, weight, bias, offset, kd,kh,kw, sd,sh,sw, pd,ph,pw, dd,dh,dw, group, deformable_group,
@@ -1643,16 +1704,25 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
     q.CG = grad_input_channels < C ? (grad_input_channels < 0 ? 0 : grad_input_channels) : C;
     const int npos = 64 * q.TZ;
-    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 34 + 4);
+    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 34 + 4 + 16);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
     if (lds <= 150 * 1024 && blocks < 0x7fffffffLL && (long long)D * H * W < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
       hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * 64 * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1,
                          64);
+      // fixed-point region (ds_add_u64): per-chunk max |W| for the quantisation bound, kept behind the grad_weight scratch in ws
+      static const int use_fx = getenv("DPF_DCN_GI_FX") ? atoi(getenv("DPF_DCN_GI_FX")) : 1;
+      float* wmaxv = ws + dpf_deform_conv3d_workspace_floats(C, K, p.T) - 64;
+      if (use_fx) hipLaunchKernelGGL(dcn_wmax_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, ws, wmaxv, p.T, CT, C);
 #define DPF_GI(NS, NWv)                                                                                                        \
   {                                                                                                                            \
-    if (set_lds(dcn_bwd_input_kernel<NS, NWv>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                          \
-    hipLaunchKernelGGL((dcn_bwd_input_kernel<NS, NWv>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT); \
+    if (use_fx) {                                                                                                              \
+      if (set_lds(dcn_bwd_input_kernel<NS, NWv, true>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                  \
+      hipLaunchKernelGGL((dcn_bwd_input_kernel<NS, NWv, true>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
+    } else {                                                                                                                   \
+      if (set_lds(dcn_bwd_input_kernel<NS, NWv, false>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                 \
+      hipLaunchKernelGGL((dcn_bwd_input_kernel<NS, NWv, false>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
+    }                                                                                                                          \
   }
       switch (q.TZ) {
         case 1: DPF_GI(1, 4); break;
