@@ -29,8 +29,12 @@ class _PluginHooks(object):
 
     def _loaders(self, train, batch_size, shuffle):
         import torch.utils.data as torch_data
-        from dataloader.loader_selector import loader_selector     # the reference's (or a user's) data package, CWD-relative
-        return torch_data.DataLoader(loader_selector(self.option, train), batch_size=batch_size, shuffle=shuffle,
+        from dataloader.loader_selector import loader_selector     # this repo's (or a user's) data package, CWD-relative
+        dataset = loader_selector(self.option, train)
+        if hasattr(dataset, 'produce'):                              # device-side FaceDP path: decode threads + preprocessing kernels
+            from .facedp import FaceDPBatcher
+            return FaceDPBatcher(dataset, batch_size, shuffle=shuffle, workers=self.option.workers, drop_last=False)
+        return torch_data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle,
                                      num_workers=self.option.workers, drop_last=False, pin_memory=self.option.pin_memory)
 
     def train_dataloader(self):

@@ -96,6 +96,8 @@ class Trainer(object):
         dataset with a DistributedSampler (shuffled by its own generator seeded with (seed, epoch), padded to a multiple of the
         world size): every rank sees the same number of batches with the same shapes, so the per-step collectives always pair up."""
         if self.world_size == 1:
+            if hasattr(loader, 'set_epoch'):
+                loader.set_epoch(epoch)                              # FaceDPBatcher: its own generator seeded with (seed, epoch)
             return loader
         key = id(loader)
         if getattr(self, '_dist_key', None) != key:
@@ -103,9 +105,12 @@ class Trainer(object):
             from torch.utils.data.distributed import DistributedSampler
             self._dist_sampler = DistributedSampler(loader.dataset, num_replicas=self.world_size, rank=self.rank, shuffle=True,
                                                     seed=int(getattr(self.option, 'seed', 1)), drop_last=False)
-            self._dist_loader = DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=self._dist_sampler,
-                                           num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
-                                           drop_last=loader.drop_last)
+            if hasattr(loader, 'with_sampler'):
+                self._dist_loader = loader.with_sampler(self._dist_sampler)
+            else:
+                self._dist_loader = DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=self._dist_sampler,
+                                               num_workers=loader.num_workers, collate_fn=loader.collate_fn,
+                                               pin_memory=loader.pin_memory, drop_last=loader.drop_last)
             self._dist_key = key
         self._dist_sampler.set_epoch(epoch)
         return self._dist_loader

@@ -182,6 +182,33 @@ int dpf_loss_backward(const float* pred_depth, const float* pred_normal, const f
 int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, double lr, double beta1,
                   double beta2, double eps, float gscale, void* stream);
 
+/* ---- FaceDP sample preprocessing: the per-sample host work of the reference's DataLoader workers,
+ * dataloader/FaceDP/path_reader.py:150-168 (read_depth), :196-232 (read_disparity), dataloader/preprocess/preprocess.py:46-88
+ * (basic_transform.apply), dataloader/preprocess/augmentation.py:62-84 (to_tensor step), :165-178 (crop), :236-262 (Lighting),
+ * :265-297 (Normalizer).  The host keeps file IO, JPEG decoding and the random draws; the decoded full-resolution arrays are
+ * uploaded once and every crop / raw view is produced from them on the device.
+ *
+ * depth: [H, W] metric depth, fp32 (depth_f64 = 0) or fp64 (depth_f64 = 1), as stored in the .npy; mask: optional u8 [H, W]
+ * (file mask > 0), NULL -> depth > 0.  a, b: disparity = a / depth + b (abvalue_list[camidx] = [a, b]).
+ * stats: dpf_dp_stats_doubles() doubles of device scratch; after dpf_dp_depth_stats stats[0] = max valid depth, stats[1] = max
+ * valid disparity (fp64, NaN-propagating like np.max), stats[3] = number of valid pixels; dpf_dp_targets adds to stats[2] the
+ * number of written pixels whose disparity or inverse depth is not finite (the reference raises on those). */
+long long dpf_dp_stats_doubles();
+int dpf_dp_depth_stats(const void* depth, int depth_f64, const unsigned char* mask, long long n, double a, double b, double* stats,
+                       void* stream);
+/* window [y0, y0 + ch) x [x0, x0 + cw) -> depth_out / mask_out / disp_out fp32 [ch, cw], idepth_out [ch, cw] in the depth's type.
+ * disp = fp32(a / fp64(depth) + b), 50 * stats[1] on invalid / NaN / Inf pixels; idepth = max_depth / depth, 0 outside the mask;
+ * depth 0 outside the mask; any output may be NULL */
+int dpf_dp_targets(const void* depth, int depth_f64, const unsigned char* mask, double* stats, double a, double b, int H, int W, int y0,
+                   int x0, int ch, int cw, float* depth_out, float* mask_out, float* disp_out, void* idepth_out, void* stream);
+/* img u8 [H, W, C] (C = 1 or 3, 4-byte aligned) window -> out fp32 [C, ch, cw] = ((lut_c[v] / 255 + shift[c]) - mean[c]) / std[c], each
+ * step rounded to fp32 (to_tensor, Lighting, Normalizer).  lut: optional device u8 [C, 256] photometric table (brightness / gamma /
+ * contrast on 8-bit values), NULL = identity; shift_host NULL = 0; mean 0 / std 1 gives the reference's raw_transform */
+int dpf_dp_image(const unsigned char* img, const unsigned char* lut, float* out, int H, int W, int C, int y0, int x0, int ch, int cw,
+                 const float* shift_host, const float* mean_host, const float* std_host, void* stream);
+/* fp32 [H, W, C] window -> [C, ch, cw] (normal / albedo maps through to_tensor) */
+int dpf_dp_hwc_to_chw(const float* src, float* dst, int H, int W, int C, int y0, int x0, int ch, int cw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,211 @@
+"""FaceDP data path on the GPU: the device preprocessing kernels behind FaceDPLoader / FaceDPBatcher against
+(1) the golden records of the reference loader, bit for bit, (2) the numpy oracle on adversarial windows and full-size frames."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dualpixelface_amd import facedp
+from oracle import facedp_preprocess as oracle
+from tests import facedp_fixture as fx
+
+pytestmark = pytest.mark.gpu
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'facedp_samples.json')))
+
+
+@pytest.fixture(scope='module')
+def datasets(tmp_path_factory):
+    built = {}
+
+    def get(case):
+        kwargs = fx.CASES[case][2]
+        key = json.dumps({k: str(v) for k, v in kwargs.items()}, sort_keys=True)
+        if key not in built:
+            built[key] = fx.build_dataset(tmp_path_factory.mktemp('facedp'), seed=0, **kwargs)
+        return built[key]
+    return get
+
+
+@pytest.mark.parametrize('case', sorted(fx.CASES))
+def test_loader_getitem_matches_reference_loader_bitwise(case, datasets, tmp_path):
+    option, training = fx.make_option(case, datasets(case))
+    ds = facedp.FaceDPLoader(option, training, device='cuda:0', cache_dir=str(tmp_path))
+    fx.seed_all(fx.CASES[case][3])
+    for i, want in enumerate(GOLDEN[case]['samples']):
+        got = ds[i]
+        assert sorted(got) == sorted(want), (case, i)
+        for key, rec in want.items():
+            if torch.is_tensor(got[key]):
+                assert got[key].is_cuda
+            assert fx.digest(got[key]) == rec, (case, i, key)
+
+
+def test_batcher_equals_per_sample_loader(datasets, tmp_path):
+    case = 'train_soft_light'
+    option, training = fx.make_option(case, datasets(case))
+    ds = facedp.FaceDPLoader(option, training, device='cuda:0', cache_dir=str(tmp_path))
+    fx.seed_all((9, 8, 7))
+    singles = [ds[i] for i in range(len(ds))]
+    fx.seed_all((9, 8, 7))
+    seen = 0
+    for batch in facedp.FaceDPBatcher(ds, batch_size=3, shuffle=False, workers=3):
+        B = batch['left'].shape[0]
+        assert batch['left'].is_cuda and batch['coords'].shape == (B, 2) and len(batch['pathname']) == B
+        for j in range(B):
+            one = singles[seen + j]
+            for key, val in one.items():
+                if torch.is_tensor(val):
+                    assert torch.equal(batch[key][j], val), (seen + j, key)
+                elif isinstance(val, np.ndarray):
+                    np.testing.assert_array_equal(batch[key][j].numpy(), val, err_msg=key)
+                else:
+                    assert batch[key][j] == val
+        seen += B
+    assert seen == len(ds)
+
+
+def test_batcher_multi_view_and_drop_last(datasets, tmp_path):
+    case = 'multi_view'
+    option, training = fx.make_option(case, datasets(case))
+    ds = facedp.FaceDPLoader(option, training, device='cuda:0', cache_dir=str(tmp_path))
+    batches = list(facedp.FaceDPBatcher(ds, batch_size=2, shuffle=True, workers=2, drop_last=True))
+    assert len(batches) == len(ds) // 2
+    assert batches[0]['lefts'].shape == (2, 6, fx.H, fx.W) and batches[0]['depths'].shape == (2, 2 * fx.H, fx.W)
+    assert batches[0]['Ks'].shape == (2, 2, 3, 3)
+
+
+def test_batcher_surfaces_reader_errors(datasets, tmp_path):
+    case = 'eval_center'
+    option, training = fx.make_option(case, datasets(case))
+    ds = facedp.FaceDPLoader(option, training, device='cuda:0', cache_dir=str(tmp_path))
+    ds.pathdata[1] = dict(ds.pathdata[1], tar_view=ds.pathdata[1]['tar_view'] + '.missing')
+    with pytest.raises(FileNotFoundError):
+        list(facedp.FaceDPBatcher(ds, batch_size=1))
+
+
+# ------------------------------------------------------------------------------------------------ kernels against the oracle
+def _raw(rng, H, W, depth_dtype=np.float32, mask_file=False, grey=False, holes=True):
+    raw = facedp.RawSample()
+    shape = (H, W) if grey else (H, W, 3)
+    raw.left = rng.randint(0, 256, shape).astype(np.uint8)
+    raw.right = rng.randint(0, 256, shape).astype(np.uint8)
+    raw.center = None
+    depth = rng.uniform(800, 1200, (H, W))
+    if holes:
+        depth[rng.uniform(size=(H, W)) < 0.3] = 0
+    raw.depth = depth.astype(depth_dtype)
+    raw.file_mask = ((rng.uniform(size=(H, W)) < 0.8) & (depth > 0)).astype(np.uint8) if mask_file else None
+    raw.normal = rng.normal(size=(H, W, 3)).astype(np.float32)
+    raw.albedo = None
+    raw.a, raw.b = facedp.ABVALUE_BY_CAMERA[3]
+    raw.K = raw.P = raw.abvalue = raw.metadata = None
+    return raw
+
+
+FLAGS = {'dual_pixel': True, 'center_img': False, 'mask': True, 'disparity': True, 'depth': True, 'idepth': True, 'normal': True,
+         'albedo': False}
+
+
+def _device_view(pre, raw, win, shifts=None, luts=None, normalise=True):
+    dev = pre.upload(raw)
+    out = facedp._allocate_view(dev, FLAGS, win[2], win[3], pre.device, '' if normalise else 'raw_')
+    plan = None
+    if normalise:
+        plan = facedp.SamplePlan()
+        plan.shift = {k: (torch.from_numpy(np.asarray(v)) if v is not None else None) for k, v in (shifts or {}).items()}
+        plan.lut = dict(luts or {})
+        for k in ('left', 'right', 'center'):
+            plan.shift.setdefault(k, None)
+            plan.lut.setdefault(k, None)
+    keep = []
+    facedp._fill_view(pre, dev, raw, FLAGS, win, out, '' if normalise else 'raw_', plan=plan, keep=keep)
+    torch.cuda.synchronize()
+    return {k[4:] if k.startswith('raw_') else k: v.cpu().numpy() for k, v in out.items()}, dev['stats'][:4].cpu().numpy()
+
+
+@pytest.mark.parametrize('H,W,win,kw', [
+    (40, 52, (0, 0, 40, 52), {}),
+    (40, 52, (5, 3, 32, 44), {}),                       # x0 odd: the row's byte offset is not dword aligned
+    (41, 51, (7, 2, 33, 37), {}),                       # cw % 4 != 0: scalar stores
+    (41, 51, (1, 0, 17, 50), {'grey': True}),
+    (64, 2100, (3, 1, 60, 2090), {}),                   # more than one 1024-pixel segment per row
+    (40, 52, (6, 4, 24, 40), {'depth_dtype': np.float64, 'mask_file': True}),
+])
+def test_views_match_oracle_bitwise(H, W, win, kw):
+    rng = np.random.RandomState(H * 1000 + W)
+    raw = _raw(rng, H, W, **kw)
+    pre = facedp.DevicePreprocessor('cuda:0')
+    shifts = {'left': rng.normal(size=3).astype(np.float32) * 0.1, 'right': None}
+    luts = {'right': np.stack([rng.permutation(256) for _ in range(1 if kw.get('grey') else 3)]).astype(np.uint8)}
+    arrays = {n: getattr(raw, n) for n in ('left', 'right', 'center', 'depth', 'file_mask', 'normal', 'albedo')}
+    for normalise in (True, False):
+        got, stats = _device_view(pre, raw, win, shifts, luts, normalise)
+        want = oracle.sample_view(arrays, FLAGS, win, shifts if normalise else None, luts if normalise else None, normalise, raw.a, raw.b)
+        assert sorted(got) == sorted(want)
+        for key in want:
+            assert got[key].dtype == want[key].dtype and got[key].shape == want[key].shape, key
+            np.testing.assert_array_equal(got[key], want[key], err_msg='%s normalise=%s' % (key, normalise))
+        assert stats[2] == 0 and stats[3] == int(oracle.depth_targets(raw.depth, raw.file_mask, raw.a, raw.b)['mask'].sum())
+
+
+def test_every_byte_value_and_every_channel_constant():
+    """ToTensor -> Lighting -> Normalizer for all 256 input values in every channel equals torch's fp32 result."""
+    pre = facedp.DevicePreprocessor('cuda:0')
+    img = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2).repeat(4, axis=0)
+    raw = _raw(np.random.RandomState(0), 4, 256)
+    raw.left = raw.right = np.ascontiguousarray(img)
+    shift = torch.tensor([0.0123, -0.0456, 0.0789])
+    got, _ = _device_view(pre, raw, (0, 0, 4, 256), {'left': shift.numpy()})
+    t = torch.from_numpy(img).permute(2, 0, 1).float().div(255)
+    t = t.add(shift.view(3, 1, 1))
+    t = t.sub(torch.tensor(facedp.IMAGENET_MEAN).view(3, 1, 1)).div(torch.tensor(facedp.IMAGENET_STD).view(3, 1, 1))
+    np.testing.assert_array_equal(got['left'], t.numpy())
+
+
+def test_full_size_frame_matches_oracle():
+    """1024 x 1536 FaceDP frame, the shipped training crop 768 x 1152 at an odd offset."""
+    rng = np.random.RandomState(42)
+    raw = _raw(rng, 1024, 1536)
+    pre = facedp.DevicePreprocessor('cuda:0')
+    win = (133, 77, 768, 1152)
+    arrays = {n: getattr(raw, n) for n in ('left', 'right', 'center', 'depth', 'file_mask', 'normal', 'albedo')}
+    got, _ = _device_view(pre, raw, win, {'left': np.float32([0.01, 0.02, -0.03])})
+    want = oracle.sample_view(arrays, FLAGS, win, {'left': np.float32([0.01, 0.02, -0.03])}, None, True, raw.a, raw.b)
+    for key in want:
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+
+def test_invalid_maps_are_reported():
+    pre = facedp.DevicePreprocessor('cuda:0')
+    rng = np.random.RandomState(1)
+    raw = _raw(rng, 16, 32, mask_file=True)
+    raw.depth[raw.file_mask > 0] = np.where(rng.uniform(size=int(raw.file_mask.sum())) < 0.1, 0, 900).astype(np.float32)  # depth 0 inside the mask
+    _, stats = _device_view(pre, raw, (0, 0, 16, 32))
+    assert stats[2] > 0
+    with pytest.raises(ValueError):
+        facedp.check_stats([torch.from_numpy(stats)])
+    empty = _raw(rng, 16, 32)
+    empty.depth[:] = 0
+    _, stats = _device_view(pre, empty, (0, 0, 16, 32))
+    assert stats[3] == 0
+    with pytest.raises(ValueError):
+        facedp.check_stats([torch.from_numpy(stats)])
+
+
+def test_abi_argument_checks():
+    from dualpixelface_amd._lib import lib, DpfError
+    l = lib()
+    x = torch.zeros(16, 16, 3, dtype=torch.uint8, device='cuda')
+    out = torch.zeros(3, 8, 8, device='cuda')
+    f = (ctypes.c_float * 3)(0, 0, 0)
+    one = (ctypes.c_float * 3)(1, 1, 1)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    with pytest.raises(DpfError):                                    # window outside the frame
+        l.call('dpf_dp_image', p(x), None, p(out), 16, 16, 3, 10, 10, 8, 8, None, f, one, None)
+    with pytest.raises(DpfError):                                    # unsupported channel count
+        l.call('dpf_dp_image', p(x), None, p(out), 16, 16, 2, 0, 0, 8, 8, None, f, one, None)
+    with pytest.raises(DpfError):
+        l.call('dpf_dp_depth_stats', None, 0, None, 10, 1.0, 1.0, None, None)

@@ -65,3 +65,32 @@ def test_entry_point_smoke():
     assert os.path.exists(os.path.join(ws, 'checkpoint_epoch=00.ckpt')) and os.path.exists(os.path.join(ws, 'log.jsonl'))
     ck = torch.load(os.path.join(ws, 'checkpoint_epoch=00.ckpt'), map_location='cpu', weights_only=False)
     assert ck['global_step'] == 2 and len(ck['state_dict']) == 512      # the reference's 511 keys + the lazy normal_estimator.grid (Q9)
+
+
+def test_training_from_a_facedp_dataset_on_disk(tmp_path, monkeypatch):
+    """The plugin's train_dataloader() over a FaceDP-format dataset on disk: loader_selector -> FaceDPLoader -> FaceDPBatcher
+    (decode threads + device preprocessing) -> Trainer.fit; validation through val_dataloader()."""
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.facedp import FaceDPBatcher
+    from dualpixelface_amd.trainer import Trainer
+    from tests import facedp_fixture as fx
+    data = fx.build_dataset(tmp_path / 'data', seed=0)
+    monkeypatch.chdir(tmp_path)                                     # the index cache is written to the working directory
+    opt = load_option()
+    assert opt.crop_aug.soft_crop.crop_factor == 96 and opt.photo_aug.light is True and opt.use_raw is True
+    opt.dataset.path = data
+    opt.dataset.viewpoint = [1, 2, 6]
+    opt.crop_aug.soft_crop.crop_factor = 16                          # 48 x 64 frames -> 32 x 48 crops
+    opt.use_raw, opt.workers, opt.batch_size, opt.epoch = False, 2, 2, 1
+    m = _model(opt)
+    loader = m.train_dataloader()
+    assert isinstance(loader, FaceDPBatcher) and len(loader.dataset) == 7 and os.path.exists('FaceDP_train_single.npy')
+    val = m.val_dataloader()
+    assert val.batch_size == 1 and len(val.dataset) == 4
+    tr = Trainer(opt, str(tmp_path / 'ws'), log_every=1, rank=0, world_size=1)
+    p0 = m.flat_parameters().clone()
+    hist = tr.fit(m, loader, val)
+    assert tr.global_step == 4 and torch.isfinite(m.flat_parameters()).all() and not torch.equal(p0, m.flat_parameters())
+    losses = [v for h in hist for k, v in h.items() if 'loss' in k]
+    assert losses and all(l == l for l in losses)
+    assert any('metrics' in h for h in hist)
