@@ -62,10 +62,7 @@ def stage_bench(args):
         fn = lambda: ops.psm_volume(ref, tar, shifts, 0)
         name = 'PSMNet concat cost volume (BASELINE configs[3])'
     else:
-        model = STEREODPNET(load_option()).to(dev)
-        model.train()
-        fn = lambda: model._cost_volume(ref, tar)
-        name = 'StereoDPNet cost volume: shift triple + masking attention + volume assembly, forward (SURVEY a2-a4)'
+XX
     with torch.no_grad():
         for _ in range(args.warmup):
             fn()
@@ -122,7 +119,7 @@ def main():
     ap.add_argument('--sync-bn', action='store_true',
                     help='BatchNorm statistics over the global batch (what the reference does under DDP); default per-rank statistics')
     ap.add_argument('--shapes', default=None, help='write a per-convolution-shape timing table to this file')
-    ap.add_argument('--workload', default='train', choices=['train', 'psm_volume', 'cost_volume'],
+    ap.add_argument('--workload', default='train', choices=['train', 'psm_volume', 'cost_volume', 'cost_volume_fix'],
                     help="'train' = the BASELINE metric; the other two time one HBM-bound stage in isolation (BASELINE configs[3], SURVEY a2-a4)")
     args = ap.parse_args()
 

@@ -71,6 +71,118 @@ __global__ void shift_triple_bwd_kernel(const float* __restrict__ g, float* __re
   }
 }
 
+// deterministic adjoint (gather form): iyi / ixi are the INVERSE tables [3][2][2][n] (iyi[m][a][s][yy] = the s-th output row y whose
+// tap (m, a) reads source row yy, -1 if none; the tap maps are monotone and at most two outputs share a source -- the host checks
+// it), wy / wx stay indexed by the output coordinate.  One thread per dfea element, <= 48 terms in a fixed order, no atomics, no
+// pre-zeroing.
+__global__ void shift_triple_bwd_gather_kernel(const float* __restrict__ g, float* __restrict__ dfea, const int* __restrict__ iyi,
+                                               const float* __restrict__ wy, const int* __restrict__ ixi, const float* __restrict__ wx,
+                                               long long BC, int h, int w) {
+  const long long hw = (long long)h * w;
+  const long long total = BC * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % w);
+    const int yy = (int)((i / w) % h);
+    const long long bc = i / hw;
+    const float* gp = g + bc * 3 * hw;
+    float acc = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy) {
+          const int y = iyi[((m * 2 + a) * 2 + sy) * h + yy];
+          if (y < 0) continue;
+          const float wa = wy[(m * 2 + a) * h + y];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+              const int x = ixi[((m * 2 + e) * 2 + sx) * w + xx];
+              if (x < 0) continue;
+              acc += (wa * wx[(m * 2 + e) * w + x]) * gp[m * hw + (long long)y * w + x];
+            }
+          }
+        }
+      }
+    }
+    dfea[i] = acc;
+  }
+}
+
+// ---- fractional Fourier-phase row shift (asm.py:59-75,112-125 with the irfft(onesided=False) semantics) ----------------
+// For a shift delta the reference multiplies the 2-D spectrum by M(ky) = exp(2 pi i delta nr(ky) / h) and inverts with a
+// complex-to-real transform that only reads the half spectrum kx <= w/2.  M is Hermitian in ky except at the Nyquist row
+// (M(h/2) = exp(-i pi delta)), so the result is NOT a pure row interpolation:
+//     out[y][x] = sum_y' mr[(y - y') mod h] src[y'][x]  +  scale (-1)^y sum_x' hm[(x - x') mod w] S[x'],   S[x'] = sum_y' (-1)^y' src[y'][x']
+// mr = real inverse DFT of M with its Nyquist bin replaced by cos(pi delta), scale = sin(pi delta) / h, hm = the discrete Hilbert
+// kernel (2/w) sum_{k=1}^{(w-1)/2} sin(2 pi k d / w) -- the part of the Nyquist row the C2R transform cannot represent leaks into
+// a rank-one term.  Tables come from the host (fp64 -> fp32, sampler_tables.py).  The adjoint is the same operator with mr and hm
+// index-reversed.
+//
+// phase_colsum: one workgroup per plane: S, then T[x] = scale * (hm (*) S)[x] -> tbuf[plane][w]
+__global__ __launch_bounds__(256) void phase_colsum_kernel(const float* __restrict__ src, long long sps, const float* __restrict__ hm,
+                                                           float scale, float* __restrict__ tbuf, int h, int w) {
+  extern __shared__ float sm[];
+  float* S = sm;            // [w]
+  float* hd = sm + w;       // [2w]: hm doubled, so (x - x' + w) needs no modulo
+  const float* p = src + (long long)blockIdx.x * sps;
+  for (int x = threadIdx.x; x < w; x += 256) {
+    float acc = 0.f;
+    for (int y = 0; y + 1 < h; y += 2) acc += p[(long long)y * w + x] - p[(long long)(y + 1) * w + x];
+    if (h & 1) acc += p[(long long)(h - 1) * w + x];
+    S[x] = acc;
+    hd[x] = hm[x];
+    hd[x + w] = hm[x];
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < w; x += 256) {
+    float acc = 0.f;
+    for (int xp = 0; xp < w; ++xp) acc += hd[x - xp + w] * S[xp];
+    tbuf[(long long)blockIdx.x * w + x] = scale * acc;
+  }
+}
+
+// phase_circ: workgroup = (32-column strip, plane).  The strip [h][32] and the doubled row kernel live in LDS; each wave owns
+// 32-row output blocks and contracts D[y][x] = sum_y' mr[(y - y') mod h] strip[y'][x] with v_mfma_f32_32x32x2_f32
+// (A: lane&31 = output row, k = source row pair; B: lane&31 = column) -- exact fp32, h/2 MFMAs per block.
+__global__ __launch_bounds__(256) void phase_circ_kernel(const float* __restrict__ src, long long sps, float* __restrict__ dst, long long dps,
+                                                         const float* __restrict__ mr, const float* __restrict__ tbuf, int h, int w) {
+  extern __shared__ float sm[];
+  const int hp = (h + 1) & ~1;            // source rows padded to a pair
+  float* strip = sm;                      // [hp][32]
+  float* md = sm + hp * 32;               // [2h + 64]: md[m] = mr[m mod h]
+  const int x0 = blockIdx.x * 32;
+  const long long plane = blockIdx.y;
+  const float* p = src + plane * sps;
+  for (int i = threadIdx.x; i < hp * 32; i += 256) {
+    const int y = i >> 5, x = x0 + (i & 31);
+    strip[i] = (y < h && x < w) ? p[(long long)y * w + x] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 2 * h + 64; i += 256) md[i] = mr[i % h];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int x = x0 + l31;
+  const float tx = (x < w) ? tbuf[plane * w + x] : 0.f;
+  float* d = dst + plane * dps;
+  for (int y0 = wv * 32; y0 < h; y0 += 128) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int abase = y0 + l31 + h - hi;          // md index of (y - y') for y' = k + hi at k = 0
+    for (int k = 0; k < hp; k += 2) {
+      const float a = md[abase - k];
+      const float b = strip[(k + hi) * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int y = y0 + (r >> 2) * 8 + hi * 4 + (r & 3);
+      if (y < h && x < w) d[(long long)y * w + x] = acc[r] + ((y & 1) ? -tx : tx);
+    }
+  }
+}
+
 // x3, s: [B,C,3,h,w]; vol: [B, CV, L, h, w]; writes channels [choff, choff+C) of every level in `levels` (bit mask)
 __global__ void cv_select_fwd_kernel(const float* __restrict__ x3, const float* __restrict__ s, float* __restrict__ vol, int B, int C,
                                      int h, int w, int CV, int L, int choff, unsigned levels) {
@@ -242,6 +354,36 @@ int dpf_shift_triple_backward(const float* g, float* dfea, const int* iy, const 
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dfea, 0, sizeof(float) * (size_t)BC * h * w, st) != hipSuccess) return DPF_ERR_LAUNCH;
   hipLaunchKernelGGL(shift_triple_bwd_kernel, dim3(dpf_ew_grid(BC * 3 * h * w)), dim3(256), 0, st, g, dfea, iy, wy, ix, wx, BC, h, w);
+  return dpf_check_launch();
+}
+
+int dpf_shift_triple_backward_gather(const float* g, float* dfea, const int* iy_inv, const float* wy, const int* ix_inv, const float* wx,
+                                     int B, int C, int h, int w, void* stream) {
+  dpf_clear_error();
+  if (!g || !dfea || !iy_inv || !wy || !ix_inv || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
+  const long long BC = (long long)B * C;
+  hipLaunchKernelGGL(shift_triple_bwd_gather_kernel, dim3(dpf_ew_grid(BC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dfea, iy_inv,
+                     wy, ix_inv, wx, BC, h, w);
+  return dpf_check_launch();
+}
+
+int dpf_phase_shift(const float* src, long long src_plane_stride, float* dst, long long dst_plane_stride, const float* mr, const float* hm,
+                    float scale, float* tbuf, long long planes, int h, int w, void* stream) {
+  dpf_clear_error();
+  if (!src || !dst || !mr || !hm || !tbuf || planes <= 0 || planes > 2147483647LL || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
+  const size_t lds_a = sizeof(float) * 3 * (size_t)w;
+  const size_t lds_b = sizeof(float) * ((size_t)((h + 1) & ~1) * 32 + 2 * (size_t)h + 64);
+  if (lds_a > 160 * 1024 || lds_b > 160 * 1024 || planes > 65535) return DPF_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(phase_colsum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(phase_circ_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(phase_colsum_kernel, dim3((unsigned)planes), dim3(256), lds_a, st, src, src_plane_stride, hm, scale, tbuf, h, w);
+  hipLaunchKernelGGL(phase_circ_kernel, dim3(dpf_div_up(w, 32), (unsigned)planes), dim3(256), lds_b, st, src, src_plane_stride, dst,
+                     dst_plane_stride, mr, tbuf, h, w);
   return dpf_check_launch();
 }
 

@@ -455,28 +455,65 @@ def nearest_up_add(lat, top):
 # ----------------------------------------------------------------------------------------------- cost volume
 class ShiftTripleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fea, iy, wy, ix, wx):
+    def forward(ctx, fea, iy, wy, ix, wx, iy_inv, ix_inv):
         fea = _c(fea)
-        _need(fea, iy, wy, ix, wx)
+        _need(fea, iy, wy, ix, wx, iy_inv, ix_inv)
         B, C, h, w = fea.shape
         out = torch.empty((B, C, 3, h, w), dtype=torch.float32, device=fea.device)
         lib().call('dpf_shift_triple_forward', _ptr(fea), _ptr(out), _ptr(iy), _ptr(wy), _ptr(ix), _ptr(wx), B, C, h, w, _stream())
-        ctx.tables = (iy, wy, ix, wx)
+        ctx.tables = (iy_inv, wy, ix_inv, wx)
         ctx.dims = (B, C, h, w)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        iy, wy, ix, wx = ctx.tables
+        iy_inv, wy, ix_inv, wx = ctx.tables
         B, C, h, w = ctx.dims
         g = _c(g)
         dfea = torch.empty((B, C, h, w), dtype=torch.float32, device=g.device)
-        lib().call('dpf_shift_triple_backward', _ptr(g), _ptr(dfea), _ptr(iy), _ptr(wy), _ptr(ix), _ptr(wx), B, C, h, w, _stream())
-        return dfea, None, None, None, None
+        lib().call('dpf_shift_triple_backward_gather', _ptr(g), _ptr(dfea), _ptr(iy_inv), _ptr(wy), _ptr(ix_inv), _ptr(wx), B, C, h, w,
+                   _stream())                                       # gather form: deterministic, no atomics, no zero fill
+        return dfea, None, None, None, None, None, None
 
 
-def shift_triple(fea, tables):
-    return ShiftTripleFn.apply(fea, *tables)
+class PhaseShiftIntoFn(torch.autograd.Function):
+    """Fills slot 2 of the shifted triple x3 [B,C,3,h,w] with the fractional Fourier-phase shift of fea (dpf_phase_shift)."""
+
+    @staticmethod
+    def forward(ctx, x3, fea, mr, hm, scale, mr_t, hm_t):
+        fea = _c(fea)
+        _need(x3, fea, mr, hm, mr_t, hm_t)
+        B, C, h, w = fea.shape
+        hw = h * w
+        tbuf = torch.empty(B * C * w, dtype=torch.float32, device=fea.device)
+        slot2 = ctypes.c_void_p(x3.data_ptr() + 2 * hw * 4)
+        lib().call('dpf_phase_shift', _ptr(fea), hw, slot2, 3 * hw, _ptr(mr), _ptr(hm), float(scale), _ptr(tbuf), B * C, h, w, _stream())
+        ctx.mark_dirty(x3)
+        ctx.tabs = (mr_t, hm_t, float(scale))
+        ctx.dims = (B, C, h, w)
+        return x3
+
+    @staticmethod
+    def backward(ctx, g):
+        mr_t, hm_t, scale = ctx.tabs
+        B, C, h, w = ctx.dims
+        g = _c(g)
+        hw = h * w
+        dfea = torch.empty((B, C, h, w), dtype=torch.float32, device=g.device)
+        tbuf = torch.empty(B * C * w, dtype=torch.float32, device=g.device)
+        slot2 = ctypes.c_void_p(g.data_ptr() + 2 * hw * 4)
+        lib().call('dpf_phase_shift', slot2, 3 * hw, _ptr(dfea), hw, _ptr(mr_t), _ptr(hm_t), scale, _ptr(tbuf), B * C, h, w, _stream())
+        # the triple's own slot 2 held no taps (zero weights in the table sampler), so its incoming gradient needs no masking
+        return g, dfea, None, None, None, None, None
+
+
+def shift_triple(fea, tables, phase=None):
+    """tables: build_shift_tables(...) on the device; phase: build_phase_tables(...) on the device for a fractional shift."""
+    x3 = ShiftTripleFn.apply(fea, *tables)
+    if phase is not None:
+        mr, hm, scale, mr_t, hm_t = phase
+        x3 = PhaseShiftIntoFn.apply(x3, fea, mr, hm, scale, mr_t, hm_t)
+    return x3
 
 
 class CvSelectFn(torch.autograd.Function):

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_SIGMOID
-from .sampler_tables import build_shift_tables
+from .sampler_tables import build_phase_tables, build_shift_tables, is_fractional
 
 try:                                    # optional: neither is installed on the MI355X image
     import pytorch_lightning as pl
@@ -377,7 +377,11 @@ class StereoDPNetCore(_Base):
         key = (h, w, float(delta), str(device))
         if key not in self._tables:
             m = self.option.model
-            self._tables[key] = tuple(t.to(device) for t in build_shift_tables(h, w, delta, m.nearest, m.bilinear, m.phase))
+            tables = tuple(t.to(device) for t in build_shift_tables(h, w, delta, m.nearest, m.bilinear, m.phase))
+            phase = None
+            if is_fractional(delta):                              # per-level shifts only (asm_grid_cache_compat = false)
+                phase = tuple(t.to(device) if torch.is_tensor(t) else t for t in build_phase_tables(h, w, delta))
+            self._tables[key] = (tables, phase)
         return self._tables[key]
 
     def _attention_parts(self, fea, delta, stat_sink=None):
@@ -386,7 +390,7 @@ class StereoDPNetCore(_Base):
         ``stat_sink`` = (zeroed mean buffer, zeroed var buffer): the BatchNorm EMA of this call is redirected there
         (it then holds momentum * batch statistic) so the caller can replay the reference's update sequence."""
         P, Bf, p = self._P, self._B, 'cost_volume.attention_layer'
-        x3 = ops.shift_triple(fea, self._shift_tables(fea.shape[2], fea.shape[3], delta, fea.device))   # [B,C,3,h,w]
+        x3 = ops.shift_triple(fea, *self._shift_tables(fea.shape[2], fea.shape[3], delta, fea.device))  # [B,C,3,h,w]
         mk = ops.conv3d(x3, P[p + '.mask_convs.0.weight'], None, 1, (0, 1, 1), 1)
         q = p + '.mask_convs.1'
         if self.training:

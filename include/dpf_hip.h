@@ -116,6 +116,16 @@ int dpf_shift_triple_forward(const float* fea, float* out, const int* iy, const 
                              int h, int w, void* stream);
 int dpf_shift_triple_backward(const float* g, float* dfea, const int* iy, const float* wy, const int* ix, const float* wx, int B, int C,
                               int h, int w, void* stream);
+/* deterministic adjoint of dpf_shift_triple_forward in gather form: iy_inv / ix_inv [3][2][2][h|w] are the inverse tap tables (the up to two
+ * output coordinates that read a given source coordinate through tap (mode, a), -1 padded), wy / wx as in forward */
+int dpf_shift_triple_backward_gather(const float* g, float* dfea, const int* iy_inv, const float* wy, const int* ix_inv, const float* wx,
+                                     int B, int C, int h, int w, void* stream);
+/* fractional Fourier-phase row shift of `planes` [h, w] planes (asm.py:59-75,112-125; only reached with per-level shifts):
+ * dst[p][y][x] = sum_y' mr[(y - y') mod h] src[p][y'][x] + scale (-1)^y sum_x' hm[(x - x') mod w] sum_y' (-1)^y' src[p][y'][x'].
+ * mr [h], hm [w]: device tables; tbuf: planes * w floats of scratch; plane strides in floats (dst may be slot 2 of the [B,C,3,h,w]
+ * triple).  The adjoint is the same call with index-reversed tables. */
+int dpf_phase_shift(const float* src, long long src_plane_stride, float* dst, long long dst_plane_stride, const float* mr, const float* hm,
+                    float scale, float* tbuf, long long planes, int h, int w, void* stream);
 int dpf_cv_select_forward(const float* x3, const float* s, float* vol, int B, int C, int h, int w, int CV, int L, int choff,
                           unsigned levels, void* stream);
 int dpf_cv_select_backward(const float* x3, const float* s, const float* dvol, float* dx3, float* ds, int B, int C, int h, int w, int CV,

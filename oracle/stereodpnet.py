@@ -28,10 +28,11 @@ class Cfg(object):
     """Model hyper-parameters (src/model/stereodpnet/config.json)."""
 
     def __init__(self, mindisp=-4, maxdisp=12, level=8, inplanes=32, dsample_num=4,
-                 loss_weight=(1.0, 0.7, 0.5), lambdas=(1.0, 1.0), flip_lr=True, use_deform=True):
+                 loss_weight=(1.0, 0.7, 0.5), lambdas=(1.0, 1.0), flip_lr=True, use_deform=True, grid_cache_compat=True):
         self.mindisp, self.maxdisp, self.level, self.inplanes = mindisp, maxdisp, level, inplanes
         self.dsample_num, self.loss_weight, self.lambdas = dsample_num, loss_weight, lambdas
         self.flip_lr, self.use_deform = flip_lr, use_deform
+        self.grid_cache_compat = grid_cache_compat      # True: the reference as written (SURVEY Q1); False: per-level shifts
 
     @property
     def costrange(self):
@@ -135,7 +136,7 @@ class StereoDPNetOracle(object):
         near = F.grid_sample(src, grid, mode='nearest', align_corners=False)
         bil = F.grid_sample(src, grid, mode='bilinear', align_corners=True)
         dr = torch.tensor(float(delta), dtype=dt) / h
-        nr = torch.cat([torch.arange(0.0, math.ceil(h // 2)), torch.arange(-float(h // 2), 0.0)]).to(torch.float64)
+        nr = torch.cat([torch.arange(0.0, math.ceil(h // 2)), torch.arange(-float(h // 2), 0.0)]).to(dt)   # fp32 like asm.py:68-75
         ang = torch.tensor(2.0 * math.pi, dtype=dt) * (dr * nr.view(h, 1).expand(h, w))
         cosv, sinv = torch.cos(ang), torch.sin(ang)
         spec = torch.fft.fft2(src.float())
@@ -154,11 +155,13 @@ class StereoDPNetOracle(object):
         prob = F.softmax(torch.sigmoid(m), dim=2)
         return torch.mean(x * prob, 2)
 
-    def cost_volume(self, ref, tar, grid_cache_compat=True):
+    def cost_volume(self, ref, tar, grid_cache_compat=None):
         """CostVolume.build_concat_volume (modules.py:181-197).  With ``grid_cache_compat`` the
         shift grid of level 0 is reused for every level, as the reference's un-keyed cache does
         (asm.py:29-30,51-57)."""
         B, C, h, w = ref.shape
+        if grid_cache_compat is None:
+            grid_cache_compat = self.cfg.grid_cache_compat
         levels = []
         for lvl, disp in enumerate(self.cfg.costrange):
             d = self.cfg.costrange[0] if grid_cache_compat else disp

@@ -164,10 +164,12 @@ def checksum(t):
 
 
 # ----------------------------------------------------------------------------- fixtures
-def gen_e2e(tag, B, H, W, train, mask_mode, stages):
+def gen_e2e(tag, B, H, W, train, mask_mode, stages, prepare=None):
     torch.manual_seed(1)
     model, opt = build_reference()
     fill_by_recipe(model)
+    if prepare is not None:
+        prepare(model)
     model.train(train)
     batch = synthetic_batch(B, H, W, seed=0, mask_mode=mask_mode)
     cap = OrderedDict()

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-def build_model(training=True):
+def build_model(training=True, **model_overrides):
     from dualpixelface_amd import load_option
     from dualpixelface_amd.plugin import STEREODPNET
     from dualpixelface_amd.recipe import fill_by_recipe
-    model = STEREODPNET(load_option())
+    model = STEREODPNET(load_option(**model_overrides))
     fill_by_recipe(model)
     model.to(DEV)
     model.train(training)
@@ -70,6 +70,55 @@ def test_eval_forward(golden_dir):
     assert res['pred_depth'].shape[1] == 1 and 'final_loss' not in res
     close(res['pred_depth'], g['pred_depth'], None, 'pred_depth', atol=5e-3)
     close(res['pred_normal'], g['pred_normal'], None, 'pred_normal', atol=1e-3)
+
+
+def test_fix_mode_per_level_shifts_vs_reference_with_cleared_grid_cache(golden_dir):
+    """asm_grid_cache_compat = false: every cost level uses its own (fractional) shift.  Fixture: the reference run with its
+    shift-grid cache cleared before every call (tests/golden/make_golden_fixmode.py); gradients against the fp32 oracle."""
+    from oracle import recipe_state
+    from oracle.stereodpnet import Cfg, StereoDPNetOracle
+    g = np.load(golden_dir + '/e2e_fixmode_train_32x48_b2.npz')
+    model = build_model(True, asm_grid_cache_compat=False)
+    res = model(load_batch(g))
+    taps = model.last_taps
+    close(taps['volume'], g['volume'], 2e-4, 'volume')
+    assert not torch.equal(taps['volume'][:, :, 0], taps['volume'][:, :, 1])
+    close(taps['out3'], g['out3'], 5e-4, 'out3')
+    close(res['pred_depth'], g['pred_depth'], None, 'pred_depth', atol=2e-3)
+    close(res['pred_normal'], g['pred_normal'], None, 'pred_normal', atol=1e-3)
+    for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
+        close(res[k], g[k], 1e-4, k)
+    sd = model.state_dict()
+    close(sd['cost_volume.attention_layer.mask_convs.1.running_mean'], g['post::cost_volume.attention_layer.mask_convs.1.running_mean'], 1e-4, 'attn rm')
+    close(sd['cost_volume.attention_layer.mask_convs.1.running_var'], g['post::cost_volume.attention_layer.mask_convs.1.running_var'], 1e-4, 'attn rv')
+    assert int(sd['cost_volume.attention_layer.mask_convs.1.num_batches_tracked']) == 16
+    # backward through the 16 attention calls and the phase-shift adjoint: gradient of the feature extractor and the attention
+    # weights against the fp64 oracle in the same mode
+    st = recipe_state(dtype=torch.float64)
+    batch64 = {k[3:]: torch.from_numpy(g[k]).double() for k in g.files if k.startswith('in_')}
+    StereoDPNetOracle(st, cfg=Cfg(grid_cache_compat=False), training=True).forward(batch64)['final_loss'].backward()
+    model = build_model(True, asm_grid_cache_compat=False)
+    model.train_step(load_batch(g))
+    pd = dict(model.named_parameters())
+    bad, checked = [], 0
+    for name in pd:
+        if not (name.startswith('cost_volume.') or name.startswith('feature_extraction.lastconv')):
+            continue
+        ref = st[name].grad
+        if ref is None or ref.norm().item() < 1e-6:
+            continue
+        checked += 1
+        rel = (pd[name].grad.detach().cpu().double() - ref).norm().item() / ref.norm().item()
+        if rel > 5e-2:
+            bad.append((name, rel))
+    assert checked >= 6 and not bad, bad
+    # eval mode
+    ge = np.load(golden_dir + '/e2e_fixmode_eval_32x48_b2.npz')
+    model = build_model(False, asm_grid_cache_compat=False)
+    with torch.no_grad():
+        res = model(load_batch(ge))
+    close(res['pred_depth'], ge['pred_depth'], None, 'pred_depth', atol=5e-3)
+    close(res['pred_normal'], ge['pred_normal'], None, 'pred_normal', atol=1e-3)
 
 
 def test_train_64x96(golden_dir):

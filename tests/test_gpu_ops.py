@@ -286,21 +286,48 @@ def test_bilinear_and_nearest(scale):
     close(gt, gt_r, 1e-5, 'nearest dtop')
 
 
-@pytest.mark.parametrize('delta', [-1.0, 1.0, 2.0])
-def test_shift_triple(delta):
+def _device_tables(h, w, delta):
+    from dualpixelface_amd.sampler_tables import build_phase_tables, build_shift_tables, is_fractional
+    tables = tuple(t.to(DEV) for t in build_shift_tables(h, w, delta))
+    phase = None
+    if is_fractional(delta):
+        phase = tuple(t.to(DEV) if torch.is_tensor(t) else t for t in build_phase_tables(h, w, delta))
+    return tables, phase
+
+
+@pytest.mark.parametrize('delta', [-1.0, 1.0, 2.0, 0.5, -0.25, 1.75, -2.5])
+@pytest.mark.parametrize('shape', [(2, 8, 12, 20), (1, 3, 40, 70), (1, 2, 256, 96)])
+def test_shift_triple(delta, shape):
+    """nearest / bilinear / Fourier-phase triple incl. fractional shifts (row circulant on MFMA + Hilbert term) and its adjoint."""
     from oracle.stereodpnet import StereoDPNetOracle
-    from dualpixelface_amd.sampler_tables import build_shift_tables
     ops = _ops()
-    fea = rnd(2, 8, 12, 20, seed=40).requires_grad_()
+    fea = rnd(*shape, seed=40).requires_grad_()
     ref = torch.stack(StereoDPNetOracle.shift_triple(fea, delta), 2)
     go = rnd(*ref.shape, seed=41)
     (gr,) = torch.autograd.grad(ref, fea, go)
-    tables = tuple(t.to(DEV) for t in build_shift_tables(12, 20, delta))
+    tables, phase = _device_tables(shape[2], shape[3], delta)
     fg = fea.detach().to(DEV).requires_grad_()
-    out = ops.shift_triple(fg, tables)
+    out = ops.shift_triple(fg, tables, phase)
     close(out, ref, 1e-5, 'shift fwd')
     (gg,) = torch.autograd.grad(out, fg, go.to(DEV))
     close(gg, gr, 1e-4, 'shift bwd')
+    # the adjoint is a gather (no atomics): bitwise reproducible
+    (gg2,) = torch.autograd.grad(ops.shift_triple(fg, tables, phase), fg, go.to(DEV))
+    assert torch.equal(gg, gg2)
+
+
+def test_shift_triple_fractional_vs_reference_fixture(golden_dir):
+    """Fractional shifts against outputs of the reference's own subpixel_shift (fresh module instance per delta)."""
+    ops = _ops()
+    g = np.load(golden_dir + '/shift_fractional.npz')
+    for ci in range(3):
+        fea = torch.from_numpy(g['fea%d' % ci]).to(DEV)
+        for di, delta in enumerate(g['deltas']):
+            for direction, sign in (('forward', 1.0), ('backward', -1.0)):
+                tables, phase = _device_tables(fea.shape[2], fea.shape[3], sign * float(delta))
+                out = ops.shift_triple(fea, tables, phase)
+                for j, nm in enumerate(('nearest', 'bilinear', 'phase')):
+                    close(out[:, :, j], torch.from_numpy(g['c%d_d%d_%s_%s' % (ci, di, direction, nm)]), 5e-6, '%s %s %s' % (nm, delta, direction))
 
 
 def test_cv_select():

@@ -47,10 +47,47 @@ def test_shift_tables_reproduce_reference_sampling(golden_dir):
         for j, nm in enumerate(('nearest', 'bilinear', 'phase')):
             assert (out[:, :, j] - torch.from_numpy(g[pre + nm])).abs().max() < 1e-6, pre + nm
     # the nearest branch zero-fills the last column (SURVEY Q2)
-    iy, wy, ix, wx = build_shift_tables(16, 24, -1.0)
+    iy, wy, ix, wx, iy_inv, ix_inv = build_shift_tables(16, 24, -1.0)
     assert ix[0, 0, -1] == -1 and (ix[0, 0, :-1] >= 0).all()
+    # inverse tables (deterministic gather adjoint): source coordinate -> output coordinate, consistent with the forward taps
+    for fwd, inv in ((iy, iy_inv), (ix, ix_inv)):
+        for m in range(3):
+            for a in range(2):
+                for out_pos, src_pos in enumerate(fwd[m, a].tolist()):
+                    if src_pos >= 0:
+                        assert out_pos in inv[m, a, :, src_pos].tolist()
+                assert int((inv[m, a] >= 0).sum()) == int((fwd[m, a] >= 0).sum())
+    # a fractional delta leaves the phase slot without taps (dpf_phase_shift fills it) ...
+    iyf = build_shift_tables(16, 24, 0.5)[0]
+    assert (iyf[2] == -1).all() and (iyf[1, 0] >= 0).any()
+
+
+def test_phase_tables_reproduce_reference_fractional_shift(golden_dir):
+    """... from tables that must reproduce the reference's irfft(onesided=False) arithmetic: row circulant + rank-one Hilbert term,
+    evaluated densely here against outputs of the reference's subpixel_shift (tests/golden/shift_fractional.npz)."""
+    from dualpixelface_amd.sampler_tables import build_phase_tables, is_fractional
+    g = np.load(golden_dir + '/shift_fractional.npz')
+    for ci in range(3):
+        fea = torch.from_numpy(g['fea%d' % ci]).double()
+        B, C, h, w = fea.shape
+        y, x = torch.arange(h), torch.arange(w)
+        sg = (1.0 - 2.0 * (y % 2)).double()
+        for di, delta in enumerate(g['deltas']):
+            for direction, sign in (('forward', 1.0), ('backward', -1.0)):
+                d = sign * float(delta)
+                if not is_fractional(d):
+                    continue
+                mr, hm, scale, mr_t, hm_t = build_phase_tables(h, w, d)
+                Cm = mr.double()[(y[:, None] - y[None, :]) % h]
+                Hm = hm.double()[(x[:, None] - x[None, :]) % w]
+                S = torch.einsum('z,bczx->bcx', sg, fea)
+                out = torch.einsum('yz,bczx->bcyx', Cm, fea) + scale * sg.view(1, 1, h, 1) * torch.einsum('xz,bcz->bcx', Hm, S).unsqueeze(2)
+                want = torch.from_numpy(g['c%d_d%d_%s_phase' % (ci, di, direction)]).double()
+                assert (out - want).abs().max() < 3e-6 * max(1.0, want.abs().max().item()), (ci, delta, direction)
+                # adjoint tables are the index-reversed kernels
+                assert torch.equal(mr_t, mr[(-y) % h]) and torch.equal(hm_t, hm[(-x) % w])
     with pytest.raises(NotImplementedError):
-        build_shift_tables(16, 24, 0.5)
+        build_phase_tables(15, 20, 0.5)
 
 
 def test_state_dict_contract_and_flat_arena(golden_dir):

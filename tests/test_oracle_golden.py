@@ -145,3 +145,46 @@ def test_psmnet_oracle_against_reference(golden_dir):
     st2 = recipe_state(requires_grad=False, keys_file=keys)
     ev = PSMNetOracle(st2, training=False).forward(batch)
     _close(ev['pred_depth'][:, :, ::2, ::2], g['eval_pred_depth_s2'], 2e-4, 'psmnet eval pred_depth')
+
+
+def test_fractional_shift_triple_vs_reference(golden_dir):
+    """subpixel_shift at fractional deltas (asm.py:59-75,112-125 through the irfft(onesided=False) semantics): the
+    oracle's three branches against outputs of fresh reference module instances."""
+    g = np.load(golden_dir + '/shift_fractional.npz')
+    for ci in range(3):
+        fea = torch.from_numpy(g['fea%d' % ci])
+        for di, delta in enumerate(g['deltas']):
+            for direction, sign in (('forward', 1.0), ('backward', -1.0)):
+                near, bil, ph = StereoDPNetOracle.shift_triple(fea, sign * float(delta))
+                key = 'c%d_d%d_%s_' % (ci, di, direction)
+                _close(near, g[key + 'nearest'], 1e-6, key + 'nearest')
+                _close(bil, g[key + 'bilinear'], 1e-6, key + 'bilinear')
+                _close(ph, g[key + 'phase'], 2e-6, key + 'phase')
+
+
+def test_fix_mode_model_vs_reference_with_cleared_grid_cache(golden_dir):
+    """Per-level shifts (asm_grid_cache_compat = false) against the reference run with its shift-grid cache cleared before every
+    call (tests/golden/make_golden_fixmode.py)."""
+    from oracle.stereodpnet import Cfg
+    g = np.load(golden_dir + '/e2e_fixmode_train_32x48_b2.npz')
+    st = recipe_state()
+    orc = StereoDPNetOracle(st, cfg=Cfg(grid_cache_compat=False), training=True)
+    res = orc.forward(_batch(g))
+    t = orc.taps
+    for j, nm in enumerate(('nearest', 'bilinear', 'phase')):
+        _close(t['shift_fwd'][:, :, j], g['shift_fwd_' + nm], 2e-6, 'shift_fwd_' + nm)
+    _close(t['volume'], g['volume'], 1e-5, 'volume')
+    v = t['volume']
+    assert not torch.equal(v[:, :, 0], v[:, :, 1])                  # the levels now differ
+    _close(res['pred_depth'], g['pred_depth'], 1e-4, 'pred_depth')
+    _close(res['pred_normal'], g['pred_normal'], 1e-4, 'pred_normal')
+    for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
+        _close(res[k], g[k], 1e-5, k)
+    _close(st['cost_volume.attention_layer.mask_convs.1.running_mean'],
+           g['post::cost_volume.attention_layer.mask_convs.1.running_mean'], 1e-5, 'attention running_mean')
+    ge = np.load(golden_dir + '/e2e_fixmode_eval_32x48_b2.npz')
+    orc = StereoDPNetOracle(recipe_state(requires_grad=False), cfg=Cfg(grid_cache_compat=False), training=False)
+    with torch.no_grad():
+        res = orc.forward(_batch(ge))
+    _close(res['pred_depth'], ge['pred_depth'], 1e-4, 'eval pred_depth')
+    _close(res['pred_normal'], ge['pred_normal'], 1e-4, 'eval pred_normal')
