@@ -62,7 +62,13 @@ def stage_bench(args):
         fn = lambda: ops.psm_volume(ref, tar, shifts, 0)
         name = 'PSMNet concat cost volume (BASELINE configs[3])'
     else:
-XX
+        fix = args.workload == 'cost_volume_fix'
+        model = STEREODPNET(load_option(asm_grid_cache_compat=not fix)).to(dev)
+        model.train()
+        fn = lambda: model._cost_volume(ref, tar)
+        name = 'StereoDPNet cost volume: shift triple + masking attention + volume assembly, forward (SURVEY a2-a4)'
+        if fix:
+            name += ', per-level fractional shifts (asm_grid_cache_compat=false: 16 attention calls instead of 2)'
     with torch.no_grad():
         for _ in range(args.warmup):
             fn()

@@ -604,6 +604,28 @@ int dpf_conv_forward(const float* x, const float* w, const float* bias, float* o
   return conv_common(x, w, bias, out, ws, p, /*mode*/ 0, K, C, (hipStream_t)stream);
 }
 
+// dpf_conv_forward that also leaves, per position tile, the (sum, sum of squares) of every output channel in `slab`
+// ([*parts_host][K][2] doubles, capacity dpf_conv_stats_slab_doubles) for the BatchNorm that follows (dpf_bn_finalize_partials): the
+// separate statistics pass over the output tensor disappears.  DPF_ERR_UNSUPPORTED when the shape does not run on the LDS-DMA
+// kernel (K > 128, rows not 16-byte aligned, 1x1 kernels ...): the caller then uses dpf_conv_forward + dpf_bn_stats.
+long long dpf_conv_stats_slab_doubles(int N, int K, int OD, int OH, int OW) {
+  return 2LL * K * N * OD * dpf_div_up(OH, 8) * dpf_div_up(OW, 32);
+}
+
+int dpf_conv_forward_stats(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                           int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw,
+                           double* slab, long long slab_doubles, int* parts_host, void* stream) {
+  dpf_clear_error();
+  if (!x || !w || !out || !ws || !slab || !parts_host || N <= 0 || C <= 0 || K <= 0) return DPF_ERR_INVALID_ARG;
+  const int OD = out_dim(ID, kd, sd, pd, dd), OH = out_dim(IH, kh, sh, ph, dh), OW = out_dim(IW, kw, sw, pw, dw);
+  if (OD <= 0 || OH <= 0 || OW <= 0) return DPF_ERR_INVALID_ARG;
+  DpfConvDesc d{N, C, K, K, 0, ID, IH, IW, OD, OH, OW, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw, 0, K, C, 0};
+  DpfConvStats stats{slab, slab_doubles, 0};
+  const int rc = dpf_igemm2_conv(x, w, bias, out, ws, d, (hipStream_t)stream, &stats);
+  if (rc == DPF_OK) *parts_host = stats.parts;
+  return rc;
+}
+
 // Transposed convolution.  x [N,C,ID,IH,IW] lives on the strided (small) grid, out [N,K,OD,OH,OW] on the dense grid;
 // (OD,OH,OW) are given by the caller (output_padding ambiguity).  `w_is_conv_layout` = 1: w is a forward-conv weight
 // [C(x chans = conv out), K(out chans = conv in), T] and this call is that conv's data gradient;

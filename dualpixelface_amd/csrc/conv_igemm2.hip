@@ -41,6 +41,7 @@ struct G2P {
   int nchunks;
   unsigned mSR, mRPC, mEH;      // ceil(2^20 / d) for d = SR, rpc, ext_h
   unsigned long long steps;     // 2-bit step code per tap (see the kernel's tap walk)
+  double* stats;                // optional [ntiles][K][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
 
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
   // contiguous tile range ordered depth-fastest -- the workgroups that share input planes and halo rows run together behind one L2
   int b = (blockIdx.x & 7) * p.cpx + (blockIdx.x >> 3);
   if (b >= p.ntiles) return;
+  const int tile_id = b;
   const int qd = b % p.OD; b /= p.OD;
   const int tw = b % p.tilesW; b /= p.tilesW;
   const int th = b % p.tilesH;
@@ -225,6 +227,55 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
             if (oh0 + t < p.OH) op[(long long)k * kstride + t * p.OW] = acc[m][t][j] + bv;
         }
       }
+    }
+  }
+  // ---- optional BatchNorm statistics of this tile (the consumer's bn_stats pass over the output tensor is then not needed):
+  // per output channel the sum and the sum of squares of the valid outputs -- lane partials in fp32 (<= NT values), everything
+  // after that in fp64 -- reduced over the 32 columns by shuffles and over the 4 waves through LDS in a fixed order, one
+  // [K][2] row per tile.  A finalize kernel folds the rows in a fixed order: deterministic, no atomics, no zero fill.
+  if (p.stats) {                                                 // uniform
+    double* red = reinterpret_cast<double*>(smem);               // [4 waves][2][MT * 16][2]; the operand buffers are dead by now
+    const bool colok = ow < p.OW;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        const float bv = (bias && k < p.K) ? bias[p.k0 + k] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float v = (colok && oh0 + t < p.OH) ? acc[m][t][j] + bv : 0.f;
+          s1 += v;
+          s2 += v * v;
+        }
+        double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          d1 += __shfl_xor(d1, o, 64);
+          d2 += __shfl_xor(d2, o, 64);
+        }
+        if (l31 == 0) {
+          double* dst = red + (((wave * 2 + hh) * MT + m) * 16 + j) * 2;
+          dst[0] = d1;
+          dst[1] = d2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < KT && tid < p.K) {
+      const int m = tid >> 5, kk = tid & 31;
+      const int h2 = (kk >> 2) & 1, j = (kk & 3) + 4 * (kk >> 3);
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        const double* src = red + (((wv * 2 + h2) * MT + m) * 16 + j) * 2;
+        a1 += src[0];
+        a2 += src[1];
+      }
+      double* row = p.stats + ((long long)tile_id * p.K + tid) * 2;
+      row[0] = a1;
+      row[1] = a2;
     }
   }
 }
@@ -544,7 +595,8 @@ long long dpf_igemm2_workspace_floats(int T, int reduce, int outc) {
   return (long long)T * (reduce + 8) * KT + ZPAGE;
 }
 
-int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st) {
+int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st,
+                    DpfConvStats* stats) {
   static const int enabled = env_int("DPF_IGEMM2", 1);
   if (!enabled) return DPF_ERR_UNSUPPORTED;
   const int T = d.kd * d.kh * d.kw;
@@ -553,6 +605,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   const long long x_chan = (long long)d.ID * d.IH * d.IW;
   if (9 * x_chan >= (1LL << 30)) return DPF_ERR_UNSUPPORTED;      // per-lane 32-bit source offsets within a chunk
   if (T == 1 && !env_int("DPF_IGEMM2_1x1", 0)) return DPF_ERR_UNSUPPORTED;   // pointwise convs are HBM-bound: generic kernel
+  if (stats && (d.transposed || d.Ktot != d.K)) return DPF_ERR_UNSUPPORTED;
   if (d.transposed && (d.sd != 1 || d.sh != 1 || d.sw != 1)) return igemm2_tr2(x, w, bias, out, ws, d, st);
 
   const int MT = (d.K + 31) / 32, KT = 32 * MT;
@@ -622,6 +675,12 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
 
   const size_t lds = 2 * buf_bytes(CC);
+  p.stats = nullptr;
+  if (stats) {
+    if (ntiles * d.K * 2 > stats->capacity_doubles || lds < (size_t)4 * 2 * MT * 16 * 2 * sizeof(double)) return DPF_ERR_UNSUPPORTED;
+    p.stats = stats->slab;
+    stats->parts = (int)ntiles;
+  }
 #define G2(M, N_, C_) return launch_g2<M, N_, C_>(x, ws, bias, out, p, lds, blocks, st)
 #define G2CC(M, N_)                                                                                                         \
   switch (CC) { case 8: G2(M, N_, 8); case 4: G2(M, N_, 4); default: G2(M, N_, 2); }

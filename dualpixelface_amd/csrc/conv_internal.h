@@ -15,7 +15,14 @@ struct DpfConvDesc {
 
 // LDS-DMA double-buffered implicit GEMM (conv_igemm2.hip).  Returns DPF_OK when it launched, DPF_ERR_UNSUPPORTED when the
 // shape is not eligible (the caller then uses the generic kernel), another error code on failure.
-int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st);
+// optional per-tile BatchNorm statistics of a forward launch: slab [parts][K][2] doubles (sum, sum of squares of the outputs)
+struct DpfConvStats {
+  double* slab;
+  long long capacity_doubles;
+  int parts;                    // out: rows written
+};
+int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st,
+                    DpfConvStats* stats = nullptr);
 // floats of workspace dpf_igemm2_conv may use for (T taps, `reduce` reduction channels, `outc` output channels)
 long long dpf_igemm2_workspace_floats(int T, int reduce, int outc);
 

@@ -67,6 +67,45 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+// batch statistics from the per-tile (sum, sum of squares) rows a convolution's epilogue wrote (dpf_conv_forward_stats):
+// slab [parts][C][2] doubles.  One workgroup per channel: strided fp64 partial sums, then a fixed-order LDS tree -> bitwise
+// reproducible.  Same outputs as bn_finalize_kernel.
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const double* __restrict__ slab, int parts, int C, double count, float eps,
+                                                                   float momentum, float* __restrict__ running_mean,
+                                                                   float* __restrict__ running_var, float* __restrict__ mean,
+                                                                   float* __restrict__ invstd) {
+  __shared__ double s1[256], s2[256];
+  const int c = blockIdx.x;
+  double a1 = 0.0, a2 = 0.0;
+  for (int t = threadIdx.x; t < parts; t += 256) {
+    const double* r = slab + ((long long)t * C + c) * 2;
+    a1 += r[0];
+    a2 += r[1];
+  }
+  s1[threadIdx.x] = a1;
+  s2[threadIdx.x] = a2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s1[threadIdx.x] += s1[threadIdx.x + o];
+      s2[threadIdx.x] += s2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mu = s1[0] / count;
+    double var = s2[0] / count - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  }
+}
+
 // cross-rank batch statistics (SyncBatchNorm): this rank's { mean, M2 = sum (x - mean)^2 } per channel from the shifted sums
 __global__ void bn_local_moments_kernel(const float* __restrict__ x, const float* __restrict__ sums, int C, long long S, double count,
                                         float* __restrict__ moments) {
@@ -329,6 +368,17 @@ int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float mom
   const int chunk = reduce_chunk(N * C, S);
   hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, ws, N, C, S, chunk);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, st, x, ws, C, S, (double)N * (double)S, eps, momentum,
+                     running_mean, running_var, mean, invstd);
+  return dpf_check_launch();
+}
+
+// Batch statistics from the partial rows of dpf_conv_forward_stats (slab [parts][C][2] doubles, count = N * S elements per channel);
+// outputs and running-statistics update as dpf_bn_stats.
+int dpf_bn_finalize_partials(const double* slab, int parts, int C, long long count, float eps, float momentum, float* running_mean,
+                             float* running_var, float* mean, float* invstd, void* stream) {
+  dpf_clear_error();
+  if (!slab || !mean || !invstd || parts <= 0 || C <= 0 || count <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, slab, parts, C, (double)count, eps, momentum,
                      running_mean, running_var, mean, invstd);
   return dpf_check_launch();
 }

@@ -5,6 +5,7 @@ step runs in the hand-written HIP kernels reached through the C ABI (include/dpf
 this file has a CPU or eager-PyTorch fallback: tensors must be fp32, contiguous and on the GPU.
 """
 import ctypes
+import os
 
 import torch
 
@@ -12,6 +13,8 @@ from ._lib import lib, DpfError
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3, 4
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+# BatchNorm statistics from the producing convolution's epilogue (dpf_conv_forward_stats) instead of a pass over its output
+FUSE_BN_STATS = os.environ.get('DPF_FUSE_BN_STATS', '1') != '0'
 
 _scratch = {}
 
@@ -89,7 +92,9 @@ def _out_dim(i, k, s, p, d):
     return (i + 2 * p - (d * (k - 1) + 1)) // s + 1
 
 
-def _conv_fwd_raw(x, w, bias, stride, pad, dil):
+def _conv_fwd_raw(x, w, bias, stride, pad, dil, stats=None):
+    """stats: a dict the caller hands to the following training BatchNorm (norm_act(..., stats=...)); when the launch runs on the
+    LDS-DMA kernel its epilogue leaves per-tile channel sums there and the BatchNorm skips its own statistics pass."""
     N, C, ID, IH, IW = x.shape
     K, _, kd, kh, kw = w.shape
     od = _out_dim(ID, kd, stride[0], pad[0], dil[0])
@@ -106,6 +111,17 @@ def _conv_fwd_raw(x, w, bias, stride, pad, dil):
     with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * od * oh * ow,
                 'fwd N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
                 4.0 * (x.numel() + out.numel() + w.numel())):
+        if stats is not None and FUSE_BN_STATS and K <= 128 and IW % 4 == 0 and kd * kh * kw > 1:
+            cap = int(L.call('dpf_conv_stats_slab_doubles', N, K, od, oh, ow))
+            slab = torch.empty(cap, dtype=torch.float64, device=x.device)
+            parts = ctypes.c_int(0)
+            rc = L.cdll.dpf_conv_forward_stats(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, kd, kh, kw,
+                                               *stride, *pad, *dil, _ptr(slab), cap, ctypes.byref(parts), _stream())
+            if rc == 0:
+                stats.update(slab=slab, parts=int(parts.value), count=N * od * oh * ow, channels=K, ptr=out.data_ptr())
+                return out
+            if rc != -3:                                               # DPF_ERR_UNSUPPORTED -> the plain launch below
+                raise DpfError('dpf_conv_forward_stats failed: %s' % rc)
         L.call('dpf_conv_forward', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, kd, kh, kw,
                *stride, *pad, *dil, _stream())
     return out
@@ -171,14 +187,14 @@ class ConvFn(torch.autograd.Function):
     """nn.Conv3d semantics on [N,C,D,H,W] (2-D callers use depth 1)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, gi_channels=None):
+    def forward(ctx, x, w, bias, stride, pad, dil, gi_channels=None, stats=None):
         x, w = _c(x), _c(w)
         _need(x, w, bias)
         ctx.cfg = (stride, pad, dil)
         ctx.gi_channels = gi_channels
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return _conv_fwd_raw(x, w, bias, stride, pad, dil)
+        return _conv_fwd_raw(x, w, bias, stride, pad, dil, stats)
 
     @staticmethod
     def backward(ctx, gy):
@@ -192,7 +208,7 @@ class ConvFn(torch.autograd.Function):
             gw = _conv_wgrad_raw(gy, x, w.shape, stride, pad, dil)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _channel_sum(gy)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class ConvTransposeFn(torch.autograd.Function):
@@ -222,9 +238,10 @@ class ConvTransposeFn(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
-def conv3d(x, w, bias=None, stride=1, pad=0, dil=1, gi_channels=None):
-    """gi_channels: only the first gi_channels input channels need a gradient (the others' data gradient is zero)."""
-    return ConvFn.apply(x, w, bias, _t3(stride), _t3(pad), _t3(dil), gi_channels)
+def conv3d(x, w, bias=None, stride=1, pad=0, dil=1, gi_channels=None, stats=None):
+    """gi_channels: only the first gi_channels input channels need a gradient (the others' data gradient is zero).
+    stats: see _conv_fwd_raw."""
+    return ConvFn.apply(x, w, bias, _t3(stride), _t3(pad), _t3(dil), gi_channels, stats)
 
 
 class ConvBf16Fn(torch.autograd.Function):
@@ -274,10 +291,10 @@ class ConvBf16Fn(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, bf16=False):
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, bf16=False, stats=None):
     if bf16 and w.shape[0] > 4:          # the handful-of-channels heads keep their direct fp32 kernels
         return ConvBf16Fn.apply(x, w, bias, int(stride), int(pad), int(dil))
-    y = ConvFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride, stride), (0, pad, pad), (1, dil, dil))
+    y = ConvFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride, stride), (0, pad, pad), (1, dil, dil), None, stats)
     return y.squeeze(2)
 
 
@@ -317,7 +334,7 @@ class NormActFn(torch.autograd.Function):
     """y = act(norm(x) * w + b + res) + res2 with norm = batch norm (training/eval) or instance norm, or no norm."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const, exchange=None):
+    def forward(ctx, x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const, exchange=None, stats=None):
         # mode: 0 none, 1 batch norm (training), 2 batch norm (eval), 3 instance norm
         # exchange: distributed.StatExchange -> training batch norm uses the statistics of the global batch (SyncBatchNorm)
         x = _c(x)
@@ -341,6 +358,13 @@ class NormActFn(torch.autograd.Function):
             counts = gathered[:, 2 * C].contiguous()
             L.call('dpf_bn_merge_moments', _ptr(moments), _ptr(counts), gathered.shape[0], C, BN_EPS, BN_MOMENTUM, _ptr(running_mean),
                    _ptr(running_var), _ptr(mean), _ptr(invstd), _stream())
+        elif mode == 1 and stats and stats.get('ptr') == x.data_ptr() and stats['channels'] == C and stats['count'] == N * S:
+            # the producing convolution already left per-tile channel sums (dpf_conv_forward_stats): no pass over x
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            L.call('dpf_bn_finalize_partials', _ptr(stats['slab']), stats['parts'], C, N * S, BN_EPS, BN_MOMENTUM, _ptr(running_mean),
+                   _ptr(running_var), _ptr(mean), _ptr(invstd), _stream())
+            stats.clear()
         elif mode == 1:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
@@ -394,12 +418,12 @@ class NormActFn(torch.autograd.Function):
             ws = scratch(3 * c_, x.device)
             L.call('dpf_norm_act_backward', *args, _ptr(ws), n_, c_, S, _stream())
         dres2 = gy if (has_res2 and ctx.needs_input_grad[5]) else None
-        return dx, dweight, dbias, dslope, dres, dres2, None, None, None, None, None, None
+        return dx, dweight, dbias, dslope, dres, dres2, None, None, None, None, None, None, None
 
 
 def norm_act(x, weight=None, bias=None, slope=None, res=None, res2=None, running_mean=None, running_var=None, mode=0, act=ACT_NONE,
-             slope_const=0.0, exchange=None):
-    return NormActFn.apply(x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const, exchange)
+             slope_const=0.0, exchange=None, stats=None):
+    return NormActFn.apply(x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const, exchange, stats)
 
 
 # ----------------------------------------------------------------------------------------------- resampling

@@ -316,21 +316,28 @@ class StereoDPNetCore(_Base):
         """nn.Conv2d; with option.precision 'bf16' / 16 on the bf16 MFMA kernel (BASELINE config 5), else exact fp32."""
         return ops.conv2d(*args, bf16=self.bf16_2d)
 
-    def _bn(self, x, p, act=ACT_NONE, slope=None, res=None, res2=None, slope_const=0.0):
+    def _bn(self, x, p, act=ACT_NONE, slope=None, res=None, res2=None, slope_const=0.0, stats=None):
         P, B = self._P, self._B
         if self.training:
             key = p + '.num_batches_tracked'
             self._pending_counts[key] = self._pending_counts.get(key, 0) + 1
         return ops.norm_act(x, P[p + '.weight'], P[p + '.bias'], slope, res, res2, B[p + '.running_mean'], B[p + '.running_var'],
-                            1 if self.training else 2, act, slope_const, self.stat_exchange if self.training else None)
+                            1 if self.training else 2, act, slope_const, self.stat_exchange if self.training else None, stats)
+
+    def _stats_holder(self):
+        """conv -> training BatchNorm pairs: the conv's epilogue leaves the channel sums, the BatchNorm skips its statistics pass
+        (per-rank statistics only; SyncBatchNorm exchanges {mean, M2} and keeps its own pass)."""
+        return {} if (self.training and self.stat_exchange is None) else None
 
     def _convbn2(self, x, p, stride=1, pad=1, dil=1, act=ACT_NONE, slope=None, res=None):
-        y = self._conv2d(x, self._P[p + '.0.weight'], None, stride, dil if dil > 1 else pad, dil)   # basics.py:17-22
-        return self._bn(y, p + '.1', act, slope, res)
+        st = self._stats_holder()
+        y = ops.conv2d(x, self._P[p + '.0.weight'], None, stride, dil if dil > 1 else pad, dil, bf16=self.bf16_2d, stats=st)  # basics.py:17-22
+        return self._bn(y, p + '.1', act, slope, res, stats=st)
 
     def _convbn3(self, x, p, stride=1, act=ACT_NONE, res=None):
-        y = ops.conv3d(x, self._P[p + '.0.weight'], None, stride, 1, 1)                            # basics.py:32-36
-        return self._bn(y, p + '.1', act, None, res)
+        st = self._stats_holder()
+        y = ops.conv3d(x, self._P[p + '.0.weight'], None, stride, 1, 1, stats=st)                  # basics.py:32-36
+        return self._bn(y, p + '.1', act, None, res, stats=st)
 
     # ------------------------------------------------------------------ feature extractor (modules.py:21-134)
     def _dpblock(self, x, p, s):
@@ -391,11 +398,13 @@ class StereoDPNetCore(_Base):
         (it then holds momentum * batch statistic) so the caller can replay the reference's update sequence."""
         P, Bf, p = self._P, self._B, 'cost_volume.attention_layer'
         x3 = ops.shift_triple(fea, *self._shift_tables(fea.shape[2], fea.shape[3], delta, fea.device))  # [B,C,3,h,w]
-        mk = ops.conv3d(x3, P[p + '.mask_convs.0.weight'], None, 1, (0, 1, 1), 1)
+        st = self._stats_holder()
+        mk = ops.conv3d(x3, P[p + '.mask_convs.0.weight'], None, 1, (0, 1, 1), 1, stats=st)
         q = p + '.mask_convs.1'
         if self.training:
             rm, rv = stat_sink if stat_sink is not None else (Bf[q + '.running_mean'], Bf[q + '.running_var'])
-            mk = ops.norm_act(mk, P[q + '.weight'], P[q + '.bias'], None, None, None, rm, rv, 1, ACT_RELU, exchange=self.stat_exchange)
+            mk = ops.norm_act(mk, P[q + '.weight'], P[q + '.bias'], None, None, None, rm, rv, 1, ACT_RELU, exchange=self.stat_exchange,
+                              stats=st)
         else:
             mk = ops.norm_act(mk, P[q + '.weight'], P[q + '.bias'], None, None, None, Bf[q + '.running_mean'], Bf[q + '.running_var'], 2,
                               ACT_RELU)

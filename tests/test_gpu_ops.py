@@ -629,3 +629,45 @@ def test_full_size_properties():
     fd = dot(yp - ym, gd) / (2 * eps)
     an = dot(god, d)
     assert abs(fd - an) <= 5e-2 * abs(an) + 50 * tol, (fd, an, tol)
+
+
+@pytest.mark.parametrize('shape', [
+    # N, C, K, D, H, W, kernel, stride, bias
+    (2, 8, 32, 1, 20, 36, (1, 3, 3), 1, False),          # ragged tiles in H and W
+    (1, 16, 81, 3, 9, 40, (3, 3, 3), 1, False),          # three row tiles, last one partial
+    (2, 32, 64, 4, 16, 32, (3, 3, 3), 2, False),         # stride 2
+    (3, 12, 35, 1, 33, 68, (1, 3, 3), 1, True),          # bias is part of the normalised value
+])
+def test_conv_epilogue_batchnorm_statistics(shape):
+    """dpf_conv_forward_stats + dpf_bn_finalize_partials (BatchNorm statistics from the conv epilogue) against the separate
+    statistics pass and against torch's batch_norm on the CPU; running statistics included; bitwise reproducible."""
+    ops = _ops()
+    N, C, K, D, H, W, ks, stride, has_bias = shape
+    x = rnd(N, C, D, H, W, seed=70)
+    w = rnd(K, C, *ks, seed=71) * 0.2
+    b = rnd(K, seed=72) if has_bias else None
+    gamma, beta = rnd(K, seed=73).abs() + 0.5, rnd(K, seed=74)
+    pad = tuple(k // 2 for k in ks)
+    y_ref = F.conv3d(x, w, b, stride, pad)
+    rm_ref, rv_ref = torch.zeros(K), torch.ones(K)
+    z_ref = F.relu(F.batch_norm(y_ref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    outs = []
+    for fuse in (True, False, True):
+        ops.FUSE_BN_STATS = fuse
+        st = {}
+        rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+        y = ops.conv3d(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), stride, pad, 1, stats=st)
+        assert bool(st) == fuse, 'the LDS-DMA kernel should have taken this shape'
+        z = ops.norm_act(y, gamma.to(DEV), beta.to(DEV), None, None, None, rm, rv, 1, 1, stats=st)
+        assert not st                                                   # consumed
+        outs.append((z, rm, rv))
+        close(z, z_ref, 1e-4, 'bn(conv) fuse=%s' % fuse)
+        close(rm, rm_ref, 1e-5, 'running_mean')
+        close(rv, rv_ref, 1e-5, 'running_var')
+    ops.FUSE_BN_STATS = True
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1]) and torch.equal(outs[0][2], outs[2][2])
+    # a stale holder (different tensor) must be ignored, not trusted
+    st = {'ptr': 1234, 'channels': K, 'count': 1, 'slab': None, 'parts': 0}
+    rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+    z = ops.norm_act(outs[0][0].new_tensor(y_ref.numpy()), gamma.to(DEV), beta.to(DEV), None, None, None, rm, rv, 1, 1, stats=st)
+    close(z, z_ref, 1e-4, 'stale holder ignored')
