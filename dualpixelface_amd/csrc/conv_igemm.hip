@@ -609,7 +609,7 @@ int dpf_conv_forward(const float* x, const float* w, const float* bias, float* o
 // separate statistics pass over the output tensor disappears.  DPF_ERR_UNSUPPORTED when the shape does not run on the LDS-DMA
 // kernel (K > 128, rows not 16-byte aligned, 1x1 kernels ...): the caller then uses dpf_conv_forward + dpf_bn_stats.
 long long dpf_conv_stats_slab_doubles(int N, int K, int OD, int OH, int OW) {
-  return 2LL * K * N * OD * dpf_div_up(OH, 8) * dpf_div_up(OW, 32);
+  return 2LL * K * ((long long)N * OD * dpf_div_up(OH, 8) * dpf_div_up(OW, 32) + 64);     // + the 64 folded rows of the finalize step
 }
 
 int dpf_conv_forward_stats(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
@@ -620,7 +620,7 @@ int dpf_conv_forward_stats(const float* x, const float* w, const float* bias, fl
   const int OD = out_dim(ID, kd, sd, pd, dd), OH = out_dim(IH, kh, sh, ph, dh), OW = out_dim(IW, kw, sw, pw, dw);
   if (OD <= 0 || OH <= 0 || OW <= 0) return DPF_ERR_INVALID_ARG;
   DpfConvDesc d{N, C, K, K, 0, ID, IH, IW, OD, OH, OW, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw, 0, K, C, 0};
-  DpfConvStats stats{slab, slab_doubles, 0};
+  DpfConvStats stats{slab, slab_doubles - 2LL * K * 64, 0};
   const int rc = dpf_igemm2_conv(x, w, bias, out, ws, d, (hipStream_t)stream, &stats);
   if (rc == DPF_OK) *parts_host = stats.parts;
   return rc;

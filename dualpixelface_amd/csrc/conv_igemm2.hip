@@ -230,36 +230,48 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
     }
   }
   // ---- optional BatchNorm statistics of this tile (the consumer's bn_stats pass over the output tensor is then not needed):
-  // per output channel the sum and the sum of squares of the valid outputs -- lane partials in fp32 (<= NT values), everything
-  // after that in fp64 -- reduced over the 32 columns by shuffles and over the 4 waves through LDS in a fixed order, one
+  // per output channel the sum and the sum of squares of the valid outputs, accumulated in fp64 from the first add, reduced over the 32 columns by shuffles and over the 4 waves through LDS in a fixed order, one
   // [K][2] row per tile.  A finalize kernel folds the rows in a fixed order: deterministic, no atomics, no zero fill.
   if (p.stats) {                                                 // uniform
     double* red = reinterpret_cast<double*>(smem);               // [4 waves][2][MT * 16][2]; the operand buffers are dead by now
     const bool colok = ow < p.OW;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+      double v1[16], v2[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
         const float bv = (bias && k < p.K) ? bias[p.k0 + k] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        double d1 = 0.0, d2 = 0.0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const float v = (colok && oh0 + t < p.OH) ? acc[m][t][j] + bv : 0.f;
-          s1 += v;
-          s2 += v * v;
+          const double v = (colok && oh0 + t < p.OH) ? (double)(acc[m][t][j] + bv) : 0.0;
+          d1 += v;
+          d2 += v * v;                                           // exact product, fp64 accumulation
         }
-        double d1 = (double)s1, d2 = (double)s2;
+        v1[j] = d1;
+        v2[j] = d2;
+      }
+      // transpose-reduce over the 32 columns: at every step a lane hands half of its remaining rows to its partner and adds the
+      // partner's half of the rows it keeps -- 8 + 4 + 2 + 1 exchanges instead of 16 x 4, then one exchange between the two
+      // lanes that ended up with the same row.  Fixed order.
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          d1 += __shfl_xor(d1, o, 64);
-          d2 += __shfl_xor(d2, o, 64);
+      for (int half = 8; half >= 1; half >>= 1) {
+        const bool upper = (l31 & (2 * half)) != 0;              // lane bit 4, 3, 2, 1 for half = 8, 4, 2, 1
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+          const double s1 = upper ? v1[i] : v1[i + half], s2 = upper ? v2[i] : v2[i + half];
+          const double k1 = upper ? v1[i + half] : v1[i], k2 = upper ? v2[i + half] : v2[i];
+          v1[i] = k1 + __shfl_xor(s1, 2 * half, 64);
+          v2[i] = k2 + __shfl_xor(s2, 2 * half, 64);
         }
-        if (l31 == 0) {
-          double* dst = red + (((wave * 2 + hh) * MT + m) * 16 + j) * 2;
-          dst[0] = d1;
-          dst[1] = d2;
-        }
+      }
+      const double r1 = v1[0] + __shfl_xor(v1[0], 1, 64), r2 = v2[0] + __shfl_xor(v2[0], 1, 64);
+      if ((l31 & 1) == 0) {
+        const int j = (l31 >> 1) & 15;                           // bit 4 -> +8, bit 3 -> +4, bit 2 -> +2, bit 1 -> +1
+        double* dst = red + (((wave * 2 + hh) * MT + m) * 16 + j) * 2;
+        dst[0] = r1;
+        dst[1] = r2;
       }
     }
     __syncthreads();

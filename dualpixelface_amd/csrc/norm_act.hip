@@ -68,41 +68,59 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
 }
 
 // batch statistics from the per-tile (sum, sum of squares) rows a convolution's epilogue wrote (dpf_conv_forward_stats):
-// slab [parts][C][2] doubles.  One workgroup per channel: strided fp64 partial sums, then a fixed-order LDS tree -> bitwise
-// reproducible.  Same outputs as bn_finalize_kernel.
-__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const double* __restrict__ slab, int parts, int C, double count, float eps,
-                                                                   float momentum, float* __restrict__ running_mean,
-                                                                   float* __restrict__ running_var, float* __restrict__ mean,
-                                                                   float* __restrict__ invstd) {
-  __shared__ double s1[256], s2[256];
-  const int c = blockIdx.x;
-  double a1 = 0.0, a2 = 0.0;
-  for (int t = threadIdx.x; t < parts; t += 256) {
-    const double* r = slab + ((long long)t * C + c) * 2;
-    a1 += r[0];
-    a2 += r[1];
-  }
-  s1[threadIdx.x] = a1;
-  s2[threadIdx.x] = a2;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      s1[threadIdx.x] += s1[threadIdx.x + o];
-      s2[threadIdx.x] += s2[threadIdx.x + o];
-    }
+// slab [parts][C][2] doubles.  Stage 1: workgroup g folds the rows g, g + G, ... -- a thread owns one channel of every (256 / C2)-th
+// of those rows, so a wave reads whole contiguous rows -- and leaves one row in part2 [G][C][2].  Stage 2: one workgroup folds the G
+// rows and finishes.  Every sum runs in a fixed order: bitwise reproducible.  Same outputs as bn_finalize_kernel.
+constexpr int FIN_G = 64;
+
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const double* __restrict__ slab, int parts, int C, double* __restrict__ part2) {
+  __shared__ double sm[512];
+  const int C2 = 2 * C;                                   // doubles per row
+  const int per = 256 / C2 > 0 ? 256 / C2 : 1;            // rows read side by side
+  const int col = threadIdx.x % C2, sub = threadIdx.x / C2;
+  double a = 0.0;
+  if (C2 <= 256) {
+    if (sub < per)
+      for (int t = blockIdx.x + FIN_G * sub; t < parts; t += FIN_G * per) a += slab[(long long)t * C2 + col];
+    sm[threadIdx.x] = a;
     __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const double mu = s1[0] / count;
-    double var = s2[0] / count - mu * mu;
-    if (var < 0) var = 0;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-      const double unb = count > 1 ? var * count / (count - 1) : var;
-      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    if (threadIdx.x < C2) {
+      double s = 0.0;
+      for (int u = 0; u < per; ++u) s += sm[u * C2 + threadIdx.x];
+      part2[(long long)blockIdx.x * C2 + threadIdx.x] = s;
     }
+  } else {                                                // C > 128 is not produced by the conv kernel; kept for completeness
+    for (int c2 = threadIdx.x; c2 < C2; c2 += 256) {
+      double s = 0.0;
+      for (int t = blockIdx.x; t < parts; t += FIN_G) s += slab[(long long)t * C2 + c2];
+      part2[(long long)blockIdx.x * C2 + c2] = s;
+    }
+  }
+}
+
+// one wave per channel: lane g holds folded row g, fixed-order shuffle tree
+__global__ __launch_bounds__(64) void bn_finalize_partials_kernel(const double* __restrict__ part2, int G, int C, double count, float eps,
+                                                                  float momentum, float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, float* __restrict__ mean,
+                                                                  float* __restrict__ invstd) {
+  const int c = blockIdx.x, g = threadIdx.x;
+  double s1 = g < G ? part2[((long long)g * C + c) * 2] : 0.0;
+  double s2 = g < G ? part2[((long long)g * C + c) * 2 + 1] : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (g != 0) return;
+  const double mu = s1 / count;
+  double var = s2 / count - mu * mu;
+  if (var < 0) var = 0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
   }
 }
 
@@ -374,11 +392,16 @@ int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float mom
 
 // Batch statistics from the partial rows of dpf_conv_forward_stats (slab [parts][C][2] doubles, count = N * S elements per channel);
 // outputs and running-statistics update as dpf_bn_stats.
-int dpf_bn_finalize_partials(const double* slab, int parts, int C, long long count, float eps, float momentum, float* running_mean,
+int dpf_bn_finalize_partials(double* slab, int parts, int C, long long count, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean, float* invstd, void* stream) {
   dpf_clear_error();
   if (!slab || !mean || !invstd || parts <= 0 || C <= 0 || count <= 0) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, slab, parts, C, (double)count, eps, momentum,
+  hipStream_t st = (hipStream_t)stream;
+  // the folded rows go behind the tile rows: the slab holds >= (parts + FIN_G) rows (dpf_conv_stats_slab_doubles)
+  double* part2 = slab + (long long)parts * C * 2;
+  const int G = parts < FIN_G ? parts : FIN_G;
+  hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(G), dim3(256), 0, st, slab, parts, C, part2);
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(64), 0, st, part2, G, C, (double)count, eps, momentum,
                      running_mean, running_var, mean, invstd);
   return dpf_check_launch();
 }

@@ -57,14 +57,15 @@ int dpf_conv_wgrad_ws(const float* g, const float* x, float* dw, float* ws, long
 
 /* dpf_conv_forward + the statistics of the BatchNorm that follows it (convbn / convbn_3d, src/module/asm/basics.py:17-36): per
  * position tile the kernel's epilogue leaves (sum, sum of squares) of every output channel in slab [*parts_host][K][2] doubles
- * (capacity dpf_conv_stats_slab_doubles(...)); dpf_bn_finalize_partials turns them into mean / invstd / running statistics, so
+ * (capacity dpf_conv_stats_slab_doubles(...), which includes the scratch rows dpf_bn_finalize_partials folds into behind the tile
+ * rows -- pass the same buffer to both); dpf_bn_finalize_partials turns them into mean / invstd / running statistics, so
  * the separate dpf_bn_stats pass over the output is not needed.  Fixed reduction order: bitwise reproducible.
  * DPF_ERR_UNSUPPORTED for shapes the LDS-DMA kernel does not take -- then call dpf_conv_forward + dpf_bn_stats. */
 long long dpf_conv_stats_slab_doubles(int N, int K, int OD, int OH, int OW);
 int dpf_conv_forward_stats(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
                            int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw,
                            double* slab, long long slab_doubles, int* parts_host, void* stream);
-int dpf_bn_finalize_partials(const double* slab, int parts, int C, long long count, float eps, float momentum, float* running_mean,
+int dpf_bn_finalize_partials(double* slab, int parts, int C, long long count, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean, float* invstd, void* stream);
 
 /* narrow outputs (K <= 4): the 32 -> 1 cost heads (modules.py:286-296) and the 32 -> 3 normal conv (normal_module.py:65);
