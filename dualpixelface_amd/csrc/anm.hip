@@ -176,6 +176,42 @@ __global__ void sigmoid_mean_bwd_kernel(const float* __restrict__ u, const float
   }
 }
 
+// y[n, :, s] = x[n, :, s] / max(||x[n, :, s]||_2, eps)   (F.normalize(dim=1), src/model/nnet/normal_module_.py:114)
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, long long S, float eps) {
+  const long long total = (long long)N * S;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / S, s = i - n * S;
+    const float* p = x + n * C * S + s;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) q += p[c * S] * p[c * S];
+    const float d = fmaxf(sqrtf(q), eps);
+    float* o = y + n * C * S + s;
+    for (int c = 0; c < C; ++c) o[c * S] = p[c * S] / d;
+  }
+}
+// dx = (g - y (y . g)) / max(||x||, eps) where the norm exceeds eps, g / eps below it
+__global__ void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dx, int N, int C, long long S,
+                                  float eps) {
+  const long long total = (long long)N * S;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / S, s = i - n * S;
+    const float* p = x + n * C * S + s;
+    const float* gp = g + n * C * S + s;
+    float q = 0.f, dot = 0.f;
+    for (int c = 0; c < C; ++c) {
+      q += p[c * S] * p[c * S];
+      dot += p[c * S] * gp[c * S];
+    }
+    const float nrm = sqrtf(q);
+    float* o = dx + n * C * S + s;
+    if (nrm > eps) {
+      for (int c = 0; c < C; ++c) o[c * S] = (gp[c * S] - p[c * S] * (dot / q)) / nrm;
+    } else {
+      for (int c = 0; c < C; ++c) o[c * S] = gp[c * S] / eps;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -228,6 +264,37 @@ int dpf_sigmoid_mean_backward(const float* u, const float* g, float* du, int B, 
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!u || !g || !du || B <= 0 || Dn <= 0 || CS <= 0) return DPF_ERR_INVALID_ARG;
   hipLaunchKernelGGL(sigmoid_mean_bwd_kernel, dim3(dpf_ew_grid((long long)B * Dn * CS)), dim3(256), 0, (hipStream_t)stream, u, g, du, B, Dn, CS);
+  return dpf_check_launch();
+}
+
+// Normalised camera-space coordinate volume: channels [choff, choff + 3) of vol [B, CV, K, h, w] = (K_imgF^-1 [u, v, 1]) * depth(sdisp),
+// min-max normalised per sample (grid_maker_3d: src/model/stereodpnet/normal_module.py:80-114, src/model/nnet/normal_module_.py:50-87).
+// sdisp [B, K, h, w] disparities, Kmat [B, 9], abvalue [B, 2] = [b, a]; mm_ws: 2 * B ints of scratch.
+int dpf_xyz_volume(const float* sdisp, const float* Kmat, const float* abvalue, float* vol, int* mm_ws, int B, int choff, int CV, int K, int h,
+                   int w, void* stream) {
+  dpf_clear_error();
+  if (!sdisp || !Kmat || !abvalue || !vol || !mm_ws || B <= 0 || K <= 0 || choff < 0 || choff + 3 > CV) return DPF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* mm = reinterpret_cast<unsigned*>(mm_ws);
+  hipLaunchKernelGGL(anm_minmax_init_kernel, dim3(dpf_div_up(B, 64)), dim3(64), 0, st, mm, B);
+  int gx = dpf_div_up((long long)K * h * w, 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(anm_xyz_kernel, dim3(gx, B), dim3(256), 0, st, Kmat, abvalue, sdisp, vol, mm, choff, K, h, w, CV);
+  hipLaunchKernelGGL(anm_xyz_norm_kernel, dim3(gx, B), dim3(256), 0, st, vol, mm, choff, K, h, w, CV);
+  return dpf_check_launch();
+}
+
+// F.normalize(x, dim=1) on x [N, C, S] and its gradient
+int dpf_l2_normalize_forward(const float* x, float* y, int N, int C, long long S, float eps, void* stream) {
+  dpf_clear_error();
+  if (!x || !y || N <= 0 || C <= 0 || S <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(dpf_ew_grid((long long)N * S)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, S, eps);
+  return dpf_check_launch();
+}
+int dpf_l2_normalize_backward(const float* x, const float* g, float* dx, int N, int C, long long S, float eps, void* stream) {
+  dpf_clear_error();
+  if (!x || !g || !dx || N <= 0 || C <= 0 || S <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(dpf_ew_grid((long long)N * S)), dim3(256), 0, (hipStream_t)stream, x, g, dx, N, C, S, eps);
   return dpf_check_launch();
 }
 

@@ -10,17 +10,21 @@
 
 namespace {
 
-__device__ __forceinline__ void ac_src(int dst, float ratio, int in, int& i0, int& i1, float& lam) {
-  const float src = ratio * (float)dst;   // align_corners=True source index (ATen area_pixel_compute_source_index)
+// off = 0: align_corners=True source index ratio * dst (ratio = (in-1)/(out-1)); off = 0.5: align_corners=False, ratio = in/out,
+// source index ratio * (dst + 0.5) - 0.5 clamped at 0 (ATen area_pixel_compute_source_index)
+__device__ __forceinline__ void ac_src(int dst, float ratio, int in, int& i0, int& i1, float& lam, float off = 0.f) {
+  float src = ratio * ((float)dst + off) - off;
+  if (src < 0.f) src = 0.f;
   i0 = (int)src;
   if (i0 > in - 1) i0 = in - 1;
   i1 = i0 + (i0 < in - 1 ? 1 : 0);
   lam = src - (float)i0;
 }
 
-__global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long NC, int h, int w, int H, int W) {
-  const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
-  const float rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long NC, int h, int w, int H, int W,
+                                    float off = 0.f) {
+  const float ry = off > 0.f ? (float)h / (float)H : (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f);
+  const float rx = off > 0.f ? (float)w / (float)W : (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f);
   const long long total = NC * H * W;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int X = (int)(i % W);
@@ -28,8 +32,8 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restri
     const long long nc = i / ((long long)W * H);
     int y0, y1, x0, x1;
     float ly, lx;
-    ac_src(Y, ry, h, y0, y1, ly);
-    ac_src(X, rx, w, x0, x1, lx);
+    ac_src(Y, ry, h, y0, y1, ly, off);
+    ac_src(X, rx, w, x0, x1, lx, off);
     const float* p = x + nc * h * w;
     const float hy = 1.f - ly, hx = 1.f - lx;
     y[i] = hy * (hx * p[y0 * w + x0] + lx * p[y0 * w + x1]) + ly * (hx * p[y1 * w + x0] + lx * p[y1 * w + x1]);
@@ -37,43 +41,44 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restri
 }
 
 // weight of destination index d on source index i along one axis
-__device__ __forceinline__ float ac_weight(int d, float ratio, int in, int i) {
+__device__ __forceinline__ float ac_weight(int d, float ratio, int in, int i, float off = 0.f) {
   int i0, i1;
   float lam;
-  ac_src(d, ratio, in, i0, i1, lam);
+  ac_src(d, ratio, in, i0, i1, lam, off);
   float wgt = 0.f;
   if (i0 == i) wgt += 1.f - lam;
   if (i1 == i) wgt += lam;
   return wgt;
 }
 
-__device__ __forceinline__ void cand_range(int i, float ratio, int out, int& lo, int& hi) {
+__device__ __forceinline__ void cand_range(int i, float ratio, int out, int& lo, int& hi, float off = 0.f) {
   if (ratio <= 0.f) { lo = 0; hi = out - 1; return; }
-  lo = (int)floorf((float)(i - 1) / ratio) - 1;
-  hi = (int)ceilf((float)(i + 1) / ratio) + 1;
+  lo = (int)floorf(((float)(i - 1) + off) / ratio - off) - 1;
+  hi = (int)ceilf(((float)(i + 1) + off) / ratio - off) + 1;
   if (lo < 0) lo = 0;
   if (hi > out - 1) hi = out - 1;
 }
 
-__global__ void bilinear_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, long long NC, int h, int w, int H, int W) {
-  const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
-  const float rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+__global__ void bilinear_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, long long NC, int h, int w, int H, int W,
+                                    float off = 0.f) {
+  const float ry = off > 0.f ? (float)h / (float)H : (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f);
+  const float rx = off > 0.f ? (float)w / (float)W : (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f);
   const long long total = NC * h * w;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int xs = (int)(i % w);
     const int ys = (int)((i / w) % h);
     const long long nc = i / ((long long)w * h);
     int ylo, yhi, xlo, xhi;
-    cand_range(ys, ry, H, ylo, yhi);
-    cand_range(xs, rx, W, xlo, xhi);
+    cand_range(ys, ry, H, ylo, yhi, off);
+    cand_range(xs, rx, W, xlo, xhi, off);
     const float* gp = g + nc * H * W;
     float acc = 0.f;
     for (int Y = ylo; Y <= yhi; ++Y) {
-      const float wy = ac_weight(Y, ry, h, ys);
+      const float wy = ac_weight(Y, ry, h, ys, off);
       if (wy == 0.f) continue;
       float row = 0.f;
       for (int X = xlo; X <= xhi; ++X) {
-        const float wx = ac_weight(X, rx, w, xs);
+        const float wx = ac_weight(X, rx, w, xs, off);
         if (wx != 0.f) row += wx * gp[(long long)Y * W + X];
       }
       acc += wy * row;
@@ -158,14 +163,32 @@ extern "C" {
 int dpf_upsample_bilinear2d_forward(const float* x, float* y, long long NC, int h, int w, int H, int W, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !y || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(dpf_ew_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC, h, w, H, W);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(dpf_ew_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC, h, w, H, W, 0.f);
   return dpf_check_launch();
 }
 
 int dpf_upsample_bilinear2d_backward(const float* g, float* dx, long long NC, int h, int w, int H, int W, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !dx || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(dpf_ew_grid(NC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dx, NC, h, w, H, W);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(dpf_ew_grid(NC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dx, NC, h, w, H, W, 0.f);
+  return dpf_check_launch();
+}
+
+// F.interpolate(x, size=(H, W), mode='bilinear', align_corners=<flag>): the half-pixel convention (align_corners=False) is what the
+// NNet feature extractor's pyramid branches use (src/model/nnet/modules.py:110-120)
+int dpf_resize_bilinear2d_forward(const float* x, float* y, long long NC, int h, int w, int H, int W, int align_corners, void* stream) {
+  dpf_clear_error();
+  if (!x || !y || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(dpf_ew_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC, h, w, H, W,
+                     align_corners ? 0.f : 0.5f);
+  return dpf_check_launch();
+}
+
+int dpf_resize_bilinear2d_backward(const float* g, float* dx, long long NC, int h, int w, int H, int W, int align_corners, void* stream) {
+  dpf_clear_error();
+  if (!g || !dx || NC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(dpf_ew_grid(NC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dx, NC, h, w, H, W,
+                     align_corners ? 0.f : 0.5f);
   return dpf_check_launch();
 }
 

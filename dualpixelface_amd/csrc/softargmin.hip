@@ -16,11 +16,17 @@ constexpr int TY = 8, TX = 32;
 
 struct HeadP {
   int B, D, h, w, L, H, W;
+  float off;            // 0: align_corners=True (ratio (in-1)/(out-1)); 0.5: align_corners=False (ratio in/out, half-pixel centres)
   float disp[MAXL];
 };
 
-__device__ __forceinline__ void ac_src(int dst, float ratio, int in, int& i0, int& i1, float& lam) {
-  const float src = ratio * (float)dst;
+__device__ __forceinline__ float head_ratio(int in, int out, float off) {
+  return off > 0.f ? (float)in / (float)out : (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f);
+}
+
+__device__ __forceinline__ void ac_src(int dst, float ratio, int in, int& i0, int& i1, float& lam, float off = 0.f) {
+  float src = ratio * ((float)dst + off) - off;       // ATen area_pixel_compute_source_index
+  if (src < 0.f) src = 0.f;
   i0 = (int)src;
   if (i0 > in - 1) i0 = in - 1;
   i1 = i0 + (i0 < in - 1 ? 1 : 0);
@@ -29,8 +35,8 @@ __device__ __forceinline__ void ac_src(int dst, float ratio, int in, int& i0, in
 
 __device__ __forceinline__ void pixel_probs(const float* __restrict__ k, const HeadP& p, int b, int Y, int X, float rd, float ry, float rx,
                                             float* prob, float& pred, int& y0, int& y1, int& x0, int& x1, float& ly, float& lx) {
-  ac_src(Y, ry, p.h, y0, y1, ly);
-  ac_src(X, rx, p.w, x0, x1, lx);
+  ac_src(Y, ry, p.h, y0, y1, ly, p.off);
+  ac_src(X, rx, p.w, x0, x1, lx, p.off);
   const float hy = 1.f - ly, hx = 1.f - lx;
   float bl[MAXD];
   const float* kb = k + (long long)b * p.D * p.h * p.w;
@@ -49,7 +55,7 @@ __device__ __forceinline__ void pixel_probs(const float* __restrict__ k, const H
     if (l < p.L) {
       int d0, d1;
       float ld;
-      ac_src(l, rd, p.D, d0, d1, ld);
+      ac_src(l, rd, p.D, d0, d1, ld, p.off);
       float v0 = 0.f, v1 = 0.f;
 #pragma unroll
       for (int d = 0; d < MAXD; ++d) {   // register-resident select (no runtime-indexed array)
@@ -77,9 +83,7 @@ __device__ __forceinline__ void pixel_probs(const float* __restrict__ k, const H
 }
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ k, float* __restrict__ pred, float* __restrict__ prob, HeadP p) {
-  const float rd = p.L > 1 ? (float)(p.D - 1) / (float)(p.L - 1) : 0.f;
-  const float ry = p.H > 1 ? (float)(p.h - 1) / (float)(p.H - 1) : 0.f;
-  const float rx = p.W > 1 ? (float)(p.w - 1) / (float)(p.W - 1) : 0.f;
+  const float rd = head_ratio(p.D, p.L, p.off), ry = head_ratio(p.h, p.H, p.off), rx = head_ratio(p.w, p.W, p.off);
   const long long total = (long long)p.B * p.H * p.W;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int X = (int)(i % p.W);
@@ -163,9 +167,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   __shared__ double tile[MAXD][TY + 2][TX + 2];
   __shared__ float s_bl[MAXD][256];   // per-thread bilinear values / gradients, thread index fastest (conflict-free)
   __shared__ float s_db[MAXD][256];
-  const float rd = p.L > 1 ? (float)(p.D - 1) / (float)(p.L - 1) : 0.f;
-  const float ry = p.H > 1 ? (float)(p.h - 1) / (float)(p.H - 1) : 0.f;
-  const float rx = p.W > 1 ? (float)(p.w - 1) / (float)(p.W - 1) : 0.f;
+  const float rd = head_ratio(p.D, p.L, p.off), ry = head_ratio(p.h, p.H, p.off), rx = head_ratio(p.w, p.W, p.off);
   const int tilesX = (p.W + TX - 1) / TX, tilesY = (p.H + TY - 1) / TY;
   int bb = blockIdx.x;
   const int tx = bb % tilesX; bb /= tilesX;
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   const int Y0 = ty * TY, X0 = tx * TX;
   int ybase, xbase, t1;
   float tl;
-  ac_src(Y0, ry, p.h, ybase, t1, tl);
-  ac_src(X0, rx, p.w, xbase, t1, tl);
+  ac_src(Y0, ry, p.h, ybase, t1, tl, p.off);
+  ac_src(X0, rx, p.w, xbase, t1, tl, p.off);
   double* flat = &tile[0][0][0];
   for (int i = threadIdx.x; i < MAXD * (TY + 2) * (TX + 2); i += 256) flat[i] = 0.0;
   __syncthreads();
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (Y < p.H && X < p.W) {
     int y0, y1, x0, x1;
     float ly, lx;
-    ac_src(Y, ry, p.h, y0, y1, ly);
-    ac_src(X, rx, p.w, x0, x1, lx);
+    ac_src(Y, ry, p.h, y0, y1, ly, p.off);
+    ac_src(X, rx, p.w, x0, x1, lx, p.off);
     const float hy = 1.f - ly, hx = 1.f - lx;
     const float* kb = k + (long long)b * p.D * p.h * p.w;
     for (int d = 0; d < p.D; ++d) {
@@ -197,14 +199,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     for (int l = 0; l < p.L; ++l) {
       int d0, d1;
       float ld;
-      ac_src(l, rd, p.D, d0, d1, ld);
+      ac_src(l, rd, p.D, d0, d1, ld, p.off);
       mx = fmaxf(mx, (1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid]);
     }
     float sum = 0.f, num = 0.f;
     for (int l = 0; l < p.L; ++l) {
       int d0, d1;
       float ld;
-      ac_src(l, rd, p.D, d0, d1, ld);
+      ac_src(l, rd, p.D, d0, d1, ld, p.off);
       const float e = __expf((1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid] - mx);
       sum += e;
       num += e * p.disp[l];
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     for (int l = 0; l < p.L; ++l) {
       int d0, d1;
       float ld;
-      ac_src(l, rd, p.D, d0, d1, ld);
+      ac_src(l, rd, p.D, d0, d1, ld, p.off);
       const float pr = __expf((1.f - ld) * s_bl[d0][tid] + ld * s_bl[d1][tid] - mx) / sum;
       const float dl = pr * (p.disp[l] - pred) * g;
       s_db[d0][tid] += (1.f - ld) * dl;
@@ -335,36 +337,54 @@ __global__ __launch_bounds__(256) void head_bwd_8x32_kernel(const float* __restr
 extern "C" {
 
 // logits [B,D,h,w] -> pred [B,H,W], prob [B,L,H,W] (NULL to skip).  disp: L host floats (hypothesis values).
-int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
-                           int H, int W, void* stream) {
+static int softargmin_fwd(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L, int H, int W,
+                          float off, hipStream_t st) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!logits || !pred || !disp_host || B <= 0 || D <= 0 || D > MAXD || L <= 0 || L > MAXL) return DPF_ERR_INVALID_ARG;
   HeadP p;
-  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W;
+  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W; p.off = off;
   for (int i = 0; i < MAXL; ++i) p.disp[i] = i < L ? disp_host[i] : 0.f;
-  if (D == 8 && L == 32)
-    hipLaunchKernelGGL(head_fwd_8x32_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, logits, pred, prob, p);
+  if (D == 8 && L == 32 && off == 0.f)
+    hipLaunchKernelGGL(head_fwd_8x32_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, st, logits, pred, prob, p);
   else
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, logits, pred, prob, p);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, st, logits, pred, prob, p);
   return dpf_check_launch();
 }
 
 // d logits [B,D,h,w] (zeroed here) from d pred [B,H,W]
-int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
-                            int L, int H, int W, void* stream) {
+static int softargmin_bwd(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w, int L,
+                          int H, int W, float off, hipStream_t st) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!logits || !gpred || !dlogits || !disp_host || B <= 0 || D <= 0 || D > MAXD || L <= 0 || L > MAXL) return DPF_ERR_INVALID_ARG;
   HeadP p;
-  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W;
+  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W; p.off = off;
   for (int i = 0; i < MAXL; ++i) p.disp[i] = i < L ? disp_host[i] : 0.f;
-  hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dlogits, 0, sizeof(float) * (size_t)B * D * h * w, st) != hipSuccess) return DPF_ERR_LAUNCH;
   const long long blocks = (long long)B * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
-  if (D == 8 && L == 32)
+  if (D == 8 && L == 32 && off == 0.f)
     hipLaunchKernelGGL(head_bwd_8x32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p);
   else
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p);
   return dpf_check_launch();
+}
+
+int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
+                           int H, int W, void* stream) {
+  return softargmin_fwd(logits, pred, prob, disp_host, B, D, h, w, L, H, W, 0.f, (hipStream_t)stream);
+}
+int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
+                            int L, int H, int W, void* stream) {
+  return softargmin_bwd(logits, gpred, dlogits, disp_host, B, D, h, w, L, H, W, 0.f, (hipStream_t)stream);
+}
+// the same head with the trilinear upsampling in either convention: align_corners = 0 is F.interpolate(scale_factor=4,
+// mode='trilinear', align_corners=False) of src/model/nnet/mainmodel.py:150-153
+int dpf_softargmin_forward_ex(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
+                              int H, int W, int align_corners, void* stream) {
+  return softargmin_fwd(logits, pred, prob, disp_host, B, D, h, w, L, H, W, align_corners ? 0.f : 0.5f, (hipStream_t)stream);
+}
+int dpf_softargmin_backward_ex(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
+                               int L, int H, int W, int align_corners, void* stream) {
+  return softargmin_bwd(logits, gpred, dlogits, disp_host, B, D, h, w, L, H, W, align_corners ? 0.f : 0.5f, (hipStream_t)stream);
 }
 
 }  // extern "C"

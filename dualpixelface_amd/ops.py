@@ -638,15 +638,79 @@ def avg_pool2d(x, k):
     return AvgPoolFn.apply(x, int(k))
 
 
-def resize_bilinear(x, H, W):
-    """F.interpolate(x, size=(H, W), mode='bilinear', align_corners=True)."""
-    return BilinearFn.apply(x, int(H), int(W))
+class ResizeBilinearFn(torch.autograd.Function):
+    """F.interpolate(x, size=(H, W), mode='bilinear', align_corners=flag)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, align_corners):
+        x = _c(x)
+        _need(x)
+        N, C, h, w = x.shape
+        y = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+        lib().call('dpf_resize_bilinear2d_forward', _ptr(x), _ptr(y), N * C, h, w, H, W, int(align_corners), _stream())
+        ctx.dims = (N, C, h, w, H, W, int(align_corners))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, h, w, H, W, ac = ctx.dims
+        gy = _c(gy)
+        dx = torch.empty((N, C, h, w), dtype=torch.float32, device=gy.device)
+        lib().call('dpf_resize_bilinear2d_backward', _ptr(gy), _ptr(dx), N * C, h, w, H, W, ac, _stream())
+        return dx, None, None, None
+
+
+def resize_bilinear(x, H, W, align_corners=True):
+    """F.interpolate(x, size=(H, W), mode='bilinear', align_corners=align_corners)."""
+    if align_corners:
+        return BilinearFn.apply(x, int(H), int(W))
+    return ResizeBilinearFn.apply(x, int(H), int(W), False)
+
+
+class L2NormalizeFn(torch.autograd.Function):
+    """F.normalize(x, dim=1)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _c(x)
+        _need(x)
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        y = torch.empty_like(x)
+        lib().call('dpf_l2_normalize_forward', _ptr(x), _ptr(y), N, C, S, float(eps), _stream())
+        ctx.save_for_backward(x)
+        ctx.cfg = (N, C, S, float(eps))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, C, S, eps = ctx.cfg
+        g = _c(g)
+        dx = torch.empty_like(x)
+        lib().call('dpf_l2_normalize_backward', _ptr(x), _ptr(g), _ptr(dx), N, C, S, eps, _stream())
+        return dx, None
+
+
+def l2_normalize(x, eps=1e-12):
+    return L2NormalizeFn.apply(x, eps)
+
+
+def xyz_volume_into(vol, choff, sdisp, Kmat, abvalue):
+    """Fills channels [choff, choff + 3) of vol [B, CV, K, h, w] with the min-max normalised camera-space coordinates of the
+    disparity levels sdisp [B, K, h, w] (constants of the batch: no gradient)."""
+    sdisp, Kmat, abvalue = _c(sdisp), _c(Kmat), _c(abvalue)
+    _need(vol, sdisp, Kmat, abvalue)
+    B, CV, K, h, w = vol.shape
+    mm = torch.empty(2 * B, dtype=torch.int32, device=vol.device)
+    lib().call('dpf_xyz_volume', _ptr(sdisp), _ptr(Kmat), _ptr(abvalue), _ptr(vol), _ptr(mm), B, int(choff), CV, K, h, w, _stream())
+    return vol
 
 
 # ----------------------------------------------------------------------------------------------- disparity head
 class SoftArgminFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, disp_values, scale, want_prob):
+    def forward(ctx, logits, disp_values, scale, want_prob, align_corners=True):
         logits = _c(logits)
         _need(logits)
         B, _, D, h, w = logits.shape
@@ -654,9 +718,9 @@ class SoftArgminFn(torch.autograd.Function):
         pred = torch.empty((B, H, W), dtype=torch.float32, device=logits.device)
         prob = torch.empty((B, Lh, H, W), dtype=torch.float32, device=logits.device) if want_prob else None
         hd = _host_floats(disp_values)
-        lib().call('dpf_softargmin_forward', _ptr(logits), _ptr(pred), _ptr(prob), hd, B, D, h, w, Lh, H, W, _stream())
+        lib().call('dpf_softargmin_forward_ex', _ptr(logits), _ptr(pred), _ptr(prob), hd, B, D, h, w, Lh, H, W, int(align_corners), _stream())
         ctx.save_for_backward(logits)
-        ctx.cfg = (tuple(disp_values), B, D, h, w, Lh, H, W)
+        ctx.cfg = (tuple(disp_values), B, D, h, w, Lh, H, W, int(align_corners))
         if prob is None:
             prob = pred.new_empty(0)
         ctx.mark_non_differentiable(prob)
@@ -665,15 +729,17 @@ class SoftArgminFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gpred, _gprob):
         (logits,) = ctx.saved_tensors
-        disp_values, B, D, h, w, Lh, H, W = ctx.cfg
+        disp_values, B, D, h, w, Lh, H, W, ac = ctx.cfg
         gpred = _c(gpred)
         dl = torch.empty_like(logits)
-        lib().call('dpf_softargmin_backward', _ptr(logits), _ptr(gpred), _ptr(dl), _host_floats(disp_values), B, D, h, w, Lh, H, W, _stream())
-        return dl, None, None, None
+        lib().call('dpf_softargmin_backward_ex', _ptr(logits), _ptr(gpred), _ptr(dl), _host_floats(disp_values), B, D, h, w, Lh, H, W, ac,
+                   _stream())
+        return dl, None, None, None, None
 
 
-def softargmin(logits, disp_values, scale=4, want_prob=True):
-    return SoftArgminFn.apply(logits, disp_values, scale, want_prob)
+def softargmin(logits, disp_values, scale=4, want_prob=True, align_corners=True):
+    """x`scale` trilinear upsampling of the [B, 1, D, h, w] logits + softmax over the scale * D hypotheses + expectation."""
+    return SoftArgminFn.apply(logits, disp_values, scale, want_prob, align_corners)
 
 
 # ----------------------------------------------------------------------------------------------- deformable conv

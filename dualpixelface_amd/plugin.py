@@ -7,6 +7,7 @@ import torch
 from . import ops
 from .losses import loss_selector
 from .selectors import metric_selector, optimizer_selector, scheduler_selector
+from .nnet import NNetCore
 from .psmnet import PSMNetCore
 from .stereodpnet import StereoDPNetCore
 
@@ -153,3 +154,11 @@ class PSMNET(_PluginHooks, PSMNetCore):
 
     def validation_epoch_end(self, outputs):
         return None
+
+
+class NNET(_PluginHooks, NNetCore):
+    """src/model/nnet/mainmodel.py::NNET (mainmodel.py:31-240)."""
+
+    def __init__(self, option):
+        NNetCore.__init__(self, option)
+        self._init_hooks(option)

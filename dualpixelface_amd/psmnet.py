@@ -52,6 +52,8 @@ def build_psmnet_spec(opt):
 
 
 class PSMNetCore(StereoDPNetCore):
+    spp_align_corners = True        # psmnet/modules.py:150-163 resizes the pooled branches with align_corners=True
+
     @staticmethod
     def _spec(option):
         return build_psmnet_spec(option)
@@ -85,7 +87,7 @@ class PSMNetCore(StereoDPNetCore):
         for i, k in ((1, 2 * c), (2, c), (3, c // 2), (4, c // 4)):
             b = ops.avg_pool2d(skip, k)
             b = self._bn(self._conv2d(b, P['%s.branch%d.1.0.weight' % (p, i)]), '%s.branch%d.1.1' % (p, i), ACT_RELU)
-            branches.append(ops.resize_bilinear(b, h, w))
+            branches.append(ops.resize_bilinear(b, h, w, self.spp_align_corners))
         feat = ops.concat_channels([raw, skip, branches[3], branches[2], branches[1], branches[0]])
         feat = self._convbn2(feat, p + '.lastconv.0', act=ACT_RELU)
         return self._conv2d(feat, P[p + '.lastconv.2.weight'])

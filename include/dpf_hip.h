@@ -119,6 +119,9 @@ int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void*
  * nearest top-down add (torchvision.ops.FeaturePyramidNetwork, call site modules.py:83-85,119) ---------------------- */
 int dpf_upsample_bilinear2d_forward(const float* x, float* y, long long NC, int h, int w, int H, int W, void* stream);
 int dpf_upsample_bilinear2d_backward(const float* g, float* dx, long long NC, int h, int w, int H, int W, void* stream);
+/* F.interpolate(size=(H, W), mode='bilinear', align_corners=<flag>): the half-pixel form is used by src/model/nnet/modules.py:110-120 */
+int dpf_resize_bilinear2d_forward(const float* x, float* y, long long NC, int h, int w, int H, int W, int align_corners, void* stream);
+int dpf_resize_bilinear2d_backward(const float* g, float* dx, long long NC, int h, int w, int H, int W, int align_corners, void* stream);
 int dpf_upsample_nearest_add_forward(const float* lat, const float* top, float* y, long long NC, int h, int w, int H, int W, void* stream);
 int dpf_upsample_nearest_backward(const float* g, float* dtop, long long NC, int h, int w, int H, int W, void* stream);
 
@@ -159,6 +162,12 @@ int dpf_softargmin_forward(const float* logits, float* pred, float* prob, const 
 int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
                             int L, int H, int W, void* stream);
 
+/* the same head with the x4 trilinear upsampling in either convention (align_corners = 0: src/model/nnet/mainmodel.py:150-153) */
+int dpf_softargmin_forward_ex(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
+                              int H, int W, int align_corners, void* stream);
+int dpf_softargmin_backward_ex(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
+                               int L, int H, int W, int align_corners, void* stream);
+
 /* ---- deformable conv3d: the reference's pybind module `DCN` (src/module/dcn3d/src/vision.cpp:4-7,
  * src/module/dcn3d/src/deform_conv.h:10-29,49-69; deform_conv_cuda.cu:18-285) -- same argument order and meaning ----- */
 long long dpf_deform_conv3d_workspace_floats(int C, int K, int T);
@@ -182,6 +191,13 @@ int dpf_anm_select(const float* disp_full, int* idx, float* sdisp, const float* 
 int dpf_anm_volume_forward(const float* cost, const int* idx, const float* sdisp, const float* Kmat, const float* abvalue, float* vol,
                            unsigned* mm_ws, int B, int C, int L, int K, int h, int w, void* stream);
 int dpf_anm_volume_backward(const float* dvol, const int* idx, float* dcost, int B, int C, int L, int K, int h, int w, void* stream);
+/* camera-space coordinate volume alone (NNet's plain normal module, src/model/nnet/normal_module_.py:50-87; same arithmetic as the XYZ
+ * channels of dpf_anm_volume_forward): channels [choff, choff + 3) of vol [B, CV, K, h, w]; sdisp [B, K, h, w]; mm_ws: 2 * B ints */
+int dpf_xyz_volume(const float* sdisp, const float* Kmat, const float* abvalue, float* vol, int* mm_ws, int B, int choff, int CV, int K, int h,
+                   int w, void* stream);
+/* F.normalize(x, dim=1) for x [N, C, S] (normal_module_.py:114) and its gradient */
+int dpf_l2_normalize_forward(const float* x, float* y, int N, int C, long long S, float eps, void* stream);
+int dpf_l2_normalize_backward(const float* x, const float* g, float* dx, int N, int C, long long S, float eps, void* stream);
 int dpf_sigmoid_mean_forward(const float* u, float* out, int B, int Dn, long long CS, void* stream);
 int dpf_sigmoid_mean_backward(const float* u, const float* g, float* du, int B, int Dn, long long CS, void* stream);
 

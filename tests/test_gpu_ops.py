@@ -671,3 +671,81 @@ def test_conv_epilogue_batchnorm_statistics(shape):
     rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
     z = ops.norm_act(outs[0][0].new_tensor(y_ref.numpy()), gamma.to(DEV), beta.to(DEV), None, None, None, rm, rv, 1, 1, stats=st)
     close(z, z_ref, 1e-4, 'stale holder ignored')
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 1, 1, 16, 24), (1, 5, 2, 3, 16, 24), (2, 4, 4, 6, 16, 24), (1, 2, 8, 12, 5, 7), (1, 2, 7, 9, 28, 36)])
+def test_resize_bilinear_half_pixel(shape):
+    """F.interpolate(size, mode='bilinear', align_corners=False) (nnet/modules.py:110-120) and its adjoint, incl. 1x1 sources,
+    downsampling and non-integer ratios."""
+    ops = _ops()
+    N, C, h, w, H, W = shape
+    x = rnd(N, C, h, w, seed=80).requires_grad_()
+    ref = F.interpolate(x, size=(H, W), mode='bilinear', align_corners=False)
+    go = rnd(*ref.shape, seed=81)
+    (gr,) = torch.autograd.grad(ref, x, go)
+    xg = x.detach().to(DEV).requires_grad_()
+    out = ops.resize_bilinear(xg, H, W, align_corners=False)
+    close(out, ref, 1e-6, 'half-pixel resize fwd')
+    (gg,) = torch.autograd.grad(out, xg, go.to(DEV))
+    close(gg, gr, 1e-5, 'half-pixel resize bwd')
+
+
+def test_l2_normalize_and_xyz_volume():
+    ops = _ops()
+    x = rnd(2, 3, 9, 14, seed=82)
+    x[0, :, 0, 0] = 0.0                                              # zero vector: eps branch
+    x = x.requires_grad_()
+    ref = F.normalize(x, dim=1)
+    go = rnd(*ref.shape, seed=83)
+    (gr,) = torch.autograd.grad(ref, x, go)
+    xg = x.detach().to(DEV).requires_grad_()
+    out = ops.l2_normalize(xg)
+    close(out, ref, 1e-6, 'normalize fwd')
+    (gg,) = torch.autograd.grad(out, xg, go.to(DEV))
+    mask = torch.ones_like(gr)
+    mask[0, :, 0, 0] = 0                                             # at the zero vector torch's gradient is g / eps = 1e12 * g: skip
+    close(gg.cpu() * mask, gr * mask, 1e-5, 'normalize bwd')
+    # coordinate volume at an arbitrary channel offset against the oracle's grid_maker_3d
+    from oracle.nnet import NNetOracle
+    from oracle.stereodpnet import Cfg
+    from dualpixelface_amd.recipe import synthetic_batch
+    batch = synthetic_batch(2, 32, 48, seed=3)
+    B, L, h, w = 2, 8, 8, 12
+    cfg = Cfg()
+    levels = torch.tensor(cfg.costrange, dtype=torch.float32).view(1, L, 1, 1).expand(B, L, h, w).contiguous()
+    vol = torch.zeros(B, 5, L, h, w, device=DEV)
+    ops.xyz_volume_into(vol, 1, levels.to(DEV), batch['K'].to(DEV), batch['abvalue'].to(DEV))
+    orc = NNetOracle({}, cfg, training=False)
+    # reuse the oracle's arithmetic through its taps: run only the front of normal_module by feeding zero features
+    class _Stop(Exception):
+        pass
+    def stop(*a, **k):
+        raise _Stop()
+    orc.convbn3 = stop
+    try:
+        orc.normal_module(torch.zeros(B, 2, L, h, w), {'K': batch['K'], 'abvalue': batch['abvalue']})
+    except _Stop:
+        pass
+    close(vol[:, 1:4], orc.taps['wc'][:, :3], 1e-5, 'xyz volume')
+    assert float(vol[:, 0].abs().max()) == 0 and float(vol[:, 4].abs().max()) == 0
+
+
+@pytest.mark.parametrize('dims', [(2, 8, 6, 10), (1, 8, 16, 40), (1, 5, 7, 9)])
+def test_softargmin_head_half_pixel(dims):
+    """x4 trilinear (align_corners=False) + softmax + expectation (nnet/mainmodel.py:150-153, modules.py:196-217) and its gradient."""
+    ops = _ops()
+    B, D, h, w = dims
+    k = rnd(B, 1, D, h, w, seed=90).requires_grad_()
+    L = 4 * D
+    disp = [i * (16.0 / L) - 4.0 for i in range(L)]
+    up = F.interpolate(k, scale_factor=4, mode='trilinear', align_corners=False).squeeze(1)
+    pr = F.softmax(up, 1)
+    ref = torch.sum(pr * torch.tensor(disp).view(1, L, 1, 1), 1)
+    go = rnd(*ref.shape, seed=91)
+    (gr,) = torch.autograd.grad(ref, k, go)
+    kg = k.detach().to(DEV).requires_grad_()
+    pred, prob = ops.softargmin(kg, disp, 4, True, align_corners=False)
+    close(pred, ref, 1e-5, 'head fwd')
+    close(prob, pr, 1e-5, 'head prob')
+    (gg,) = torch.autograd.grad(pred, kg, go.to(DEV))
+    close(gg, gr, 1e-4, 'head bwd')
