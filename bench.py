@@ -118,7 +118,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', default=None, metavar='HxW:threads[,threads...]',
                     help='time only the CPU oracle at the given size for each thread count (e.g. 1024x1536:16,128) and exit')
-    ap.add_argument('--model', default='stereodpnet', choices=['stereodpnet', 'psmnet', 'nnet'],
+    ap.add_argument('--model', default='stereodpnet', choices=['stereodpnet', 'psmnet', 'nnet', 'stereonet'],
                     help='psmnet = BASELINE configs[3] (cross-model plugin check): the PSMNet plugin on the same kernels; nnet = the NNet plugin')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
                     help="bf16 = BASELINE configs[4]: bf16-operand MFMA for the 2-D convs, fp32 everywhere else (default: exact fp32)")
@@ -140,7 +140,7 @@ def main():
 
     from dualpixelface_amd import load_option, ops
     from dualpixelface_amd.distributed import init_from_env, make_reducer, broadcast_flat
-    from dualpixelface_amd.plugin import NNET, PSMNET, STEREODPNET
+    from dualpixelface_amd.plugin import NNET, PSMNET, STEREODPNET, STEREONET
     from dualpixelface_amd.recipe import synthetic_batch
     import torch.distributed as dist
 
@@ -155,10 +155,10 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(1)
-    opt = load_option({'psmnet': 'train_faceDP_psmnet', 'nnet': 'train_faceDP_nnet'}.get(args.model, 'train_faceDP'))
+    opt = load_option({'psmnet': 'train_faceDP_psmnet', 'nnet': 'train_faceDP_nnet', 'stereonet': 'train_faceDP_stereonet'}.get(args.model, 'train_faceDP'))
     if args.precision == 'bf16':
         opt.precision = 'bf16'
-    model = {'psmnet': PSMNET, 'nnet': NNET}.get(args.model, STEREODPNET)(opt)     # reference initialisation scheme, random weights
+    model = {'psmnet': PSMNET, 'nnet': NNET, 'stereonet': STEREONET}.get(args.model, STEREODPNET)(opt)     # reference initialisation scheme, random weights
     model.to(dev)
     broadcast_flat(model.flat_parameters(), 0)
     reducer = make_reducer(model) if world > 1 else None
@@ -224,12 +224,12 @@ def main():
                     'families': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3} for k, v in fam.items()}}
         pixels = args.height * args.width
         line = {
-            'metric': 'train samples/sec, %s %dx%d DP pair' % ({'psmnet': 'PSMNet', 'nnet': 'NNet'}.get(args.model, 'StereoDPNet'), args.height, args.width), 'value': value, 'unit': 'samples/s', 'n_gpus': world,
+            'metric': 'train samples/sec, %s %dx%d DP pair' % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.height, args.width), 'value': value, 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16 2-D conv operands, f32 elsewhere',
             'data': 'synthetic',
             'config': {'workload': '%s train step (fwd+loss+bwd+grad all-reduce+Adam), %d x %dx%d synthetic DP pairs per GPU'
-                                   % ({'psmnet': 'PSMNet', 'nnet': 'NNet'}.get(args.model, 'StereoDPNet'), args.batch, args.height, args.width),
+                                   % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.batch, args.height, args.width),
                        'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,
                        'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics'},
             'final_loss': loss,

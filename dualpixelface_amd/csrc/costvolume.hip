@@ -332,6 +332,49 @@ __global__ __launch_bounds__(256) void psm_volume_bwd_kernel(const float* __rest
   }
 }
 
+// StereoNet's difference volume (src/model/stereonet/mainmodel.py:97-112): vol[b,c,l,y,x] = ref[b,c,y,x] - tar[b,c,y+d_l,x] on the rows the
+// reference writes (same row rule as the PSMNet volume), 0 elsewhere.  One thread per 4 output columns.
+__global__ __launch_bounds__(256) void diff_volume_kernel(const float* __restrict__ ref, const float* __restrict__ tar, float* __restrict__ vol,
+                                                          PsmP p) {
+  const long long plane = (long long)p.h * p.w;
+  const long long total = (long long)p.B * p.C * p.L * plane;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * 1024) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = i + j;
+      if (e >= total) break;
+      const int x = (int)(e % p.w);
+      const int y = (int)((e / p.w) % p.h);
+      const int l = (int)((e / plane) % p.L);
+      const long long bc = e / (plane * p.L);
+      const int d = p.shift[l];
+      const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);
+      vol[e] = rowok ? ref[bc * plane + (long long)y * p.w + x] - tar[bc * plane + (long long)(y + d) * p.w + x] : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void diff_volume_bwd_kernel(const float* __restrict__ dvol, float* __restrict__ dref, float* __restrict__ dtar,
+                                                              PsmP p) {
+  const long long plane = (long long)p.h * p.w;
+  const long long total = (long long)p.B * p.C * plane;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % p.w);
+    const int y = (int)((i / p.w) % p.h);
+    const long long bc = i / plane;
+    const float* dv = dvol + bc * p.L * plane + x;
+    float gr = 0.f, gt = 0.f;
+    for (int l = 0; l < p.L; ++l) {
+      const int d = p.shift[l];
+      if (d >= 0 ? (y < p.h - d) : (y >= -d)) gr += dv[((long long)l * p.h + y) * p.w];
+      const int ys = y - d;
+      if (ys >= 0 && ys < p.h && (d >= 0 ? (ys < p.h - d) : (ys >= -d))) gt -= dv[((long long)l * p.h + ys) * p.w];
+    }
+    dref[i] = gr;
+    dtar[i] = gt;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -429,6 +472,29 @@ int dpf_psm_volume_backward(const float* ref, const float* tar, const float* dvo
   for (int i = 0; i < 16; ++i) p.shift[i] = i < L ? shifts_host[i] : 0;
   hipLaunchKernelGGL(psm_volume_bwd_kernel, dim3(dpf_ew_grid((long long)B * C * h * w)), dim3(256), 0, (hipStream_t)stream, ref, tar, dvol, dref, dtar,
                      p);
+  return dpf_check_launch();
+}
+
+// StereoNet difference volume: vol [B, C, L, h, w] = ref - shifted target (stereonet/mainmodel.py:97-112) and its adjoint
+int dpf_diff_volume_forward(const float* ref, const float* tar, float* vol, const int* shifts_host, int B, int C, int h, int w, int L,
+                            void* stream) {
+  dpf_clear_error();
+  if (!ref || !tar || !vol || !shifts_host || B <= 0 || C <= 0 || L <= 0 || L > 16) return DPF_ERR_INVALID_ARG;
+  PsmP p;
+  p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.G = 0;
+  for (int i = 0; i < 16; ++i) p.shift[i] = i < L ? shifts_host[i] : 0;
+  hipLaunchKernelGGL(diff_volume_kernel, dim3(dpf_ew_grid(((long long)B * C * L * h * w + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ref, tar,
+                     vol, p);
+  return dpf_check_launch();
+}
+int dpf_diff_volume_backward(const float* dvol, float* dref, float* dtar, const int* shifts_host, int B, int C, int h, int w, int L,
+                             void* stream) {
+  dpf_clear_error();
+  if (!dvol || !dref || !dtar || !shifts_host || B <= 0 || C <= 0 || L <= 0 || L > 16) return DPF_ERR_INVALID_ARG;
+  PsmP p;
+  p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.G = 0;
+  for (int i = 0; i < 16; ++i) p.shift[i] = i < L ? shifts_host[i] : 0;
+  hipLaunchKernelGGL(diff_volume_bwd_kernel, dim3(dpf_ew_grid((long long)B * C * h * w)), dim3(256), 0, (hipStream_t)stream, dvol, dref, dtar, p);
   return dpf_check_launch();
 }
 

@@ -613,6 +613,33 @@ def psm_volume(ref, tar, shifts, groups=0):
     return PsmVolumeFn.apply(ref, tar, [int(v) for v in shifts], int(groups))
 
 
+class DiffVolumeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref, tar, shifts):
+        ref, tar = _c(ref), _c(tar)
+        _need(ref, tar)
+        B, C, h, w = ref.shape
+        L = len(shifts)
+        vol = torch.empty((B, C, L, h, w), dtype=torch.float32, device=ref.device)
+        lib().call('dpf_diff_volume_forward', _ptr(ref), _ptr(tar), _ptr(vol), _host_ints(shifts), B, C, h, w, L, _stream())
+        ctx.cfg = (tuple(int(v) for v in shifts), B, C, h, w)
+        return vol
+
+    @staticmethod
+    def backward(ctx, gv):
+        shifts, B, C, h, w = ctx.cfg
+        gv = _c(gv)
+        dref = torch.empty((B, C, h, w), dtype=torch.float32, device=gv.device)
+        dtar = torch.empty_like(dref)
+        lib().call('dpf_diff_volume_backward', _ptr(gv), _ptr(dref), _ptr(dtar), _host_ints(shifts), B, C, h, w, len(shifts), _stream())
+        return dref, dtar, None
+
+
+def diff_volume(ref, tar, shifts):
+    """StereoNet's difference volume [B, C, L, h, w] (stereonet/mainmodel.py:97-112)."""
+    return DiffVolumeFn.apply(ref, tar, [int(v) for v in shifts])
+
+
 class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k):

@@ -9,6 +9,7 @@ from .losses import loss_selector
 from .selectors import metric_selector, optimizer_selector, scheduler_selector
 from .nnet import NNetCore
 from .psmnet import PSMNetCore
+from .stereonet import StereoNetCore
 from .stereodpnet import StereoDPNetCore
 
 
@@ -161,4 +162,12 @@ class NNET(_PluginHooks, NNetCore):
 
     def __init__(self, option):
         NNetCore.__init__(self, option)
+        self._init_hooks(option)
+
+
+class STEREONET(_PluginHooks, StereoNetCore):
+    """src/model/stereonet/mainmodel.py::STEREONET (mainmodel.py:30-220)."""
+
+    def __init__(self, option):
+        StereoNetCore.__init__(self, option)
         self._init_hooks(option)

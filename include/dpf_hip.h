@@ -152,6 +152,13 @@ int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const
 int dpf_psm_volume_backward(const float* ref, const float* tar, const float* dvol, float* dref, float* dtar, const int* shifts_host, int B, int C,
                             int h, int w, int L, int groups, void* stream);
 
+/* StereoNet's difference volume (src/model/stereonet/mainmodel.py:97-112): vol [B, C, L, h, w] = ref - target shifted by shifts_host[l] rows on
+ * the rows the reference writes, 0 elsewhere; and its adjoint */
+int dpf_diff_volume_forward(const float* ref, const float* tar, float* vol, const int* shifts_host, int B, int C, int h, int w, int L,
+                            void* stream);
+int dpf_diff_volume_backward(const float* dvol, float* dref, float* dtar, const int* shifts_host, int B, int C, int h, int w, int L,
+                             void* stream);
+
 /* ---- nn.AvgPool2d(k, stride k) of PSMNet's SPP branches (src/model/psmnet/modules.py:84-102) ---------------------- */
 int dpf_avg_pool2d_forward(const float* x, float* y, long long NC, int H, int W, int k, void* stream);
 int dpf_avg_pool2d_backward(const float* g, float* dx, long long NC, int H, int W, int k, void* stream);

@@ -310,6 +310,55 @@ def test_psmnet_plugin_against_reference_golden(golden_dir):
     assert torch.isfinite(r2['final_loss'])
 
 
+def test_stereonet_plugin_against_reference_golden(golden_dir):
+    """the StereoNet plugin (5x5 stride-2 feature convs, difference volume, 8-level soft-argmin, full-resolution
+    edge-aware refinement with half-pixel bilinear upsampling) against vectors produced by importing the reference's
+    src/model/stereonet (tests/golden/make_golden_stereonet.py)."""
+    import json
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.plugin import STEREONET
+    from dualpixelface_amd.recipe import fill_by_recipe, synthetic_batch
+    g = np.load(golden_dir + '/stereonet_64x96_b2.npz')
+    keys = json.load(open(golden_dir + '/stereonet_state_dict_keys.json'))
+    model = STEREONET(load_option('train_faceDP_stereonet'))
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == keys and list(model.state_dict()) == list(keys)
+    fill_by_recipe(model)
+    model.to(DEV).train()
+    batch = {k: v.to(DEV) for k, v in synthetic_batch(2, 64, 96, seed=13).items()}
+    model.flat_gradients(zero=True)
+    res = model(batch)
+    close(model.last_taps['logits'], g['train_logits'], 2e-4, 'stereonet logits')
+    close(res['pred_depth'], g['train_pred_depth'], 2e-4, 'stereonet pred_depth')
+    close(res['prob_depth'], g['train_prob'], None, 'stereonet prob', atol=1e-5)
+    close(res['ref_feature'], g['train_ref_feature'], 2e-4, 'stereonet ref_feature')
+    close(res['final_loss'], g['final_loss'], 1e-4, 'stereonet loss')
+    res['final_loss'].backward()
+    pd = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith('grad::'):
+            ref = torch.from_numpy(g[k]).double()
+            if ref.norm() < 1e-6:
+                continue
+            rel = ((pd[k[6:]].grad.detach().cpu().double() - ref).norm() / ref.norm()).item()
+            assert rel <= 2e-2, (k, rel)
+    unused = pd['feature_extraction.residual_blocks.0.conv2.0.weight'].grad
+    assert unused is None or float(unused.abs().max()) == 0.0                    # BasicBlock never applies conv2 (modules.py:19-27)
+    sd = model.state_dict()
+    close(sd['filter.0.0.1.running_mean'], g['post::filter.0.0.1.running_mean'], 1e-4, 'filter.0 rm')
+    close(sd['feature_extraction.residual_blocks.0.conv2.1.running_var'],
+          g['post::feature_extraction.residual_blocks.0.conv2.1.running_var'], 1e-6, 'unused bn')
+    fill_by_recipe(model)
+    model.eval()
+    with torch.no_grad():
+        ev = model(batch)
+    close(ev['pred_depth'], g['eval_pred_depth'], 5e-4, 'stereonet eval pred_depth')
+    model.train()
+    before = model.state_dict()['feature_extraction.residual_blocks.0.conv2.0.weight'].clone()
+    r2 = model.train_step(batch, None, lr=1e-4)
+    assert torch.isfinite(r2['final_loss'])
+    assert torch.equal(before, model.state_dict()['feature_extraction.residual_blocks.0.conv2.0.weight'])   # zero gradient: Adam leaves it
+
+
 def test_nnet_plugin_against_reference_golden(golden_dir):
     """the NNet plugin (PSMNet-style features with half-pixel pyramid resizing, integer-shift volume, residual 3-D stack,
     per-level 2-D refinement with dilations up to 16, half-pixel trilinear head, plain normal module with (2,3,3) depth-halving convs)

@@ -749,3 +749,31 @@ def test_softargmin_head_half_pixel(dims):
     close(prob, pr, 1e-5, 'head prob')
     (gg,) = torch.autograd.grad(pred, kg, go.to(DEV))
     close(gg, gr, 1e-4, 'head bwd')
+
+
+def test_diff_volume():
+    """StereoNet's difference volume (stereonet/mainmodel.py:97-112) and its adjoint, positive / zero / negative shifts."""
+    ops = _ops()
+    B, C, h, w = 2, 5, 9, 14
+    shifts = [-2, -1, 0, 0, 1, 3]
+    ref = rnd(B, C, h, w, seed=95).requires_grad_()
+    tar = rnd(B, C, h, w, seed=96).requires_grad_()
+    parts = []
+    for d in shifts:
+        lvl = torch.zeros(B, C, h, w)
+        if d == 0:
+            lvl = ref - tar
+        elif d > 0:
+            lvl = torch.cat([ref[:, :, :-d] - tar[:, :, d:], lvl[:, :, h - d:]], 2)
+        else:
+            lvl = torch.cat([lvl[:, :, :-d], ref[:, :, -d:] - tar[:, :, :d]], 2)
+        parts.append(lvl)
+    want = torch.stack(parts, 2)
+    go = rnd(*want.shape, seed=97)
+    gr = torch.autograd.grad(want, (ref, tar), go)
+    rg, tg = ref.detach().to(DEV).requires_grad_(), tar.detach().to(DEV).requires_grad_()
+    vol = ops.diff_volume(rg, tg, shifts)
+    assert torch.equal(vol.cpu(), want.detach())
+    gg = torch.autograd.grad(vol, (rg, tg), go.to(DEV))
+    close(gg[0], gr[0], 1e-6, 'diff volume dref')
+    close(gg[1], gr[1], 1e-6, 'diff volume dtar')

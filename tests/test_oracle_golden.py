@@ -232,3 +232,39 @@ def test_nnet_oracle_against_reference(golden_dir):
         out = ev.forward(batch)
     _close(out['pred_depth'][:, :, ::2, ::2], g['eval_pred_depth_s2'], 2e-4, 'nnet eval pred_depth')
     _close(out['pred_normal'][:, :, :, ::2, ::2], g['eval_pred_normal_s2'], 2e-4, 'nnet eval pred_normal')
+
+
+def test_stereonet_oracle_against_reference(golden_dir):
+    """StereoNet (src/model/stereonet): logits, both predictions, probabilities, loss, gradients and BatchNorm buffers of the oracle
+    against vectors made by importing the reference (tests/golden/make_golden_stereonet.py)."""
+    import os
+    from dualpixelface_amd.recipe import synthetic_batch
+    from oracle.stereonet import StereoNetOracle
+    g = np.load(golden_dir + '/stereonet_64x96_b2.npz')
+    keys = os.path.join(golden_dir, 'stereonet_state_dict_keys.json')
+    st = recipe_state(keys_file=keys)
+    batch = synthetic_batch(2, 64, 96, seed=13)
+    orc = StereoNetOracle(st, training=True)
+    res = orc.forward(batch)
+    _close(orc.taps['logits'], g['train_logits'][:, 0], 1e-4, 'stereonet logits')
+    _close(res['pred_depth'], g['train_pred_depth'], 1e-4, 'stereonet pred_depth')
+    _close(res['prob_depth'], g['train_prob'], 1e-4, 'stereonet prob')
+    _close(res['ref_feature'], g['train_ref_feature'], 1e-4, 'stereonet ref_feature')
+    _close(res['final_loss'], g['final_loss'], 1e-5, 'stereonet loss')
+    res['final_loss'].backward()
+    for key in g.files:
+        if key.startswith('grad::'):
+            ref = torch.from_numpy(g[key]).double()
+            if ref.norm() < 1e-6:
+                continue
+            mine = st[key[6:]].grad.double()
+            assert (mine - ref).norm() / ref.norm() < 1e-2, (key, ((mine - ref).norm() / ref.norm()).item())
+    assert bool(g['unused_grad_is_none']) and st['feature_extraction.residual_blocks.0.conv2.0.weight'].grad is None
+    _close(st['filter.0.0.1.running_mean'], g['post::filter.0.0.1.running_mean'], 1e-4, 'filter.0 running_mean')
+    # conv2's BatchNorm is never called: its buffers keep their initial values
+    _close(st['feature_extraction.residual_blocks.0.conv2.1.running_var'],
+           g['post::feature_extraction.residual_blocks.0.conv2.1.running_var'], 1e-6, 'unused bn')
+    ev = StereoNetOracle(recipe_state(requires_grad=False, keys_file=keys), training=False)
+    with torch.no_grad():
+        out = ev.forward(batch)
+    _close(out['pred_depth'], g['eval_pred_depth'], 1e-4, 'stereonet eval pred_depth')
