@@ -339,7 +339,12 @@ def test_stereonet_plugin_against_reference_golden(golden_dir):
             ref = torch.from_numpy(g[k]).double()
             if ref.norm() < 1e-6:
                 continue
-            rel = ((pd[k[6:]].grad.detach().cpu().double() - ref).norm() / ref.norm()).item()
+            mine = pd[k[6:]].grad.detach().cpu().double()
+            if k.endswith('conv3d_alone.bias'):
+                # a constant added to every level cancels in the softmax: the true gradient is 0 and both sides hold rounding noise
+                assert float(mine.abs().max()) <= 1e-3 and float(ref.abs().max()) <= 1e-3, (k, mine, ref)
+                continue
+            rel = ((mine - ref).norm() / ref.norm()).item()
             assert rel <= 2e-2, (k, rel)
     unused = pd['feature_extraction.residual_blocks.0.conv2.0.weight'].grad
     assert unused is None or float(unused.abs().max()) == 0.0                    # BasicBlock never applies conv2 (modules.py:19-27)
