@@ -94,3 +94,50 @@ def test_training_from_a_facedp_dataset_on_disk(tmp_path, monkeypatch):
     losses = [v for h in hist for k, v in h.items() if 'loss' in k]
     assert losses and all(l == l for l in losses)
     assert any('metrics' in h for h in hist)
+
+
+def test_reference_entry_point_call_sequence_through_the_pl_shim(tmp_path, monkeypatch):
+    """compat/pytorch_lightning: the exact sequence of calls the reference's main.py makes (main.py:20-61 -- seed_everything,
+    TensorBoardLogger, LearningRateMonitor, ModelCheckpoint, Trainer(<its 14 keyword arguments>).fit(model=model), then a resumed
+    Trainer and .test) on the native trainer, over a FaceDP dataset on disk."""
+    import sys
+    from dualpixelface_amd import load_option
+    from tests import facedp_fixture as fx
+    monkeypatch.syspath_prepend(os.path.join(ROOT, 'compat'))
+    for name in [n for n in sys.modules if n == 'pytorch_lightning' or n.startswith('pytorch_lightning.')]:
+        monkeypatch.delitem(sys.modules, name)
+    from pytorch_lightning import Trainer, seed_everything
+    from pytorch_lightning import loggers as pl_loggers
+    from pytorch_lightning.callbacks import LearningRateMonitor, ModelCheckpoint
+    data = fx.build_dataset(tmp_path / 'data', seed=0)
+    monkeypatch.chdir(tmp_path)
+    opt = load_option()
+    opt.dataset.path, opt.dataset.viewpoint = data, [1, 2, 6]
+    opt.crop_aug.soft_crop.crop_factor = 16
+    opt.use_raw, opt.workers, opt.batch_size, opt.epoch = False, 2, 2, 2
+    opt.workspace_path, opt.logger_path = str(tmp_path / 'ws'), str(tmp_path / 'ws' / 'log')
+    seed_everything(1)
+    model = _model(opt)
+
+    def make_trainer(resume):
+        logger = pl_loggers.TensorBoardLogger(str(opt.logger_path))
+        callbacks = [LearningRateMonitor(logging_interval='step'),
+                     ModelCheckpoint(dirpath=str(opt.workspace_path), filename='checkpoint_{epoch:02d}', save_top_k=-1, period=1)]
+        return Trainer(logger=logger, checkpoint_callback=True, callbacks=callbacks, resume_from_checkpoint=resume,
+                       check_val_every_n_epoch=1, accelerator=opt.accelerator, benchmark=True, deterministic=False,
+                       gpus=torch.cuda.device_count(), precision=opt.precision, max_epochs=opt.epoch, sync_batchnorm=opt.sync_batch,
+                       amp_level='O2', profiler='pytorch')
+
+    runner = make_trainer(None)
+    runner.fit(model=model)
+    ck0, ck1 = (os.path.join(opt.workspace_path, 'checkpoint_epoch=%02d.ckpt' % e) for e in (0, 1))
+    assert os.path.exists(ck0) and os.path.exists(ck1) and runner.native.global_step == 8
+    assert os.path.exists(os.path.join(opt.logger_path, 'scalars.jsonl'))
+    # resume from the first epoch's checkpoint: one more epoch is run, not two
+    opt.load_model = None
+    model2 = _model(opt)
+    runner2 = make_trainer(ck0)
+    runner2.fit(model=model2)
+    assert runner2.native.epoch == 2 and runner2.native.global_step == 8
+    rows = make_trainer(None).test(model=model2, verbose=False)
+    assert set(rows[0]) == {'absolute_dp', 'affine_dp', 'normal_dp'}
