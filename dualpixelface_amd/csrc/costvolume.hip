@@ -16,30 +16,49 @@
 namespace {
 
 // tables: iy [3][2][h] int32 (-1 = no tap), wy [3][2][h] float, ix [3][2][w], wx [3][2][w]
-__global__ void shift_triple_fwd_kernel(const float* __restrict__ fea, float* __restrict__ out, const int* __restrict__ iy,
-                                        const float* __restrict__ wy, const int* __restrict__ ix, const float* __restrict__ wx,
-                                        long long BC, int h, int w) {
-  const long long total = BC * 3 * h * w;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % w);
-    const int y = (int)((i / w) % h);
-    const int m = (int)((i / ((long long)w * h)) % 3);
-    const long long bc = i / ((long long)w * h * 3);
-    const float* src = fea + bc * h * w;
-    float acc = 0.f;
+// grid (row chunks, BC * 3 planes): the plane index (b, c, mode) comes from blockIdx.y, a thread owns 4 consecutive columns of a row:
+// one 32-bit division per 4 outputs, the row taps are uniform per row, the column taps are read as vectors, 16-byte stores.
+constexpr int ST_ROWS = 8;
+__global__ __launch_bounds__(256) void shift_triple_fwd_kernel(const float* __restrict__ fea, float* __restrict__ out, const int* __restrict__ iy,
+                                                               const float* __restrict__ wy, const int* __restrict__ ix,
+                                                               const float* __restrict__ wx, int h, int w) {
+  const int m = blockIdx.y % 3;
+  const long long bc = blockIdx.y / 3;
+  const int y0 = blockIdx.x * ST_ROWS;
+  const int nrow = min(ST_ROWS, h - y0);
+  const int w4 = (w + 3) >> 2;
+  const float* src = fea + bc * h * w;
+  float* dst = out + ((bc * 3 + m) * h + y0) * (long long)w;
+  const int* ixm = ix + m * 2 * w;
+  const float* wxm = wx + m * 2 * w;
+  const bool vec = (w & 3) == 0;
+  for (int idx = threadIdx.x; idx < nrow * w4; idx += 256) {
+    const int r = idx / w4, x = (idx - r * w4) * 4;
+    const int y = y0 + r;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int yy = iy[(m * 2 + a) * h + y];
       if (yy < 0) continue;
       const float wa = wy[(m * 2 + a) * h + y];
+      const float* row = src + (long long)yy * w;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int xx = ix[(m * 2 + e) * w + x];
-        if (xx < 0) continue;
-        acc += (wa * wx[(m * 2 + e) * w + x]) * src[(long long)yy * w + xx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (x + j < w) {
+            const int xx = ixm[e * w + x + j];
+            if (xx >= 0) acc[j] += (wa * wxm[e * w + x + j]) * row[xx];
+          }
+        }
       }
     }
-    out[i] = acc;
+    float* o = dst + (long long)r * w + x;
+    if (vec) {
+      *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      for (int j = 0; j < 4 && x + j < w; ++j) o[j] = acc[j];
+    }
   }
 }
 
@@ -75,17 +94,21 @@ __global__ void shift_triple_bwd_kernel(const float* __restrict__ g, float* __re
 // tap (m, a) reads source row yy, -1 if none; the tap maps are monotone and at most two outputs share a source -- the host checks
 // it), wy / wx stay indexed by the output coordinate.  One thread per dfea element, <= 48 terms in a fixed order, no atomics, no
 // pre-zeroing.
-__global__ void shift_triple_bwd_gather_kernel(const float* __restrict__ g, float* __restrict__ dfea, const int* __restrict__ iyi,
-                                               const float* __restrict__ wy, const int* __restrict__ ixi, const float* __restrict__ wx,
-                                               long long BC, int h, int w) {
+__global__ __launch_bounds__(256) void shift_triple_bwd_gather_kernel(const float* __restrict__ g, float* __restrict__ dfea,
+                                                                      const int* __restrict__ iyi, const float* __restrict__ wy,
+                                                                      const int* __restrict__ ixi, const float* __restrict__ wx, int h, int w) {
+  const long long bc = blockIdx.y;
+  const int y0 = blockIdx.x * ST_ROWS;
+  const int nrow = min(ST_ROWS, h - y0);
+  const int w4 = (w + 3) >> 2;
   const long long hw = (long long)h * w;
-  const long long total = BC * hw;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int xx = (int)(i % w);
-    const int yy = (int)((i / w) % h);
-    const long long bc = i / hw;
-    const float* gp = g + bc * 3 * hw;
-    float acc = 0.f;
+  const float* gp = g + bc * 3 * hw;
+  float* dst = dfea + bc * hw + (long long)y0 * w;
+  const bool vec = (w & 3) == 0;
+  for (int idx = threadIdx.x; idx < nrow * w4; idx += 256) {
+    const int r = idx / w4, xx0 = (idx - r * w4) * 4;
+    const int yy = y0 + r;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
 #pragma unroll
@@ -95,19 +118,29 @@ __global__ void shift_triple_bwd_gather_kernel(const float* __restrict__ g, floa
           const int y = iyi[((m * 2 + a) * 2 + sy) * h + yy];
           if (y < 0) continue;
           const float wa = wy[(m * 2 + a) * h + y];
+          const float* grow = gp + m * hw + (long long)y * w;
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
-              const int x = ixi[((m * 2 + e) * 2 + sx) * w + xx];
-              if (x < 0) continue;
-              acc += (wa * wx[(m * 2 + e) * w + x]) * gp[m * hw + (long long)y * w + x];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (xx0 + j < w) {
+                  const int x = ixi[((m * 2 + e) * 2 + sx) * w + xx0 + j];
+                  if (x >= 0) acc[j] += (wa * wx[(m * 2 + e) * w + x]) * grow[x];
+                }
+              }
             }
           }
         }
       }
     }
-    dfea[i] = acc;
+    float* o = dst + (long long)r * w + xx0;
+    if (vec) {
+      *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      for (int j = 0; j < 4 && xx0 + j < w; ++j) o[j] = acc[j];
+    }
   }
 }
 
@@ -384,8 +417,9 @@ int dpf_shift_triple_forward(const float* fea, float* out, const int* iy, const 
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!fea || !out || !iy || !wy || !ix || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
   const long long BC = (long long)B * C;
-  hipLaunchKernelGGL(shift_triple_fwd_kernel, dim3(dpf_ew_grid(BC * 3 * h * w)), dim3(256), 0, (hipStream_t)stream, fea, out, iy, wy, ix,
-                     wx, BC, h, w);
+  if (BC * 3 > 65535) return DPF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(shift_triple_fwd_kernel, dim3(dpf_div_up(h, ST_ROWS), (unsigned)(BC * 3)), dim3(256), 0, (hipStream_t)stream, fea, out,
+                     iy, wy, ix, wx, h, w);
   return dpf_check_launch();
 }
 
@@ -405,8 +439,9 @@ int dpf_shift_triple_backward_gather(const float* g, float* dfea, const int* iy_
   dpf_clear_error();
   if (!g || !dfea || !iy_inv || !wy || !ix_inv || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
   const long long BC = (long long)B * C;
-  hipLaunchKernelGGL(shift_triple_bwd_gather_kernel, dim3(dpf_ew_grid(BC * h * w)), dim3(256), 0, (hipStream_t)stream, g, dfea, iy_inv,
-                     wy, ix_inv, wx, BC, h, w);
+  if (BC > 65535) return DPF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(shift_triple_bwd_gather_kernel, dim3(dpf_div_up(h, ST_ROWS), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, g, dfea,
+                     iy_inv, wy, ix_inv, wx, h, w);
   return dpf_check_launch();
 }
 

@@ -499,7 +499,8 @@ class StereoDPNetCore(_Base):
             self._index()
         if not m.use_sampling:
             raise NotImplementedError('use_sampling=false is not on the StereoDPNet hot path')
-        vol, _ = ops.anm_volume(cost, disp_full, batch['K'].float(), batch['abvalue'].float(), self.costrange, int(m.dsample_num))
+        vol, idx = ops.anm_volume(cost, disp_full, batch['K'].float(), batch['abvalue'].float(), self.costrange, int(m.dsample_num))
+        self.last_anm_idx = idx                  # selected cost levels [B, k, h, w] (diagnostics / tests)
         if m.use_deform:
             # the 3 XYZ channels of `vol` are constants of the batch (no gradient consumer): skip their grad_input
             v1, off1 = self._deform(vol, p + '.deform_conv1', gi_channels=C)

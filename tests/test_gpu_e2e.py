@@ -431,13 +431,25 @@ def test_c2_shape_forward_and_loss_vs_cpu_oracle():
     close(res['pred_depth'], ref['pred_depth'], None, 'pred_depth', atol=3e-3)
     # The normal head samples the 4 cost levels nearest to the predicted disparity (normal_module.py:80-138): a discontinuous
     # selection.  Over 98 304 quarter-resolution pixels a prediction that sits within fp32 rounding of a level boundary can pick
-    # the neighbouring level on one side only (observed: one run in five, a single pixel, |d normal| = 0.08), so this size is
-    # checked with an outlier budget instead of a hard maximum: <= 1e-4 of the values beyond 1e-3, mean error <= 2e-5 (measured
-    # 0.9e-5 .. 1.1e-5 over repeated runs; the unit normals' fp32 noise floor through ~100 layers).
-    err = (res['pred_normal'].detach().cpu().double() - ref['pred_normal'].double()).abs()
-    assert float((err > 1e-3).double().mean()) <= 1e-4 and float(err.mean()) <= 2e-5, (float(err.max()), float(err.mean()))
-    for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
-        close(res[k], ref[k], 2e-4, k)
+    # the neighbouring level on one side only (observed: one run in eight, a single pixel), and that pixel's different cost
+    # slices then reach every normal inside the head's receptive field (two 3x3x3 deformable convs + 2-D dilations 1,2,4,8,1,1:
+    # about +-24 quarter-resolution pixels).  So: the selected levels are compared first (at most 8 pixels may differ), the
+    # normals are compared outside the receptive fields of those pixels to 1e-3, and inside them to a loose 0.2.
+    idx_gpu = model.last_anm_idx.cpu().long()
+    idx_cpu = orc.taps['anm_idx'].long()
+    flipped = (idx_gpu != idx_cpu).any(1, keepdim=True).float()                       # [B, 1, h, w]
+    assert int(flipped.sum()) <= 8, int(flipped.sum())
+    R = 24
+    near = torch.nn.functional.max_pool2d(flipped, 2 * R + 1, 1, R)
+    near = torch.nn.functional.interpolate(near, scale_factor=4, mode='nearest').bool()  # [B, 1, H, W]
+    err = (res['pred_normal'].detach().cpu().double() - ref['pred_normal'].double()).abs()   # [B, 1, 3, H, W]
+    outside = err.masked_fill(near.unsqueeze(2), 0.0)
+    assert float(outside.max()) <= 1e-3 and float(err.max()) <= 0.2, (float(outside.max()), float(err.max()), int(flipped.sum()))
+    assert float(outside.mean()) <= 2e-5, float(outside.mean())
+    close(res['smoothL1_loss'], ref['smoothL1_loss'], 2e-4, 'smoothL1_loss')
+    loose = 2e-4 if int(flipped.sum()) == 0 else 5e-3                                 # a flipped pixel moves the normals around it
+    for k in ('cosine_loss', 'final_loss'):
+        close(res[k], ref[k], loose, k)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 

@@ -22,6 +22,13 @@ SHAPES = {
     'anm64d8': (16, 64, 1, 256, 384, 64, (1, 3, 3), (1, 1, 1), (0, 8, 8), (1, 8, 8)),
     'off81': (4, 64, 4, 256, 384, 81, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     'off81a': (4, 35, 4, 256, 384, 81, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    'pw32': (4, 32, 1, 256, 384, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    'pw32x3': (4, 32, 3, 256, 384, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    'pw64': (4, 64, 1, 128, 192, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    'pw128': (4, 128, 1, 64, 96, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    'pw128_32': (4, 128, 1, 64, 96, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    'pw32s2': (4, 32, 1, 512, 768, 32, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),
+    'pw64_128s2': (4, 64, 1, 128, 192, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),
 }
 args = sys.argv[1:]
 check = '--check' in args
