@@ -502,6 +502,11 @@ int conv_common(const float* x, const float* w, const float* bias, float* out, f
     {   // LDS-DMA double-buffered kernel where the shape is eligible (conv_igemm2.hip)
       DpfConvDesc d{p.N, p.C, Kc, p.Ktot, k0, p.ID, p.IH, p.IW, p.OD, p.OH, p.OW, p.kd, p.kh, p.kw, p.sd, p.sh, p.sw,
                     p.pd, p.ph, p.pw, p.dd, p.dh, p.dw, p.transposed, wA, wB, repack_mode};
+      if (T == 1) {                                  // pointwise: HBM-bound direct kernel (conv_pointwise.hip)
+        const int rcp = dpf_pointwise_conv(x, w, bias, out, d, st);
+        if (rcp == DPF_OK) continue;
+        if (rcp != DPF_ERR_UNSUPPORTED) return rcp;
+      }
       const int rc2 = dpf_igemm2_conv(x, w, bias, out, wt_ws, d, st);
       if (rc2 == DPF_OK) continue;
       if (rc2 != DPF_ERR_UNSUPPORTED) return rc2;
@@ -663,7 +668,10 @@ int dpf_conv_transpose_ex(const float* x, const float* w, const float* bias, flo
 
 // dW[K][C][T] += ...   (dw must be zero-initialised or hold the running gradient)
 // g [N,K,QD,QH,QW] on the small grid, x [N,C,ID,IH,IW] on the dense grid.
-long long dpf_conv_wgrad_workspace_floats(int T, int C, int K) { return dpf_wgrad2_workspace_floats(T, C, K); }
+long long dpf_conv_wgrad_workspace_floats(int T, int C, int K) {
+  const long long a = dpf_wgrad2_workspace_floats(T, C, K), b = T == 1 ? dpf_pointwise_wgrad_workspace_floats(C, K < 128 ? K : 128) : 0;
+  return a > b ? a : b;
+}
 
 // as dpf_conv_wgrad below, with caller scratch (dpf_conv_wgrad_workspace_floats floats): eligible shapes run the LDS-DMA kernel
 // with a deterministic slab reduction (conv_wgrad2.hip) instead of float atomics
@@ -679,7 +687,8 @@ int dpf_conv_wgrad_ws(const float* g, const float* x, float* dw, float* ws, long
     int rc = DPF_ERR_UNSUPPORTED;
     if (ws) {
       DpfWgradDesc d{N, C, Kc, K, k0, ID, IH, IW, QD, QH, QW, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_};
-      rc = dpf_wgrad2(g, x, dwk, ws, ws_floats, d, accumulate, (hipStream_t)stream);
+      if (T == 1) rc = dpf_pointwise_wgrad(g, x, dwk, ws, ws_floats, d, accumulate, (hipStream_t)stream);
+      if (rc == DPF_ERR_UNSUPPORTED) rc = dpf_wgrad2(g, x, dwk, ws, ws_floats, d, accumulate, (hipStream_t)stream);
     }
     if (rc == DPF_ERR_UNSUPPORTED) {
       if (!accumulate && hipMemsetAsync(dwk, 0, sizeof(float) * (size_t)Kc * C * T, (hipStream_t)stream) != hipSuccess) return DPF_ERR_LAUNCH;

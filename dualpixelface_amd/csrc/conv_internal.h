@@ -36,3 +36,9 @@ struct DpfWgradDesc {
 // accumulate = 0: dw is overwritten (no zero-initialisation needed), 1: dw += ...
 int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, int accumulate, hipStream_t st);
 long long dpf_wgrad2_workspace_floats(int T, int C, int K);
+
+// Pointwise (1x1x1) convolutions, HBM-bound direct kernels (conv_pointwise.hip); DPF_ERR_UNSUPPORTED -> caller falls back.
+int dpf_pointwise_conv(const float* x, const float* w, const float* bias, float* out, const DpfConvDesc& d, hipStream_t st);
+int dpf_pointwise_wgrad(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, int accumulate,
+                        hipStream_t st);
+long long dpf_pointwise_wgrad_workspace_floats(int C, int K);

@@ -433,13 +433,15 @@ def test_c2_shape_forward_and_loss_vs_cpu_oracle():
     # selection.  Over 98 304 quarter-resolution pixels a prediction that sits within fp32 rounding of a level boundary can pick
     # the neighbouring level on one side only (observed: one run in eight, a single pixel), and that pixel's different cost
     # slices then reach every normal inside the head's receptive field (two 3x3x3 deformable convs + 2-D dilations 1,2,4,8,1,1:
-    # about +-24 quarter-resolution pixels).  So: the selected levels are compared first (at most 8 pixels may differ), the
-    # normals are compared outside the receptive fields of those pixels to 1e-3, and inside them to a loose 0.2.
+    # measured with tools/c2_flip_probe.py over 30 runs: 2 runs with one flipped pixel, error 8e-2 at the pixel, 7e-4 beyond 24
+    # quarter-resolution pixels, 2.7e-4 beyond 32; 1.0e-4 .. 1.3e-4 everywhere when nothing flips).  So: the selected levels are
+    # compared first (at most 8 pixels may differ), the normals are compared outside a 32-pixel neighbourhood of those pixels to
+    # 1e-3, and inside it to a loose 0.2.
     idx_gpu = model.last_anm_idx.cpu().long()
     idx_cpu = orc.taps['anm_idx'].long()
     flipped = (idx_gpu != idx_cpu).any(1, keepdim=True).float()                       # [B, 1, h, w]
     assert int(flipped.sum()) <= 8, int(flipped.sum())
-    R = 24
+    R = 32
     near = torch.nn.functional.max_pool2d(flipped, 2 * R + 1, 1, R)
     near = torch.nn.functional.interpolate(near, scale_factor=4, mode='nearest').bool()  # [B, 1, H, W]
     err = (res['pred_normal'].detach().cpu().double() - ref['pred_normal'].double()).abs()   # [B, 1, 3, H, W]

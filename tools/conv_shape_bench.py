@@ -52,15 +52,17 @@ for nm in names:
         del xr, wr, yr, gxr, gwr, gx, gw
     for what in ('fwd', 'dgrad', 'wgrad'):
         ts = []
-        for it in range(6):
+        REPS = 10                                   # back-to-back launches per timing: amortises the ~40 us launch + sync floor
+        for it in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            if what == 'fwd':
-                ops.ConvFn.apply(x.detach(), w.detach(), None, st, pd, dl)
-            elif what == 'dgrad':
-                ops._conv_transpose_raw(go, w.detach(), None, x.shape[2:], w.shape[2:], st, pd, dl)
-            else:
-                ops._conv_wgrad_raw(go, x.detach(), w.shape, st, pd, dl)
-            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            for _ in range(REPS):
+                if what == 'fwd':
+                    ops.ConvFn.apply(x.detach(), w.detach(), None, st, pd, dl)
+                elif what == 'dgrad':
+                    ops._conv_transpose_raw(go, w.detach(), None, x.shape[2:], w.shape[2:], st, pd, dl)
+                else:
+                    ops._conv_wgrad_raw(go, x.detach(), w.shape, st, pd, dl)
+            torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / REPS)
         t = min(ts[1:])
         res.append('%s %.3f ms %.1f TF' % (what, t * 1e3, flops / t * 1e-12))
     print('%-9s' % nm, ' | '.join(res), flush=True)
