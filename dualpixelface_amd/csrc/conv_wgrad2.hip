@@ -290,7 +290,17 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
   }
 }
 
-// dw[i] += sum_{chunk} slab[chunk][i]  in chunk order (deterministic)
+// dw[i] (+)= sum_{chunk} slab[chunk][i] in a fixed order (deterministic), in two levels so that the fold is not one serial chain of
+// nchunk dependent loads per thread on a quarter-filled chip: grid.y groups of W2_RG chunks -> part[group][i], then the groups
+constexpr int W2_RG = 16;
+__global__ void wgrad2_fold_kernel(const float* __restrict__ slab, float* __restrict__ part, long long n, int nchunk) {
+  const int c0 = blockIdx.y * W2_RG, c1 = c0 + W2_RG < nchunk ? c0 + W2_RG : nchunk;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = c0; c < c1; ++c) s += slab[(long long)c * n + i];
+    part[(long long)blockIdx.y * n + i] = s;
+  }
+}
 __global__ void wgrad2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nchunk, int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -344,7 +354,7 @@ long long dpf_wgrad2_workspace_floats(int T, int C, int K) {
   const long long cols = (long long)C * T;
   const long long groups = ((cols + 223) / 224) * ((Kc + 31) / 32);
   const long long nchunk = w2_maxblocks() / groups + 8;
-  return nchunk * Kc * cols + 64;
+  return (nchunk + nchunk / 16 + 2) * Kc * cols + 64;          // slabs + the group sums of the two-level fold
 }
 
 int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, int accumulate, hipStream_t st) {
@@ -439,6 +449,13 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   }
   if (rc != DPF_OK) return rc;
   const long long n = p.slab_stride;
-  hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, st, ws, dw, n, p.nchunk, accumulate);
+  const int groups2 = (p.nchunk + W2_RG - 1) / W2_RG;
+  if (p.nchunk > 2 * W2_RG && (nchunk + groups2) * n <= ws_floats) {
+    float* part = ws + nchunk * n;
+    hipLaunchKernelGGL(wgrad2_fold_kernel, dim3(dpf_ew_grid(n), groups2), dim3(256), 0, st, ws, part, n, p.nchunk);
+    hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, st, part, dw, n, groups2, accumulate);
+  } else {
+    hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, st, ws, dw, n, p.nchunk, accumulate);
+  }
   return dpf_check_launch();
 }
