@@ -9,6 +9,10 @@ python bench.py --height 512 --width 768 --no-cpu-baseline > gpurun_out/r02/r02_
 python bench.py --model psmnet --batch 2 --no-cpu-baseline > gpurun_out/r02/r02_bench_c4_psmnet_train.json 2>> gpurun_out/r02/bench.err
 python bench.py --precision bf16 --no-cpu-baseline > gpurun_out/r02/r02_bench_c5_bf16_b4.json 2>> gpurun_out/r02/bench.err
 python bench.py --workload cost_volume --no-cpu-baseline > gpurun_out/r02/r02_bench_cost_volume_stage.json 2>> gpurun_out/r02/bench.err
+python bench.py --workload cost_volume_fix --no-cpu-baseline > gpurun_out/r02/r02_bench_cost_volume_fix_stage.json 2>> gpurun_out/r02/bench.err
+python bench.py --model nnet --batch 2 --no-cpu-baseline > gpurun_out/r02/r02_bench_nnet_train.json 2>> gpurun_out/r02/bench.err
+python bench.py --model stereonet --no-cpu-baseline > gpurun_out/r02/r02_bench_stereonet_train.json 2>> gpurun_out/r02/bench.err
+python tools/facedp_bench.py --out gpurun_out/r02/r02_facedp_bench.json > /dev/null 2>> gpurun_out/r02/bench.err
 python bench.py --workload psm_volume --batch 2 --no-cpu-baseline > gpurun_out/r02/r02_bench_psm_volume.json 2>> gpurun_out/r02/bench.err
 bash tools/gpu_prof.sh r02 > gpurun_out/r02/r02_bench_family_ms.txt 2>&1
 cp gpurun_out/prof_r02_kernel_stats.csv gpurun_out/r02/r02_bench_kernel_stats.csv
@@ -16,7 +20,7 @@ rm -rf gpurun_out/pmc_f2 gpurun_out/pmc_w2
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f2 -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w2 -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 tools/pmc_traffic.py gpurun_out/pmc_f2/p_counter_collection.csv gpurun_out/pmc_w2/p_counter_collection.csv gpurun_out/r02/r02_pmc_traffic.json
-export PMC_FILTER="igemm2 wgrad2 dcn_"
+export PMC_FILTER="igemm2 wgrad2 dcn_ pointwise"
 bash tools/gpu_pmc.sh r02sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02/r02_sq_counters.txt 2>&1
 bash tools/gpu_pmc.sh r02grbm GRBM_GUI_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02/r02_grbm_cycles.txt 2>&1
 python bench.py --cpu-baseline-only 512x768:16,64 > gpurun_out/r02/r02_cpu_baseline_c2.txt 2>> gpurun_out/r02/bench.err

@@ -11,11 +11,15 @@ import sys
 
 
 def family(name):
-    for key in ('igemm2', 'wgrad2', 'conv_igemm_kernel', 'conv_wgrad_kernel', 'dcn_bwd_input', 'dcn_fwd', 'dcn_bwd_offset', 'dcn_wgrad_region',
-                'smallk', 'bn_', 'head_'):
+    for key in ('igemm2', 'wgrad2', 'pointwise', 'conv_igemm_kernel', 'conv_wgrad_kernel', 'dcn_bwd_input', 'dcn_fwd', 'dcn_bwd_offset',
+                'dcn_wgrad_region', 'smallk', 'bn_', 'head_'):
         if key in name:
             return key
     return None
+
+
+# helper launches of a family (weight packs, slab folds): their bytes belong to the operation, but "per launch" means per main kernel
+HELPERS = ('igemm2_pack', 'wgrad2_reduce', 'wgrad2_fold', 'pointwise_wgrad_fold', 'pointwise_wgrad_reduce', 'bn_finalize', 'bn_fold')
 
 
 def agg(path, counter):
@@ -29,7 +33,8 @@ def agg(path, counter):
         tot[fam] += float(r['Counter_Value'])
         if r['Dispatch_Id'] not in seen:
             seen.add(r['Dispatch_Id'])
-            n[fam] += 1
+            if not any(h in r['Kernel_Name'] for h in HELPERS):
+                n[fam] += 1
     return tot, n
 
 
