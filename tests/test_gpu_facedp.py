@@ -209,3 +209,26 @@ def test_abi_argument_checks():
         l.call('dpf_dp_image', p(x), None, p(out), 16, 16, 2, 0, 0, 8, 8, None, f, one, None)
     with pytest.raises(DpfError):
         l.call('dpf_dp_depth_stats', None, 0, None, 10, 1.0, 1.0, None, None)
+
+
+def test_batcher_under_a_distributed_sampler(datasets, tmp_path):
+    """What the trainer does under torchrun: the batcher re-sharded with a DistributedSampler -- the two ranks see disjoint padded
+    halves of every epoch, the same number of equal-shape batches, and a different order per epoch."""
+    from torch.utils.data.distributed import DistributedSampler
+    case = 'train_soft_light'
+    option, training = fx.make_option(case, datasets(case))
+    ds = facedp.FaceDPLoader(option, training, device='cuda:0', cache_dir=str(tmp_path))
+    base = facedp.FaceDPBatcher(ds, batch_size=2, shuffle=True, workers=2)
+    seen = {}
+    for rank in (0, 1):
+        sampler = DistributedSampler(ds, num_replicas=2, rank=rank, shuffle=True, seed=1, drop_last=False)
+        shard = base.with_sampler(sampler)
+        for epoch in (0, 1):
+            shard.set_epoch(epoch)
+            names = [bytes(P.numpy().tobytes()) for batch in shard for P in batch['P']]   # the pose is unique per index entry
+            assert len(shard) == 2 and len(names) == 4                       # 7 samples padded to 8, 4 per rank, batches of 2
+            seen[(rank, epoch)] = names
+    for epoch in (0, 1):
+        both = seen[(0, epoch)] + seen[(1, epoch)]
+        assert len(set(both)) == 7                                           # every sample once, one of them twice (padding)
+    assert seen[(0, 0)] != seen[(0, 1)]
