@@ -663,9 +663,15 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   // channels per chunk: the largest of {8, 4, 2} whose two buffers leave room for >= 3 resident workgroups
   auto buf_bytes = [&](int cc) { return (size_t)(cc * p.chanStride + T * cc * KT) * sizeof(float); };
   auto nseg_of = [&](int cc) { return cc * p.rpc * p.SR; };
+  // Launches that fill the chip several times over run best with the smallest chunk (more resident workgroups hide the DMA
+  // latency: +1..5 % on every large shape, tools/conv_shape_bench.py sweep); small launches (< 2 tiles per CU) keep the larger
+  // chunks, which shorten their few workgroups' barrier chains.
+  const long long ntiles_est = (long long)d.N * d.OD * dpf_div_up(d.OH, TH) * dpf_div_up(d.OW, 32);
   int CC = 0;
-  for (int cc : {8, 4, 2})
-    if (2 * buf_bytes(cc) <= (size_t)lds_target && nseg_of(cc) <= NLD * 256) { CC = cc; break; }
+  if (ntiles_est >= 512 && 2 * buf_bytes(2) <= (size_t)lds_target && nseg_of(2) <= NLD * 256) CC = 2;
+  if (!CC)
+    for (int cc : {8, 4, 2})
+      if (2 * buf_bytes(cc) <= (size_t)lds_target && nseg_of(cc) <= NLD * 256) { CC = cc; break; }
   if (cc_over == 2 || cc_over == 4 || cc_over == 8) CC = cc_over;
   if (!CC) CC = 2;
   if (nseg_of(CC) > NLD * 256 || 2 * buf_bytes(CC) > 160 * 1024) return DPF_ERR_UNSUPPORTED;
