@@ -201,24 +201,30 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restri
 }
 
 // Forward specialised for 3x3 (x KD) stride-1 / dilation-1 windows and KK output channels: all loops unrolled, the 27 * KK weights
-// of a channel are wave-uniform scalar loads, every input row is loaded once as XB + 2 values and feeds 3 taps x XB outputs.
+// of a channel are wave-uniform scalar loads.  A thread owns SKR consecutive output rows x XB columns: per (channel, depth tap) it
+// loads the SKR + 2 input rows once (XB + 2 values each) and every row feeds the three row taps of up to three outputs -- 1.5 row
+// loads per output row instead of 3 (the kernel is bound by cache bandwidth: 32 channels x 27 taps re-read the same lines).
+constexpr int SKR = 4;
 template <int KK, int KD, bool VEC>
 __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, SkP p) {
   const long long oplane = (long long)p.OH * p.OW, ovol = oplane * p.OD;
   const long long iplane = (long long)p.IH * p.IW, ivol = iplane * p.ID;
   const int wq = (p.OW + XB - 1) / XB;
-  const long long total = (long long)p.N * p.OD * p.OH * wq;
+  const int hq = (p.OH + SKR - 1) / SKR;
+  const long long total = (long long)p.N * p.OD * hq * wq;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int ow0 = (int)(i % wq) * XB;
-    const int oh = (int)((i / wq) % p.OH);
-    const int od = (int)((i / ((long long)wq * p.OH)) % p.OD);
-    const int n = (int)(i / ((long long)wq * p.OH * p.OD));
-    float acc[KK][XB];
+    const int oh0 = (int)((i / wq) % hq) * SKR;
+    const int od = (int)((i / ((long long)wq * hq)) % p.OD);
+    const int n = (int)(i / ((long long)wq * hq * p.OD));
+    float acc[KK][SKR][XB];
 #pragma unroll
     for (int k = 0; k < KK; ++k)
 #pragma unroll
-      for (int j = 0; j < XB; ++j) acc[k][j] = bias ? bias[k] : 0.f;
+      for (int r = 0; r < SKR; ++r)
+#pragma unroll
+        for (int j = 0; j < XB; ++j) acc[k][r][j] = bias ? bias[k] : 0.f;
     const float* xn = x + (long long)n * p.C * ivol;
     const int iw0 = ow0 - p.pw;
     bool cok[XB + 2];
@@ -232,8 +238,8 @@ __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restric
         const int id = od - p.pd + a * p.dd;
         const bool dok = id >= 0 && id < p.ID;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const int ih = oh - p.ph + b;
+        for (int rr = 0; rr < SKR + 2; ++rr) {                 // input row ih = oh0 - ph + rr feeds outputs oh0 + rr - b, b = 0..2
+          const int ih = oh0 - p.ph + rr;
           const bool rok = dok && ih >= 0 && ih < p.IH;
           const float* row = xc + (long long)id * iplane + (long long)ih * p.IW + iw0;
           float v[XB + 2];
@@ -248,21 +254,30 @@ __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restric
             for (int u = 0; u < XB + 2; ++u) v[u] = (rok && cok[u]) ? row[u] : 0.f;
           }
 #pragma unroll
-          for (int k = 0; k < KK; ++k) {
-            const float* wk = wc + (long long)k * p.C * (KD * 9) + (a * 3 + b) * 3;
-            const float w0 = wk[0], w1 = wk[1], w2 = wk[2];
+          for (int b = 0; b < 3; ++b) {
+            const int r = rr - b;                               // compile-time after unrolling
+            if (r < 0 || r >= SKR) continue;
 #pragma unroll
-            for (int j = 0; j < XB; ++j) acc[k][j] = fmaf(w0, v[j], fmaf(w1, v[j + 1], fmaf(w2, v[j + 2], acc[k][j])));
+            for (int k = 0; k < KK; ++k) {
+              const float* wk = wc + (long long)k * p.C * (KD * 9) + (a * 3 + b) * 3;
+              const float w0 = wk[0], w1 = wk[1], w2 = wk[2];
+#pragma unroll
+              for (int j = 0; j < XB; ++j) acc[k][r][j] = fmaf(w0, v[j], fmaf(w1, v[j + 1], fmaf(w2, v[j + 2], acc[k][r][j])));
+            }
           }
         }
       }
     }
-    const long long obase = ((long long)od * p.OH + oh) * p.OW + ow0;
 #pragma unroll
-    for (int k = 0; k < KK; ++k)
+    for (int r = 0; r < SKR; ++r) {
+      if (oh0 + r >= p.OH) break;
+      const long long obase = ((long long)od * p.OH + oh0 + r) * p.OW + ow0;
 #pragma unroll
-      for (int j = 0; j < XB; ++j)
-        if (ow0 + j < p.OW) out[((long long)n * p.K + k) * ovol + obase + j] = acc[k][j];
+      for (int k = 0; k < KK; ++k)
+#pragma unroll
+        for (int j = 0; j < XB; ++j)
+          if (ow0 + j < p.OW) out[((long long)n * p.K + k) * ovol + obase + j] = acc[k][r][j];
+    }
   }
 }
 
@@ -386,7 +401,7 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
   if (sw != 1 || dw != 1 || kw > 3) return DPF_ERR_UNSUPPORTED;
   const long long total = (long long)N * p.OD * p.OH * ((p.OW + XB - 1) / XB);
   if (kh == 3 && kw == 3 && (kd == 1 || kd == 3) && sd == 1 && sh == 1 && dh == 1 && !getenv("DPF_SMALLK_FWD_GENERIC")) {
-    const dim3 grid(dpf_ew_grid(total));
+    const dim3 grid(dpf_ew_grid((long long)N * p.OD * ((p.OH + SKR - 1) / SKR) * ((p.OW + XB - 1) / XB)));
     hipStream_t st = (hipStream_t)stream;
     const bool vec = pw == 1 && (IW & 3) == 0 && (p.OW & 3) == 0 && XB == 4;
 #define DPF_SKF(KKv, KDv)                                                                                         \
