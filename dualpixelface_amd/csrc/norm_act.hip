@@ -178,9 +178,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ invstd, const float* __restrict__ w,
                                                        const float* __restrict__ bsh, int wmod, const float* __restrict__ res,
                                                        const float* __restrict__ res2, int act, const float* __restrict__ slope_p,
-                                                       float slope_c, float* __restrict__ y, int C, long long S) {
+                                                       float slope_c, float* __restrict__ y, int C, long long S, int yC = 0, int yc0 = 0) {
   const int row = blockIdx.y;
   const int c = row % C;
+  // y may be a channel slice [yc0, yc0 + C) of a tensor with yC channels (the consumer's concatenation buffer)
+  if (yC > 0) y += (((long long)(row / C) * yC + yc0 + c) - row) * S;
   float scale = 1.f, shift = 0.f;
   if (mean) {
     const float g = w ? w[c % wmod] : 1.f;
@@ -218,10 +220,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ w, const float* __restrict__ bsh, int wmod,
                                                             const float* __restrict__ res, int act, const float* __restrict__ slope_p,
-                                                            float slope_c, float* __restrict__ sums, int C, long long S, int chunk) {
+                                                            float slope_c, float* __restrict__ sums, int C, long long S, int chunk, int gC = 0,
+                                                            int gc0 = 0) {
   __shared__ float sm[4];
   const int row = blockIdx.y;
   const int c = row % C;
+  if (gC > 0) dy += (((long long)(row / C) * gC + gc0 + c) - row) * S;      // dy is a channel slice of a [N, gC, S] tensor
   float mu = 0.f, is = 1.f, g = 1.f, be = 0.f;
   if (mean) {
     mu = mean[c];
@@ -271,8 +275,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ res, int act, const float* __restrict__ slope_p,
                                                            float slope_c, const float* __restrict__ sums, float inv_count,
                                                            int training, float* __restrict__ dx, float* __restrict__ dres, int C,
-                                                           long long S, const float* __restrict__ count_dev) {
+                                                           long long S, const float* __restrict__ count_dev, int gC = 0, int gc0 = 0) {
   const int row = blockIdx.y;
+  if (gC > 0) dy += (((long long)(row / (C)) * gC + gc0 + (row % C)) - row) * S;
   if (count_dev) inv_count = 1.f / count_dev[0];     // SyncBatchNorm: the global element count, summed over the ranks on the device
   const int c = row % C;
   float mu = 0.f, is = 1.f, g = 1.f, be = 0.f, m_dz = 0.f, m_dzx = 0.f;
@@ -452,15 +457,28 @@ int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd,
   return dpf_check_launch();
 }
 
+// dpf_norm_act_forward writing into the channel slice [y_c0, y_c0 + C) of y [N, y_channels, S]: the normalised branches of a
+// torch.cat(dim=1) go straight into the concatenated tensor (DPBlock.conv_dilate, src/model/stereodpnet/modules.py:43-45)
+int dpf_norm_act_forward_slice(const float* x, const float* mean, const float* invstd, const float* w, const float* b, int wmod,
+                               const float* res, const float* res2, int act, const float* slope, float slope_const, float* y, int y_channels,
+                               int y_c0, int N, int C, long long S, void* stream) {
+  dpf_clear_error();
+  if (!x || !y || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535 || y_c0 < 0 || y_c0 + C > y_channels) return DPF_ERR_INVALID_ARG;
+  if (wmod <= 0) wmod = C;
+  hipLaunchKernelGGL(bn_apply_kernel, row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, w, b, wmod, res, res2, act,
+                     slope, slope_const, y, C, S, y_channels, y_c0);
+  return dpf_check_launch();
+}
+
 // Backward of dpf_norm_act_forward w.r.t. x, res, w, b, slope (res2's gradient is dy itself).
 // ws: >= 3*C floats.  dweight/dbias [wmod], dslope [1] are WRITTEN (=); any may be NULL.
 // phase 0: everything.  phase 1: only the per-channel reductions (ws[3c] = sum dz, ws[3c+1] = sum dz*xhat) and the parameter
 // gradients; phase 2: only dx / dres from a ws the caller has summed over the ranks, with count = global N*S (SyncBatchNorm), or
 // count < 0: the global count is read from ws[3*C] (the caller put its local count there before the all-reduce: no host sync).
-int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
-                             int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
-                             float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, int phase,
-                             double count, void* stream) {
+static int norm_act_backward_impl(const float* x, const float* dy, int gC, int gc0, const float* mean, const float* invstd, const float* w,
+                                  const float* b, int wmod, const float* res, int act, const float* slope, float slope_const, int training,
+                                  float* dx, float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S,
+                                  int phase, double count, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !dy || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535 || phase < 0 || phase > 2) return DPF_ERR_INVALID_ARG;
   if (wmod <= 0) wmod = C;
@@ -470,7 +488,7 @@ int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean,
     if (hipMemsetAsync(ws, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
     const int chunk = reduce_chunk(N * C, S);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act,
-                       slope, slope_const, ws, C, S, chunk);
+                       slope, slope_const, ws, C, S, chunk, gC, gc0);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpf_div_up(wmod, 64)), dim3(64), 0, st, ws, C, wmod, mean ? dweight : nullptr,
                        mean ? dbias : nullptr, act == DPF_ACT_PRELU ? dslope : nullptr);
   }
@@ -480,9 +498,28 @@ int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean,
     const float* count_dev = (phase == 2 && count < 0) ? ws + 3 * (long long)C : nullptr;
     if (count <= 0) count = (double)N * (double)S;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope,
-                       slope_const, ws, (float)(1.0 / count), training, dx, dres, C, S, count_dev);
+                       slope_const, ws, (float)(1.0 / count), training, dx, dres, C, S, count_dev, gC, gc0);
   }
   return dpf_check_launch();
+}
+
+int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
+                             int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
+                             float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, int phase,
+                             double count, void* stream) {
+  return norm_act_backward_impl(x, dy, 0, 0, mean, invstd, w, b, wmod, res, act, slope, slope_const, training, dx, dres, dweight, dbias,
+                                dslope, ws, N, C, S, phase, count, stream);
+}
+
+// dpf_norm_act_backward with dy given as the channel slice [dy_c0, dy_c0 + C) of a [N, dy_channels, S] tensor (the gradient of
+// the concatenation the forward wrote into)
+int dpf_norm_act_backward_slice(const float* x, const float* dy, int dy_channels, int dy_c0, const float* mean, const float* invstd,
+                                const float* w, const float* b, int wmod, const float* res, int act, const float* slope, float slope_const,
+                                int training, float* dx, float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C,
+                                long long S, void* stream) {
+  if (dy_c0 < 0 || dy_c0 + C > dy_channels) return DPF_ERR_INVALID_ARG;
+  return norm_act_backward_impl(x, dy, dy_channels, dy_c0, mean, invstd, w, b, wmod, res, act, slope, slope_const, training, dx, dres,
+                                dweight, dbias, dslope, ws, N, C, S, 0, 0.0, stream);
 }
 
 int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,

@@ -426,6 +426,79 @@ def norm_act(x, weight=None, bias=None, slope=None, res=None, res2=None, running
     return NormActFn.apply(x, weight, bias, slope, res, res2, running_mean, running_var, mode, act, slope_const, exchange, stats)
 
 
+class NormActCatFn(torch.autograd.Function):
+    """torch.cat([act(batch_norm(x_i)) for i], dim=1) without the copies: every branch's normalisation kernel writes its channel
+    slice of the concatenated tensor, the backward reads its slice of the incoming gradient (dpf_norm_act_*_slice)."""
+
+    @staticmethod
+    def forward(ctx, mode, act, holders, *tensors):
+        n = len(tensors) // 5
+        xs = [_c(tensors[5 * i]) for i in range(n)]
+        ws = [tensors[5 * i + 1] for i in range(n)]
+        bs = [tensors[5 * i + 2] for i in range(n)]
+        rms = [tensors[5 * i + 3] for i in range(n)]
+        rvs = [tensors[5 * i + 4] for i in range(n)]
+        _need(*xs)
+        N = xs[0].shape[0]
+        Cs = [x.shape[1] for x in xs]
+        S = xs[0].numel() // (N * Cs[0])
+        Ctot = sum(Cs)
+        cat = torch.empty((N, Ctot) + tuple(xs[0].shape[2:]), dtype=torch.float32, device=xs[0].device)
+        L = lib()
+        saved, c0 = [], 0
+        for i in range(n):
+            x, C = xs[i], Cs[i]
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            st = holders[i] if holders else None
+            if mode == 1 and st and st.get('ptr') == x.data_ptr() and st['channels'] == C and st['count'] == N * S:
+                L.call('dpf_bn_finalize_partials', _ptr(st['slab']), st['parts'], C, N * S, BN_EPS, BN_MOMENTUM, _ptr(rms[i]), _ptr(rvs[i]),
+                       _ptr(mean), _ptr(invstd), _stream())
+                st.clear()
+            elif mode == 1:
+                wsb = scratch(2 * C, x.device)
+                L.call('dpf_bn_stats', _ptr(x), N, C, S, BN_EPS, BN_MOMENTUM, _ptr(rms[i]), _ptr(rvs[i]), _ptr(mean), _ptr(invstd), _ptr(wsb),
+                       _stream())
+            else:
+                L.call('dpf_bn_eval_stats', _ptr(rms[i]), _ptr(rvs[i]), C, BN_EPS, _ptr(mean), _ptr(invstd), _stream())
+            L.call('dpf_norm_act_forward_slice', _ptr(x), _ptr(mean), _ptr(invstd), _ptr(ws[i]), _ptr(bs[i]), C, None, None, act, None, 0.0,
+                   _ptr(cat), Ctot, c0, N, C, S, _stream())
+            saved += [x, ws[i], bs[i], mean, invstd]
+            c0 += C
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (mode, act, n, N, tuple(Cs), S, Ctot)
+        return cat
+
+    @staticmethod
+    def backward(ctx, gcat):
+        mode, act, n, N, Cs, S, Ctot = ctx.cfg
+        gcat = _c(gcat)
+        sv = ctx.saved_tensors
+        L = lib()
+        grads, c0 = [], 0
+        for i in range(n):
+            x, w, b, mean, invstd = sv[5 * i:5 * i + 5]
+            C = Cs[i]
+            dx = torch.empty_like(x) if ctx.needs_input_grad[3 + 5 * i] else None
+            dw = torch.empty_like(w) if ctx.needs_input_grad[3 + 5 * i + 1] else None
+            db = torch.empty_like(b) if ctx.needs_input_grad[3 + 5 * i + 2] else None
+            wsb = scratch(3 * C, x.device)
+            L.call('dpf_norm_act_backward_slice', _ptr(x), _ptr(gcat), Ctot, c0, _ptr(mean), _ptr(invstd), _ptr(w), _ptr(b), C, None, act,
+                   None, 0.0, 1 if mode == 1 else 0, _ptr(dx), None, _ptr(dw), _ptr(db), None, _ptr(wsb), N, C, S, _stream())
+            grads += [dx, dw, db, None, None]
+            c0 += C
+        return (None, None, None) + tuple(grads)
+
+
+def norm_act_concat(branches, mode, act=ACT_NONE):
+    """branches: list of (x, weight, bias, running_mean, running_var, stats holder or None) with equal batch / spatial shape;
+    mode 1 = training batch norm (per-rank statistics), 2 = eval.  -> [N, sum C_i, ...]."""
+    flat = []
+    for x, w, b, rm, rv, _ in branches:
+        flat += [x, w, b, rm, rv]
+    return NormActCatFn.apply(mode, act, [br[5] for br in branches], *flat)
+
+
 # ----------------------------------------------------------------------------------------------- resampling
 class BilinearFn(torch.autograd.Function):
     @staticmethod

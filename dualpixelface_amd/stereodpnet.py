@@ -334,6 +334,22 @@ class StereoDPNetCore(_Base):
         y = ops.conv2d(x, self._P[p + '.0.weight'], None, stride, dil if dil > 1 else pad, dil, bf16=self.bf16_2d, stats=st)  # basics.py:17-22
         return self._bn(y, p + '.1', act, slope, res, stats=st)
 
+    def _convbn2_concat(self, x, prefixes, dilations):
+        """torch.cat([convbn(x; dilation d) for d], 1) (DPBlock.conv_dilate, modules.py:43-45): every branch's BatchNorm writes its
+        channel slice of the concatenated tensor directly."""
+        if self.training and self.stat_exchange is not None:      # SyncBatchNorm exchanges {mean, M2}: the plain path
+            return ops.concat_channels([self._convbn2(x, q, 1, d, d) for q, d in zip(prefixes, dilations)])
+        P, B = self._P, self._B
+        branches = []
+        for q, d in zip(prefixes, dilations):
+            st = self._stats_holder()
+            y = ops.conv2d(x, P[q + '.0.weight'], None, 1, d if d > 1 else 1, d, bf16=self.bf16_2d, stats=st)
+            if self.training:
+                key = q + '.1.num_batches_tracked'
+                self._pending_counts[key] = self._pending_counts.get(key, 0) + 1
+            branches.append((y, P[q + '.1.weight'], P[q + '.1.bias'], B[q + '.1.running_mean'], B[q + '.1.running_var'], st))
+        return ops.norm_act_concat(branches, 1 if self.training else 2, ACT_NONE)
+
     def _convbn3(self, x, p, stride=1, act=ACT_NONE, res=None):
         st = self._stats_holder()
         y = ops.conv3d(x, self._P[p + '.0.weight'], None, stride, 1, 1, stats=st)                  # basics.py:32-36
@@ -344,7 +360,7 @@ class StereoDPNetCore(_Base):
         P = self._P
         o1 = self._convbn2(x, p + '.conv1.0', act=ACT_PRELU, slope=P[p + '.conv1.1.weight'])
         o2 = self._convbn2(o1, p + '.conv2.0', act=ACT_PRELU, slope=P[p + '.conv2.1.weight'])
-        o2 = ops.concat_channels([self._convbn2(o2, p + '.conv_dilate.%d' % i, 1, 2 * i + 1, 2 * i + 1) for i in range(3)])
+        o2 = self._convbn2_concat(o2, [p + '.conv_dilate.%d' % i for i in range(3)], [2 * i + 1 for i in range(3)])
         o = self._convbn2(o2, p + '.conv3', act=ACT_PRELU, slope=P[p + '.prelu.weight'], res=o1)       # prelu(conv3 + out1)
         o = self._convbn2(o, p + '.conv4.0', s, s, 2, act=ACT_PRELU, slope=P[p + '.conv4.1.weight'])
         d = ops.depthwise_conv3x3(o, P[p + '.conv5.depthwise.weight'])

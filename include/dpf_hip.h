@@ -102,6 +102,15 @@ int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd,
 int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
                           int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
                           float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, void* stream);
+/* the same pair with y / dy given as a channel slice of a wider tensor: the normalised branches of a torch.cat(dim=1) are written
+ * straight into the concatenated tensor and their gradients read from its gradient (DPBlock.conv_dilate, modules.py:43-45) */
+int dpf_norm_act_forward_slice(const float* x, const float* mean, const float* invstd, const float* w, const float* b, int wmod,
+                               const float* res, const float* res2, int act, const float* slope, float slope_const, float* y, int y_channels,
+                               int y_c0, int N, int C, long long S, void* stream);
+int dpf_norm_act_backward_slice(const float* x, const float* dy, int dy_channels, int dy_c0, const float* mean, const float* invstd,
+                                const float* w, const float* b, int wmod, const float* res, int act, const float* slope, float slope_const,
+                                int training, float* dx, float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C,
+                                long long S, void* stream);
 /* SyncBatchNorm (the reference enables torch SyncBatchNorm under DDP: config_manager.py:57, main.py:55).  Statistics: each rank
  * computes dpf_bn_local_moments -> moments[2*C] = {mean, M2}; the host all-gathers them (RCCL) and dpf_bn_merge_moments produces
  * the global mean / invstd and the running-statistics update.  Backward: dpf_norm_act_backward_ex phase 1 (local reductions

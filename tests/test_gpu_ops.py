@@ -777,3 +777,31 @@ def test_diff_volume():
     gg = torch.autograd.grad(vol, (rg, tg), go.to(DEV))
     close(gg[0], gr[0], 1e-6, 'diff volume dref')
     close(gg[1], gr[1], 1e-6, 'diff volume dtar')
+
+
+def test_norm_act_concat_matches_separate_norm_and_cat():
+    """BatchNorm branches written straight into their slice of the concatenation (dpf_norm_act_*_slice) against
+    torch.cat([batch_norm(x_i)]) with autograd, training and eval, running statistics included."""
+    ops = _ops()
+    N, H, W = 2, 12, 20
+    Cs = (8, 5, 16)
+    xs = [rnd(N, C, H, W, seed=100 + i).requires_grad_() for i, C in enumerate(Cs)]
+    ws = [(rnd(C, seed=110 + i).abs() + 0.5).requires_grad_() for i, C in enumerate(Cs)]
+    bs = [rnd(C, seed=120 + i).requires_grad_() for i, C in enumerate(Cs)]
+    for mode in (1, 2):
+        rms = [rnd(C, seed=130 + i) * 0.1 for i, C in enumerate(Cs)]
+        rvs = [rnd(C, seed=140 + i).abs() + 0.5 for i, C in enumerate(Cs)]
+        rms_r, rvs_r = [t.clone() for t in rms], [t.clone() for t in rvs]
+        ref = torch.cat([F.batch_norm(x, rm, rv, w, b, mode == 1, 0.1, 1e-5) for x, w, b, rm, rv in zip(xs, ws, bs, rms_r, rvs_r)], 1)
+        go = rnd(*ref.shape, seed=150)
+        gr = torch.autograd.grad(ref, xs + ws + bs, go)
+        dev = lambda t: t.detach().to(DEV).requires_grad_(t.requires_grad)
+        gx, gw, gb = [dev(t) for t in xs], [dev(t) for t in ws], [dev(t) for t in bs]
+        grm, grv = [t.to(DEV) for t in rms], [t.to(DEV) for t in rvs]
+        out = ops.norm_act_concat([(x, w, b, rm, rv, None) for x, w, b, rm, rv in zip(gx, gw, gb, grm, grv)], mode)
+        close(out, ref, 1e-5, 'concat fwd mode %d' % mode)
+        gg = torch.autograd.grad(out, gx + gw + gb, go.to(DEV))
+        for a, b_, nm in zip(gg, gr, ['dx'] * 3 + ['dw'] * 3 + ['db'] * 3):
+            close(a, b_, 1e-4, 'concat %s mode %d' % (nm, mode))
+        for a, b_ in zip(grm + grv, rms_r + rvs_r):
+            close(a, b_, 1e-5, 'running stats')
