@@ -16,6 +16,7 @@ constexpr int TY = 8, TX = 32;
 
 struct HeadP {
   int B, D, h, w, L, H, W;
+  long long pbs;        // batch stride of the probability output (0: L * H * W, dense)
   float off;            // 0: align_corners=True (ratio (in-1)/(out-1)); 0.5: align_corners=False (ratio in/out, half-pixel centres)
   float disp[MAXL];
 };
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     pixel_probs(k, p, b, Y, X, rd, ry, rx, pr, e, y0, y1, x0, x1, ly, lx);
     pred[i] = e;
     if (prob) {
-      float* q = prob + (long long)b * p.L * p.H * p.W + (long long)Y * p.W + X;
+      float* q = prob + (long long)b * (p.pbs ? p.pbs : (long long)p.L * p.H * p.W) + (long long)Y * p.W + X;
 #pragma unroll
       for (int l = 0; l < MAXL; ++l)
         if (l < p.L) q[(long long)l * p.H * p.W] = pr[l];
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void head_fwd_8x32_kernel(const float* __restr
     }
     pred[i] = e;
     if (prob) {
-      float* q = prob + (long long)b * L * plane + (long long)Y * p.W + X;
+      float* q = prob + (long long)b * (p.pbs ? p.pbs : L * plane) + (long long)Y * p.W + X;
 #pragma unroll
       for (int l = 0; l < L; ++l) q[(long long)l * plane] = pr[l];
     }
@@ -338,11 +339,11 @@ extern "C" {
 
 // logits [B,D,h,w] -> pred [B,H,W], prob [B,L,H,W] (NULL to skip).  disp: L host floats (hypothesis values).
 static int softargmin_fwd(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L, int H, int W,
-                          float off, hipStream_t st) {
+                          float off, hipStream_t st, long long prob_batch_stride = 0) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!logits || !pred || !disp_host || B <= 0 || D <= 0 || D > MAXD || L <= 0 || L > MAXL) return DPF_ERR_INVALID_ARG;
   HeadP p;
-  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W; p.off = off;
+  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W; p.off = off; p.pbs = prob_batch_stride;
   for (int i = 0; i < MAXL; ++i) p.disp[i] = i < L ? disp_host[i] : 0.f;
   if (D == 8 && L == 32 && off == 0.f)
     hipLaunchKernelGGL(head_fwd_8x32_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, st, logits, pred, prob, p);
@@ -357,7 +358,7 @@ static int softargmin_bwd(const float* logits, const float* gpred, float* dlogit
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!logits || !gpred || !dlogits || !disp_host || B <= 0 || D <= 0 || D > MAXD || L <= 0 || L > MAXL) return DPF_ERR_INVALID_ARG;
   HeadP p;
-  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W; p.off = off;
+  p.B = B; p.D = D; p.h = h; p.w = w; p.L = L; p.H = H; p.W = W; p.off = off; p.pbs = 0;
   for (int i = 0; i < MAXL; ++i) p.disp[i] = i < L ? disp_host[i] : 0.f;
   if (hipMemsetAsync(dlogits, 0, sizeof(float) * (size_t)B * D * h * w, st) != hipSuccess) return DPF_ERR_LAUNCH;
   const long long blocks = (long long)B * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
@@ -381,6 +382,14 @@ int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlog
 int dpf_softargmin_forward_ex(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
                               int H, int W, int align_corners, void* stream) {
   return softargmin_fwd(logits, pred, prob, disp_host, B, D, h, w, L, H, W, align_corners ? 0.f : 0.5f, (hipStream_t)stream);
+}
+// forward with the probability volume written at a batch stride (floats): head i of n writes slice [:, i] of a [B, n, L, H, W]
+// tensor directly -- the torch.stack of the per-head volumes (modules.py:352-362 + mainmodel.py:98-99) costs no copy
+int dpf_softargmin_forward_strided(const float* logits, float* pred, float* prob, long long prob_batch_stride, const float* disp_host, int B,
+                                   int D, int h, int w, int L, int H, int W, int align_corners, void* stream) {
+  if (prob && prob_batch_stride < (long long)L * H * W) return DPF_ERR_INVALID_ARG;
+  return softargmin_fwd(logits, pred, prob, disp_host, B, D, h, w, L, H, W, align_corners ? 0.f : 0.5f, (hipStream_t)stream,
+                        prob_batch_stride);
 }
 int dpf_softargmin_backward_ex(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
                                int L, int H, int W, int align_corners, void* stream) {

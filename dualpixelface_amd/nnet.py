@@ -141,13 +141,9 @@ class NNetCore(PSMNetCore):
             c = self._residual3(c, n)
         costs = ops.conv3d(self._convbn3(c, 'classify.0', 1, ACT_RELU), self._P['classify.2.weight'], None, 1, 1, 1)
         costss = self._refine(ref, costs)
-        preds, probs = [], []
-        for l in (costs, costss):
-            pr, pb = ops.softargmin(l, self.disp_values, 4, True, align_corners=False)      # mainmodel.py:150-153
-            preds.append(pr)
-            probs.append(pb)
+        _, pred_all, prob_all = ops.softargmin_heads([costs, costss], self.disp_values, 4, align_corners=False)     # mainmodel.py:150-153
         normal = self._normals(cost_in0, c, batch) if m.predict_normal else None
-        return {'pred_depth': ops.stack_dim1(preds), 'prob_depth': ops.stack_dim1(probs),
+        return {'pred_depth': pred_all, 'prob_depth': prob_all,
                 'pred_normal': normal.unsqueeze(1) if normal is not None else None,
                 'ref_feature': ops.channel_max(ref),
                 '_taps': {'fea_ref': ref, 'fea_tar': tar, 'volume': vol, 'cost0': c, 'costs': costs, 'costss': costss}}

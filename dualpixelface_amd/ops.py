@@ -810,19 +810,29 @@ def xyz_volume_into(vol, choff, sdisp, Kmat, abvalue):
 # ----------------------------------------------------------------------------------------------- disparity head
 class SoftArgminFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, disp_values, scale, want_prob, align_corners=True):
+    def forward(ctx, logits, disp_values, scale, want_prob, align_corners=True, prob_into=None):
         logits = _c(logits)
         _need(logits)
         B, _, D, h, w = logits.shape
         Lh, H, W = D * scale, h * scale, w * scale
         pred = torch.empty((B, H, W), dtype=torch.float32, device=logits.device)
-        prob = torch.empty((B, Lh, H, W), dtype=torch.float32, device=logits.device) if want_prob else None
         hd = _host_floats(disp_values)
-        lib().call('dpf_softargmin_forward_ex', _ptr(logits), _ptr(pred), _ptr(prob), hd, B, D, h, w, Lh, H, W, int(align_corners), _stream())
+        if prob_into is not None:
+            # (stacked [B, n, Lh, H, W], head index): this head's probabilities go straight into their slice of the stacked tensor
+            stacked, head = prob_into
+            assert stacked.is_contiguous() and tuple(stacked.shape[2:]) == (Lh, H, W) and stacked.shape[0] == B
+            slice_ptr = ctypes.c_void_p(stacked.data_ptr() + 4 * head * Lh * H * W)
+            lib().call('dpf_softargmin_forward_strided', _ptr(logits), _ptr(pred), slice_ptr, stacked.shape[1] * Lh * H * W, hd, B, D, h, w, Lh,
+                       H, W, int(align_corners), _stream())
+            prob = pred.new_empty(0)
+        else:
+            prob = torch.empty((B, Lh, H, W), dtype=torch.float32, device=logits.device) if want_prob else None
+            lib().call('dpf_softargmin_forward_ex', _ptr(logits), _ptr(pred), _ptr(prob), hd, B, D, h, w, Lh, H, W, int(align_corners),
+                       _stream())
+            if prob is None:
+                prob = pred.new_empty(0)
         ctx.save_for_backward(logits)
         ctx.cfg = (tuple(disp_values), B, D, h, w, Lh, H, W, int(align_corners))
-        if prob is None:
-            prob = pred.new_empty(0)
         ctx.mark_non_differentiable(prob)
         return pred, prob
 
@@ -834,12 +844,23 @@ class SoftArgminFn(torch.autograd.Function):
         dl = torch.empty_like(logits)
         lib().call('dpf_softargmin_backward_ex', _ptr(logits), _ptr(gpred), _ptr(dl), _host_floats(disp_values), B, D, h, w, Lh, H, W, ac,
                    _stream())
-        return dl, None, None, None, None
+        return dl, None, None, None, None, None
 
 
-def softargmin(logits, disp_values, scale=4, want_prob=True, align_corners=True):
-    """x`scale` trilinear upsampling of the [B, 1, D, h, w] logits + softmax over the scale * D hypotheses + expectation."""
-    return SoftArgminFn.apply(logits, disp_values, scale, want_prob, align_corners)
+def softargmin(logits, disp_values, scale=4, want_prob=True, align_corners=True, prob_into=None):
+    """x`scale` trilinear upsampling of the [B, 1, D, h, w] logits + softmax over the scale * D hypotheses + expectation.
+    prob_into = (stacked [B, n, scale * D, H, W], head): write the probabilities into that slice instead of a new tensor."""
+    return SoftArgminFn.apply(logits, disp_values, scale, want_prob, align_corners, prob_into)
+
+
+def softargmin_heads(logit_list, disp_values, scale=4, align_corners=True):
+    """All heads of a model: -> (list of pred [B, H, W], pred [B, n, H, W], prob [B, n, scale * D, H, W]); the probability volumes (no
+    gradient consumer) are written by each head directly into the stacked tensor."""
+    B, _, D, h, w = logit_list[0].shape
+    n = len(logit_list)
+    prob = torch.empty((B, n, D * scale, h * scale, w * scale), dtype=torch.float32, device=logit_list[0].device)
+    preds = [softargmin(l, disp_values, scale, True, align_corners, prob_into=(prob, i))[0] for i, l in enumerate(logit_list)]
+    return preds, stack_dim1(preds), prob
 
 
 # ----------------------------------------------------------------------------------------------- deformable conv

@@ -108,10 +108,6 @@ class PSMNetCore(StereoDPNetCore):
             raise NotImplementedError('cost volume style is not defined : %s' % m.cost_volume)
         vol = ops.psm_volume(ref, tar, [int(d) for d in self.costrange], groups)          # int() truncation, SURVEY Q14
         logits, costs = self._aggregate(vol)
-        preds, probs = [], []
-        for l in logits:
-            pr, pb = ops.softargmin(l, self.disp_values, 4, True)
-            preds.append(pr)
-            probs.append(pb)
-        return {'pred_depth': ops.stack_dim1(preds), 'prob_depth': ops.stack_dim1(probs), 'ref_feature': ops.channel_max(ref),
+        _, pred_all, prob_all = ops.softargmin_heads(logits, self.disp_values, 4, True)
+        return {'pred_depth': pred_all, 'prob_depth': prob_all, 'ref_feature': ops.channel_max(ref),
                 '_taps': {'fea_ref': ref, 'fea_tar': tar, 'volume': vol, 'out3': costs[0]}}

@@ -548,14 +548,10 @@ class StereoDPNetCore(_Base):
         tar = self._features(batch[b])
         vol = self._cost_volume(ref, tar)
         logits, costs = self._aggregate(vol)
-        preds, probs = [], []
-        for l in logits:
-            pr, pb = ops.softargmin(l, self.disp_values, 4, True)
-            preds.append(pr)
-            probs.append(pb)
+        preds, pred_all, prob_all = ops.softargmin_heads(logits, self.disp_values, 4, True)
         normal = None
         if opt.model.predict_normal:
             normal, _, _ = self._normals(costs[0], preds[0], batch)
-        return {'pred_depth': ops.stack_dim1(preds), 'prob_depth': ops.stack_dim1(probs),
+        return {'pred_depth': pred_all, 'prob_depth': prob_all,
                 'pred_normal': normal.unsqueeze(1) if normal is not None else None,
                 'ref_feature': ops.channel_max(ref), '_taps': {'fea_ref': ref, 'fea_tar': tar, 'volume': vol, 'out3': costs[0]}}

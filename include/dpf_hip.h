@@ -181,6 +181,9 @@ int dpf_softargmin_backward(const float* logits, const float* gpred, float* dlog
 /* the same head with the x4 trilinear upsampling in either convention (align_corners = 0: src/model/nnet/mainmodel.py:150-153) */
 int dpf_softargmin_forward_ex(const float* logits, float* pred, float* prob, const float* disp_host, int B, int D, int h, int w, int L,
                               int H, int W, int align_corners, void* stream);
+/* forward with the probability volume written at a batch stride: head i of n fills slice [:, i] of a [B, n, L, H, W] tensor */
+int dpf_softargmin_forward_strided(const float* logits, float* pred, float* prob, long long prob_batch_stride, const float* disp_host, int B,
+                                   int D, int h, int w, int L, int H, int W, int align_corners, void* stream);
 int dpf_softargmin_backward_ex(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
                                int L, int H, int W, int align_corners, void* stream);
 
