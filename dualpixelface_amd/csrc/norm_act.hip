@@ -480,12 +480,13 @@ static int norm_act_backward_impl(const float* x, const float* dy, int gC, int g
                                   float* dx, float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S,
                                   int phase, double count, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
-  if (!x || !dy || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535 || phase < 0 || phase > 2) return DPF_ERR_INVALID_ARG;
+  if (!x || !dy || !ws || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535 || phase < 0 || phase > 3) return DPF_ERR_INVALID_ARG;
   if (wmod <= 0) wmod = C;
   hipStream_t st = (hipStream_t)stream;
   const bool need_reduce = (mean != nullptr) || (act == DPF_ACT_PRELU && dslope);
   if (need_reduce && phase != 2) {
-    if (hipMemsetAsync(ws, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
+    // phase 3: as phase 0 with a ws the caller guarantees to be zero (a slot of a pre-zeroed arena: one memset per arena, not per layer)
+    if (phase != 3 && hipMemsetAsync(ws, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
     const int chunk = reduce_chunk(N * C, S);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act,
                        slope, slope_const, ws, C, S, chunk, gC, gc0);

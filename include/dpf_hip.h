@@ -114,7 +114,8 @@ int dpf_norm_act_backward_slice(const float* x, const float* dy, int dy_channels
 /* SyncBatchNorm (the reference enables torch SyncBatchNorm under DDP: config_manager.py:57, main.py:55).  Statistics: each rank
  * computes dpf_bn_local_moments -> moments[2*C] = {mean, M2}; the host all-gathers them (RCCL) and dpf_bn_merge_moments produces
  * the global mean / invstd and the running-statistics update.  Backward: dpf_norm_act_backward_ex phase 1 (local reductions
- * into ws + parameter gradients), host all-reduce(sum) of ws[3*C], phase 2 (dx / dres) with count = global N*S. */
+ * into ws + parameter gradients), host all-reduce(sum) of ws[3*C], phase 2 (dx / dres) with count = global N*S.
+ * phase 0 = everything; phase 3 = everything with a ws the caller guarantees to be zero (no memset: slots of a pre-zeroed arena). */
 int dpf_bn_local_moments(const float* x, int N, int C, long long S, float* moments, float* ws, void* stream);
 int dpf_bn_merge_moments(const float* moments, const float* counts, int W, int C, float eps, float momentum, float* running_mean,
                          float* running_var, float* mean, float* invstd, void* stream);
