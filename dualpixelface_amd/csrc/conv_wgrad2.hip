@@ -22,6 +22,7 @@
 //   * no float atomics: every workgroup stores its partial dW to a slab, a second kernel adds the slabs in a fixed order ->
 //     bitwise reproducible gradients.
 #include "conv_internal.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -430,10 +431,19 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   long long nchunk = capacity / p.groups;
   if (nchunk < 1) nchunk = 1;
   if (nchunk > p.ntiles) nchunk = p.ntiles;
+  // position chunks in multiples of 16 (8 XCD labels x 2): the workgroups of a chunk share their x / g tiles through one XCD's L2, and
+  // an uneven deal of chunks to XCDs costs 15-25 % (K = 81 layers: 42 chunks 73 TFLOP/s, 32 chunks 89; 68 chunks 73, 64 chunks 86)
+  if (!cap_over || getenv("DPF_W2_ROUND")) {
+    if (nchunk >= 16 && (nchunk & 7)) nchunk &= ~15LL;          // already a multiple of 8: keep (56 chunks beat 48 on the 96-channel layer)
+    else if (nchunk > 8 && nchunk < 16) nchunk = 8;
+  }
   p.per = (p.ntiles + nchunk - 1) / nchunk;
   nchunk = (p.ntiles + p.per - 1) / p.per;
   p.nchunk = (int)nchunk;
   p.slab_stride = (long long)d.K * d.C * T;
+  if (getenv("DPF_W2_DEBUG"))
+    fprintf(stderr, "wgrad2 C%d K%d T%d s%d: NCT %d CCW %d lds %zu occ %d groups %d capacity %d nchunk %lld per %lld ntiles %lld\n", d.C, d.K, T, d.sh, NCT, CCW,
+            lds0, occ, p.groups, capacity, nchunk, (long long)p.per, (long long)p.ntiles);
   if (nchunk * p.slab_stride > ws_floats) return DPF_ERR_UNSUPPORTED;
 
   const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
