@@ -365,7 +365,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   static const int min_t = env_int("DPF_W2_MINT", 9);
   if (T > 27 || T < min_t || d.K > 128) return DPF_ERR_UNSUPPORTED;
   if ((d.IW & 3) || (d.QW & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(g) & 15)) return DPF_ERR_UNSUPPORTED;
-  static const int maxdil = env_int("DPF_W2_MAXDIL", 5);
+  static const int maxdil = env_int("DPF_W2_MAXDIL", 8);
   if (d.dh > maxdil || d.dw > maxdil || d.dd > maxdil) return DPF_ERR_UNSUPPORTED;   // widely dilated: polyphase kernel (conv_igemm.hip)
   if (d.sw > 2 || d.sh > 2) return DPF_ERR_UNSUPPORTED;
   const long long x_chan = (long long)d.ID * d.IH * d.IW;
