@@ -491,7 +491,7 @@ int launch_igemm(const float* x, const float* wt, const float* bias, float* out,
 int conv_launch(const float* x, const float* wt_ws, const float* bias, float* out, ConvP p, hipStream_t st);
 
 int conv_common(const float* x, const float* w, const float* bias, float* out, float* wt_ws, ConvP p, int repack_mode,
-                int wA, int wB, hipStream_t st, int Ktot = 0) {
+                int wA, int wB, hipStream_t st, int Ktot = 0, int accumulate = 0) {
   const int T = p.kd * p.kh * p.kw;
   if (T > MAXT || T < 1) return DPF_ERR_UNSUPPORTED;
   // one launch covers up to 128 output channels (4 MFMA row tiles); wider outputs are split
@@ -501,8 +501,8 @@ int conv_common(const float* x, const float* w, const float* bias, float* out, f
     const int Kc = Kfull - k0 < 128 ? Kfull - k0 : 128;
     {   // LDS-DMA double-buffered kernel where the shape is eligible (conv_igemm2.hip)
       DpfConvDesc d{p.N, p.C, Kc, p.Ktot, k0, p.ID, p.IH, p.IW, p.OD, p.OH, p.OW, p.kd, p.kh, p.kw, p.sd, p.sh, p.sw,
-                    p.pd, p.ph, p.pw, p.dd, p.dh, p.dw, p.transposed, wA, wB, repack_mode};
-      if (T == 1) {                                  // pointwise: HBM-bound direct kernel (conv_pointwise.hip)
+                    p.pd, p.ph, p.pw, p.dd, p.dh, p.dw, p.transposed, wA, wB, repack_mode, accumulate};
+      if (T == 1 && !accumulate) {                   // pointwise: HBM-bound direct kernel (conv_pointwise.hip)
         const int rcp = dpf_pointwise_conv(x, w, bias, out, d, st);
         if (rcp == DPF_OK) continue;
         if (rcp != DPF_ERR_UNSUPPORTED) return rcp;
@@ -511,6 +511,7 @@ int conv_common(const float* x, const float* w, const float* bias, float* out, f
       if (rc2 == DPF_OK) continue;
       if (rc2 != DPF_ERR_UNSUPPORTED) return rc2;
     }
+    if (accumulate) return DPF_ERR_UNSUPPORTED;      // the first-generation kernel only stores
     const int KT = 32 * ((Kc + 31) / 32);
     const long long total = (long long)T * p.C * KT;
     hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wt_ws, wA, wB, T, KT, repack_mode, k0, Kc);
@@ -660,6 +661,22 @@ int dpf_conv_transpose_ex(const float* x, const float* w, const float* bias, flo
   p.kd = kd; p.kh = kh; p.kw = kw; p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw;
   p.transposed = 1;
   return conv_common(x, w, bias, out, ws, p, /*mode*/ 1, C, Ktot, (hipStream_t)stream, Ktot);
+}
+
+// dpf_conv_transpose_ex with out += result when accumulate != 0: the data gradients of several convolutions that read the same tensor
+// (the three dilated branches of a DPBlock, modules.py:43-45) are summed in the kernel epilogue instead of by separate add passes.
+// DPF_ERR_UNSUPPORTED (nothing written) when the shape would not run on the LDS-DMA kernel: compute into a temporary and add.
+int dpf_conv_transpose_acc(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                           int K, int Ktot, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                           int dd, int dh, int dw, int accumulate, void* stream) {
+  dpf_clear_error();
+  if (!x || !w || !out || !ws || N <= 0 || C <= 0 || K <= 0 || Ktot < K) return DPF_ERR_INVALID_ARG;
+  if (accumulate && K > 128) return DPF_ERR_UNSUPPORTED;      // split launches: a failure midway would leave a partial sum
+  ConvP p{};
+  p.N = N; p.C = C; p.K = K; p.ID = ID; p.IH = IH; p.IW = IW; p.OD = OD; p.OH = OH; p.OW = OW;
+  p.kd = kd; p.kh = kh; p.kw = kw; p.sd = sd; p.sh = sh; p.sw = sw; p.pd = pd; p.ph = ph; p.pw = pw; p.dd = dd; p.dh = dh; p.dw = dw;
+  p.transposed = 1;
+  return conv_common(x, w, bias, out, ws, p, /*mode*/ 1, C, Ktot, (hipStream_t)stream, Ktot, accumulate ? 1 : 0);
 }
 
 // Forward conv with the weight stored transposed-conv style w[K_reduce=C? ...]:

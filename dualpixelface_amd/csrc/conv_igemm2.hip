@@ -41,6 +41,7 @@ struct G2P {
   int nchunks;
   unsigned mSR, mRPC, mEH;      // ceil(2^20 / d) for d = SR, rpc, ext_h
   unsigned long long steps;     // 2-bit step code per tap (see the kernel's tap walk)
+  int accum;                    // 1: out += result
   double* stats;                // optional [ntiles][K][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
@@ -224,7 +225,10 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
           const float bv = bias ? bias[p.k0 + k] : 0.f;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            if (oh0 + t < p.OH) op[(long long)k * kstride + t * p.OW] = acc[m][t][j] + bv;
+            if (oh0 + t < p.OH) {
+              float* o = op + (long long)k * kstride + t * p.OW;
+              *o = acc[m][t][j] + bv + (p.accum ? *o : 0.f);
+            }
         }
       }
     }
@@ -618,6 +622,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   if (9 * x_chan >= (1LL << 30)) return DPF_ERR_UNSUPPORTED;      // per-lane 32-bit source offsets within a chunk
   if (T == 1 && !env_int("DPF_IGEMM2_1x1", 1)) return DPF_ERR_UNSUPPORTED;   // pointwise convs (HBM-bound): 1.8x the generic kernel
   if (stats && (d.transposed || d.Ktot != d.K)) return DPF_ERR_UNSUPPORTED;
+  if (d.accumulate && d.transposed && (d.sd != 1 || d.sh != 1 || d.sw != 1)) return DPF_ERR_UNSUPPORTED;   // class-fused kernel: plain stores
   if (d.transposed && (d.sd != 1 || d.sh != 1 || d.sw != 1)) return igemm2_tr2(x, w, bias, out, ws, d, st);
 
   const int MT = (d.K + 31) / 32, KT = 32 * MT;
@@ -630,6 +635,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   p.N = d.N; p.C = d.C; p.K = d.K; p.Ktot = d.Ktot; p.k0 = d.k0;
   p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.OD = d.OD; p.OH = d.OH; p.OW = d.OW;
   p.T = T;
+  p.accum = d.accumulate;
   int ext_w;
   if (!d.transposed) {
     p.sxd = d.sd; p.sxh = d.sh; p.sxw = d.sw;

@@ -11,6 +11,7 @@ struct DpfConvDesc {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
   int transposed;
   int wA, wB, mode;
+  int accumulate;               // 1: out += result (data gradients of several consumers of one tensor summed in the epilogue)
 };
 
 // LDS-DMA double-buffered implicit GEMM (conv_igemm2.hip).  Returns DPF_OK when it launched, DPF_ERR_UNSUPPORTED when the

@@ -509,6 +509,114 @@ class NormActCatFn(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+def _conv_transpose_acc(x, w, out, ksize, stride, pad, dil):
+    """out += conv_transpose(x, w) (the data gradient of another consumer of the same tensor), in the kernel epilogue when the shape
+    runs on the LDS-DMA kernel, else through a temporary."""
+    N, C, ID, IH, IW = x.shape
+    K = w.shape[1]
+    kd, kh, kw = ksize
+    L = lib()
+    ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
+    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW,
+                'tr  N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
+                4.0 * (x.numel() + 2 * out.numel() + w.numel())):
+        rc = L.cdll.dpf_conv_transpose_acc(_ptr(x), _ptr(w), None, _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, K, *out.shape[2:], kd, kh, kw,
+                                           *stride, *pad, *dil, 1, _stream())
+    if rc == -3:
+        out.add_(_conv_transpose_raw(x, w, None, out.shape[2:], ksize, stride, pad, dil))
+    elif rc != 0:
+        raise DpfError('dpf_conv_transpose_acc failed: %s' % rc)
+    return out
+
+
+class ConvBnCatFn(torch.autograd.Function):
+    """torch.cat([batch_norm(conv2d(x, w_i, dilation d_i)) for i], 1) as one node (DPBlock.conv_dilate, modules.py:43-45): the
+    BatchNorms write their slices of the concatenation (no cat copies), and in the backward the branches' data gradients are summed
+    into one tensor by the transposed-conv epilogue (no autograd add passes)."""
+
+    @staticmethod
+    def forward(ctx, mode, dils, x, *params):
+        n = len(dils)
+        x = _c(x)
+        _need(x)
+        x5 = x.unsqueeze(2)
+        N = x.shape[0]
+        L = lib()
+        ys, saved, Cs = [], [], []
+        for i in range(n):
+            w, bw, bb, rm, rv = params[5 * i:5 * i + 5]
+            d = dils[i]
+            st = {} if mode == 1 else None
+            ys.append(_conv_fwd_raw(x5, _c(w).unsqueeze(2), None, (1, 1, 1), (0, d, d), (1, d, d), st))
+            Cs.append(w.shape[0])
+            saved.append(st)
+        S = ys[0].numel() // (N * Cs[0])
+        Ctot = sum(Cs)
+        cat = torch.empty((N, Ctot) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        keep, c0 = [x], 0
+        for i in range(n):
+            w, bw, bb, rm, rv = params[5 * i:5 * i + 5]
+            y, C, st = ys[i], Cs[i], saved[i]
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            if mode == 1 and st:
+                L.call('dpf_bn_finalize_partials', _ptr(st['slab']), st['parts'], C, N * S, BN_EPS, BN_MOMENTUM, _ptr(rm), _ptr(rv), _ptr(mean),
+                       _ptr(invstd), _stream())
+            elif mode == 1:
+                wsb = scratch(2 * C, x.device)
+                L.call('dpf_bn_stats', _ptr(y), N, C, S, BN_EPS, BN_MOMENTUM, _ptr(rm), _ptr(rv), _ptr(mean), _ptr(invstd), _ptr(wsb), _stream())
+            else:
+                L.call('dpf_bn_eval_stats', _ptr(rm), _ptr(rv), C, BN_EPS, _ptr(mean), _ptr(invstd), _stream())
+            L.call('dpf_norm_act_forward_slice', _ptr(y), _ptr(mean), _ptr(invstd), _ptr(bw), _ptr(bb), C, None, None, ACT_NONE, None, 0.0,
+                   _ptr(cat), Ctot, c0, N, C, S, _stream())
+            keep += [w, y, bw, bb, mean, invstd]
+            c0 += C
+        ctx.save_for_backward(*keep)
+        ctx.cfg = (mode, tuple(dils), n, N, tuple(Cs), S, Ctot)
+        return cat
+
+    @staticmethod
+    def backward(ctx, gcat):
+        mode, dils, n, N, Cs, S, Ctot = ctx.cfg
+        gcat = _c(gcat)
+        sv = ctx.saved_tensors
+        x = sv[0]
+        x5 = x.unsqueeze(2)
+        L = lib()
+        need_dx = ctx.needs_input_grad[2]
+        dx5 = None
+        grads, c0 = [], 0
+        for i in range(n):
+            w, y, bw, bb, mean, invstd = sv[1 + 6 * i:7 + 6 * i]
+            C, d = Cs[i], dils[i]
+            dy = torch.empty_like(y)
+            dbw = torch.empty_like(bw) if ctx.needs_input_grad[3 + 5 * i + 1] else None
+            dbb = torch.empty_like(bb) if ctx.needs_input_grad[3 + 5 * i + 2] else None
+            wsb = scratch(3 * C, x.device)
+            L.call('dpf_norm_act_backward_slice', _ptr(y), _ptr(gcat), Ctot, c0, _ptr(mean), _ptr(invstd), _ptr(bw), _ptr(bb), C, None, ACT_NONE,
+                   None, 0.0, 1 if mode == 1 else 0, _ptr(dy), None, _ptr(dbw), _ptr(dbb), None, _ptr(wsb), N, C, S, _stream())
+            w5 = w.unsqueeze(2)
+            gw = None
+            if ctx.needs_input_grad[3 + 5 * i]:
+                gw = _conv_wgrad_raw(dy, x5, w5.shape, (1, 1, 1), (0, d, d), (1, d, d)).squeeze(2)
+            if need_dx:
+                if dx5 is None:
+                    dx5 = _conv_transpose_raw(dy, w5, None, x5.shape[2:], w5.shape[2:], (1, 1, 1), (0, d, d), (1, d, d))
+                else:
+                    _conv_transpose_acc(dy, w5, dx5, w5.shape[2:], (1, 1, 1), (0, d, d), (1, d, d))
+            grads += [gw, dbw, dbb, None, None]
+            c0 += C
+        return (None, None, dx5.squeeze(2) if dx5 is not None else None) + tuple(grads)
+
+
+def conv_bn_concat(x, branches, dilations, training):
+    """branches: list of (conv weight [K, C, 3, 3], bn weight, bn bias, running_mean, running_var); padding = dilation."""
+    flat = []
+    for br in branches:
+        flat += list(br)
+    return ConvBnCatFn.apply(1 if training else 2, tuple(int(d) for d in dilations), x, *flat)
+
+
 def norm_act_concat(branches, mode, act=ACT_NONE):
     """branches: list of (x, weight, bias, running_mean, running_var, stats holder or None) with equal batch / spatial shape;
     mode 1 = training batch norm (per-rank statistics), 2 = eval.  -> [N, sum C_i, ...]."""

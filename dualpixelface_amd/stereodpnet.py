@@ -340,15 +340,23 @@ class StereoDPNetCore(_Base):
         if self.training and self.stat_exchange is not None:      # SyncBatchNorm exchanges {mean, M2}: the plain path
             return ops.concat_channels([self._convbn2(x, q, 1, d, d) for q, d in zip(prefixes, dilations)])
         P, B = self._P, self._B
+        if self.bf16_2d:                                            # bf16-operand convs keep their own autograd node
+            branches = []
+            for q, d in zip(prefixes, dilations):
+                y = ops.conv2d(x, P[q + '.0.weight'], None, 1, d if d > 1 else 1, d, bf16=True)
+                if self.training:
+                    key = q + '.1.num_batches_tracked'
+                    self._pending_counts[key] = self._pending_counts.get(key, 0) + 1
+                branches.append((y, P[q + '.1.weight'], P[q + '.1.bias'], B[q + '.1.running_mean'], B[q + '.1.running_var'], None))
+            return ops.norm_act_concat(branches, 1 if self.training else 2, ACT_NONE)
         branches = []
-        for q, d in zip(prefixes, dilations):
-            st = self._stats_holder()
-            y = ops.conv2d(x, P[q + '.0.weight'], None, 1, d if d > 1 else 1, d, bf16=self.bf16_2d, stats=st)
+        for q in prefixes:
             if self.training:
                 key = q + '.1.num_batches_tracked'
                 self._pending_counts[key] = self._pending_counts.get(key, 0) + 1
-            branches.append((y, P[q + '.1.weight'], P[q + '.1.bias'], B[q + '.1.running_mean'], B[q + '.1.running_var'], st))
-        return ops.norm_act_concat(branches, 1 if self.training else 2, ACT_NONE)
+            branches.append((P[q + '.0.weight'], P[q + '.1.weight'], P[q + '.1.bias'], B[q + '.1.running_mean'], B[q + '.1.running_var']))
+        # one autograd node: no cat copies, and the three data gradients are summed in the transposed-conv epilogue
+        return ops.conv_bn_concat(x, branches, [d if d > 1 else 1 for d in dilations], self.training)
 
     def _convbn3(self, x, p, stride=1, act=ACT_NONE, res=None):
         st = self._stats_holder()

@@ -45,6 +45,11 @@ int dpf_conv_transpose(const float* x, const float* w, const float* bias, float*
 int dpf_conv_transpose_ex(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
                           int K, int Ktot, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
                           int dd, int dh, int dw, void* stream);
+/* dpf_conv_transpose_ex with out += result when accumulate != 0 (data gradients of several convolutions reading one tensor summed in
+ * the epilogue); DPF_ERR_UNSUPPORTED with nothing written when the shape does not run on the LDS-DMA kernel */
+int dpf_conv_transpose_acc(const float* x, const float* w, const float* bias, float* out, float* ws, int N, int C, int ID, int IH, int IW,
+                           int K, int Ktot, int OD, int OH, int OW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                           int dd, int dh, int dw, int accumulate, void* stream);
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
 /* same, with caller scratch `ws` of dpf_conv_wgrad_workspace_floats(T, C, K) floats: eligible shapes (16-byte aligned rows, 3x3 /

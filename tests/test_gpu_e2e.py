@@ -447,7 +447,9 @@ def test_c2_shape_forward_and_loss_vs_cpu_oracle():
     err = (res['pred_normal'].detach().cpu().double() - ref['pred_normal'].double()).abs()   # [B, 1, 3, H, W]
     outside = err.masked_fill(near.unsqueeze(2), 0.0)
     assert float(outside.max()) <= 1e-3 and float(err.max()) <= 0.2, (float(outside.max()), float(err.max()), int(flipped.sum()))
-    assert float(outside.mean()) <= 2e-5, float(outside.mean())
+    # mean error: 1.0e-5 when nothing flips; a flipped pixel also moves the head's BatchNorm batch statistics a little, which every
+    # normal sees (measured 2.06e-5 in 2 of 10 runs)
+    assert float(outside.mean()) <= (2e-5 if int(flipped.sum()) == 0 else 6e-5), (float(outside.mean()), int(flipped.sum()))
     close(res['smoothL1_loss'], ref['smoothL1_loss'], 2e-4, 'smoothL1_loss')
     loose = 2e-4 if int(flipped.sum()) == 0 else 5e-3                                 # a flipped pixel moves the normals around it
     for k in ('cosine_loss', 'final_loss'):

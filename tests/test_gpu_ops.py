@@ -805,3 +805,33 @@ def test_norm_act_concat_matches_separate_norm_and_cat():
             close(a, b_, 1e-4, 'concat %s mode %d' % (nm, mode))
         for a, b_ in zip(grm + grv, rms_r + rvs_r):
             close(a, b_, 1e-5, 'running stats')
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_conv_bn_concat_node(training):
+    """cat([batch_norm(conv2d(x, w_i, dilation d_i))]) as one autograd node (no cat copies, data gradients summed in the
+    transposed-conv epilogue) against torch autograd."""
+    ops = _ops()
+    N, C, H, W = 2, 8, 20, 36
+    dils = (1, 3, 5)
+    x = rnd(N, C, H, W, seed=200).requires_grad_()
+    ws = [(rnd(C, C, 3, 3, seed=201 + i) * 0.2).requires_grad_() for i in range(3)]
+    gs = [(rnd(C, seed=210 + i).abs() + 0.5).requires_grad_() for i in range(3)]
+    bs = [rnd(C, seed=220 + i).requires_grad_() for i in range(3)]
+    rms = [rnd(C, seed=230 + i) * 0.1 for i in range(3)]
+    rvs = [rnd(C, seed=240 + i).abs() + 0.5 for i in range(3)]
+    rms_r, rvs_r = [t.clone() for t in rms], [t.clone() for t in rvs]
+    ref = torch.cat([F.batch_norm(F.conv2d(x, w, None, 1, d, d), rm, rv, g, b, training, 0.1, 1e-5)
+                     for w, g, b, rm, rv, d in zip(ws, gs, bs, rms_r, rvs_r, dils)], 1)
+    go = rnd(*ref.shape, seed=250)
+    gr = torch.autograd.grad(ref, [x] + ws + gs + bs, go)
+    dev = lambda t: t.detach().to(DEV).requires_grad_(t.requires_grad)
+    xg, wg, gg_, bg = dev(x), [dev(t) for t in ws], [dev(t) for t in gs], [dev(t) for t in bs]
+    rmg, rvg = [t.to(DEV) for t in rms], [t.to(DEV) for t in rvs]
+    out = ops.conv_bn_concat(xg, [(w, g, b, rm, rv) for w, g, b, rm, rv in zip(wg, gg_, bg, rmg, rvg)], dils, training)
+    close(out, ref, 1e-4, 'conv-bn-cat fwd')
+    got = torch.autograd.grad(out, [xg] + wg + gg_ + bg, go.to(DEV))
+    for a, b_, nm in zip(got, gr, ['dx'] + ['dw'] * 3 + ['dgamma'] * 3 + ['dbeta'] * 3):
+        close(a, b_, 2e-4, 'conv-bn-cat %s' % nm)
+    for a, b_ in zip(rmg + rvg, rms_r + rvs_r):
+        close(a, b_, 1e-5, 'running stats')
