@@ -215,7 +215,21 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
   const long long kstride = (long long)p.OD * out_plane;
   const int oh0 = q0h + wave * NT;
   float* op = out + ((long long)n * p.Ktot + p.k0) * kstride + ((long long)qd * p.OH + oh0) * p.OW + ow;
-  if (ow < p.OW) {
+  if (ow < p.OW && !p.accum) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (k < p.K) {
+          const float bv = bias ? bias[p.k0 + k] : 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (oh0 + t < p.OH) op[(long long)k * kstride + t * p.OW] = acc[m][t][j] + bv;
+        }
+      }
+    }
+  } else if (ow < p.OW) {                                         // out += result (kept apart: the plain path has no load in its store loop)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
           for (int t = 0; t < NT; ++t)
             if (oh0 + t < p.OH) {
               float* o = op + (long long)k * kstride + t * p.OW;
-              *o = acc[m][t][j] + bv + (p.accum ? *o : 0.f);
+              *o += acc[m][t][j] + bv;
             }
         }
       }

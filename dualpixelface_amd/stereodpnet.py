@@ -9,6 +9,7 @@ in ONE flat HBM arena (one fused Adam launch, one RCCL all-reduce over the match
 and the forward pass is a straight-line program over the HIP operator layer (ops.py).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -340,10 +341,10 @@ class StereoDPNetCore(_Base):
         if self.training and self.stat_exchange is not None:      # SyncBatchNorm exchanges {mean, M2}: the plain path
             return ops.concat_channels([self._convbn2(x, q, 1, d, d) for q, d in zip(prefixes, dilations)])
         P, B = self._P, self._B
-        if self.bf16_2d:                                            # bf16-operand convs keep their own autograd node
+        if self.bf16_2d or os.environ.get('DPF_CONV_BN_CAT', '1') == '0':   # bf16-operand convs keep their own autograd node
             branches = []
             for q, d in zip(prefixes, dilations):
-                y = ops.conv2d(x, P[q + '.0.weight'], None, 1, d if d > 1 else 1, d, bf16=True)
+                y = ops.conv2d(x, P[q + '.0.weight'], None, 1, d if d > 1 else 1, d, bf16=self.bf16_2d)
                 if self.training:
                     key = q + '.1.num_batches_tracked'
                     self._pending_counts[key] = self._pending_counts.get(key, 0) + 1
