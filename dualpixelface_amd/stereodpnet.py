@@ -341,7 +341,10 @@ class StereoDPNetCore(_Base):
         if self.training and self.stat_exchange is not None:      # SyncBatchNorm exchanges {mean, M2}: the plain path
             return ops.concat_channels([self._convbn2(x, q, 1, d, d) for q, d in zip(prefixes, dilations)])
         P, B = self._P, self._B
-        if self.bf16_2d or os.environ.get('DPF_CONV_BN_CAT', '1') == '0':   # bf16-operand convs keep their own autograd node
+        # DPF_CONV_BN_CAT=1: conv + BatchNorm + cat as ONE autograd node whose backward sums the three data gradients in the transposed-conv
+        # epilogue (ops.ConvBnCatFn).  Measured +0.2 % on the step (the epilogue's read-modify-write costs what the two add passes cost), so
+        # the default keeps the convolutions as plain launches and only fuses BatchNorm + cat.
+        if self.bf16_2d or os.environ.get('DPF_CONV_BN_CAT', '0') != '1':
             branches = []
             for q, d in zip(prefixes, dilations):
                 y = ops.conv2d(x, P[q + '.0.weight'], None, 1, d if d > 1 else 1, d, bf16=self.bf16_2d)
