@@ -52,34 +52,88 @@ __global__ void anm_select_kernel(const float* __restrict__ disp_full, int* __re
 }
 
 // vol[b, c, j, y, x] = cost[b, c, idx[b,j,y,x], y, x]   for c < C;   vol has CV = C+3 channels
-__global__ void anm_gather_kernel(const float* __restrict__ cost, const int* __restrict__ idx, float* __restrict__ vol, int B, int C, int L,
-                                  int K, int h, int w, int CV) {
+// A thread owns 4 consecutive pixels of one (b, channel group): the K selected levels are read once (int4 per level) and reused for
+// ACH channels -- no per-element 64-bit division, 16-byte accesses along the pixel axis.
+constexpr int ANM_MAXK = 8, ANM_ACH = 8;
+__global__ __launch_bounds__(256) void anm_gather_kernel(const float* __restrict__ cost, const int* __restrict__ idx, float* __restrict__ vol,
+                                                         int B, int C, int L, int K, int h, int w, int CV) {
   const long long hw = (long long)h * w;
-  const long long total = (long long)B * C * K * hw;
+  const long long q4 = (hw + 3) >> 2;
+  const int cgroups = (C + ANM_ACH - 1) / ANM_ACH;
+  const long long total = (long long)B * cgroups * q4;
+  const bool vec = (hw & 3) == 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i % hw;
-    const int j = (int)((i / hw) % K);
-    const int c = (int)((i / (hw * K)) % C);
-    const int b = (int)(i / (hw * K * C));
-    const int l = idx[((long long)b * K + j) * hw + pix];
-    vol[(((long long)b * CV + c) * K + j) * hw + pix] = cost[(((long long)b * C + c) * L + l) * hw + pix];
+    const long long pix = (i % q4) * 4;
+    const int cg = (int)((i / q4) % cgroups);
+    const int b = (int)(i / (q4 * cgroups));
+    int lv[ANM_MAXK][4];
+#pragma unroll
+    for (int j = 0; j < ANM_MAXK; ++j)
+      if (j < K)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lv[j][e] = pix + e < hw ? idx[((long long)b * K + j) * hw + pix + e] : 0;
+    for (int c = cg * ANM_ACH; c < min(C, (cg + 1) * ANM_ACH); ++c) {
+      const float* cb = cost + ((long long)b * C + c) * L * hw + pix;
+      float* vb = vol + ((long long)b * CV + c) * K * hw + pix;
+#pragma unroll
+      for (int j = 0; j < ANM_MAXK; ++j) {
+        if (j >= K) break;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pix + e < hw ? cb[(long long)lv[j][e] * hw + e] : 0.f;
+        if (vec) {
+          *reinterpret_cast<float4*>(vb + (long long)j * hw) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int e = 0; e < 4 && pix + e < hw; ++e) vb[(long long)j * hw + e] = v[e];
+        }
+      }
+    }
   }
 }
 
-// dcost[b,c,l,y,x] = sum_j [idx==l] dvol[b,c,j,y,x]
-__global__ void anm_gather_bwd_kernel(const float* __restrict__ dvol, const int* __restrict__ idx, float* __restrict__ dcost, int B, int C,
-                                      int L, int K, int h, int w, int CV) {
+// dcost[b,c,l,y,x] = sum_j [idx==l] dvol[b,c,j,y,x]: same ownership; the L outputs of a pixel are built in registers from the K
+// incoming values (the selected levels are distinct and ascending) and stored as float4 rows.
+constexpr int ANM_MAXL = 16;
+__global__ __launch_bounds__(256) void anm_gather_bwd_kernel(const float* __restrict__ dvol, const int* __restrict__ idx, float* __restrict__ dcost,
+                                                             int B, int C, int L, int K, int h, int w, int CV) {
   const long long hw = (long long)h * w;
-  const long long total = (long long)B * C * L * hw;
+  const long long q4 = (hw + 3) >> 2;
+  const int cgroups = (C + ANM_ACH - 1) / ANM_ACH;
+  const long long total = (long long)B * cgroups * q4;
+  const bool vec = (hw & 3) == 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i % hw;
-    const int l = (int)((i / hw) % L);
-    const int c = (int)((i / (hw * L)) % C);
-    const int b = (int)(i / (hw * L * C));
-    float v = 0.f;
-    for (int j = 0; j < K; ++j)
-      if (idx[((long long)b * K + j) * hw + pix] == l) v += dvol[(((long long)b * CV + c) * K + j) * hw + pix];
-    dcost[i] = v;
+    const long long pix = (i % q4) * 4;
+    const int cg = (int)((i / q4) % cgroups);
+    const int b = (int)(i / (q4 * cgroups));
+    int lv[ANM_MAXK][4];
+#pragma unroll
+    for (int j = 0; j < ANM_MAXK; ++j)
+      if (j < K)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lv[j][e] = pix + e < hw ? idx[((long long)b * K + j) * hw + pix + e] : -1;
+    for (int c = cg * ANM_ACH; c < min(C, (cg + 1) * ANM_ACH); ++c) {
+      const float* gb = dvol + ((long long)b * CV + c) * K * hw + pix;
+      float* ob = dcost + ((long long)b * C + c) * L * hw + pix;
+      float g[ANM_MAXK][4];
+#pragma unroll
+      for (int j = 0; j < ANM_MAXK; ++j)
+        if (j < K)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[j][e] = pix + e < hw ? gb[(long long)j * hw + e] : 0.f;
+      for (int l = 0; l < L; ++l) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < ANM_MAXK; ++j)
+          if (j < K)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += lv[j][e] == l ? g[j][e] : 0.f;
+        if (vec) {
+          *reinterpret_cast<float4*>(ob + (long long)l * hw) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int e = 0; e < 4 && pix + e < hw; ++e) ob[(long long)l * hw + e] = v[e];
+        }
+      }
+    }
   }
 }
 
@@ -235,7 +289,9 @@ int dpf_anm_volume_forward(const float* cost, const int* idx, const float* sdisp
   if (!cost || !idx || !sdisp || !Kmat || !abvalue || !vol || !mm_ws || B <= 0 || B > 65535) return DPF_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int CV = C + 3;
-  hipLaunchKernelGGL(anm_gather_kernel, dim3(dpf_ew_grid((long long)B * C * K * h * w)), dim3(256), 0, st, cost, idx, vol, B, C, L, K, h, w, CV);
+  if (K > ANM_MAXK) return DPF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(anm_gather_kernel, dim3(dpf_ew_grid((long long)B * ((C + ANM_ACH - 1) / ANM_ACH) * (((long long)h * w + 3) / 4))), dim3(256), 0, st, cost,
+                     idx, vol, B, C, L, K, h, w, CV);
   hipLaunchKernelGGL(anm_minmax_init_kernel, dim3(dpf_div_up(B, 64)), dim3(64), 0, st, mm_ws, B);
   int gx = dpf_div_up((long long)K * h * w, 256);
   if (gx > 512) gx = 512;
@@ -248,8 +304,9 @@ int dpf_anm_volume_forward(const float* cost, const int* idx, const float* sdisp
 int dpf_anm_volume_backward(const float* dvol, const int* idx, float* dcost, int B, int C, int L, int K, int h, int w, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!dvol || !idx || !dcost || B <= 0) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(anm_gather_bwd_kernel, dim3(dpf_ew_grid((long long)B * C * L * h * w)), dim3(256), 0, (hipStream_t)stream, dvol, idx,
-                     dcost, B, C, L, K, h, w, C + 3);
+  if (K > ANM_MAXK || L > ANM_MAXL) return DPF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(anm_gather_bwd_kernel, dim3(dpf_ew_grid((long long)B * ((C + ANM_ACH - 1) / ANM_ACH) * (((long long)h * w + 3) / 4))), dim3(256), 0,
+                     (hipStream_t)stream, dvol, idx, dcost, B, C, L, K, h, w, C + 3);
   return dpf_check_launch();
 }
 
