@@ -36,22 +36,37 @@ __global__ __launch_bounds__(256) void shift_triple_fwd_kernel(const float* __re
     const int r = idx / w4, x = (idx - r * w4) * 4;
     const int y = y0 + r;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // column taps of these 4 outputs: one 16-byte load per table row when the row length allows it
+    int cx[2][4];
+    float cw[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (vec) {
+        const int4 iv = *reinterpret_cast<const int4*>(ixm + e * w + x);
+        const float4 wv = *reinterpret_cast<const float4*>(wxm + e * w + x);
+        cx[e][0] = iv.x; cx[e][1] = iv.y; cx[e][2] = iv.z; cx[e][3] = iv.w;
+        cw[e][0] = wv.x; cw[e][1] = wv.y; cw[e][2] = wv.z; cw[e][3] = wv.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cx[e][j] = x + j < w ? ixm[e * w + x + j] : -1;
+          cw[e][j] = x + j < w ? wxm[e * w + x + j] : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int yy = iy[(m * 2 + a) * h + y];
       if (yy < 0) continue;
       const float wa = wy[(m * 2 + a) * h + y];
+      if (wa == 0.f) continue;
       const float* row = src + (long long)yy * w;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (x + j < w) {
-            const int xx = ixm[e * w + x + j];
-            if (xx >= 0) acc[j] += (wa * wxm[e * w + x + j]) * row[xx];
-          }
-        }
-      }
+        for (int j = 0; j < 4; ++j)
+          if (cx[e][j] >= 0 && cw[e][j] != 0.f) acc[j] += (wa * cw[e][j]) * row[cx[e][j]];     // zero-weight taps (the second
+      }                                                                                         // bilinear column tap) are not fetched
     }
     float* o = dst + (long long)r * w + x;
     if (vec) {
@@ -111,6 +126,29 @@ __global__ __launch_bounds__(256) void shift_triple_bwd_gather_kernel(const floa
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
+      // inverse column taps of these 4 source columns and their weights (zero-weight taps are dropped here, once per mode)
+      int cx[2][2][4];
+      float cw[2][2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const int* tab = ixi + ((m * 2 + e) * 2 + sx) * w + xx0;
+          int t4[4];
+          if (vec) {
+            const int4 iv = *reinterpret_cast<const int4*>(tab);
+            t4[0] = iv.x; t4[1] = iv.y; t4[2] = iv.z; t4[3] = iv.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t4[j] = xx0 + j < w ? tab[j] : -1;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float wv = t4[j] >= 0 ? wx[(m * 2 + e) * w + t4[j]] : 0.f;
+            cx[e][sx][j] = wv != 0.f ? t4[j] : -1;
+            cw[e][sx][j] = wv;
+          }
+        }
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -118,20 +156,15 @@ __global__ __launch_bounds__(256) void shift_triple_bwd_gather_kernel(const floa
           const int y = iyi[((m * 2 + a) * 2 + sy) * h + yy];
           if (y < 0) continue;
           const float wa = wy[(m * 2 + a) * h + y];
+          if (wa == 0.f) continue;
           const float* grow = gp + m * hw + (long long)y * w;
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
+          for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
+            for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (xx0 + j < w) {
-                  const int x = ixi[((m * 2 + e) * 2 + sx) * w + xx0 + j];
-                  if (x >= 0) acc[j] += (wa * wx[(m * 2 + e) * w + x]) * grow[x];
-                }
-              }
-            }
-          }
+              for (int j = 0; j < 4; ++j)
+                if (cx[e][sx][j] >= 0) acc[j] += (wa * cw[e][sx][j]) * grow[cx[e][sx][j]];
         }
       }
     }
