@@ -116,6 +116,9 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--wgrad-async', action='store_true',
+                    help='weight gradients on a side stream (faster step; per-kernel durations then overlap, so the roofline '
+                         'attribution of this run is not per kernel -- see DESIGN.md)')
     ap.add_argument('--cpu-baseline-only', default=None, metavar='HxW:threads[,threads...]',
                     help='time only the CPU oracle at the given size for each thread count (e.g. 1024x1536:16,128) and exit')
     ap.add_argument('--model', default='stereodpnet', choices=['stereodpnet', 'psmnet', 'nnet', 'stereonet'],
@@ -171,6 +174,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.wgrad_async:
+        ops.WGRAD_ASYNC = True
     for _ in range(args.warmup):
         model.train_step(batch, reducer)
     sync()
@@ -231,7 +236,8 @@ def main():
             'config': {'workload': '%s train step (fwd+loss+bwd+grad all-reduce+Adam), %d x %dx%d synthetic DP pairs per GPU'
                                    % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.batch, args.height, args.width),
                        'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,
-                       'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics'},
+                       'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics',
+                       'weight_gradients': 'side stream' if ops.WGRAD_ASYNC else 'in line'},
             'final_loss': loss,
             'flop_frac_of_f32_peak': (value * FLOP_PER_PIXEL_FWD_BWD * pixels / (world * PEAK_F32_TFLOPS * 1e12)) if args.model == 'stereodpnet' else None,
             'roofline': roof,

@@ -194,6 +194,51 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
     return dw
 
 
+# Weight gradients are leaves of the backward graph: nothing consumes them before the optimiser.  With a registry installed
+# (train_step does) they are launched on a side stream, where the MFMA-bound wgrad kernels share the chip with the HBM-bound
+# normalisation / elementwise kernels of the main chain instead of queueing behind them.  Results are handed back by
+# wgrad_async_finish(), which joins the side stream before anything reads them.
+WGRAD_ASYNC = os.environ.get('DPF_WGRAD_ASYNC', '0') == '1'
+_wgrad_registry = None
+_wgrad_pending = []
+_wgrad_side = {}
+
+
+def wgrad_async_begin(params):
+    """params: the leaf weights whose gradients may be deferred (matched by storage address and shape)."""
+    global _wgrad_registry
+    _wgrad_registry = {p.data_ptr(): p for p in params} if WGRAD_ASYNC else None
+    del _wgrad_pending[:]
+
+
+def wgrad_async_finish():
+    """Join the side stream and return [(parameter, gradient)] in launch order."""
+    global _wgrad_registry
+    _wgrad_registry = None
+    out = list(_wgrad_pending)
+    del _wgrad_pending[:]
+    if out:
+        torch.cuda.current_stream().wait_stream(_wgrad_side[out[0][1].device])
+    return out
+
+
+def _wgrad_dispatch(w, g, x, wshape, stride, pad, dil):
+    """The weight gradient, or None when it was deferred to the side stream."""
+    p = _wgrad_registry.get(w.data_ptr()) if _wgrad_registry is not None else None
+    if p is None or p.numel() != w.numel():
+        return _conv_wgrad_raw(g, x, wshape, stride, pad, dil)
+    side = _wgrad_side.get(x.device)
+    if side is None:
+        side = _wgrad_side[x.device] = torch.cuda.Stream(device=x.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gw = _conv_wgrad_raw(g, x, wshape, stride, pad, dil)
+    g.record_stream(side)
+    x.record_stream(side)
+    _wgrad_pending.append((p, gw.view(p.shape)))
+    return None
+
+
 def _channel_sum(g):
     N, C = g.shape[0], g.shape[1]
     S = g.numel() // (N * C)
@@ -224,7 +269,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _conv_transpose_raw(gy, w, None, x.shape[2:], w.shape[2:], stride, pad, dil, k_needed=ctx.gi_channels)
         if ctx.needs_input_grad[1]:
-            gw = _conv_wgrad_raw(gy, x, w.shape, stride, pad, dil)
+            gw = _wgrad_dispatch(w, gy, x, w.shape, stride, pad, dil)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _channel_sum(gy)
         return gx, gw, gb, None, None, None, None, None
@@ -253,7 +298,7 @@ class ConvTransposeFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _conv_fwd_raw(gy, w, None, stride, pad, dil)          # w read as [K=C_in][C=C_out][T]
         if ctx.needs_input_grad[1]:
-            gw = _conv_wgrad_raw(x, gy, w.shape, stride, pad, dil)     # g := x (strided grid), x := gy (dense grid)
+            gw = _wgrad_dispatch(w, x, gy, w.shape, stride, pad, dil)  # g := x (strided grid), x := gy (dense grid)
         return gx, gw, None, None, None
 
 

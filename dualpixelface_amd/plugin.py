@@ -104,8 +104,11 @@ class _PluginHooks(object):
             pairs = self._grad_pairs()
             for p, _ in pairs:
                 p.grad = None
+            ops.wgrad_async_begin([p for p, _ in pairs])
             results = self.forward(batch)
             results['final_loss'].backward()
+            for p, g in ops.wgrad_async_finish():
+                p.grad = g if p.grad is None else p.grad + g
             views, grads = [], []
             for p, v in pairs:
                 if p.grad is None:

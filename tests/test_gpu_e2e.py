@@ -520,3 +520,36 @@ def test_gradients_no_worse_than_the_reference_vs_fp64(golden_dir):
         e_ref = ((ref32 - exact).norm() / exact.norm()).item()
         e_mine = ((mine - exact).norm() / exact.norm()).item()
         assert e_mine <= 2.0 * e_ref + 1e-3, (k, e_mine, e_ref)
+
+
+def test_side_stream_weight_gradients_match_in_line(golden_dir, monkeypatch):
+    """DPF_WGRAD_ASYNC: the weight-gradient launches move to a side stream; the gradients that reach Adam must be the same ones."""
+    from dualpixelface_amd import ops
+    g = np.load(golden_dir + '/e2e_train_64x96_b1.npz')
+    grads = []
+    for flag in (False, True):
+        monkeypatch.setattr(ops, 'WGRAD_ASYNC', flag)
+        deferred = []
+        real = ops.wgrad_async_finish
+
+        def spy():
+            out = real()
+            deferred.append(len(out))
+            return out
+        monkeypatch.setattr(ops, 'wgrad_async_finish', spy)
+        model = build_model(True)
+        model.train_step(load_batch(g))
+        torch.cuda.synchronize()
+        grads.append(model.flat_gradients(zero=False).clone())
+        monkeypatch.setattr(ops, 'wgrad_async_finish', real)
+        assert (deferred[0] > 100) == flag, deferred
+    ref, got = grads
+    rel = (got - ref).norm().item() / ref.norm().item()
+    assert rel < 1e-5 and torch.isfinite(got).all(), rel
+    # per parameter too: a gradient that never arrived (or arrived twice) would hide in the global norm of 3.7 M values
+    model_layout = model._layout
+    for name, off, numel, shape in model_layout:
+        a, b = ref[off:off + numel], got[off:off + numel]
+        n = a.norm().item()
+        if n > 1e-6:
+            assert (a - b).norm().item() / n < 1e-3, name
