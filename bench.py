@@ -123,7 +123,7 @@ def main():
                     help='time only the CPU oracle at the given size for each thread count (e.g. 1024x1536:16,128) and exit')
     ap.add_argument('--model', default='stereodpnet', choices=['stereodpnet', 'psmnet', 'nnet', 'stereonet'],
                     help='psmnet = BASELINE configs[3] (cross-model plugin check): the PSMNet plugin on the same kernels; nnet = the NNet plugin')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16-2d'],
                     help="bf16 = BASELINE configs[4]: bf16-operand MFMA for the 2-D convs, fp32 everywhere else (default: exact fp32)")
     ap.add_argument('--sync-bn', action='store_true',
                     help='BatchNorm statistics over the global batch (what the reference does under DDP); default per-rank statistics')
@@ -159,8 +159,8 @@ def main():
 
     torch.manual_seed(1)
     opt = load_option({'psmnet': 'train_faceDP_psmnet', 'nnet': 'train_faceDP_nnet', 'stereonet': 'train_faceDP_stereonet'}.get(args.model, 'train_faceDP'))
-    if args.precision == 'bf16':
-        opt.precision = 'bf16'
+    if args.precision != 'f32':
+        opt.precision = args.precision
     model = {'psmnet': PSMNET, 'nnet': NNET, 'stereonet': STEREONET}.get(args.model, STEREODPNET)(opt)     # reference initialisation scheme, random weights
     model.to(dev)
     broadcast_flat(model.flat_parameters(), 0)
@@ -231,7 +231,8 @@ def main():
         line = {
             'metric': 'train samples/sec, %s %dx%d DP pair' % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.height, args.width), 'value': value, 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16 2-D conv operands, f32 elsewhere',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'f32': 'f32', 'bf16': 'bf16 conv operands (2-D and 3-D), f32 accumulate / tensors / everything else',
+                                                      'bf16-2d': 'bf16 2-D conv operands, f32 elsewhere'}[args.precision],
             'data': 'synthetic',
             'config': {'workload': '%s train step (fwd+loss+bwd+grad all-reduce+Adam), %d x %dx%d synthetic DP pairs per GPU'
                                    % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.batch, args.height, args.width),

@@ -586,7 +586,17 @@ int dpf_conv_wgrad_slice(const float* g, const float* x, float* dw, int N, int C
                          int QH, int QW, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_,
                          void* stream);
 
+namespace { int g_operand_bf16 = 0; }
+int dpf_conv_operand_bf16() { return g_operand_bf16; }
+
 extern "C" {
+
+// 0: exact fp32 operands (default); 1: the dense convolution kernels (forward, stride-1 data gradient, weight gradient) round their
+// operands to bf16 (RNE) while staging them, accumulate and store in fp32.  Process-wide; the host side sets it around each launch.
+int dpf_set_conv_operand_precision(int bf16) {
+  g_operand_bf16 = bf16 ? 1 : 0;
+  return DPF_OK;
+}
 
 // workspace (floats) needed for the repacked weights of a conv with `T` taps, `reduce` reduction channels
 // and `outc` output channels

@@ -46,6 +46,17 @@ struct G2P {
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> two bf16 (round to nearest even) in one register: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  const f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+
 __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
@@ -57,12 +68,18 @@ constexpr int g2_occ() {
   return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
 }
 
-template <int MT, int NT, int CC>
-__global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+// BF = true (operand precision "bf16"): same staging (fp32 patch by LDS-DMA), but a chunk is 8 channels, the weights are packed as
+// bf16 [tap][half][k][4], and a tap is ONE v_mfma_f32_32x32x8_bf16 per (row tile, position row): a lane reads its 4 channels of the
+// fp32 patch, rounds them to bf16 (RNE) and contracts 8 channels at once -- 1/8 of the matrix-pipe cycles of the exact-f32 path,
+// fp32 accumulation, fp32 output.  The result equals an fp32 convolution of the bf16-rounded operands up to summation order.
+template <int MT, int NT, int CC, bool BF = false>
+__global__ __launch_bounds__(256, (BF ? 2 : g2_occ<MT, NT, CC>())) void igemm2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                                          const float* __restrict__ bias, float* __restrict__ out, G2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(!BF || CC == 8, "the bf16 path contracts 8 channels per MFMA");
   constexpr int KT = 32 * MT;
   constexpr int TH = 4 * NT;
+  constexpr int NLDK = BF ? 2 * NLD : NLD;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,14 +100,14 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
   const int a0 = q0w * p.sxw + p.e0w - p.colshift;     // 16-byte aligned first staged column
 
   const int patchFloats = CC * p.chanStride;
-  const int bufFloats = patchFloats + p.T * CC * KT;
+  const int bufFloats = patchFloats + 4 * p.nwseg;
   const long long x_chan = (long long)p.ID * p.IH * p.IW;
   const float* xn = x + (long long)n * p.C * x_chan;
 
   // ---- per-lane DMA descriptors: segment f = tid + 256 j of the flat [row][SR] patch image
-  int goff[NLD];
+  int goff[NLDK];
 #pragma unroll
-  for (int j = 0; j < NLD; ++j) {
+  for (int j = 0; j < NLDK; ++j) {
     const unsigned f = tid + 256 * j;
     const unsigned row = (f * p.mSR) >> 20;
     const int seg = f - row * p.SR;
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
     const int crem = p.C - chunk * CC;
     const int flimit = (crem < CC ? crem : CC) * p.rpc * p.SR;    // segments of channels beyond C read the zero page
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
+    for (int j = 0; j < NLDK; ++j) {
       if (j * 256 < p.nseg) {                                     // wave-uniform
         const int f = tid + 256 * j;
         if (f < p.nseg) {
@@ -136,7 +153,7 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
 
   int lanebase[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) lanebase[t] = ((wave * NT + t) * p.sxh) * p.RS + l31 * p.sxw + p.colshift + hh * p.chanStride;
+  for (int t = 0; t < NT; ++t) lanebase[t] = ((wave * NT + t) * p.sxh) * p.RS + l31 * p.sxw + p.colshift + hh * (BF ? 4 : 1) * p.chanStride;
   const int abase = hh * KT + l31;
 
   issue(0, 0);
@@ -149,62 +166,116 @@ __global__ __launch_bounds__(256, (g2_occ<MT, NT, CC>())) void igemm2_kernel(con
     if (chunk + 1 < p.nchunks) issue(chunk + 1, buf ^ 1);
     const float* s_in = smem + buf * bufFloats;
     const float* s_w = s_in + patchFloats;
-    // Two operand register sets (A, B), taps two at a time: the LDS reads of tap s+1 are issued before the MFMAs of tap s, so
-    // the matrix pipe never waits for an operand fetch.  Tap offsets advance incrementally on the scalar unit
-    // (tap (a, b, c) -> base + a*stepA + b*stepB + c*stepC; weights are packed in the same order).
-    float aA[CC / 2][MT], bA[CC / 2][NT], aB[CC / 2][MT], bB[CC / 2][NT];
-    int slotn = 0, toff = tap0, woff = 0;
-    auto load_ops = [&](float (&a)[CC / 2][MT], float (&bb)[CC / 2][NT]) {
-      const float* wrow = s_w + abase + woff;
+    if constexpr (BF) {
+      // bf16 operands: per tap a lane fetches its 4 channels of the fp32 patch (4 ds_read_b32) and its 4 packed bf16 weights per
+      // row tile (one ds_read_b64); same two-set software pipeline and scalar tap walk as the exact-f32 path below.
+      const short* s_wb = reinterpret_cast<const short*>(s_w) + (hh * KT + l31) * 4;
+      s16x4 aA[MT], aB[MT];
+      float bA[NT][4], bB[NT][4];
+      int slotn = 0, toff = tap0, woff = 0;
+      auto load_ops = [&](s16x4 (&a)[MT], float (&bb)[NT][4]) {
 #pragma unroll
-      for (int cp = 0; cp < CC / 2; ++cp) {
+        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const s16x4*>(s_wb + woff + m * 128);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[cp][m] = wrow[(2 * cp) * KT + m * 32];
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bb[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
+          for (int i = 0; i < 4; ++i) bb[t][i] = s_in[lanebase[t] + i * chanStride + toff];
+        const unsigned code = (unsigned)(steps >> (2 * slotn)) & 3u;
+        const int inc = stepC + (code > 0 ? dB : 0) + (code > 1 ? dA : 0);
+        toff = code == 3 ? tap0 : toff + inc;
+        woff = code == 3 ? 0 : woff + 8 * KT;
+        slotn = code == 3 ? 0 : slotn + 1;
+      };
+      auto mfmas = [&](const s16x4 (&a)[MT], const float (&bb)[NT][4]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const u32x2 u = {pk_bf16(bb[t][0], bb[t][1]), pk_bf16(bb[t][2], bb[t][3])};
+          const s16x4 bv = __builtin_bit_cast(s16x4, u);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a[m], bv, acc[m][t], 0, 0, 0);
+        }
+      };
+      auto touch = [&](const s16x4 (&a)[MT], const float (&bb)[NT][4]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a[m]));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(bb[t][i]));
+        asm volatile("" ::: "memory");
+      };
+      load_ops(aA, bA);
+      for (int slot = 0; slot + 1 < nv; slot += 2) {
+        touch(aA, bA);
+        load_ops(aB, bB);
+        __builtin_amdgcn_sched_barrier(6);
+        mfmas(aA, bA);
+        __builtin_amdgcn_sched_barrier(0);
+        touch(aB, bB);
+        load_ops(aA, bA);
+        __builtin_amdgcn_sched_barrier(6);
+        mfmas(aB, bB);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      // advance to the next tap on the scalar unit: 2-bit step codes, one per tap (0: next column, 1: next row, 2: next plane,
-      // 3: wrap to tap 0 -- the wrapped fetch of the final iteration is a valid address whose data is not used)
-      const unsigned code = (unsigned)(steps >> (2 * slotn)) & 3u;
-      const int inc = stepC + (code > 0 ? dB : 0) + (code > 1 ? dA : 0);     // arithmetic, not a select of kernel-argument loads
-      toff = code == 3 ? tap0 : toff + inc;
-      woff = code == 3 ? 0 : woff + CC * KT;
-      slotn = code == 3 ? 0 : slotn + 1;
-    };
-    auto mfmas = [&](const float (&a)[CC / 2][MT], const float (&bb)[CC / 2][NT]) {
-#pragma unroll
-      for (int cp = 0; cp < CC / 2; ++cp)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp][m], bb[cp][t], acc[m][t], 0, 0, 0);
-    };
-    // `touch` = an empty asm that reads a whole operand set: hipcc retires LDS reads with lgkmcnt(0) at the first use, so the
-    // use is placed BEFORE the other set's fetch is issued -- each wait then only covers reads issued a full MFMA group earlier.
-    auto touch = [&](const float (&a)[CC / 2][MT], const float (&bb)[CC / 2][NT]) {
-#pragma unroll
-      for (int cp = 0; cp < CC / 2; ++cp) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a[cp][m]));
-#pragma unroll
-        for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(bb[cp][t]));
+      if (nv & 1) mfmas(aA, bA);
+    } else {
+      // Two operand register sets (A, B), taps two at a time: the LDS reads of tap s+1 are issued before the MFMAs of tap s, so
+      // the matrix pipe never waits for an operand fetch.  Tap offsets advance incrementally on the scalar unit
+      // (tap (a, b, c) -> base + a*stepA + b*stepB + c*stepC; weights are packed in the same order).
+      float aA[CC / 2][MT], bA[CC / 2][NT], aB[CC / 2][MT], bB[CC / 2][NT];
+      int slotn = 0, toff = tap0, woff = 0;
+      auto load_ops = [&](float (&a)[CC / 2][MT], float (&bb)[CC / 2][NT]) {
+        const float* wrow = s_w + abase + woff;
+  #pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp) {
+  #pragma unroll
+          for (int m = 0; m < MT; ++m) a[cp][m] = wrow[(2 * cp) * KT + m * 32];
+  #pragma unroll
+          for (int t = 0; t < NT; ++t) bb[cp][t] = s_in[lanebase[t] + (2 * cp) * chanStride + toff];
+        }
+        // advance to the next tap on the scalar unit: 2-bit step codes, one per tap (0: next column, 1: next row, 2: next plane,
+        // 3: wrap to tap 0 -- the wrapped fetch of the final iteration is a valid address whose data is not used)
+        const unsigned code = (unsigned)(steps >> (2 * slotn)) & 3u;
+        const int inc = stepC + (code > 0 ? dB : 0) + (code > 1 ? dA : 0);     // arithmetic, not a select of kernel-argument loads
+        toff = code == 3 ? tap0 : toff + inc;
+        woff = code == 3 ? 0 : woff + CC * KT;
+        slotn = code == 3 ? 0 : slotn + 1;
+      };
+      auto mfmas = [&](const float (&a)[CC / 2][MT], const float (&bb)[CC / 2][NT]) {
+  #pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp)
+  #pragma unroll
+          for (int m = 0; m < MT; ++m)
+  #pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp][m], bb[cp][t], acc[m][t], 0, 0, 0);
+      };
+      // `touch` = an empty asm that reads a whole operand set: hipcc retires LDS reads with lgkmcnt(0) at the first use, so the
+      // use is placed BEFORE the other set's fetch is issued -- each wait then only covers reads issued a full MFMA group earlier.
+      auto touch = [&](const float (&a)[CC / 2][MT], const float (&bb)[CC / 2][NT]) {
+  #pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp) {
+  #pragma unroll
+          for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a[cp][m]));
+  #pragma unroll
+          for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(bb[cp][t]));
+        }
+        asm volatile("" ::: "memory");
+      };
+      load_ops(aA, bA);
+      for (int slot = 0; slot + 1 < nv; slot += 2) {
+        touch(aA, bA);
+        load_ops(aB, bB);       // tap slot+1
+        __builtin_amdgcn_sched_barrier(6);   // VALU / SALU may cross, LDS reads and MFMAs may not
+        mfmas(aA, bA);          // tap slot
+        __builtin_amdgcn_sched_barrier(0);
+        touch(aB, bB);
+        load_ops(aA, bA);       // tap slot+2 (wrapped, unused, when slot+2 == nv)
+        __builtin_amdgcn_sched_barrier(6);
+        mfmas(aB, bB);          // tap slot+1
+        __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("" ::: "memory");
-    };
-    load_ops(aA, bA);
-    for (int slot = 0; slot + 1 < nv; slot += 2) {
-      touch(aA, bA);
-      load_ops(aB, bB);       // tap slot+1
-      __builtin_amdgcn_sched_barrier(6);   // VALU / SALU may cross, LDS reads and MFMAs may not
-      mfmas(aA, bA);          // tap slot
-      __builtin_amdgcn_sched_barrier(0);
-      touch(aB, bB);
-      load_ops(aA, bA);       // tap slot+2 (wrapped, unused, when slot+2 == nv)
-      __builtin_amdgcn_sched_barrier(6);
-      mfmas(aB, bB);          // tap slot+1
-      __builtin_amdgcn_sched_barrier(0);
+      if (nv & 1) mfmas(aA, bA);
     }
-    if (nv & 1) mfmas(aA, bA);
     __builtin_amdgcn_sched_barrier(0);                           // keep the MFMAs of this chunk in front of the DMA wait
     __syncthreads();                                             // vmcnt(0): chunk+1 landed; barrier: this buffer is free
   }
@@ -541,6 +612,30 @@ __global__ void igemm2_pack_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// bf16 operand path: wpk[0, ZPAGE floats) = 0; then shorts [chunk][tap][half][k][4] = bf16(w(out = k0 + k, reduce = 8*chunk + 4*half + i, tap))
+__global__ void igemm2_pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int KT, int nchunks,
+                                        int mode, int k0, int K, int C) {
+  const long long total = (long long)nchunks * T * 8 * KT + 2 * ZPAGE;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (i >= 2 * ZPAGE) {
+      const long long e = i - 2 * ZPAGE;
+      const int ii = (int)(e & 3);
+      const int k = (int)((e >> 2) % KT);
+      const int half = (int)((e / (4LL * KT)) & 1);
+      const int t = (int)((e / (8LL * KT)) % T);
+      const int chunk = (int)(e / (8LL * KT * T));
+      const int c = chunk * 8 + half * 4 + ii;
+      if (k < K && c < C) {
+        const int a = mode == 0 ? k0 + k : c;
+        const int bb = mode == 0 ? c : k0 + k;
+        v = w[((long long)a * wB + bb) * T + t];
+      }
+    }
+    wpk[i] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
+  }
+}
+
 unsigned magic20(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 
 int env_int(const char* name, int dflt) {
@@ -548,17 +643,17 @@ int env_int(const char* name, int dflt) {
   return s ? atoi(s) : dflt;
 }
 
-template <int MT, int NT, int CC>
+template <int MT, int NT, int CC, bool BF = false>
 int launch_g2(const float* x, const float* wpk, const float* bias, float* out, const G2P& p, size_t lds, long long blocks, hipStream_t st) {
   if (lds > 48 * 1024) {
     static bool done = false;   // per instantiation
     if (!done) {
-      if (hipFuncSetAttribute((const void*)igemm2_kernel<MT, NT, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)igemm2_kernel<MT, NT, CC, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return DPF_ERR_LAUNCH;
       done = true;
     }
   }
-  hipLaunchKernelGGL((igemm2_kernel<MT, NT, CC>), dim3((unsigned)blocks), dim3(256), lds, st, x, wpk, bias, out, p);
+  hipLaunchKernelGGL((igemm2_kernel<MT, NT, CC, BF>), dim3((unsigned)blocks), dim3(256), lds, st, x, wpk, bias, out, p);
   return dpf_check_launch();
 }
 
@@ -643,6 +738,25 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   static const int nt_over = env_int("DPF_G2_NT", 0), cc_over = env_int("DPF_G2_CC", 0), lds_target = env_int("DPF_G2_LDS", 53 * 1024);
   int NT = MT == 1 ? 4 : 2;
   if (nt_over == 2 || (nt_over == 4 && MT <= 2)) NT = nt_over;
+  // operand precision "bf16" (dpf_set_conv_operand_precision): 8-channel chunks; 16 position rows per workgroup when two buffers
+  // of that patch fit the LDS, else 8
+  bool bf = dpf_conv_operand_bf16() != 0 && T > 1;
+  if (bf) {
+    auto patch_for = [&](int nt) {      // bytes of an 8-channel fp32 patch
+      const int sxh = d.transposed ? 1 : d.sh, sxw = d.transposed ? 1 : d.sw;
+      const int e0w = d.transposed ? d.pw - (d.kw - 1) * d.dw : -d.pw;
+      const int ext_d = (d.kd - 1) * d.dd + 1, ext_h = (4 * nt - 1) * sxh + (d.kh - 1) * d.dh + 1, ext_w = 31 * sxw + (d.kw - 1) * d.dw + 1;
+      const int rs = ((((e0w % 4) + 4) % 4 + ext_w + 3) / 4) * 4;
+      return (long long)8 * ext_d * ext_h * rs * 4;
+    };
+    const long long wbytes = (long long)T * KT * 16;
+    static const int bf_lds = env_int("DPF_G2_BF_LDS", 76 * 1024);
+    auto fits = [&](int nt, long long budget) { return patch_for(nt) + wbytes <= budget && patch_for(nt) <= 2LL * NLD * 256 * 16; };
+    if (MT <= 2 && fits(4, bf_lds)) NT = 4;
+    else if (fits(2, 80 * 1024)) NT = 2;
+    else bf = false;                    // e.g. stride-2 forward patches: exact-f32 kernel below
+    if (bf && (nt_over == 2 || (nt_over == 4 && MT <= 2)) && fits(nt_over, 80 * 1024)) NT = nt_over;
+  }
   const int TH = 4 * NT;
 
   G2P p{};
@@ -694,14 +808,17 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
       if (2 * buf_bytes(cc) <= (size_t)lds_target && nseg_of(cc) <= NLD * 256) { CC = cc; break; }
   if (cc_over == 2 || cc_over == 4 || cc_over == 8) CC = cc_over;
   if (!CC) CC = 2;
-  if (nseg_of(CC) > NLD * 256 || 2 * buf_bytes(CC) > 160 * 1024) return DPF_ERR_UNSUPPORTED;
+  if (bf) CC = 8;
+  const size_t bf_buf = (size_t)8 * p.chanStride * sizeof(float) + (size_t)T * KT * 16;
+  if (bf ? (nseg_of(8) > 2 * NLD * 256 || 2 * bf_buf > 160 * 1024) : (nseg_of(CC) > NLD * 256 || 2 * buf_bytes(CC) > 160 * 1024))
+    return DPF_ERR_UNSUPPORTED;
   p.nseg = nseg_of(CC);
-  p.nwseg = T * CC * KT / 4;
+  p.nwseg = bf ? T * KT : T * CC * KT / 4;
   p.nchunks = (d.C + CC - 1) / CC;
   p.tilesH = dpf_div_up(d.OH, TH);
   p.tilesW = dpf_div_up(d.OW, 32);
   p.mSR = magic20(p.SR); p.mRPC = magic20(p.rpc); p.mEH = magic20(p.ext_h);
-  if ((long long)NLD * 256 * (p.SR > p.rpc ? p.SR : p.rpc) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
+  if ((long long)(bf ? 2 : 1) * NLD * 256 * (p.SR > p.rpc ? p.SR : p.rpc) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
   const long long ntiles = (long long)d.N * d.OD * p.tilesH * p.tilesW;
   if (ntiles <= 0 || ntiles > 0x3fffffffLL) return DPF_ERR_INVALID_ARG;
   p.ntiles = (int)ntiles;
@@ -709,16 +826,33 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   const long long blocks = 8LL * p.cpx;
 
   const long long total = (long long)p.nchunks * T * CC * KT + ZPAGE;
-  hipLaunchKernelGGL(igemm2_pack_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, ws, d.wA, d.wB, T, KT, CC, p.nchunks, d.mode, d.k0, d.K, d.C);
+  if (bf)
+    hipLaunchKernelGGL(igemm2_pack_bf16_kernel, dim3(dpf_ew_grid(total + ZPAGE)), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(ws), d.wA,
+                       d.wB, T, KT, p.nchunks, d.mode, d.k0, d.K, d.C);
+  else
+    hipLaunchKernelGGL(igemm2_pack_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, ws, d.wA, d.wB, T, KT, CC, p.nchunks, d.mode, d.k0, d.K, d.C);
   if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
 
-  const size_t lds = 2 * buf_bytes(CC);
+  const size_t lds = bf ? 2 * bf_buf : 2 * buf_bytes(CC);
   p.stats = nullptr;
   if (stats) {
     if (ntiles * d.K * 2 > stats->capacity_doubles || lds < (size_t)4 * 2 * MT * 16 * 2 * sizeof(double)) return DPF_ERR_UNSUPPORTED;
     p.stats = stats->slab;
     stats->parts = (int)ntiles;
   }
+#define G2B(M, N_) return launch_g2<M, N_, 8, true>(x, ws, bias, out, p, lds, blocks, st)
+  if (bf) {
+    if (NT == 4) {
+      if (MT == 1) { G2B(1, 4); } else { G2B(2, 4); }
+    }
+    switch (MT) {
+      case 1: G2B(1, 2);
+      case 2: G2B(2, 2);
+      case 3: G2B(3, 2);
+      default: G2B(4, 2);
+    }
+  }
+#undef G2B
 #define G2(M, N_, C_) return launch_g2<M, N_, C_>(x, ws, bias, out, p, lds, blocks, st)
 #define G2CC(M, N_)                                                                                                         \
   switch (CC) { case 8: G2(M, N_, 8); case 4: G2(M, N_, 4); default: G2(M, N_, 2); }

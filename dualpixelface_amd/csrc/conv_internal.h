@@ -14,6 +14,10 @@ struct DpfConvDesc {
   int accumulate;               // 1: out += result (data gradients of several consumers of one tensor summed in the epilogue)
 };
 
+// operand precision of the dense convolution kernels (dpf_set_conv_operand_precision): 0 = exact fp32, 1 = operands rounded to bf16
+// (RNE) in the staging path, fp32 accumulation and storage
+int dpf_conv_operand_bf16();
+
 // LDS-DMA double-buffered implicit GEMM (conv_igemm2.hip).  Returns DPF_OK when it launched, DPF_ERR_UNSUPPORTED when the
 // shape is not eligible (the caller then uses the generic kernel), another error code on failure.
 // optional per-tile BatchNorm statistics of a forward launch: slab [parts][K][2] doubles (sum, sum of squares of the outputs)

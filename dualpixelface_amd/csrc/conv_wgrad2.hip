@@ -47,6 +47,18 @@ struct W2P {
   long long slab_stride;       // floats between position-chunk slabs  (K * C * T)
 };
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// four floats -> four bf16 (round to nearest even): two v_cvt_pk_bf16_f32
+__device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) {
+  const f32x2 lo = {a, b}, hi = {c, d};
+  const u32x2 u = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2))};
+  return __builtin_bit_cast(s16x4, u);
+}
+
 __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
@@ -58,7 +70,10 @@ constexpr int w2_occ_of(int nct) {
 template <int NCT>
 constexpr int w2_occ() { return w2_occ_of(NCT); }
 
-template <int NCT>
+// BF = true (operand precision "bf16"): the 4 positions a lane half holds of a group are exactly the 4 reduction indices a lane half
+// feeds to v_mfma_f32_32x32x8_bf16, so a (group, column tile) unit is ONE bf16 MFMA on the RNE-rounded g / x values instead of four
+// exact-f32 ones; staging, fp32 accumulation, slab fold are unchanged.
+template <int NCT, bool BF = false>
 __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                      float* __restrict__ slab, W2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -204,13 +219,22 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
       }
     };
     auto mfmas = [&](int pr, const f32x4& a, const float (&bb)[2][4]) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
+      if constexpr (BF) {
+        const s16x4 av = pack4_bf16(a[0], a[1], a[2], a[3]);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int t = 2 * pr + u;
-          if (t < NCT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[u][i], acc[t], 0, 0, 0);
+          if (t < NCT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(av, pack4_bf16(bb[u][0], bb[u][1], bb[u][2], bb[u][3]), acc[t], 0, 0, 0);
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int t = 2 * pr + u;
+            if (t < NCT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[u][i], acc[t], 0, 0, 0);
+          }
+      }
     };
     auto touch = [&](const f32x4& a, const float (&bb)[2][4], int pr) {
       asm volatile("" ::"v"(a));
@@ -333,16 +357,20 @@ int gather_conflicts(const DpfWgradDesc& d, int T, int ncolmax, int RS, int PS, 
   return total;
 }
 
-template <int NCT>
-int launch_w2(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
+template <int NCT, bool BF>
+int launch_w2b(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
   static bool done = false;
   if (lds > 48 * 1024 && !done) {
-    if (hipFuncSetAttribute((const void*)wgrad2_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)wgrad2_kernel<NCT, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return DPF_ERR_LAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((wgrad2_kernel<NCT>), dim3(blocks), dim3(256), lds, st, g, x, slab, p);
+  hipLaunchKernelGGL((wgrad2_kernel<NCT, BF>), dim3(blocks), dim3(256), lds, st, g, x, slab, p);
   return dpf_check_launch();
+}
+template <int NCT>
+int launch_w2(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
+  return dpf_conv_operand_bf16() ? launch_w2b<NCT, true>(g, x, slab, p, lds, blocks, st) : launch_w2b<NCT, false>(g, x, slab, p, lds, blocks, st);
 }
 
 int w2_maxblocks() { return 1024; }     // upper bound of resident workgroups (4 per CU): sizes the slab workspace

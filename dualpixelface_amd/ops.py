@@ -107,6 +107,33 @@ def _t3(v):
 
 
 # ----------------------------------------------------------------------------------------------- convolution
+CONV_OPERANDS_BF16 = False      # current operand precision of the dense conv kernels; the autograd functions capture it at forward time
+
+
+class conv_operands(object):
+    """``with conv_operands(True):`` dense convolutions launched inside round their operands to bf16 while staging them (fp32
+    accumulation, fp32 tensors): the reference's ``precision: 16`` for its Conv2d / Conv3d layers.  Backward passes re-enter the
+    precision their forward ran with."""
+
+    def __init__(self, bf16):
+        self.bf16 = bool(bf16)
+
+    def __enter__(self):
+        global CONV_OPERANDS_BF16
+        self.prev = CONV_OPERANDS_BF16
+        if self.bf16 != self.prev:
+            lib().call('dpf_set_conv_operand_precision', int(self.bf16))
+            CONV_OPERANDS_BF16 = self.bf16
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_OPERANDS_BF16
+        if self.bf16 != self.prev:
+            lib().call('dpf_set_conv_operand_precision', int(self.prev))
+            CONV_OPERANDS_BF16 = self.prev
+        return False
+
+
 def _out_dim(i, k, s, p, d):
     return (i + 2 * p - (d * (k - 1) + 1)) // s + 1
 
@@ -258,6 +285,7 @@ class ConvFn(torch.autograd.Function):
         ctx.gi_channels = gi_channels
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.bf16 = CONV_OPERANDS_BF16
         return _conv_fwd_raw(x, w, bias, stride, pad, dil, stats)
 
     @staticmethod
@@ -266,10 +294,11 @@ class ConvFn(torch.autograd.Function):
         stride, pad, dil = ctx.cfg
         gy = _c(gy)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = _conv_transpose_raw(gy, w, None, x.shape[2:], w.shape[2:], stride, pad, dil, k_needed=ctx.gi_channels)
-        if ctx.needs_input_grad[1]:
-            gw = _wgrad_dispatch(w, gy, x, w.shape, stride, pad, dil)
+        with conv_operands(ctx.bf16):
+            if ctx.needs_input_grad[0]:
+                gx = _conv_transpose_raw(gy, w, None, x.shape[2:], w.shape[2:], stride, pad, dil, k_needed=ctx.gi_channels)
+            if ctx.needs_input_grad[1]:
+                gw = _wgrad_dispatch(w, gy, x, w.shape, stride, pad, dil)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _channel_sum(gy)
         return gx, gw, gb, None, None, None, None, None
@@ -287,6 +316,7 @@ class ConvTransposeFn(torch.autograd.Function):
         out_dims = tuple((x.shape[2 + i] - 1) * stride[i] - 2 * pad[i] + ks[i] + outpad[i] for i in range(3))
         ctx.cfg = (stride, pad, dil)
         ctx.save_for_backward(x, w)
+        ctx.bf16 = CONV_OPERANDS_BF16
         return _conv_transpose_raw(x, w, None, out_dims, ks, stride, pad, dil)
 
     @staticmethod
@@ -295,10 +325,11 @@ class ConvTransposeFn(torch.autograd.Function):
         stride, pad, dil = ctx.cfg
         gy = _c(gy)
         gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = _conv_fwd_raw(gy, w, None, stride, pad, dil)          # w read as [K=C_in][C=C_out][T]
-        if ctx.needs_input_grad[1]:
-            gw = _wgrad_dispatch(w, x, gy, w.shape, stride, pad, dil)  # g := x (strided grid), x := gy (dense grid)
+        with conv_operands(ctx.bf16):
+            if ctx.needs_input_grad[0]:
+                gx = _conv_fwd_raw(gy, w, None, stride, pad, dil)          # w read as [K=C_in][C=C_out][T]
+            if ctx.needs_input_grad[1]:
+                gw = _wgrad_dispatch(w, x, gy, w.shape, stride, pad, dil)  # g := x (strided grid), x := gy (dense grid)
         return gx, gw, None, None, None
 
 

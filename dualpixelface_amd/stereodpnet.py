@@ -194,8 +194,12 @@ class StereoDPNetCore(_Base):
         self._tables = {}
         self._pending_counts = {}
         self.stat_exchange = None          # distributed.StatExchange -> SyncBatchNorm (see enable_sync_batchnorm)
-        # mixed precision: the reference's `precision: 16` is PL autocast; here 16 / 'bf16' select bf16-operand 2-D convs
-        self.bf16_2d = str(getattr(option, 'precision', 32)) in ('16', 'bf16')
+        # mixed precision: the reference's `precision: 16` is PL autocast (every nn.Conv2d / nn.Conv3d in half precision).  Here 16 / 'bf16'
+        # make the dense conv kernels round their operands to bf16 (fp32 accumulation, fp32 tensors; ops.conv_operands); 'bf16-2d' is
+        # BASELINE configs[4] read literally: only the 2-D convs, on the stand-alone bf16 kernel (conv_bf16.hip).
+        prec = str(getattr(option, 'precision', 32))
+        self.bf16_all = prec in ('16', 'bf16')
+        self.bf16_2d = prec == 'bf16-2d'
         self._build_parameters(self._spec(option))
 
     @staticmethod
@@ -344,7 +348,7 @@ class StereoDPNetCore(_Base):
         # DPF_CONV_BN_CAT=1: conv + BatchNorm + cat as ONE autograd node whose backward sums the three data gradients in the transposed-conv
         # epilogue (ops.ConvBnCatFn).  Measured +0.2 % on the step (the epilogue's read-modify-write costs what the two add passes cost), so
         # the default keeps the convolutions as plain launches and only fuses BatchNorm + cat.
-        if self.bf16_2d or os.environ.get('DPF_CONV_BN_CAT', '0') != '1':
+        if self.bf16_2d or self.bf16_all or os.environ.get('DPF_CONV_BN_CAT', '0') != '1':
             branches = []
             for q, d in zip(prefixes, dilations):
                 y = ops.conv2d(x, P[q + '.0.weight'], None, 1, d if d > 1 else 1, d, bf16=self.bf16_2d)
@@ -549,6 +553,10 @@ class StereoDPNetCore(_Base):
 
     # ------------------------------------------------------------------ whole network (mainmodel.py:67-104)
     def network(self, batch):
+        with ops.conv_operands(self.bf16_all):
+            return self._network(batch)
+
+    def _network(self, batch):
         opt = self.option
         a, b = 'left', 'right'
         if 'groupname' in batch and not self.training:

@@ -242,28 +242,34 @@ def test_validation_step_runs_the_metric_hooks():
     model.validation_epoch_end([results])
 
 
-def test_bf16_mixed_precision_mode_tracks_fp32(golden_dir):
-    """option.precision = 'bf16' (BASELINE config 5: bf16-operand 2-D convs, fp32 everywhere else): same graph; outputs within
-    bf16 rounding of the fp32 golden run.  8 mantissa bits through ~70 conv + BatchNorm layers of a random-weight network move
-    the soft-argmin by 0.05 px on average (0.4 px worst pixel, measured: tools/bf16_check.py): mean |d disp| <= 0.1 px,
-    max <= 1 px, mean |d normal| <= 0.05, loss within 1 %.  The operator itself is checked to 1e-5 in test_gpu_ops.py."""
-    from dualpixelface_amd import load_option
+@pytest.mark.parametrize('precision', ['bf16', 'bf16-2d'])
+def test_bf16_mixed_precision_mode_tracks_fp32(golden_dir, precision):
+    """option.precision = 'bf16' / 16 (the reference's PL `precision: 16`: every dense conv with bf16 operands, fp32 accumulation and
+    tensors) and 'bf16-2d' (BASELINE config 5 read literally: the 2-D convs only): same graph; outputs within bf16 rounding of the
+    fp32 golden run.  8 mantissa bits through ~70 conv + BatchNorm layers of a random-weight network move the soft-argmin by a few
+    hundredths of a pixel on average: mean |d disp| <= 0.1 px, max <= 1 px, mean |d normal| <= 0.05, loss within 1 % (2 % with the 3-D
+    aggregation in bf16 as well).  The operators themselves are checked to 1e-5 in test_gpu_ops.py."""
+    from dualpixelface_amd import load_option, ops
     from dualpixelface_amd.plugin import STEREODPNET
     from dualpixelface_amd.recipe import fill_by_recipe
     g = np.load(golden_dir + '/e2e_train_32x48_b2.npz')
     opt = load_option()
-    opt.precision = 'bf16'
+    opt.precision = precision
     model = STEREODPNET(opt)
     fill_by_recipe(model)
     model.to(DEV).train()
-    assert model.bf16_2d
+    assert model.bf16_all == (precision == 'bf16') and model.bf16_2d == (precision == 'bf16-2d')
     res = model.forward(load_batch(g))
+    assert not ops.CONV_OPERANDS_BF16                     # the precision does not leak out of the forward
     assert torch.isfinite(res['final_loss'])
     d = (res['pred_depth'].detach().cpu() - torch.from_numpy(g['pred_depth'])).abs()
-    assert float(d.mean()) <= 0.1 and float(d.max()) <= 1.0, (float(d.mean()), float(d.max()))
     dn = (res['pred_normal'].detach().cpu() - torch.from_numpy(g['pred_normal'])).abs()
-    assert float(dn.mean()) <= 0.05, float(dn.mean())
-    assert abs(float(res['final_loss']) - float(g['final_loss'])) <= 1e-2 * abs(float(g['final_loss']))
+    dl = abs(float(res['final_loss']) - float(g['final_loss'])) / abs(float(g['final_loss']))
+    measured = (float(d.mean()), float(d.max()), float(dn.mean()), dl)
+    assert float(d.mean()) <= 0.1 and float(d.max()) <= 1.0, measured
+    assert float(dn.mean()) <= 0.05, measured
+    assert dl <= (2e-2 if precision == 'bf16' else 1e-2), measured
+    assert float(d.mean()) > 1e-5, ('bf16 kernels not engaged?', measured)
     res['final_loss'].backward()
     gsum = sum(float(p.grad.abs().sum()) for p in model.parameters() if p.grad is not None)
     assert np.isfinite(gsum) and gsum > 0

@@ -530,6 +530,53 @@ def test_conv2d_bf16_operands(case):
     close(gb, go.sum((0, 2, 3)), 1e-4, 'bgrad')
 
 
+BF16_OPERAND_CASES = [c for c in CONV_CASES if c[4] % 4 == 0 and c[6] != (1, 1, 1) and c[5] > 4]
+
+
+@pytest.mark.parametrize('case', BF16_OPERAND_CASES)
+def test_conv_operands_bf16(case):
+    """ops.conv_operands(True) (precision 16 / 'bf16'): the LDS-DMA kernels round their operands to bf16 while staging them.  A launch must
+    equal an fp32 convolution of the bf16-rounded operands up to summation order (products of bf16 values are exact in fp32) -- 1e-5 of
+    the tensor scale for forward / data gradient, 2e-4 for the weight gradient -- or, for the launches the bf16 kernels do not cover
+    (8-channel stride-2 patches do not fit the LDS; > 128 output rows; the class-fused stride-2 data gradient), the exact fp32 result.
+    The 3x3x3 stride-1 cases must take the bf16 kernels in all three directions."""
+    ops = _ops()
+    N, C, D, H, W, K, ks, st, pd, dl = case
+    x = rnd(N, C, D, H, W, seed=1)
+    w = rnd(K, C, *ks, seed=2, scale=0.1)
+    b = rnd(K, seed=3)
+    rb = lambda t: t.bfloat16().float()
+    xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+    with ops.conv_operands(True):
+        y = ops.ConvFn.apply(xg, wg, bg, st, pd, dl)
+    assert not ops.CONV_OPERANDS_BF16
+    go = rnd(*y.shape, seed=4)
+    gx, gw, gb = torch.autograd.grad(y, (xg, wg, bg), go.to(DEV))          # outside the context: the node re-enters its precision
+
+    def refs(xx, ww, gg):
+        xx, ww = xx.clone().requires_grad_(), ww.clone().requires_grad_()
+        yy = F.conv3d(xx, ww, b, st, pd, dl)
+        return (yy.detach(),) + torch.autograd.grad(yy, (xx, ww), gg)
+
+    y_b, gx_b, gw_b = refs(rb(x), rb(w), rb(go))
+    y_f, gx_f, gw_f = refs(x, w, go)
+    must = ks == (3, 3, 3) and st == (1, 1, 1) and K <= 128 and C <= 128
+    for name, got, ref_b, ref_f, tol in (('fwd', y, y_b, y_f, 1e-5), ('dgrad', gx, gx_b, gx_f, 1e-5), ('wgrad', gw, gw_b, gw_f, 2e-4)):
+        scale = float(ref_f.abs().max())
+        # one launch covers <= 128 output channels and picks its kernel on its own (27 x 128 bf16 weight rows + the patch exceed the LDS)
+        step = 128 if name != 'wgrad' else got.shape[0]
+        for c0 in range(0, got.shape[1] if name != 'wgrad' else 1, step):
+            sl = (slice(None), slice(c0, c0 + step)) if name != 'wgrad' else (slice(None),)
+            eb, ef = float((got.cpu()[sl] - ref_b[sl]).abs().max()) / scale, float((got.cpu()[sl] - ref_f[sl]).abs().max()) / scale
+            assert min(eb, ef) < tol, (name, c0, eb, ef)
+            if must:
+                assert eb < ef, (name, 'expected the bf16-operand kernel', eb, ef)
+    close(gb, go.sum((0, 2, 3, 4)), 1e-4, 'bgrad')
+    # and the default precision is untouched afterwards
+    y32 = ops.ConvFn.apply(xg, wg, bg, st, pd, dl)
+    close(y32, y_f, 1e-4, 'fp32 after the context')
+
+
 def test_avg_pool_and_resize_and_psm_volume_backward():
     """PSMNet-specific operators: AvgPool2d(k, k), bilinear resize to an arbitrary size (align_corners=True, incl. from 1x1), and the
     gradient of the integer-shift volume (concat and group-wise correlation) against autograd through the oracle."""
