@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PIXEL_FWD_BWD = 2.708e6        # SURVEY.md section 8d (fwd 902 764 FLOP/pixel/pair, fwd+bwd = 3x)
 PEAK_F32_TFLOPS = 157.3                 # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0               # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
 def cpu_baseline(threads, H=512, W=768):
@@ -224,7 +225,10 @@ def main():
                 rec = json.load(open(tpath)).get(fam_key)
                 if rec:
                     traffic = rec['hbm_bytes_per_launch']
-            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
+            # the dense conv kernels contract on the bf16 matrix cores in --precision bf16: price them against THAT peak (they are then
+            # staging-bound -- LDS-DMA / LDS reads of the fp32 patch -- far below it)
+            peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                     'traffic': traffic, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n, 'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed,
                     'families': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3} for k, v in fam.items()}}
         pixels = args.height * args.width

@@ -42,6 +42,7 @@ struct G2P {
   unsigned mSR, mRPC, mEH;      // ceil(2^20 / d) for d = SR, rpc, ext_h
   unsigned long long steps;     // 2-bit step code per tap (see the kernel's tap walk)
   int accum;                    // 1: out += result
+  int single;                   // 1: one LDS buffer (more resident workgroups hide the DMA instead of a second buffer)
   double* stats;                // optional [ntiles][K][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
@@ -72,8 +73,14 @@ constexpr int g2_occ() {
 // bf16 [tap][half][k][4], and a tap is ONE v_mfma_f32_32x32x8_bf16 per (row tile, position row): a lane reads its 4 channels of the
 // fp32 patch, rounds them to bf16 (RNE) and contracts 8 channels at once -- 1/8 of the matrix-pipe cycles of the exact-f32 path,
 // fp32 accumulation, fp32 output.  The result equals an fp32 convolution of the bf16-rounded operands up to summation order.
+template <int MT, int NT>
+constexpr int g2_occ_bf() {
+  constexpr int est = MT * NT * 16 + 2 * (2 * MT + 4 * NT) + 2 * NLD + 44;
+  return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
+}
+
 template <int MT, int NT, int CC, bool BF = false>
-__global__ __launch_bounds__(256, (BF ? 2 : g2_occ<MT, NT, CC>())) void igemm2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+__global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>())) void igemm2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                                          const float* __restrict__ bias, float* __restrict__ out, G2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(!BF || CC == 8, "the bf16 path contracts 8 channels per MFMA");
@@ -161,9 +168,10 @@ __global__ __launch_bounds__(256, (BF ? 2 : g2_occ<MT, NT, CC>())) void igemm2_k
   const int nv = p.T;
   const int tap0 = p.tap0, stepC = p.stepC, dB = p.incB - p.stepC, dA = p.incA - p.incB, chanStride = p.chanStride;
   const unsigned long long steps = p.steps;
+  const int single = p.single;
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    const int buf = chunk & 1;
-    if (chunk + 1 < p.nchunks) issue(chunk + 1, buf ^ 1);
+    const int buf = single ? 0 : chunk & 1;
+    if (!single && chunk + 1 < p.nchunks) issue(chunk + 1, buf ^ 1);
     const float* s_in = smem + buf * bufFloats;
     const float* s_w = s_in + patchFloats;
     if constexpr (BF) {
@@ -278,6 +286,10 @@ __global__ __launch_bounds__(256, (BF ? 2 : g2_occ<MT, NT, CC>())) void igemm2_k
     }
     __builtin_amdgcn_sched_barrier(0);                           // keep the MFMAs of this chunk in front of the DMA wait
     __syncthreads();                                             // vmcnt(0): chunk+1 landed; barrier: this buffer is free
+    if (single && chunk + 1 < p.nchunks) {
+      issue(chunk + 1, 0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: D row = (j&3) + 8*(j>>2) + 4*(lane>>5), col = lane&31
@@ -741,6 +753,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   // operand precision "bf16" (dpf_set_conv_operand_precision): 8-channel chunks; 16 position rows per workgroup when two buffers
   // of that patch fit the LDS, else 8
   bool bf = dpf_conv_operand_bf16() != 0 && T > 1;
+  int p_single = 0;
   if (bf) {
     auto patch_for = [&](int nt) {      // bytes of an 8-channel fp32 patch
       const int sxh = d.transposed ? 1 : d.sh, sxw = d.transposed ? 1 : d.sw;
@@ -750,12 +763,31 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
       return (long long)8 * ext_d * ext_h * rs * 4;
     };
     const long long wbytes = (long long)T * KT * 16;
-    static const int bf_lds = env_int("DPF_G2_BF_LDS", 76 * 1024);
-    auto fits = [&](int nt, long long budget) { return patch_for(nt) + wbytes <= budget && patch_for(nt) <= 2LL * NLD * 256 * 16; };
-    if (MT <= 2 && fits(4, bf_lds)) NT = 4;
-    else if (fits(2, 80 * 1024)) NT = 2;
-    else bf = false;                    // e.g. stride-2 forward patches: exact-f32 kernel below
-    if (bf && (nt_over == 2 || (nt_over == 4 && MT <= 2)) && fits(nt_over, 80 * 1024)) NT = nt_over;
+    // (rows per workgroup, one or two LDS buffers): the candidate with the most resident workgroups per CU wins (LDS and the
+    // register budget of the instantiation; more than 3 buys nothing) -- at equal residency two buffers beat one and 16 rows beat 8
+    // (less halo).  tools/conv_bf16_bench.py: the 3-D K = 32 convs run 2x faster on 8 rows x 1 buffer (3 resident) than on 2 buffers.
+    static const int single_over = env_int("DPF_G2_BF_SINGLE", -1);
+    auto occ_regs = [&](int nt) {
+      const int est = MT * nt * 16 + 2 * (2 * MT + 4 * nt) + 2 * NLD + 44;
+      return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
+    };
+    int best = -1;
+    for (int nt : {4, 2}) {
+      if ((nt == 4 && MT > 2) || patch_for(nt) > 2LL * NLD * 256 * 16) continue;
+      if ((nt_over == 2 || nt_over == 4) && nt != nt_over) continue;
+      for (int single = 0; single < 2; ++single) {
+        if (single_over >= 0 && single != single_over) continue;
+        const long long lds_c = (single ? 1 : 2) * (patch_for(nt) + wbytes);
+        if (lds_c > 160 * 1024) continue;
+        int resid = (int)(160 * 1024 / lds_c);
+        if (resid > occ_regs(nt)) resid = occ_regs(nt);
+        if (resid > 3) resid = 3;
+        const int score = resid * 4 + (single ? 0 : 2) + (nt == 4 ? 1 : 0);
+        if (score > best) { best = score; NT = nt; p_single = single; }
+      }
+    }
+    if (best < 0) { bf = false; p_single = 0; }     // e.g. stride-2 forward patches: exact-f32 kernel below
+    if (!bf) { NT = MT == 1 ? 4 : 2; if (nt_over == 2 || (nt_over == 4 && MT <= 2)) NT = nt_over; }
   }
   const int TH = 4 * NT;
 
@@ -833,7 +865,8 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
     hipLaunchKernelGGL(igemm2_pack_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, ws, d.wA, d.wB, T, KT, CC, p.nchunks, d.mode, d.k0, d.K, d.C);
   if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
 
-  const size_t lds = bf ? 2 * bf_buf : 2 * buf_bytes(CC);
+  p.single = p_single;
+  const size_t lds = bf ? (p_single ? 1 : 2) * bf_buf : 2 * buf_bytes(CC);
   p.stats = nullptr;
   if (stats) {
     if (ntiles * d.K * 2 > stats->capacity_doubles || lds < (size_t)4 * 2 * MT * 16 * 2 * sizeof(double)) return DPF_ERR_UNSUPPORTED;

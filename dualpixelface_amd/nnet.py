@@ -122,7 +122,7 @@ class NNetCore(PSMNetCore):
         f = ops.upsample_bilinear(f, 4)
         return ops.l2_normalize(f)
 
-    def network(self, batch):
+    def _network(self, batch):
         """NNET.forward without the loss (mainmodel.py:112-167)."""
         opt, m = self.option, self.option.model
         a, b = 'left', 'right'

@@ -92,7 +92,7 @@ class PSMNetCore(StereoDPNetCore):
         feat = self._convbn2(feat, p + '.lastconv.0', act=ACT_RELU)
         return self._conv2d(feat, P[p + '.lastconv.2.weight'])
 
-    def network(self, batch):
+    def _network(self, batch):
         """PSMNET.forward without the loss (psmnet/mainmodel.py:67-97)."""
         opt, m = self.option, self.option.model
         a, b = 'left', 'right'

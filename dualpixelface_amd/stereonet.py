@@ -89,7 +89,7 @@ class StereoNetCore(StereoDPNetCore):
         out = self._conv2d(x, P[p + '.conv2d_out.weight'], P[p + '.conv2d_out.bias'], 1, 1, 1)
         return ops.norm_act(out, res=up, act=ACT_RELU).squeeze(1)                      # ReLU(twice_disparity + conv2d_out)
 
-    def network(self, batch):
+    def _network(self, batch):
         """STEREONET.forward without the loss (mainmodel.py:79-141)."""
         opt = self.option
         a, b = 'left', 'right'
