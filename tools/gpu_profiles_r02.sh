@@ -7,7 +7,11 @@ mkdir -p gpurun_out/r02
 python bench.py --shapes gpurun_out/r02/r02_conv_shape_table.txt > gpurun_out/r02/r02_bench.json 2> gpurun_out/r02/bench.err
 python bench.py --height 512 --width 768 --no-cpu-baseline > gpurun_out/r02/r02_bench_c2_512x768.json 2>> gpurun_out/r02/bench.err
 python bench.py --model psmnet --batch 2 --no-cpu-baseline > gpurun_out/r02/r02_bench_c4_psmnet_train.json 2>> gpurun_out/r02/bench.err
-python bench.py --precision bf16 --no-cpu-baseline > gpurun_out/r02/r02_bench_c5_bf16_b4.json 2>> gpurun_out/r02/bench.err
+python bench.py --precision bf16 --no-cpu-baseline --shapes gpurun_out/r02/r02_conv_shape_table_bf16.txt > gpurun_out/r02/r02_bench_c5_bf16_b4.json 2>> gpurun_out/r02/bench.err
+python bench.py --precision bf16-2d --no-cpu-baseline > gpurun_out/r02/r02_bench_c5_bf16_2d_only.json 2>> gpurun_out/r02/bench.err
+python bench.py --wgrad-async --no-cpu-baseline > gpurun_out/r02/r02_bench_wgrad_async.json 2>> gpurun_out/r02/bench.err
+python bench.py --precision bf16 --wgrad-async --no-cpu-baseline > gpurun_out/r02/r02_bench_c5_bf16_wgrad_async.json 2>> gpurun_out/r02/bench.err
+python tools/conv_bf16_bench.py > gpurun_out/r02/r02_conv_bf16_vs_f32_per_shape.txt 2>> gpurun_out/r02/bench.err
 python bench.py --workload cost_volume --no-cpu-baseline > gpurun_out/r02/r02_bench_cost_volume_stage.json 2>> gpurun_out/r02/bench.err
 python bench.py --workload cost_volume_fix --no-cpu-baseline > gpurun_out/r02/r02_bench_cost_volume_fix_stage.json 2>> gpurun_out/r02/bench.err
 python bench.py --model nnet --batch 2 --no-cpu-baseline > gpurun_out/r02/r02_bench_nnet_train.json 2>> gpurun_out/r02/bench.err
@@ -16,6 +20,8 @@ python tools/facedp_bench.py --out gpurun_out/r02/r02_facedp_bench.json > /dev/n
 python bench.py --workload psm_volume --batch 2 --no-cpu-baseline > gpurun_out/r02/r02_bench_psm_volume.json 2>> gpurun_out/r02/bench.err
 bash tools/gpu_prof.sh r02 > gpurun_out/r02/r02_bench_family_ms.txt 2>&1
 cp gpurun_out/prof_r02_kernel_stats.csv gpurun_out/r02/r02_bench_kernel_stats.csv
+bash tools/gpu_prof.sh r02bf16 --precision bf16 > gpurun_out/r02/r02_bench_c5_bf16_family_ms.txt 2>&1
+cp gpurun_out/prof_r02bf16_kernel_stats.csv gpurun_out/r02/r02_bench_c5_bf16_kernel_stats.csv
 rm -rf gpurun_out/pmc_f2 gpurun_out/pmc_w2
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f2 -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w2 -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
