@@ -11,6 +11,10 @@ python bench.py --precision bf16 --no-cpu-baseline --shapes gpurun_out/r02/r02_c
 python bench.py --precision bf16-2d --no-cpu-baseline > gpurun_out/r02/r02_bench_c5_bf16_2d_only.json 2>> gpurun_out/r02/bench.err
 python bench.py --wgrad-async --no-cpu-baseline > gpurun_out/r02/r02_bench_wgrad_async.json 2>> gpurun_out/r02/bench.err
 python bench.py --precision bf16 --wgrad-async --no-cpu-baseline > gpurun_out/r02/r02_bench_c5_bf16_wgrad_async.json 2>> gpurun_out/r02/bench.err
+python bench.py --model psmnet --batch 2 --precision bf16 --no-cpu-baseline > gpurun_out/r02/r02_bench_psmnet_bf16.json 2>> gpurun_out/r02/bench.err
+python bench.py --model nnet --batch 2 --precision bf16 --no-cpu-baseline > gpurun_out/r02/r02_bench_nnet_bf16.json 2>> gpurun_out/r02/bench.err
+python bench.py --model stereonet --precision bf16 --no-cpu-baseline > gpurun_out/r02/r02_bench_stereonet_bf16.json 2>> gpurun_out/r02/bench.err
+python bench.py --height 512 --width 768 --precision bf16 --no-cpu-baseline > gpurun_out/r02/r02_bench_c2_512x768_bf16.json 2>> gpurun_out/r02/bench.err
 python tools/conv_bf16_bench.py > gpurun_out/r02/r02_conv_bf16_vs_f32_per_shape.txt 2>> gpurun_out/r02/bench.err
 python bench.py --workload cost_volume --no-cpu-baseline > gpurun_out/r02/r02_bench_cost_volume_stage.json 2>> gpurun_out/r02/bench.err
 python bench.py --workload cost_volume_fix --no-cpu-baseline > gpurun_out/r02/r02_bench_cost_volume_fix_stage.json 2>> gpurun_out/r02/bench.err
