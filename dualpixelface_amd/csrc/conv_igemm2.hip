@@ -445,7 +445,7 @@ constexpr T2Table t2_table() {
   return tb;
 }
 
-template <int CC>
+template <int CC, bool BF = false>
 __global__ __launch_bounds__(256, 2) void igemm2_tr2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, float* __restrict__ out, T2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -461,8 +461,9 @@ __global__ __launch_bounds__(256, 2) void igemm2_tr2_kernel(const float* __restr
   const int n = b / p.tilesH;
   const int q0h = th * 4, q0w = tw * 32;
 
+  static_assert(!BF || CC == 8, "the bf16 path contracts 8 channels per MFMA");
   const int patchFloats = CC * p.chanStride;
-  const int bufFloats = patchFloats + 27 * CC * KT;
+  const int bufFloats = patchFloats + 4 * p.nwseg;
   const long long x_chan = (long long)p.ID * p.IH * p.IW;
   const float* xn = x + (long long)n * p.C * x_chan;
 
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void igemm2_tr2_kernel(const float* __restr
   const int planeStride = 5 * p.RS;
   int shoff[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) shoff[e] = (e >> 2) * planeStride + (wave + ((e >> 1) & 1)) * p.RS + l31 + (e & 1) + hh * p.chanStride;
+  for (int e = 0; e < 8; ++e) shoff[e] = (e >> 2) * planeStride + (wave + ((e >> 1) & 1)) * p.RS + l31 + (e & 1) + hh * (BF ? 4 : 1) * p.chanStride;
   const int abase = hh * KT + l31;
   const int chanStride = p.chanStride;
 
@@ -523,47 +524,96 @@ __global__ __launch_bounds__(256, 2) void igemm2_tr2_kernel(const float* __restr
     const int buf = chunk & 1;
     if (chunk + 1 < p.nchunks) issue(chunk + 1, buf ^ 1);
     const float* s_in = smem + buf * bufFloats;
-    const float* s_w = s_in + patchFloats + abase;
-    // units of (channel pair, shift) software pipelined over two register sets
-    float aA[8], aB[8], bA, bB;
-    auto load_unit = [&](int cp, int ui, float (&a)[8], float& bv) {
-      const T2Unit& u = TB.u[ui];
-      bv = s_in[shoff[u.e] + (2 * cp) * chanStride];
+    if constexpr (BF) {
+      // bf16 operands: a unit is one shift e; its B operand is the lane's 4 channels at that shift (rounded to bf16), its A operands
+      // the packed bf16 weights [tap][half][k][4] of the (class, tap) combinations the shift serves: one 32x32x8 MFMA each
+      const short* s_wb = reinterpret_cast<const short*>(s_in + patchFloats) + (hh * KT + l31) * 4;
+      s16x4 aA[8], aB[8];
+      float bA[4], bB[4];
+      auto load_unit = [&](int ui, s16x4 (&a)[8], float (&bv)[4]) {
+        const T2Unit& u = TB.u[ui];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < u.n) a[i] = s_w[(u.c[i].tap * CC + 2 * cp) * KT];
-    };
-    auto mfma_unit = [&](int ui, const float (&a)[8], float bv) {
-      const T2Unit& u = TB.u[ui];
+        for (int i = 0; i < 4; ++i) bv[i] = s_in[shoff[u.e] + i * chanStride];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < u.n) acc[u.c[i].cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv, acc[u.c[i].cls], 0, 0, 0);
-    };
-    auto touch = [&](int ui, const float (&a)[8], float bv) {
-      asm volatile("" ::"v"(bv));
+        for (int i = 0; i < 8; ++i)
+          if (i < u.n) a[i] = *reinterpret_cast<const s16x4*>(s_wb + u.c[i].tap * (8 * KT));
+      };
+      auto mfma_unit = [&](int ui, const s16x4 (&a)[8], const float (&bv)[4]) {
+        const T2Unit& u = TB.u[ui];
+        const u32x2 pk = {pk_bf16(bv[0], bv[1]), pk_bf16(bv[2], bv[3])};
+        const s16x4 b = __builtin_bit_cast(s16x4, pk);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < TB.u[ui].n) asm volatile("" ::"v"(a[i]));
-      asm volatile("" ::: "memory");
-    };
-    load_unit(0, 0, aA, bA);
+        for (int i = 0; i < 8; ++i)
+          if (i < u.n) acc[u.c[i].cls] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a[i], b, acc[u.c[i].cls], 0, 0, 0);
+      };
+      auto touch = [&](int ui, const s16x4 (&a)[8], const float (&bv)[4]) {
 #pragma unroll
-    for (int cp = 0; cp < CC / 2; ++cp) {
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(bv[i]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < TB.u[ui].n) asm volatile("" ::"v"(a[i]));
+        asm volatile("" ::: "memory");
+      };
+      load_unit(0, aA, bA);
 #pragma unroll
       for (int ui = 0; ui < 8; ++ui) {
-        const int ncp = ui + 1 < 8 ? cp : cp + 1, nui = ui + 1 < 8 ? ui + 1 : 0;
         if ((ui & 1) == 0) {
           touch(ui, aA, bA);
-          if (ncp < CC / 2) load_unit(ncp, nui, aB, bB);
+          if (ui + 1 < 8) load_unit(ui + 1, aB, bB);
           __builtin_amdgcn_sched_barrier(6);
           mfma_unit(ui, aA, bA);
           __builtin_amdgcn_sched_barrier(0);
         } else {
           touch(ui, aB, bB);
-          if (ncp < CC / 2) load_unit(ncp, nui, aA, bA);
+          if (ui + 1 < 8) load_unit(ui + 1, aA, bA);
           __builtin_amdgcn_sched_barrier(6);
           mfma_unit(ui, aB, bB);
           __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      const float* s_w = s_in + patchFloats + abase;
+      // units of (channel pair, shift) software pipelined over two register sets
+      float aA[8], aB[8], bA, bB;
+      auto load_unit = [&](int cp, int ui, float (&a)[8], float& bv) {
+        const T2Unit& u = TB.u[ui];
+        bv = s_in[shoff[u.e] + (2 * cp) * chanStride];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < u.n) a[i] = s_w[(u.c[i].tap * CC + 2 * cp) * KT];
+      };
+      auto mfma_unit = [&](int ui, const float (&a)[8], float bv) {
+        const T2Unit& u = TB.u[ui];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < u.n) acc[u.c[i].cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv, acc[u.c[i].cls], 0, 0, 0);
+      };
+      auto touch = [&](int ui, const float (&a)[8], float bv) {
+        asm volatile("" ::"v"(bv));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < TB.u[ui].n) asm volatile("" ::"v"(a[i]));
+        asm volatile("" ::: "memory");
+      };
+      load_unit(0, 0, aA, bA);
+#pragma unroll
+      for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+        for (int ui = 0; ui < 8; ++ui) {
+          const int ncp = ui + 1 < 8 ? cp : cp + 1, nui = ui + 1 < 8 ? ui + 1 : 0;
+          if ((ui & 1) == 0) {
+            touch(ui, aA, bA);
+            if (ncp < CC / 2) load_unit(ncp, nui, aB, bB);
+            __builtin_amdgcn_sched_barrier(6);
+            mfma_unit(ui, aA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            touch(ui, aB, bB);
+            if (ncp < CC / 2) load_unit(ncp, nui, aA, bA);
+            __builtin_amdgcn_sched_barrier(6);
+            mfma_unit(ui, aB, bB);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
@@ -673,14 +723,14 @@ int launch_g2(const float* x, const float* wpk, const float* bias, float* out, c
 
 
 namespace {
-template <int CC>
+template <int CC, bool BF = false>
 int launch_t2(const float* x, const float* wpk, const float* bias, float* out, const T2P& p, size_t lds, hipStream_t st) {
   static bool done = false;
   if (lds > 48 * 1024 && !done) {
-    if (hipFuncSetAttribute((const void*)igemm2_tr2_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DPF_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)igemm2_tr2_kernel<CC, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DPF_ERR_LAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((igemm2_tr2_kernel<CC>), dim3(8u * p.cpx), dim3(256), lds, st, x, wpk, bias, out, p);
+  hipLaunchKernelGGL((igemm2_tr2_kernel<CC, BF>), dim3(8u * p.cpx), dim3(256), lds, st, x, wpk, bias, out, p);
   return dpf_check_launch();
 }
 
@@ -695,13 +745,14 @@ int igemm2_tr2(const float* x, const float* w, const float* bias, float* out, fl
   if (d.OD > 2 * d.ID || d.OH > 2 * d.IH || d.OW > 2 * d.IW) return DPF_ERR_UNSUPPORTED;
   const long long x_chan = (long long)d.ID * d.IH * d.IW;
   if (9 * x_chan >= (1LL << 30)) return DPF_ERR_UNSUPPORTED;
-  const int CC = (cc_over == 4 || cc_over == 8 || cc_over == 2) ? cc_over : 8;
+  const bool bf = dpf_conv_operand_bf16() != 0;
+  const int CC = bf ? 8 : ((cc_over == 4 || cc_over == 8 || cc_over == 2) ? cc_over : 8);
   T2P p{};
   p.N = d.N; p.C = d.C; p.Ktot = d.Ktot;
   p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.OD = d.OD; p.OH = d.OH; p.OW = d.OW;
   p.RS = 36; p.SR = 9; p.rpc = 2 * 5; p.chanStride = p.rpc * p.RS;
   p.nseg = CC * p.rpc * p.SR;
-  p.nwseg = 27 * CC * 32 / 4;
+  p.nwseg = bf ? 27 * 32 : 27 * CC * 32 / 4;
   p.nchunks = (d.C + CC - 1) / CC;
   p.QD = dpf_div_up(d.OD, 2);
   p.tilesH = dpf_div_up(dpf_div_up(d.OH, 2), 4);
@@ -711,14 +762,23 @@ int igemm2_tr2(const float* x, const float* w, const float* bias, float* out, fl
   p.ntiles = (int)ntiles;
   p.cpx = (int)((ntiles + 7) / 8);
   p.mSR = magic20(p.SR); p.mRPC = magic20(p.rpc); p.mEH = magic20(5);
-  const size_t lds = 2 * (size_t)(CC * p.chanStride + 27 * CC * 32) * sizeof(float);
+  const size_t lds = 2 * (size_t)(CC * p.chanStride + 4 * p.nwseg) * sizeof(float);
   for (int k0 = 0; k0 < d.K; k0 += 32) {
     const int Kc = d.K - k0 < 32 ? d.K - k0 : 32;
     p.K = Kc; p.k0 = d.k0 + k0;
     const long long total = (long long)p.nchunks * 27 * CC * 32 + ZPAGE;
-    hipLaunchKernelGGL(igemm2_pack_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, ws, d.wA, d.wB, 27, 32, CC, p.nchunks, d.mode, p.k0, Kc, d.C);
+    if (bf)
+      hipLaunchKernelGGL(igemm2_pack_bf16_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(ws), d.wA, d.wB, 27,
+                         32, p.nchunks, d.mode, p.k0, Kc, d.C);
+    else
+      hipLaunchKernelGGL(igemm2_pack_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, ws, d.wA, d.wB, 27, 32, CC, p.nchunks, d.mode, p.k0, Kc, d.C);
     if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
     int rc;
+    if (bf) {
+      rc = launch_t2<8, true>(x, ws, bias, out, p, lds, st);
+      if (rc != DPF_OK) return rc;
+      continue;
+    }
     switch (CC) { case 2: rc = launch_t2<2>(x, ws, bias, out, p, lds, st); break; case 4: rc = launch_t2<4>(x, ws, bias, out, p, lds, st); break;
                   default: rc = launch_t2<8>(x, ws, bias, out, p, lds, st); break; }
     if (rc != DPF_OK) return rc;

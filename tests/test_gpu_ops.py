@@ -569,8 +569,10 @@ def test_conv_operands_bf16(case):
             sl = (slice(None), slice(c0, c0 + step)) if name != 'wgrad' else (slice(None),)
             eb, ef = float((got.cpu()[sl] - ref_b[sl]).abs().max()) / scale, float((got.cpu()[sl] - ref_f[sl]).abs().max()) / scale
             assert min(eb, ef) < tol, (name, c0, eb, ef)
-            if must:
-                assert eb < ef, (name, 'expected the bf16-operand kernel', eb, ef)
+            # the class-fused stride-2 data gradient (16-byte aligned g rows) has its bf16 variant too
+            s2 = name == 'dgrad' and ks == (3, 3, 3) and st == (2, 2, 2) and y.shape[4] % 4 == 0 and K <= 128
+            if must or s2:
+                assert eb < ef and eb < tol, (name, 'expected the bf16-operand kernel', eb, ef)
     close(gb, go.sum((0, 2, 3, 4)), 1e-4, 'bgrad')
     # and the default precision is untouched afterwards
     y32 = ops.ConvFn.apply(xg, wg, bg, st, pd, dl)
