@@ -597,6 +597,7 @@ int dpf_set_conv_operand_precision(int bf16) {
   g_operand_bf16 = bf16 ? 1 : 0;
   return DPF_OK;
 }
+int dpf_get_conv_operand_precision(void) { return g_operand_bf16; }
 
 // workspace (floats) needed for the repacked weights of a conv with `T` taps, `reduce` reduction channels
 // and `outc` output channels

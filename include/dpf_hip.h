@@ -55,6 +55,7 @@ int dpf_conv_transpose_acc(const float* x, const float* w, const float* bias, fl
  * the reference's `precision: 16` (PL autocast, config_/train_faceDP.json) for its nn.Conv2d / nn.Conv3d layers.  Process-wide state;
  * shapes the bf16 kernels do not cover run exact fp32. */
 int dpf_set_conv_operand_precision(int bf16);
+int dpf_get_conv_operand_precision(void);
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
 /* same, with caller scratch `ws` of dpf_conv_wgrad_workspace_floats(T, C, K) floats: eligible shapes (16-byte aligned rows, 3x3 /

@@ -39,6 +39,28 @@ def test_ops_fail_loudly_without_gpu_tensors():
         ops.conv3d(x, w, None, 1, (0, 1, 1), 1)
 
 
+def test_conv_operand_precision_context_nests_and_restores():
+    """ops.conv_operands: the process-wide operand precision of the dense conv kernels follows the innermost context and is put back
+    on exit, also when the body raises (host-only state of the library: no GPU needed)."""
+    from dualpixelface_amd import ops
+    from dualpixelface_amd._lib import lib
+    get = lib().cdll.dpf_get_conv_operand_precision
+    assert get() == 0 and not ops.CONV_OPERANDS_BF16
+    with ops.conv_operands(True):
+        assert get() == 1 and ops.CONV_OPERANDS_BF16
+        with ops.conv_operands(False):                       # e.g. an fp32 node's backward running inside a bf16 forward
+            assert get() == 0 and not ops.CONV_OPERANDS_BF16
+        assert get() == 1 and ops.CONV_OPERANDS_BF16
+        with ops.conv_operands(True):
+            assert get() == 1
+        assert get() == 1
+    assert get() == 0 and not ops.CONV_OPERANDS_BF16
+    with pytest.raises(RuntimeError):
+        with ops.conv_operands(True):
+            raise RuntimeError('body failed')
+    assert get() == 0 and not ops.CONV_OPERANDS_BF16
+
+
 def test_shift_tables_reproduce_reference_sampling(golden_dir):
     g = np.load(golden_dir + '/e2e_train_32x48_b2.npz')
     for fea_k, pre, d in (('fea_ref', 'shift_fwd_', -1.0), ('fea_tar', 'shift_bwd_', +1.0)):
