@@ -281,6 +281,65 @@ __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restric
   }
 }
 
+// Data gradient of a conv with K <= 4 output channels (3 x 3 (x KD) window, stride 1, dilation 1): dx[n,c,i] = sum_{k,t} w[k,c,t] g[n,k,i+p-t].
+// The implicit-GEMM kernels run this shape with one real reduction channel per MFMA step (11 TFLOP/s = 0.48 ms for the 1 -> 32
+// channel cost heads at 8 x 256 x 384); here a thread owns 4 consecutive W positions, loads the K x KD x 3 rows of g it needs ONCE
+// (an aligned float4 + 2 edge values per row) and produces all C input channels from registers: 27 K wave-uniform (scalar) weight
+// loads and one float4 store per channel -- the kernel is a 402 MB stream of stores.
+template <int KK, int KD>
+__global__ __launch_bounds__(256) void smallk_dgrad3_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx, SkP p) {
+  const int wq = p.IW / 4;
+  const long long total = (long long)p.N * p.ID * p.IH * wq;
+  const long long oplane = (long long)p.OH * p.OW, ovol = oplane * p.OD;
+  const long long iplane = (long long)p.IH * p.IW, ivol = iplane * p.ID;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int iw0 = (int)(i % wq) * 4;
+    const int ih = (int)((i / wq) % p.IH);
+    const int id = (int)((i / ((long long)wq * p.IH)) % p.ID);
+    const int n = (int)(i / ((long long)wq * p.IH * p.ID));
+    // g window: v[k][a][b][u] = g[n][k][id + pd - a][ih + ph - b][iw0 + pw - 2 + u], u = 0..5 (tap cc of position j reads u = j + 2 - cc)
+    float v[KK][KD][3][6];
+    const int ow0 = iw0 + p.pw - 2;
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+      for (int a = 0; a < KD; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const int od = id + p.pd - a, oh = ih + p.ph - b;
+          const bool rok = od >= 0 && od < p.OD && oh >= 0 && oh < p.OH;
+          const float* row = g + ((long long)n * p.K + k) * ovol + (long long)od * oplane + (long long)oh * p.OW + ow0;
+          if (p.pw == 1 && (p.OW & 3) == 0) {       // ow0 + 1 = iw0: aligned float4 in the middle
+            const float4 mid = rok ? *reinterpret_cast<const float4*>(row + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[k][a][b][0] = (rok && ow0 >= 0) ? row[0] : 0.f;
+            v[k][a][b][1] = mid.x; v[k][a][b][2] = mid.y; v[k][a][b][3] = mid.z; v[k][a][b][4] = mid.w;
+            v[k][a][b][5] = (rok && ow0 + 5 < p.OW) ? row[5] : 0.f;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) v[k][a][b][u] = (rok && ow0 + u >= 0 && ow0 + u < p.OW) ? row[u] : 0.f;
+          }
+        }
+    float* dst = dx + (long long)n * p.C * ivol + (long long)id * iplane + (long long)ih * p.IW + iw0;
+    for (int c = 0; c < p.C; ++c) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
+        const float* wk = w + ((long long)k * p.C + c) * (KD * 9);          // wave-uniform: scalar loads
+#pragma unroll
+        for (int a = 0; a < KD; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            const float w0 = wk[(a * 3 + b) * 3], w1 = wk[(a * 3 + b) * 3 + 1], w2 = wk[(a * 3 + b) * 3 + 2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[j] = fmaf(w0, v[k][a][b][j + 2], fmaf(w1, v[k][a][b][j + 1], fmaf(w2, v[k][a][b][j], acc[j])));
+          }
+      }
+      *reinterpret_cast<float4*>(dst + (long long)c * ivol) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+  }
+}
+
 // Weight gradient, 3x3 (x KD) stride-1 windows: no LDS.  One wave owns (n, od, channel, 64-column strip, row range) and marches
 // down the rows with lanes along W: per step it loads the newly entering input row of each kernel plane in its three column
 // shifts (9 coalesced loads for KD = 3, served by L1 after the first), keeps the other two rows of the window in registers, and
@@ -422,6 +481,31 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
 }
 
 // dw[K][C][T] += sum g[n,k,q] * x[n,c,q*s - p + t*dil]   (g [N,K,OD,OH,OW], x [N,C,ID,IH,IW])
+// data gradient of dpf_conv_smallk_forward's shapes: g [N,K,OD,OH,OW] (K <= 4) -> dx [N,C,ID,IH,IW]; 3 x 3 (x 1 or 3) windows, stride 1,
+// dilation 1, IW % 4 == 0 and 16-byte aligned dx; DPF_ERR_UNSUPPORTED otherwise (the caller then uses dpf_conv_transpose)
+int dpf_conv_smallk_dgrad(const float* g, const float* w, float* dx, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int pd,
+                          int ph, int pw, void* stream) {
+  dpf_clear_error();
+  if (!g || !w || !dx) return DPF_ERR_INVALID_ARG;
+  SkP p{};
+  int rc = fill(p, N, C, ID, IH, IW, K, kd, kh, kw, 1, 1, 1, pd, ph, pw, 1, 1, 1);
+  if (rc != DPF_OK) return rc;
+  if (kh != 3 || kw != 3 || (kd != 1 && kd != 3) || (IW & 3) || (reinterpret_cast<uintptr_t>(dx) & 15) || (reinterpret_cast<uintptr_t>(g) & 15) ||
+      K * kd > 6 || getenv("DPF_SMALLK_DGRAD_OFF"))
+    return DPF_ERR_UNSUPPORTED;
+  const long long total = (long long)N * ID * IH * (IW / 4);
+  const dim3 grid(dpf_ew_grid(total));
+  hipStream_t st = (hipStream_t)stream;
+#define DPF_SKD(KKv, KDv) hipLaunchKernelGGL((smallk_dgrad3_kernel<KKv, KDv>), grid, dim3(256), 0, st, g, w, dx, p)
+  if (kd == 3) {
+    if (K == 1) DPF_SKD(1, 3); else DPF_SKD(2, 3);
+  } else {
+    switch (K) { case 1: DPF_SKD(1, 1); break; case 2: DPF_SKD(2, 1); break; case 3: DPF_SKD(3, 1); break; default: DPF_SKD(4, 1); break; }
+  }
+#undef DPF_SKD
+  return dpf_check_launch();
+}
+
 int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int sd,
                           int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream) {
   dpf_clear_error();

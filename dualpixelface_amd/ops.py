@@ -181,6 +181,16 @@ def _conv_transpose_raw(x, w, bias, out_dims, ksize, stride, pad, dil, k_needed=
     kd, kh, kw = ksize
     out = torch.empty((N, K) + tuple(out_dims), dtype=torch.float32, device=x.device)
     L = lib()
+    if (C <= 4 and bias is None and k_needed is None and tuple(stride) == (1, 1, 1) and tuple(dil) == (1, 1, 1) and kh == 3 and kw == 3
+            and out_dims[2] % 4 == 0):
+        # data gradient of a conv with <= 4 output channels (cost heads, normal conv): register-window kernel instead of an MFMA tile
+        # with one real reduction channel
+        with _Timed('conv_smallk', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW, 'skd N%d C%d K%d in%dx%dx%d' % (N, C, K, ID, IH, IW)):
+            rc = L.cdll.dpf_conv_smallk_dgrad(_ptr(x), _ptr(w), _ptr(out), N, K, *out_dims, C, kd, kh, kw, *pad, _stream())
+        if rc == 0:
+            return out
+        if rc != -3:
+            raise DpfError('dpf_conv_smallk_dgrad failed: %s' % rc)
     if k_needed is not None and 0 < k_needed < K:
         out[:, k_needed:].zero_()
         ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')

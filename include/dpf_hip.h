@@ -83,6 +83,10 @@ int dpf_bn_finalize_partials(double* slab, int parts, int C, long long count, fl
  * same conventions as dpf_conv_forward / dpf_conv_wgrad, direct (non-MFMA) HBM-bound kernels */
 int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, float* out, int N, int C, int ID, int IH, int IW, int K, int kd,
                             int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw, void* stream);
+/* data gradient of the same shapes (replaces cuDNN's dgrad behind the 32 -> 1 cost heads, modules.py:331-337, and the 32 -> 3 normal
+ * conv): g [N,K,OD,OH,OW], K <= 4, 3x3(x1|x3) window, stride 1, dilation 1, IW % 4 == 0; DPF_ERR_UNSUPPORTED otherwise */
+int dpf_conv_smallk_dgrad(const float* g, const float* w, float* dx, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int pd,
+                          int ph, int pw, void* stream);
 int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int sd,
                           int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
 

@@ -67,6 +67,11 @@ CONV_CASES = [
     (1, 40, 2, 5, 8, 160, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     (2, 33, 1, 20, 36, 96, (1, 3, 3), (1, 1, 1), (0, 0, 0), (1, 1, 1)),      # no padding: the data gradient's patch starts outside the tensor
     (1, 192, 1, 9, 12, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    # <= 4 output channels: register-window forward / data-gradient / weight-gradient kernels (conv_smallk.hip)
+    (2, 16, 5, 7, 24, 2, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    (3, 24, 1, 9, 16, 4, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    (2, 8, 3, 6, 12, 1, (3, 3, 3), (1, 1, 1), (0, 0, 0), (1, 1, 1)),        # no padding: the data gradient's window leaves the g tensor on every side
+    (1, 8, 4, 6, 16, 1, (3, 3, 3), (1, 1, 1), (1, 2, 2), (1, 1, 1)),        # padding 2 along H / W
 ]
 
 
