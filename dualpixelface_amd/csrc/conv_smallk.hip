@@ -205,24 +205,24 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const float* __restri
 // loads the SKR + 2 input rows once (XB + 2 values each) and every row feeds the three row taps of up to three outputs -- 1.5 row
 // loads per output row instead of 3 (the kernel is bound by cache bandwidth: 32 channels x 27 taps re-read the same lines).
 constexpr int SKR = 4;
-template <int KK, int KD, bool VEC>
+template <int KK, int KD, bool VEC, int SKRT = SKR>
 __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, SkP p) {
   const long long oplane = (long long)p.OH * p.OW, ovol = oplane * p.OD;
   const long long iplane = (long long)p.IH * p.IW, ivol = iplane * p.ID;
   const int wq = (p.OW + XB - 1) / XB;
-  const int hq = (p.OH + SKR - 1) / SKR;
+  const int hq = (p.OH + SKRT - 1) / SKRT;
   const long long total = (long long)p.N * p.OD * hq * wq;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int ow0 = (int)(i % wq) * XB;
-    const int oh0 = (int)((i / wq) % hq) * SKR;
+    const int oh0 = (int)((i / wq) % hq) * SKRT;
     const int od = (int)((i / ((long long)wq * hq)) % p.OD);
     const int n = (int)(i / ((long long)wq * hq * p.OD));
-    float acc[KK][SKR][XB];
+    float acc[KK][SKRT][XB];
 #pragma unroll
     for (int k = 0; k < KK; ++k)
 #pragma unroll
-      for (int r = 0; r < SKR; ++r)
+      for (int r = 0; r < SKRT; ++r)
 #pragma unroll
         for (int j = 0; j < XB; ++j) acc[k][r][j] = bias ? bias[k] : 0.f;
     const float* xn = x + (long long)n * p.C * ivol;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restric
         const int id = od - p.pd + a * p.dd;
         const bool dok = id >= 0 && id < p.ID;
 #pragma unroll
-        for (int rr = 0; rr < SKR + 2; ++rr) {                 // input row ih = oh0 - ph + rr feeds outputs oh0 + rr - b, b = 0..2
+        for (int rr = 0; rr < SKRT + 2; ++rr) {                 // input row ih = oh0 - ph + rr feeds outputs oh0 + rr - b, b = 0..2
           const int ih = oh0 - p.ph + rr;
           const bool rok = dok && ih >= 0 && ih < p.IH;
           const float* row = xc + (long long)id * iplane + (long long)ih * p.IW + iw0;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restric
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
             const int r = rr - b;                               // compile-time after unrolling
-            if (r < 0 || r >= SKR) continue;
+            if (r < 0 || r >= SKRT) continue;
 #pragma unroll
             for (int k = 0; k < KK; ++k) {
               const float* wk = wc + (long long)k * p.C * (KD * 9) + (a * 3 + b) * 3;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restric
       }
     }
 #pragma unroll
-    for (int r = 0; r < SKR; ++r) {
+    for (int r = 0; r < SKRT; ++r) {
       if (oh0 + r >= p.OH) break;
       const long long obase = ((long long)od * p.OH + oh0 + r) * p.OW + ow0;
 #pragma unroll
@@ -463,6 +463,14 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
     const dim3 grid(dpf_ew_grid((long long)N * p.OD * ((p.OH + SKR - 1) / SKR) * ((p.OW + XB - 1) / XB)));
     hipStream_t st = (hipStream_t)stream;
     const bool vec = pw == 1 && (IW & 3) == 0 && (p.OW & 3) == 0 && XB == 4;
+    // the 32 -> 1 cost heads (8 x 256 x 384 volumes): two rows per thread instead of four -- twice the threads hide the load latency
+    // better than the larger window saves loads (0.43 vs 0.52 ms per launch; one row 0.58, eight rows 0.82)
+    static const int rows_over = getenv("DPF_SKF_ROWS") ? atoi(getenv("DPF_SKF_ROWS")) : 2;
+    if (K == 1 && kd == 3 && vec && rows_over == 2) {
+      const dim3 grid2(dpf_ew_grid((long long)N * p.OD * ((p.OH + 1) / 2) * ((p.OW + XB - 1) / XB)));
+      hipLaunchKernelGGL((smallk_fwd3_kernel<1, 3, true, 2>), grid2, dim3(256), 0, st, x, w, bias, out, p);
+      return dpf_check_launch();
+    }
 #define DPF_SKF(KKv, KDv)                                                                                         \
   {                                                                                                               \
     if (vec) hipLaunchKernelGGL((smallk_fwd3_kernel<KKv, KDv, true>), grid, dim3(256), 0, st, x, w, bias, out, p); \
@@ -480,7 +488,6 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
   return dpf_check_launch();
 }
 
-// dw[K][C][T] += sum g[n,k,q] * x[n,c,q*s - p + t*dil]   (g [N,K,OD,OH,OW], x [N,C,ID,IH,IW])
 // data gradient of dpf_conv_smallk_forward's shapes: g [N,K,OD,OH,OW] (K <= 4) -> dx [N,C,ID,IH,IW]; 3 x 3 (x 1 or 3) windows, stride 1,
 // dilation 1, IW % 4 == 0 and 16-byte aligned dx; DPF_ERR_UNSUPPORTED otherwise (the caller then uses dpf_conv_transpose)
 int dpf_conv_smallk_dgrad(const float* g, const float* w, float* dx, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int pd,
@@ -506,6 +513,7 @@ int dpf_conv_smallk_dgrad(const float* g, const float* w, float* dx, int N, int 
   return dpf_check_launch();
 }
 
+// dw[K][C][T] += sum g[n,k,q] * x[n,c,q*s - p + t*dil]   (g [N,K,OD,OH,OW], x [N,C,ID,IH,IW])
 int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int kd, int kh, int kw, int sd,
                           int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream) {
   dpf_clear_error();
