@@ -219,7 +219,7 @@ def main():
             flops, secs, n, alg_bytes = fam[dom]
             ach = flops / secs / 1e12
             traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+            tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r02_pmc_traffic.json')
             if os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
                 fam_key = {'conv_igemm': 'igemm2', 'conv_wgrad': 'wgrad2'}.get(dom)
                 rec = json.load(open(tpath)).get(fam_key)

@@ -30,6 +30,10 @@ rm -rf gpurun_out/pmc_f2 gpurun_out/pmc_w2
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f2 -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w2 -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 tools/pmc_traffic.py gpurun_out/pmc_f2/p_counter_collection.csv gpurun_out/pmc_w2/p_counter_collection.csv gpurun_out/r02/r02_pmc_traffic.json
+rm -rf gpurun_out/pmc_f3 gpurun_out/pmc_w3
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f3 -o p -- python3 bench.py --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w3 -o p -- python3 bench.py --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 tools/pmc_traffic.py gpurun_out/pmc_f3/p_counter_collection.csv gpurun_out/pmc_w3/p_counter_collection.csv gpurun_out/r02/r02_pmc_traffic_bf16.json
 export PMC_FILTER="igemm2 wgrad2 dcn_ pointwise"
 bash tools/gpu_pmc.sh r02sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02/r02_sq_counters.txt 2>&1
 bash tools/gpu_pmc.sh r02grbm GRBM_GUI_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02/r02_grbm_cycles.txt 2>&1
