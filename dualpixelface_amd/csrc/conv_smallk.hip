@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restric
     for (int c = 0; c < p.C; ++c) {
       const float* xc = xn + (long long)c * ivol;
       const float* wc = w + (long long)c * (KD * 9);
+      // all row loads of the channel first, into their own registers: with one window array reused per row the compiler waits for
+      // every row before it issues the next one ((SKRT + 2) * KD dependent round trips to L2 / HBM per channel, ~13 us)
+      float vv[KD][SKRT + 2][XB + 2];
 #pragma unroll
       for (int a = 0; a < KD; ++a) {
         const int id = od - p.pd + a * p.dd;
@@ -241,18 +244,30 @@ __global__ __launch_bounds__(256) void smallk_fwd3_kernel(const float* __restric
         for (int rr = 0; rr < SKRT + 2; ++rr) {                 // input row ih = oh0 - ph + rr feeds outputs oh0 + rr - b, b = 0..2
           const int ih = oh0 - p.ph + rr;
           const bool rok = dok && ih >= 0 && ih < p.IH;
-          const float* row = xc + (long long)id * iplane + (long long)ih * p.IW + iw0;
-          float v[XB + 2];
+          float (&v)[XB + 2] = vv[a][rr];
           if (VEC) {
-            // pw == 1 and IW % 4 == 0: the four centre values are one aligned 16-byte load (consecutive lanes: 1 KiB contiguous)
-            const float4 mid = rok ? *reinterpret_cast<const float4*>(row + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[0] = (rok && cok[0]) ? row[0] : 0.f;
-            v[1] = mid.x; v[2] = mid.y; v[3] = mid.z; v[4] = mid.w;
-            v[5] = (rok && cok[5]) ? row[5] : 0.f;
+            // pw == 1 and IW % 4 == 0: the four centre values are one aligned 16-byte load (consecutive lanes: 1 KiB contiguous).
+            // Loads are UNCONDITIONAL from clamped (always valid) addresses and zeroed by selects afterwards: a conditional load is a
+            // branch, and behind a branch the compiler retires every row before it issues the next one.
+            const int idc = id < 0 ? 0 : (id >= p.ID ? p.ID - 1 : id), ihc = ih < 0 ? 0 : (ih >= p.IH ? p.IH - 1 : ih);
+            const float* rowc = xc + (long long)idc * iplane + (long long)ihc * p.IW + iw0;
+            const float4 mid = *reinterpret_cast<const float4*>(rowc + 1);
+            const float e0 = rowc[cok[0] ? 0 : 1], e5 = rowc[cok[5] ? 5 : 4];
+            v[0] = (rok && cok[0]) ? e0 : 0.f;
+            v[1] = rok ? mid.x : 0.f; v[2] = rok ? mid.y : 0.f; v[3] = rok ? mid.z : 0.f; v[4] = rok ? mid.w : 0.f;
+            v[5] = (rok && cok[5]) ? e5 : 0.f;
           } else {
+            const float* row = xc + (long long)id * iplane + (long long)ih * p.IW + iw0;
 #pragma unroll
             for (int u = 0; u < XB + 2; ++u) v[u] = (rok && cok[u]) ? row[u] : 0.f;
           }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < KD; ++a) {
+#pragma unroll
+        for (int rr = 0; rr < SKRT + 2; ++rr) {
+          const float (&v)[XB + 2] = vv[a][rr];
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
             const int r = rr - b;                               // compile-time after unrolling
@@ -463,9 +478,8 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
     const dim3 grid(dpf_ew_grid((long long)N * p.OD * ((p.OH + SKR - 1) / SKR) * ((p.OW + XB - 1) / XB)));
     hipStream_t st = (hipStream_t)stream;
     const bool vec = pw == 1 && (IW & 3) == 0 && (p.OW & 3) == 0 && XB == 4;
-    // the 32 -> 1 cost heads (8 x 256 x 384 volumes): two rows per thread instead of four -- twice the threads hide the load latency
-    // better than the larger window saves loads (0.43 vs 0.52 ms per launch; one row 0.58, eight rows 0.82)
-    static const int rows_over = getenv("DPF_SKF_ROWS") ? atoi(getenv("DPF_SKF_ROWS")) : 2;
+    // rows per thread: 4 (default; 0.30 ms per 32 -> 1 cost head at 8 x 256 x 384 once the loads are unconditional) or 2 (0.37 ms)
+    static const int rows_over = getenv("DPF_SKF_ROWS") ? atoi(getenv("DPF_SKF_ROWS")) : 4;
     if (K == 1 && kd == 3 && vec && rows_over == 2) {
       const dim3 grid2(dpf_ew_grid((long long)N * p.OD * ((p.OH + 1) / 2) * ((p.OW + XB - 1) / XB)));
       hipLaunchKernelGGL((smallk_fwd3_kernel<1, 3, true, 2>), grid2, dim3(256), 0, st, x, w, bias, out, p);
