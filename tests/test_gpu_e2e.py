@@ -559,3 +559,35 @@ def test_side_stream_weight_gradients_match_in_line(golden_dir, monkeypatch):
         n = a.norm().item()
         if n > 1e-6:
             assert (a - b).norm().item() / n < 1e-3, name
+
+
+@pytest.mark.parametrize('family', ['psmnet', 'nnet'])
+def test_other_plugins_honour_bf16_operand_precision(golden_dir, family):
+    """option.precision = 'bf16' on the PSMNet / NNet plugins (StereoNet shares their code path; bench.py --model stereonet --precision bf16): same graph, the dense convs round their operands to bf16.  The
+    loss stays within 2 % of the plugin's own fp32 golden loss (a different but nearby number proves the kernels engaged), the
+    gradients are finite, and the precision does not leak out of the forward."""
+    from dualpixelface_amd import load_option, ops
+    from dualpixelface_amd.plugin import NNET, PSMNET
+    from dualpixelface_amd.recipe import fill_by_recipe, synthetic_batch
+    cls, cfg, gold, bs, hw, seed = {
+        'psmnet': (PSMNET, 'train_faceDP_psmnet', 'psmnet_256x256_b2.npz', 2, (256, 256), 7),
+        'nnet': (NNET, 'train_faceDP_nnet', 'nnet_256x256_b2.npz', 2, (256, 256), 11),
+    }[family]
+    g = np.load(golden_dir + '/' + gold)
+    opt = load_option(cfg)
+    opt.precision = 'bf16'
+    model = cls(opt)
+    assert model.bf16_all
+    fill_by_recipe(model)
+    model.to(DEV).train()
+    batch = {k: v.to(DEV) for k, v in synthetic_batch(bs, hw[0], hw[1], seed=seed).items()}
+    model.flat_gradients(zero=True)
+    res = model(batch)
+    assert not ops.CONV_OPERANDS_BF16
+    ref = float(g['final_loss'])
+    got = float(res['final_loss'])
+    assert np.isfinite(got) and abs(got - ref) <= 2e-2 * abs(ref), (got, ref)
+    assert abs(got - ref) > 1e-7 * abs(ref), ('bf16 kernels not engaged?', got, ref)
+    res['final_loss'].backward()
+    gsum = sum(float(p.grad.abs().sum()) for p in model.parameters() if p.grad is not None)
+    assert np.isfinite(gsum) and gsum > 0
