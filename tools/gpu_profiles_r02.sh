@@ -37,5 +37,8 @@ python3 tools/pmc_traffic.py gpurun_out/pmc_f3/p_counter_collection.csv gpurun_o
 export PMC_FILTER="igemm2 wgrad2 dcn_ pointwise"
 bash tools/gpu_pmc.sh r02sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02/r02_sq_counters.txt 2>&1
 bash tools/gpu_pmc.sh r02grbm GRBM_GUI_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02/r02_grbm_cycles.txt 2>&1
+export PMC_FILTER="igemm2 wgrad2"
+bash tools/gpu_pmc.sh r02sqbf SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02/r02_sq_counters_bf16.txt 2>&1
+bash tools/gpu_pmc.sh r02grbmbf GRBM_GUI_ACTIVE -- bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02/r02_grbm_cycles_bf16.txt 2>&1
 python bench.py --cpu-baseline-only 512x768:16,64 > gpurun_out/r02/r02_cpu_baseline_c2.txt 2>> gpurun_out/r02/bench.err
 cat gpurun_out/r02/r02_bench.json; cat gpurun_out/r02/r02_bench_family_ms.txt; cat gpurun_out/r02/r02_pmc_traffic.json | head -40; cat gpurun_out/r02/r02_cpu_baseline_c2.txt
