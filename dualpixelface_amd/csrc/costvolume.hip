@@ -449,10 +449,13 @@ int dpf_shift_triple_forward(const float* fea, float* out, const int* iy, const 
                              int h, int w, void* stream) {
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!fea || !out || !iy || !wy || !ix || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
-  const long long BC = (long long)B * C;
-  if (BC * 3 > 65535) return DPF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(shift_triple_fwd_kernel, dim3(dpf_div_up(h, ST_ROWS), (unsigned)(BC * 3)), dim3(256), 0, (hipStream_t)stream, fea, out,
-                     iy, wy, ix, wx, h, w);
+  const long long BC = (long long)B * C, hw = (long long)h * w;
+  // the plane index rides in gridDim.y (<= 65535): larger batch x channel counts are launched in slices
+  for (long long bc0 = 0; bc0 < BC; bc0 += 21845) {
+    const long long n = BC - bc0 < 21845 ? BC - bc0 : 21845;
+    hipLaunchKernelGGL(shift_triple_fwd_kernel, dim3(dpf_div_up(h, ST_ROWS), (unsigned)(n * 3)), dim3(256), 0, (hipStream_t)stream,
+                       fea + bc0 * hw, out + bc0 * 3 * hw, iy, wy, ix, wx, h, w);
+  }
   return dpf_check_launch();
 }
 
@@ -471,10 +474,12 @@ int dpf_shift_triple_backward_gather(const float* g, float* dfea, const int* iy_
                                      int B, int C, int h, int w, void* stream) {
   dpf_clear_error();
   if (!g || !dfea || !iy_inv || !wy || !ix_inv || !wx || B <= 0 || C <= 0 || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
-  const long long BC = (long long)B * C;
-  if (BC > 65535) return DPF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(shift_triple_bwd_gather_kernel, dim3(dpf_div_up(h, ST_ROWS), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, g, dfea,
-                     iy_inv, wy, ix_inv, wx, h, w);
+  const long long BC = (long long)B * C, hw = (long long)h * w;
+  for (long long bc0 = 0; bc0 < BC; bc0 += 65535) {      // gridDim.y slices
+    const long long n = BC - bc0 < 65535 ? BC - bc0 : 65535;
+    hipLaunchKernelGGL(shift_triple_bwd_gather_kernel, dim3(dpf_div_up(h, ST_ROWS), (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       g + bc0 * 3 * hw, dfea + bc0 * hw, iy_inv, wy, ix_inv, wx, h, w);
+  }
   return dpf_check_launch();
 }
 
@@ -484,17 +489,25 @@ int dpf_phase_shift(const float* src, long long src_plane_stride, float* dst, lo
   if (!src || !dst || !mr || !hm || !tbuf || planes <= 0 || planes > 2147483647LL || h <= 0 || w <= 0) return DPF_ERR_INVALID_ARG;
   const size_t lds_a = sizeof(float) * 3 * (size_t)w;
   const size_t lds_b = sizeof(float) * ((size_t)((h + 1) & ~1) * 32 + 2 * (size_t)h + 64);
-  if (lds_a > 160 * 1024 || lds_b > 160 * 1024 || planes > 65535) return DPF_ERR_UNSUPPORTED;
+  if (lds_a > 160 * 1024 || lds_b > 160 * 1024) return DPF_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(phase_colsum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(phase_circ_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+  // the attribute belongs to the (function, device) pair: set once per device, and a failure is an error, not a later launch fault
+  static unsigned long long attr_done_mask = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DPF_ERR_LAUNCH;
+  if (dev < 0 || dev >= 64 || !((attr_done_mask >> dev) & 1ull)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(phase_colsum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(phase_circ_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return DPF_ERR_LAUNCH;
+    if (dev >= 0 && dev < 64) attr_done_mask |= 1ull << dev;
   }
-  hipLaunchKernelGGL(phase_colsum_kernel, dim3((unsigned)planes), dim3(256), lds_a, st, src, src_plane_stride, hm, scale, tbuf, h, w);
-  hipLaunchKernelGGL(phase_circ_kernel, dim3(dpf_div_up(w, 32), (unsigned)planes), dim3(256), lds_b, st, src, src_plane_stride, dst,
-                     dst_plane_stride, mr, tbuf, h, w);
+  for (long long p0 = 0; p0 < planes; p0 += 65535) {      // gridDim.y slices
+    const long long n = planes - p0 < 65535 ? planes - p0 : 65535;
+    hipLaunchKernelGGL(phase_colsum_kernel, dim3((unsigned)n), dim3(256), lds_a, st, src + p0 * src_plane_stride, src_plane_stride, hm, scale,
+                       tbuf + p0 * w, h, w);
+    hipLaunchKernelGGL(phase_circ_kernel, dim3(dpf_div_up(w, 32), (unsigned)n), dim3(256), lds_b, st, src + p0 * src_plane_stride,
+                       src_plane_stride, dst + p0 * dst_plane_stride, dst_plane_stride, mr, tbuf + p0 * w, h, w);
+  }
   return dpf_check_launch();
 }
 

@@ -23,10 +23,31 @@ def init_from_env(backend=None):
     if backend == 'nccl':
         torch.cuda.set_device(local)
     if not dist.is_initialized():
-        import datetime
-        # long timeout: ranks wait in a barrier while rank 0 validates (trainer.py)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(hours=4))
+        # default timeout: a dead rank or a mismatched training collective fails fast (the long wait for rank-0 validation has its own
+        # group, see wait_for_rank0)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+_wait_group = None
+
+
+def wait_for_rank0(hours=4.0):
+    """Host-side rendezvous after rank 0's validation pass: a gloo barrier on a dedicated group with its own long timeout, so the
+    training collectives keep the default one and no GPU spins in an RCCL barrier meanwhile.  If rank 0 dies its sockets close and
+    the waiting ranks raise (non-zero exit) instead of hanging."""
+    global _wait_group
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    if _wait_group is None:
+        import datetime
+        _wait_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=hours))
+    dist.monitored_barrier(group=_wait_group, timeout=datetime_timeout(hours), wait_all_ranks=False)
+
+
+def datetime_timeout(hours):
+    import datetime
+    return datetime.timedelta(hours=hours)
 
 
 class FlatGradReducer(object):

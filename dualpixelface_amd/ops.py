@@ -66,11 +66,15 @@ def _c(t):
 
 
 def scratch(nfloats, device, tag='ws'):
-    """Stream-ordered reusable scratch (all ops of one process run on the current stream)."""
-    key = (device, tag)
+    """Stream-ordered reusable scratch, one buffer per (device, tag, current stream): launches on the side stream of
+    DPF_WGRAD_ASYNC never share a slab with launches on the main stream, and a buffer that grows is replaced only for its
+    own stream (the old one is released stream-ordered by the caching allocator, which was told who used it)."""
+    s = torch.cuda.current_stream(device)
+    key = (device, tag, s.cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
+        buf.record_stream(s)
         _scratch[key] = buf
     return buf
 

@@ -40,6 +40,9 @@ def epoch_lr(option, epoch):
     raise NotImplementedError('scheduler is not defined, please check your scheduler configuration !')
 
 
+CKPT_VERSION = 2
+
+
 class Trainer(object):
     def __init__(self, option, workspace_path=None, log_every=10, max_steps=None, rank=None, world_size=None):
         self.option = option
@@ -61,7 +64,9 @@ class Trainer(object):
         path = path or self.checkpoint_path(self.epoch)
         adam = model._adam or {}
         ckpt = {
-            'epoch': self.epoch + 1, 'global_step': self.global_step,      # PL 1.4.9 dump_checkpoint: the NEXT epoch to run
+            # PL 1.4.9 dump_checkpoint: the NEXT epoch to run and global_step + 1; 'dpf_ckpt_version' tells load_checkpoint which
+            # convention a file follows (absent + no 'pytorch-lightning_version' = round-1 files: 'epoch' was the FINISHED epoch)
+            'dpf_ckpt_version': CKPT_VERSION, 'epoch': self.epoch + 1, 'global_step': self.global_step + 1,
             'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
             'optimizer_states': [{'kind': 'flat_adam', 'step': int(adam.get('step', 0)),
                                   'm': adam['m'].detach().cpu() if 'm' in adam else None,
@@ -84,6 +89,10 @@ class Trainer(object):
         if resume:
             self.epoch = int(ckpt.get('epoch', 0))                            # PL restores current_epoch = ckpt['epoch']
             self.global_step = int(ckpt.get('global_step', 0))
+            if int(ckpt.get('dpf_ckpt_version', 0)) >= 2:
+                self.global_step = max(self.global_step - 1, 0)               # our own files: undo dump_checkpoint's + 1 exactly
+            elif 'pytorch-lightning_version' not in ckpt and 'epoch' in ckpt:
+                self.epoch += 1                                               # legacy file: 'epoch' = the epoch that had finished
             states = ckpt.get('optimizer_states') or []
             if states and states[0].get('kind') == 'flat_adam' and states[0].get('m') is not None:
                 dev = model.flat_parameters().device
@@ -179,8 +188,7 @@ class Trainer(object):
                 rows = self.validate(model, val_loader)
                 self._log({'epoch': self.epoch, 'metrics': rows})
             if self.world_size > 1:
-                import torch.distributed as dist
-                dist.barrier()                 # the other ranks wait here, not inside the next epoch's first all-reduce
+                dd.wait_for_rank0()            # the other ranks wait here (host-side, own long timeout), not inside the next epoch's first all-reduce
             self.save_checkpoint(model)
             self.epoch += 1
         if reducer is not None:

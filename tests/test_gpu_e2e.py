@@ -528,9 +528,13 @@ def test_gradients_no_worse_than_the_reference_vs_fp64(golden_dir):
         assert e_mine <= 2.0 * e_ref + 1e-3, (k, e_mine, e_ref)
 
 
-def test_side_stream_weight_gradients_match_in_line(golden_dir, monkeypatch):
-    """DPF_WGRAD_ASYNC: the weight-gradient launches move to a side stream; the gradients that reach Adam must be the same ones."""
+@pytest.mark.parametrize('bn_cat', ['0', '1'])
+def test_side_stream_weight_gradients_match_in_line(golden_dir, monkeypatch, bn_cat):
+    """DPF_WGRAD_ASYNC: the weight-gradient launches move to a side stream; the gradients that reach Adam must be the same ones.
+    bn_cat = '1' also turns on DPF_CONV_BN_CAT, whose backward launches its weight gradients on the MAIN stream while the
+    registry sends the others to the side stream: the two share no scratch slab (ops.scratch is keyed by stream)."""
     from dualpixelface_amd import ops
+    monkeypatch.setenv('DPF_CONV_BN_CAT', bn_cat)
     g = np.load(golden_dir + '/e2e_train_64x96_b1.npz')
     grads = []
     for flag in (False, True):

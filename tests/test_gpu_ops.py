@@ -321,6 +321,28 @@ def test_shift_triple(delta, shape):
     assert torch.equal(gg, gg2)
 
 
+@pytest.mark.parametrize('delta', [1.0, 0.5])
+def test_shift_triple_many_planes(delta):
+    """B*C*3 > 65535 planes (the plane index rides in gridDim.y): the launchers slice; every plane still equals the oracle's."""
+    from oracle.stereodpnet import StereoDPNetOracle
+    ops = _ops()
+    shape = (2, 33000, 4, 8)                               # 66 000 (b, c) planes, 198 000 output planes
+    fea = rnd(*shape, seed=44)
+    tables, phase = _device_tables(shape[2], shape[3], delta)
+    fg = fea.to(DEV).requires_grad_()
+    out = ops.shift_triple(fg, tables, phase)
+    sel = [0, 1, 21844, 21845, 21846, 32999]               # around the slice seams
+    ref = torch.stack(StereoDPNetOracle.shift_triple(fea[:, sel].clone().requires_grad_(), delta), 2)
+    close(out[:, sel], ref, 1e-5, 'shift fwd, many planes')
+    go = rnd(*out.shape, seed=45)
+    (gg,) = torch.autograd.grad(out, fg, go.to(DEV))
+    fs = fea[:, sel].clone().requires_grad_()
+    (gr,) = torch.autograd.grad(torch.stack(StereoDPNetOracle.shift_triple(fs, delta), 2), fs, go[:, sel])
+    close(gg[:, sel], gr, 1e-4, 'shift bwd, many planes')
+    # second half of the batch lives past plane 65535 of the adjoint's grid too
+    assert torch.isfinite(gg).all() and gg[1].abs().sum().item() > 0
+
+
 def test_shift_triple_fractional_vs_reference_fixture(golden_dir):
     """Fractional shifts against outputs of the reference's own subpixel_shift (fresh module instance per delta)."""
     ops = _ops()

@@ -1,13 +1,15 @@
 #!/bin/bash
 # rocprofv3 per-kernel totals of any python command: tools/gpu_kstats.sh <tag> <script.py> [args]  -> top kernels by time
-cd $GRAFT_REPO_ROOT
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run through gpurun)}"
 export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/ks_$tag
-rm -rf $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 "$@" > gpurun_out/ks_$tag.log 2>&1
-f=$(find $out -name "*kernel_stats.csv" | head -1)
-cp $f gpurun_out/ks_${tag}_kernel_stats.csv
+rm -rf "$out"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o p -- python3 "$@" > gpurun_out/ks_$tag.log 2>&1
+f=$(find "$out" -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] || { echo "no kernel_stats.csv under $out (rocprofv3 failed, see the .log beside it)" >&2; exit 1; }
+cp "$f" gpurun_out/ks_${tag}_kernel_stats.csv
 python3 - "$f" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: -float(r['TotalDurationNs']))

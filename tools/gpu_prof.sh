@@ -1,13 +1,15 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the bench step: tools/gpu_prof.sh <tag> [bench args]
-cd $GRAFT_REPO_ROOT
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run through gpurun)}"
 export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/prof_$tag
-rm -rf $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/prof_$tag.log 2>&1
-f=$(find $out -name "*kernel_stats.csv" | head -1)
-cp $f gpurun_out/prof_${tag}_kernel_stats.csv
+rm -rf "$out"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/prof_$tag.log 2>&1
+f=$(find "$out" -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] || { echo "no kernel_stats.csv under $out (rocprofv3 failed, see the .log beside it)" >&2; exit 1; }
+cp "$f" gpurun_out/prof_${tag}_kernel_stats.csv
 python3 - "$f" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
