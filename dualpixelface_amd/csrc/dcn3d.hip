@@ -589,6 +589,270 @@ __global__ __launch_bounds__(256) void dcn_wmax_kernel(const float* __restrict__
   if (threadIdx.x == 0) wmax[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
+// ------------------------------------------------------------------------------------------ backward: input, packed pairs
+// Same LDS-privatised scatter as dcn_bwd_input_kernel<.., FX = true>, with TWO channels per ds_add_u64: a contribution of the
+// channel pair (2m, 2m+1) is the signed 64-bit integer  q_even * 2^32 + q_odd  (q = round(w * gcol * qscale), |sum q| < 2^31).
+// 64-bit adds are linear, so the cell holds  (sum q_even) * 2^32 + (sum q_odd)  exactly; the flush decodes the low field by sign
+// extension and the high field as (total - low) >> 32.  A cell of 8 u64 therefore carries 16 channels: half the passes (table
+// phases, region fills, weight-fragment loads) of the 8-channel version, half the atomics per channel (the LDS atomic unit retires
+// ~5.4 u64 lanes/clk/CU whatever they carry), and the gcol MFMA chain has 16 distinct columns (the 8-channel kernel mirrors 8).
+// Lane l15 of a 16-lane group owns column c0 + l15 of gcol; one DPP quad_perm hands it its neighbour's column, so lanes (2m, 2m+1)
+// both hold the pair m and split the 8 corners (even lane: corners 0-3, odd lane: 4-7).
+// 32-bit fields need a tight bound on sum |w * gcol| per cell: |gcol| <= gbound * max|W| as before, and the WEIGHT MASS a cell can
+// collect (sum of trilinear weights landing on it: ~30-60 for sigma ~ 1 offsets, 6912 if every sample of the tile hit one cell) is
+// measured instead of assumed: the first pass scatters the weights themselves into a u32 side region (s_mass) from the table phase
+// and runs with the bound MASS0; if the measured mass exceeds it (pathological offset fields) that pass is repeated with the
+// measured bound -- far-corner global atomics are emitted on the first attempt only.  Later passes use the measured bound.
+// Error per contribution <= 0.5 unit, unit = gbound * wmax * mass / 2^30: ~1e-6 of the tensor scale at MASS0, deterministic
+// (integer adds commute).
+constexpr int PK_CH = 16, PK_CS = 8;
+constexpr float PK_MASS0 = 128.f, PK_MASS_Q = 131072.f;   // first-pass mass bound; fixed-point scale of the mass counters (6912 * 2^17 < 2^30)
+
+template <int NST, int NW>
+__global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
+                                                                   const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT,
+                                                                   const float* __restrict__ wmaxv /*[chunks of GI_CH] max |W|*/) {
+  extern __shared__ __align__(16) long long smem_q[];
+  constexpr int NT = 64 * NW;
+  constexpr int npos = 16 * NST * NW;
+  constexpr bool HALVES = NW == 8;   // thread pair per voxel in the table phase
+  const int regvox = q.RZmax * q.RY * q.RX;
+  long long* s_regq = smem_q;                                    // [regvox + 1][PK_CS]: cell = 8 packed channel pairs; last cell = dummy
+  int* s_lidx = (int*)(s_regq + (size_t)(regvox + 1) * PK_CS);   // [npos][8] u64 index of the corner's cell (dummy cell when outside)
+  int* s_vox = s_lidx + npos * 8;                                // [npos][8] global voxel index, >= 0 only for far corners
+  float* s_w = (float*)(s_vox + npos * 8);                       // [npos][8] corner weight, 0 outside the region
+  float* s_wfar = s_w + npos * 8;                                // [npos][8] corner weight (far pass)
+  unsigned* s_mass = (unsigned*)(s_wfar + npos * 8);             // [regvox + 4] weight mass per cell, PK_MASS_Q fixed point
+  int* s_far = (int*)(s_mass + ((regvox + 4) & ~3));             // [4] per-tap flag: some corner left the region
+  int* s_farm = s_far + 4;                                       // [2][npos] per-voxel flag (one row per thread of a pair)
+  float* s_gmax = (float*)(s_farm + 2 * npos);                   // [NW]
+  unsigned* s_mmax = (unsigned*)(s_gmax + NW);                   // [NW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int pr = l15 >> 1;           // channel pair within the 16-channel chunk
+  const int jb = (l15 & 1) * 4;      // this lane's corners: 0-3 (even lane) or 4-7 (odd lane)
+  const bool odd = (l15 & 1) != 0;
+
+  int bb = blockIdx.x;
+  const int tx = bb % q.tilesX; bb /= q.tilesX;
+  const int ty = bb % q.tilesY; bb /= q.tilesY;
+  const int tz = bb % q.tilesZ;
+  const int b = bb / q.tilesZ;
+  const int z0 = tz * q.TZ, y0 = ty * GI_TY, x0 = tx * GI_TX;
+  const int rz0u = z0 * p.sd - p.pd - GI_R, ry0 = y0 * p.sh - p.ph - GI_R, rx0 = x0 * p.sw - p.pw - GI_R;
+  const int rz0 = rz0u < 0 ? 0 : rz0u;
+  int rz1 = rz0u + (q.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * GI_R;
+  if (rz1 > p.D) rz1 = p.D;
+  int RZ = rz1 - rz0;
+  if (RZ > q.RZmax) RZ = q.RZmax;
+
+  const long long chan = (long long)p.D * p.H * p.W;
+  const float* off_b = offset + (long long)b * 3 * p.T * p.P;
+  float* dxb = dx + (long long)b * p.C * chan;
+
+  const int vox = HALVES ? (tid & (npos - 1)) : tid;       // this thread's voxel in the table phase
+  const int half = HALVES ? tid / npos : 0;
+  const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
+  const int zo = z0 + pdz, yo = y0 + pdy, xo = x0 + pdx;
+  const bool pvalid = (HALVES || tid < npos) && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
+
+  // A fragments: go[k][voxel] for this wave's NST sub-tiles, all k (K <= 64 -> 16 k-steps of 4), kept in registers
+  float afrag[NST][16];
+#pragma unroll
+  for (int st = 0; st < NST; ++st) {
+    const int pl = (wave * NST + st) * 16 + l15;
+    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+    const int gz = z0 + az, gy = y0 + ay, gx = x0 + ax;
+    const bool ok = az < q.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
+    const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = 4 * ks + lg;
+      afrag[st][ks] = (ok && k < p.K) ? go[((long long)b * p.K + k) * p.P + gpos] : 0.f;
+    }
+  }
+
+  float gbound = 0.f;   // max over this workgroup's voxels of sum_k |go[k][voxel]|
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      float sa = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) sa += fabsf(afrag[st][ks]);
+      sa += __shfl_xor(sa, 16, 64);
+      sa += __shfl_xor(sa, 32, 64);
+      m = fmaxf(m, sa);
+    }
+    m = dpf_wave_max(m);
+    if (lane == 0) s_gmax[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gbound = fmaxf(gbound, s_gmax[w]);
+  }
+
+  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
+  const float* offp0 = off_b + (pvalid ? ppos : 0);
+  const int dummy = regvox * PK_CS;
+  float massb = PK_MASS0;      // bound on the weight mass of a cell that the current pass is scaled for
+  bool need_mass = true;       // the running pass also measures the mass
+  int attempt = 0;             // 1: this pass is a repeat (far corners already emitted)
+  for (int c0 = 0; c0 < q.CG;) {      // only the channels whose gradient the caller needs
+    __syncthreads();                                            // previous pass flushed
+    float qscale = 0.f, qinv = 0.f;
+    {
+      float wm = wmaxv[c0 / GI_CH];
+      if (c0 + GI_CH < p.C) wm = fmaxf(wm, wmaxv[c0 / GI_CH + 1]);
+      const float B = gbound * wm * massb;
+      if (B > 0.f) { qscale = 1073741824.f / B; qinv = B * (1.f / 1073741824.f); }
+    }
+    for (int i = tid; i < (regvox + 1) * PK_CS; i += NT) s_regq[i] = 0;
+    if (need_mass)
+      for (int i = tid; i < regvox + 1; i += NT) s_mass[i] = 0u;
+    if (tid == 0) s_far[0] = 0;
+    const int cc = c0 + l15;                                    // this lane's gcol column (B fragment); < CT always
+    const int ce = c0 + 2 * pr;                                 // even channel of the pair this lane scatters
+    const float* offp = offp0;
+    Off3 onext = load_off_ptr(offp, p.P, pvalid);
+    TapIt it = {0, 0, 0};
+    float bnext[16];
+    const float* wtn = wt2 + (long long)lg * CT + cc;           // rows k >= K of the repacked tensor are zero
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
+    for (int t = 0; t < p.T; ++t) {
+      __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
+      if (tid == 0) s_far[(t + 1) & 1] = 0;
+      const Off3 ocur = onext;
+      offp += 3 * p.P;
+      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);
+      const TapIt itc = it;
+      tap_next(p, it);
+      if (HALVES || tid < npos) {
+        const Corner cn = corner_at(p, pvalid, zb, yb, xbase, itc, ocur);
+        int anyfar = 0;
+#pragma unroll
+        for (int jj = 0; jj < (HALVES ? 4 : 8); ++jj) {
+          const int j = HALVES ? 4 * half + jj : jj;
+          float wg;
+          const int v = corner_index32(p, cn, j, wg);
+          int li = dummy;
+          bool in = false;
+          if (v >= 0) {
+            const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
+            const int lz = cn.d0 + jd - rz0, ly = cn.h0 + jh - ry0, lx = cn.w0 + jw - rx0;
+            if (lz >= 0 && lz < RZ && ly >= 0 && ly < q.RY && lx >= 0 && lx < q.RX) {
+              li = ((lz * q.RY + ly) * q.RX + lx) * PK_CS;
+              in = true;
+            }
+          }
+          s_lidx[vox * 8 + j] = li;
+          s_vox[vox * 8 + j] = (in || v < 0) ? -1 : (int)v;
+          s_w[vox * 8 + j] = in ? wg : 0.f;
+          s_wfar[vox * 8 + j] = wg;
+          if (need_mass && in) atomicAdd(&s_mass[li / PK_CS], (unsigned)__float2int_rn(wg * PK_MASS_Q));
+          if (!in && v >= 0) anyfar = 1;
+        }
+        s_farm[half * npos + vox] = anyfar;
+        if (anyfar) s_far[t & 1] = 1;
+      }
+      float bfrag[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bfrag[ks] = bnext[ks];
+      if (t + 1 < p.T) {
+        wtn += 64 * CT;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
+      }
+      __syncthreads();                                          // tables visible
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
+        float ge[4], gd[4];    // gcol of the pair's even / odd channel for the 4 voxels (D rows) of this lane group
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mine = acc[r];
+          const float other = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]: lane ^ 1
+          ge[r] = odd ? other : mine;
+          gd[r] = odd ? mine : other;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pl = (wave * NST + st) * 16 + 4 * lg + r;   // D row = voxel
+          const int4 la = *reinterpret_cast<const int4*>(&s_lidx[pl * 8 + jb]);
+          const float4 wa = *reinterpret_cast<const float4*>(&s_w[pl * 8 + jb]);
+          const int li[4] = {la.x, la.y, la.z, la.w};
+          const float wv[4] = {wa.x, wa.y, wa.z, wa.w};
+          const float es = ge[r] * qscale, os = gd[r] * qscale;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int qe = __float2int_rn(es * wv[j]), qo = __float2int_rn(os * wv[j]);
+            const long long pk = ((long long)qe << 32) + (long long)qo;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&s_regq[li[j] + pr]), (unsigned long long)pk);
+          }
+        }
+        if (attempt == 0 && s_far[t & 1] != 0) {                      // block-uniform: some corner of this tap left the region
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pl = (wave * NST + st) * 16 + 4 * lg + r;
+            if ((s_farm[pl] | (HALVES ? s_farm[npos + pl] : 0)) == 0) continue;
+            for (int j = 0; j < 4; ++j) {
+              const int v = s_vox[pl * 8 + jb + j];
+              if (v >= 0) {
+                const float wf = s_wfar[pl * 8 + jb + j];
+                if (ce < q.CG) atomicAdd(&dxb[(long long)ce * chan + v], wf * ge[r]);       // direct scatter
+                if (ce + 1 < q.CG) atomicAdd(&dxb[(long long)(ce + 1) * chan + v], wf * gd[r]);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (need_mass) {      // was the pass scaled for enough mass?
+      unsigned m = 0u;
+      for (int i = tid; i < regvox; i += NT) m = max(m, s_mass[i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+      if (lane == 0) s_mmax[wave] = m;
+      __syncthreads();
+      m = 0u;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m = max(m, s_mmax[w]);
+      const float measured = (float)m * (1.001f / PK_MASS_Q) + 0.05f;
+      need_mass = false;
+      if (measured > massb) {      // repeat this pass with the measured bound (block-uniform branch)
+        massb = measured;
+        attempt = 1;
+        continue;
+      }
+      massb = fmaxf(measured, 1.f);
+    }
+    // flush: a unit = 16 consecutive cells = 1 KB of LDS read as one conflict-free ds_read_b128 per lane (lane = (cell, quarter cell):
+    // 4 channels); the global atomics of a quarter run along x (64-byte segments per channel plane)
+    const int ncell = RZ * q.RY * q.RX;
+    for (int u = wave; u * 16 < ncell; u += NW) {
+      const int cell = u * 16 + (lane >> 2), qt = lane & 3;
+      if (cell >= ncell) continue;
+      const int lx = cell % q.RX, zy = cell / q.RX;
+      const int ly = zy % q.RY, lz = zy / q.RY;
+      const int gz = rz0 + lz, gy = ry0 + ly, gx = rx0 + lx;
+      if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) continue;
+      const long long t0 = s_regq[cell * PK_CS + 2 * qt], t1 = s_regq[cell * PK_CS + 2 * qt + 1];
+      const int lo0 = (int)t0, lo1 = (int)t1;
+      const int hi0 = (int)((t0 - (long long)lo0) >> 32), hi1 = (int)((t1 - (long long)lo1) >> 32);
+      const float v[4] = {(float)hi0 * qinv, (float)lo0 * qinv, (float)hi1 * qinv, (float)lo1 * qinv};
+      float* dst = dxb + (long long)(c0 + 4 * qt) * chan + ((long long)gz * p.H + gy) * p.W + gx;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c0 + 4 * qt + k < q.CG && v[k] != 0.f) atomicAdd(dst + (long long)k * chan, v[k]);
+    }
+    attempt = 0;
+    c0 += PK_CH;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward: weight
 // grid = T * nchunk; block = one tap, a strided set of voxel tiles; dW[k][c][t] += sum_p go[k][p] * S[c][p]
 template <int MT, int MTC>
@@ -1420,6 +1684,293 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
 }
 
 
+// ---- role-split grad_offset + grad_weight: 16 waves = 8 SAMPLER waves (a thread PAIR per voxel, each thread half of the chunk's
+// channels: corner reads, coordinate derivatives, samples), 4 GCOL waves (gcol = W^T go for 64 voxels each) and 4 WGRAD waves (dW partial
+// for 16 output channels each).  Every SIMD hosts two sampler waves and one wave of each MFMA role, so its matrix pipe (two MFMA
+// streams), its vector ALU and the LDS pipe run concurrently; the fused 4-wave kernel above alternates the phases in lockstep at one
+// wave per SIMD and holds both go layouts plus the sampling state in one 410-register wave (counters of a 4-sampler version: VALU 25 %,
+// MFMA 28 %, LDS 19 % busy, 61 % of the wave cycles waiting -- one sampler wave per SIMD is a single dependent chain).  Here each MFMA
+// role holds ONE layout of go (64 registers) and the samplers none, inside the 128-register budget of four waves per SIMD.  Steps
+// are the flattened (channel chunk, tap) pairs; three [CH][256] tiles rotate:
+//   step i:  GCOL writes gcol(i+1) into X[(i+1)%3] | SAMPLERS read gcol(i) from X[i%3], overwrite their own half column with the samples
+//            S(i) | WGRAD contracts S(i-1) from X[(i-1)%3]                                  -- one barrier per step.
+// The two halves of a voxel's coordinate gradient meet one step later: the upper-half thread leaves its partial in s_part[i&1], the
+// lower-half thread adds it during step i+1 and does the read-modify-write of grad_offset (whose read was issued a step earlier).
+// gcol(i+1) and the dW product do not touch the staged region, so the pipeline runs through the chunk boundaries; only the
+// re-staging itself (all 1024 threads) is bracketed by barriers.
+constexpr int XS = 260;    // padded row of a rotating tile (wgrad B reads: rows l15, 4 consecutive voxels per lane group)
+
+// one sampler step of half H: partial coordinate gradient (gd, gh, gw) over this half's channels; the samples replace the gcol column.
+// Fast path: the 8 corners in two straight-line groups of 4 (8 ds_read_b128 in flight).  Slow path (some corner outside the staged
+// box, rare): channel by channel from global memory, rolled, so that it costs the fast path no registers.
+template <int CH, int H>
+__device__ __forceinline__ void rs_sample_half(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
+                                               const float* __restrict__ xb, int c0, long long chan, float* col, float& gd, float& gh, float& gw) {
+  constexpr int NC = CH / 2;
+  gd = gh = gw = 0.f;
+  float* colh = col + H * NC * XS;
+  if (!sp.valid) {
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) colh[ch * XS] = 0.f;
+    return;
+  }
+  // dot_j = sum_ch gcol[ch] * x[corner j][ch]; the three coordinate derivatives weight it with the other two trilinear factors and the
+  // signed in-volume mask of their own axis (cuh:131-187)
+  float dots[8];
+  if (sp.fast) {
+    float gcv[NC], sval[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) { gcv[ch] = colh[ch * XS]; sval[ch] = 0.f; }   // gcol is zero for channels beyond C (zero weight columns)
+#pragma unroll
+    for (int jd = 0; jd < 2; ++jd) {
+      float v[4][NC];
+#pragma unroll
+      for (int jy = 0; jy < 4; ++jy) corner_half<CH, H>(g, sp, s_reg, jd, jy >> 1, jy & 1, v[jy]);
+#pragma unroll
+      for (int jy = 0; jy < 4; ++jy) {
+        float dot = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) dot = fmaf(gcv[ch], v[jy][ch], dot);
+        dots[4 * jd + jy] = dot;
+        const float wj = sp.wz[jd] * sp.wy[jy >> 1] * sp.wx[jy & 1];
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) sval[ch] = fmaf(wj, v[jy][ch], sval[ch]);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the second group's reads behind the first group's arithmetic (registers)
+    }
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) colh[ch * XS] = sval[ch];
+  } else {
+    int vx[8];
+    float wj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+      const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
+      const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
+      vx[j] = in ? (d * p.H + h) * p.W + w : -1;
+      wj[j] = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+      dots[j] = 0.f;
+    }
+#pragma unroll 1
+    for (int ch = 0; ch < NC; ++ch) {
+      const int cg = c0 + H * NC + ch;
+      const float* xc = xb + (long long)(cg < p.C ? cg : p.C - 1) * chan;
+      const float gval = colh[ch * XS];
+      float sv = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = (vx[j] >= 0 && cg < p.C) ? xc[vx[j]] : 0.f;
+        dots[j] = fmaf(gval, xv, dots[j]);
+        sv = fmaf(wj[j], xv, sv);
+      }
+      colh[ch * XS] = sv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+    gd += (jd ? sp.mz[1] : -sp.mz[0]) * sp.wy[jh] * sp.wx[jw] * dots[j];
+    gh += (jh ? sp.my[1] : -sp.my[0]) * sp.wz[jd] * sp.wx[jw] * dots[j];
+    gw += (jw ? sp.mx[1] : -sp.mx[0]) * sp.wz[jd] * sp.wy[jh] * dots[j];
+  }
+}
+
+template <int CH>
+__global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                                 const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
+                                                                 const float* __restrict__ go, float* __restrict__ doff, float* __restrict__ dwtmp,
+                                                                 DcnP p, RegGeo g, int CT, int nchunk, int vec) {
+  extern __shared__ __align__(16) float smem[];
+  float* s_reg = smem;                                 // [RV][VS]
+  float* s_x = s_reg + RegCfg<CH>::VS * g.RV;          // [3][CH][XS]
+  float* s_part = s_x + 3 * CH * XS;                   // [2][3][256] upper-half partials of (gd, gh, gw)
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave_u < 8 ? 0 : (wave_u < 12 ? 1 : 2);   // sampler, gcol, wgrad
+  const int rw = wave_u & 3;
+  const RegCtx c = region_ctx(p, g, blockIdx.x);
+  const long long chan = (long long)p.D * p.H * p.W;
+  const float* xb = x + (long long)c.b * p.C * chan;
+  const int NS = nchunk * p.T;
+  constexpr int XT = CH * XS;
+  const int dbg = vec >> 1;   // TEMP ablation switches
+  vec &= 1;
+
+  if (role == 0) {
+    // ------------------------------------------------------------------------------------------------ samplers
+    const int vox = tid & 255, half = wave_u >> 2;
+    const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
+    float* doff_b = doff + (long long)c.b * 3 * p.T * p.P;
+    const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
+    const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
+    const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+    const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
+    const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
+    const float* offp0 = off_b + (pvalid ? ppos : 0);
+    stage_region_any<CH>(p, g, c, xb, 0, s_reg, tid, 768, vec != 0);
+    const float* offp = offp0;
+    Off3 onext = load_off_ptr(offp, p.P, pvalid);
+    __syncthreads();                                   // prologue: region of chunk 0 staged, gcol(0) written
+    TapIt it = {0, 0, 0};
+    int t = 0, c0 = 0;
+    // lower half: the previous step's own partial and its grad_offset address.  The first channel chunk stores, the later ones add with
+    // a no-return float atomic (same thread, same address, chunks apart in time): no read of the running value has to be waited for
+    float pg[3] = {0.f, 0.f, 0.f};
+    float* dqp = doff_b;
+    bool first_chunk = true;
+#pragma unroll 1
+    for (int i = 0; i <= NS; ++i) {
+      if (half == 0 && i >= 1 && pvalid && !(dbg & 1)) {      // finish step i - 1: both halves of the channel chunk
+        const float* pp = s_part + ((i - 1) & 1) * 768 + vox;
+        const float a0 = pg[0] + pp[0], a1 = pg[1] + pp[256], a2 = pg[2] + pp[512];
+        if (first_chunk) { dqp[0] = a0; dqp[p.P] = a1; dqp[2 * p.P] = a2; }
+        else { atomicAdd(dqp, a0); atomicAdd(dqp + p.P, a1); atomicAdd(dqp + 2 * p.P, a2); }
+      }
+      if (i == NS) break;
+      first_chunk = c0 == 0;
+      const Off3 ocur = onext;
+      const bool last_tap = t + 1 == p.T;
+      offp = last_tap ? offp0 : offp + 3 * p.P;
+      onext = load_off_ptr(offp, p.P, pvalid && i + 1 < NS);   // next step's offsets (tap 0 again after the last tap of a chunk)
+      dqp = doff_b + (long long)(3 * t) * p.P + ppos;
+      const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
+      Samp sp = make_samp(p, g, c, cn);
+      if (dbg & 2) sp.valid = false;
+      float* col = s_x + (i % 3) * XT + vox;
+      float gd, gh, gw;
+      if (half == 0) {
+        rs_sample_half<CH, 0>(p, g, sp, cn, s_reg, xb, c0, chan, col, gd, gh, gw);
+        pg[0] = gd; pg[1] = gh; pg[2] = gw;
+      } else {
+        rs_sample_half<CH, 1>(p, g, sp, cn, s_reg, xb, c0, chan, col, gd, gh, gw);
+        float* pp = s_part + (i & 1) * 768 + vox;
+        pp[0] = gd; pp[256] = gh; pp[512] = gw;
+      }
+      tap_next(p, it);
+      __syncthreads();                                 // step barrier
+      if (last_tap) {
+        t = 0; c0 += CH; it = TapIt{0, 0, 0};
+        if (i + 1 < NS) {
+          stage_region_any<CH>(p, g, c, xb, c0, s_reg, tid, 1024, vec != 0);
+          __syncthreads();
+        }
+      } else {
+        ++t;
+      }
+    }
+  } else if (role == 1) {
+    // ------------------------------------------------------------------------------------------------ gcol = W^T . go
+    // B fragments: go[k][voxel] for this wave's 4 sub-tiles of 16 voxels, all k (K <= 64)
+    float bfrag[4][16];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int pl = rw * 64 + st * 16 + l15;
+      const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+      const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
+      const bool ok = az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
+      const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int k = 4 * ks + lg;
+        bfrag[st][ks] = (ok && k < p.K) ? go[((long long)c.b * p.K + k) * p.P + gpos] : 0.f;
+      }
+    }
+    // A fragments of step j: W[k = 4 ks + lg][cj + l15][tj] (rows k >= K and columns >= C of the repacked tensor are zero), fetched one step ahead
+    float aN[16];
+    {
+      const float* wtt = wt2 + (long long)lg * CT + l15;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) aN[ks] = wtt[(4 * ks) * CT];
+    }
+    int tj = 0, cj = 0;                                // (tap, chunk origin) of step j
+#pragma unroll 1
+    for (int j = 0; j <= NS; ++j) {                    // iteration j writes gcol(j) during step j - 1 (j = 0: the prologue)
+      int tn = tj + 1, cn0 = cj;                       // step j + 1
+      if (tn == p.T) { tn = 0; cn0 += CH; }
+      if (j < NS) {
+        float a[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) a[ks] = aN[ks];
+        if (j + 1 < NS) {
+          const float* wtt = wt2 + ((long long)tn * 64 + lg) * CT + cn0 + l15;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) aN[ks] = wtt[(4 * ks) * CT];
+        }
+        float* dst = s_x + (j % 3) * XT + rw * 64 + l15;
+#pragma unroll
+        for (int sp2 = 0; sp2 < 2; ++sp2) {            // two sub-tiles at a time: 8 accumulator registers
+          f32x4 acc[2];
+          acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (!(dbg & 16))
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bfrag[2 * sp2 + u][ks], acc[u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (CH == 16 || 4 * lg + r < CH) dst[(4 * lg + r) * XS + (2 * sp2 + u) * 16] = acc[u][r];   // D row = channel, col = voxel
+        }
+      }
+      __syncthreads();                                 // j = 0: prologue barrier; else the barrier of step j - 1
+      tj = tn; cj = cn0;                               // now (tap, chunk) of step j + 1
+      if (j >= 1 && j < NS && (j % p.T) == 0) {        // step j - 1 was the last tap of its chunk: help re-staging the region for step j
+        stage_region_any<CH>(p, g, c, xb, (j / p.T) * CH, s_reg, tid, 1024, vec != 0);
+        __syncthreads();
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ dW partial = go . S^T
+    // A fragments: go[k = 16 rw + l15][voxel 4 ks + lg], 64 k-steps over the 256 voxels of the tile
+    float wfrag[64];
+    const int kk = 16 * rw + l15;
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) {
+      const int pl = 4 * ks + lg;
+      const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+      const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
+      const bool ok = kk < p.K && az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
+      wfrag[ks] = ok ? go[((long long)c.b * p.K + kk) * p.P + ((long long)gz * p.Ho + gy) * p.Wo + gx] : 0.f;
+    }
+    float* rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
+    const int brow = (l15 < CH ? l15 : CH - 1) * XS + lg;      // B operand: S[channel l15][voxel 4 ks + lg]; rows beyond CH are masked below
+    stage_region_any<CH>(p, g, c, xb, 0, s_reg, tid - 256, 768, vec != 0);
+    __syncthreads();                                   // prologue barrier
+    int ts = 0, cs = 0;                                // (tap, chunk index) of the step whose samples are contracted next
+#pragma unroll 1
+    for (int i = 0; i <= NS; ++i) {                    // iteration i contracts S(i - 1) during step i (i = NS: after the last barrier)
+      if (i >= 1) {
+        const float* src = s_x + ((i - 1) % 3) * XT + brow;
+        f32x4 wacc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 8))
+#pragma unroll
+        for (int ks = 0; ks < 64; ks += 4)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[ks + u], src[4 * (ks + u)], wacc[u], 0, 0, 0);
+        if (l15 < CH && cs * CH + l15 < p.C && !(dbg & 4)) {
+          float* dst = rep + ((long long)(ts * nchunk + cs) * 64 + 16 * rw + 4 * lg) * 16 + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * rw + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], (wacc[0][r] + wacc[1][r]) + (wacc[2][r] + wacc[3][r]));
+        }
+        if (++ts == p.T) { ts = 0; ++cs; }
+      }
+      if (i < NS) {
+        __syncthreads();                               // barrier of step i
+        if (i + 1 < NS && (i + 1) % p.T == 0) {        // step i was the last tap of its chunk
+          stage_region_any<CH>(p, g, c, xb, ((i + 1) / p.T) * CH, s_reg, tid, 1024, vec != 0);
+          __syncthreads();
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- grad_weight
 // dW[k][c][t] = sum_{b,p} go[k][p] * S[c][p;t].  Per (chunk, tap) the sampled tile S[16][256] goes to LDS and each wave
 // contracts it against its 16 output channels of go (kept in registers) with v_mfma_f32_16x16x4_f32 (D row = k, col = c);
@@ -1724,13 +2275,33 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
       hipLaunchKernelGGL((dcn_bwd_input_kernel<NS, NWv, false>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
     }                                                                                                                          \
   }
-      switch (q.TZ) {
-        case 1: DPF_GI(1, 4); break;
-        case 2: DPF_GI(2, 4); break;
-        case 3: DPF_GI(3, 4); break;
-        default:
-          if (getenv("DPF_DCN_GI4")) DPF_GI(4, 4) else DPF_GI(2, 8)   // 256 voxels: 8 waves (two per SIMD)
-          break;
+      // packed pairs (two channels per ds_add_u64, 16 channels per pass) unless DPF_DCN_GI_PK=0; needs the per-chunk max |W| too
+      static const int use_pk = getenv("DPF_DCN_GI_PK") ? atoi(getenv("DPF_DCN_GI_PK")) : 1;
+      const size_t lds_pk = sizeof(long long) * (size_t)(q.RZmax * q.RY * q.RX + 1) * PK_CS + sizeof(float) * ((size_t)npos * 34 + 4 + 32) +
+                            sizeof(unsigned) * (size_t)((q.RZmax * q.RY * q.RX + 4) & ~3);
+      if (use_pk && lds_pk <= 160 * 1024) {
+        if (!use_fx) hipLaunchKernelGGL(dcn_wmax_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, ws, wmaxv, p.T, CT, C);
+#define DPF_GIP(NS, NWv)                                                                                                       \
+  {                                                                                                                            \
+    if (set_lds(dcn_bwd_input_pk_kernel<NS, NWv>, lds_pk) != DPF_OK) return DPF_ERR_LAUNCH;                                    \
+    hipLaunchKernelGGL((dcn_bwd_input_pk_kernel<NS, NWv>), grid, dim3(64 * NWv), lds_pk, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
+  }
+        switch (q.TZ) {
+          case 1: DPF_GIP(1, 4); break;
+          case 2: DPF_GIP(2, 4); break;
+          case 3: DPF_GIP(3, 4); break;
+          default: DPF_GIP(2, 8); break;
+        }
+#undef DPF_GIP
+      } else {
+        switch (q.TZ) {
+          case 1: DPF_GI(1, 4); break;
+          case 2: DPF_GI(2, 4); break;
+          case 3: DPF_GI(3, 4); break;
+          default:
+            if (getenv("DPF_DCN_GI4")) DPF_GI(4, 4) else DPF_GI(2, 8)   // 256 voxels: 8 waves (two per SIMD)
+            break;
+        }
       }
 #undef DPF_GI
       dx_done = true;
@@ -1761,7 +2332,40 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   }
   // (A role-split variant of this kernel -- sampler waves + MFMA waves over three rotating tiles, like dcn_fwd_rs_kernel -- was built and
   // measured slower, 17.9 vs 13.7 ms on the 64-channel layer: its MFMA waves carry both matrix products and the 256-register budget spills.)
-  if (region_ok && dx_done) {
+  // role-split variant (sampler / gcol / wgrad waves, three rotating tiles): its own region geometry, the widest halo that fits next to
+  // the three tiles; DPF_DCN_OFF_RS=0 selects the fused 4-wave kernel
+  static const int use_off_rs = getenv("DPF_DCN_OFF_RS") ? atoi(getenv("DPF_DCN_OFF_RS")) : 1;
+  bool rs_done = false;
+  if (region_ok && dx_done && fuse_wg && use_off_rs) {
+    RegGeo gr{};
+    auto lds_of = [&](const RegGeo& qq) { return sizeof(float) * ((size_t)CHb * qq.RV + (size_t)3 * CHb * XS + 2 * 3 * 256); };
+    bool ok = false;
+    int vec_rs = 0;
+    if (can_vec) {
+      const int cand[6][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}};
+      for (int i = 0; i < 6 && !ok; ++i)
+        if (region_geo(gr, p, CHb, cand[i][0], true, cand[i][1]) == DPF_OK && lds_of(gr) <= 160 * 1024) { ok = true; vec_rs = 1; }
+    }
+    if (!ok) {
+      for (int R = 4; R >= 3 && !ok; --R)
+        if (region_geo(gr, p, CHb, R) == DPF_OK && lds_of(gr) <= 160 * 1024) ok = true;
+    }
+    if (ok) {
+      const size_t lds = lds_of(gr);
+      const dim3 grid((unsigned)((long long)B * gr.tilesZ * gr.tilesY * gr.tilesX));
+#define DPF_OFFRS(Cw)                                                                                                          \
+  {                                                                                                                            \
+    if (set_lds(dcn_bwd_offset_rs_kernel<Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                           \
+    hipLaunchKernelGGL((dcn_bwd_offset_rs_kernel<Cw>), grid, dim3(1024), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, p, gr, \
+                       CT, nchunk, vec_rs | ((getenv("DPF_DBG") ? atoi(getenv("DPF_DBG")) : 0) << 1));                                                                                    \
+  }
+      if (CHb == 16) DPF_OFFRS(16) else DPF_OFFRS(12)
+#undef DPF_OFFRS
+      rs_done = true;
+    }
+  }
+  if (rs_done) {
+  } else if (region_ok && dx_done) {
     const size_t lds = region_lds(rg, CHb);
     const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
 #define DPF_OFF(WGv, Cw)                                                                                                        \

@@ -420,6 +420,40 @@ def test_deform_conv(cfg):
     close(y0, F.conv3d(x, wt, bs, padding=1), 1e-4, 'dcn zero offset')
 
 
+@pytest.mark.parametrize('gi', [None, 5, 17])
+def test_deform_conv_collapsed_samples(gi):
+    """Offsets that send every sample of a 4x2x32 tile to the same point: the weight mass of one grad_input cell is ~6900, far above the
+    bound the packed fixed-point scatter assumes for its first pass -- it must measure that and repeat the pass (no wrap-around).  `gi`
+    exercises grad_input for a channel prefix (odd counts split a packed channel pair)."""
+    from oracle import dcn3d
+    ops = _ops()
+    B, C, K, D, H, W = 1, 20, 8, 4, 4, 64
+    x = rnd(B, C, D, H, W, seed=75)
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing='ij')
+    off = torch.zeros(B, 81, D, H, W)
+    for t in range(27):
+        ti, tj, tk = t // 9, (t // 3) % 3, t % 3
+        off[0, 3 * t] = 1.3 - (zz - 1 + ti).float()
+        off[0, 3 * t + 1] = (2 * (yy // 2)).float() + 0.4 - (yy - 1 + tj).float()
+        off[0, 3 * t + 2] = (32 * (xx // 32)).float() + 16.3 - (xx - 1 + tk).float()
+    off = off + 0.01 * rnd(*off.shape, seed=76)
+    wt = rnd(K, C, 3, 3, 3, seed=77, scale=0.1)
+    bs = rnd(K, seed=78)
+    y_ref = dcn3d.deform_conv3d_forward(x.double(), off.double(), wt.double(), bs.double())          # fp64 oracle: ~6900 terms per cell
+    go = rnd(*y_ref.shape, seed=79)
+    gr = dcn3d.deform_conv3d_backward(x.double(), off.double(), wt.double(), bs.double(), go.double())
+    xg, og, wg, bg = [t.to(DEV).requires_grad_() for t in (x, off, wt, bs)]
+    y = ops.deform_conv3d(xg, og, wg, bg, gi_channels=gi)
+    close(y, y_ref, 1e-4, 'dcn fwd (collapsed)')
+    gg = torch.autograd.grad(y, (xg, og, wg, bg), go.to(DEV))
+    gx_ref = gr[0].clone()
+    if gi is not None:
+        gx_ref[:, gi:] = 0
+    close(gg[0], gx_ref, 1e-4, 'dcn grad_input (collapsed)')   # fp32 coordinate arithmetic (like the reference) against the fp64 oracle
+    for a, r, nm in zip(gg[1:], gr[1:], ('grad_offset', 'grad_weight', 'grad_bias')):
+        close(a, r, 2e-4, 'dcn ' + nm)
+
+
 def test_anm_volume_and_sigmoid_mean():
     from oracle import recipe_state
     from oracle.stereodpnet import StereoDPNetOracle
