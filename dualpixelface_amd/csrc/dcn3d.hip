@@ -1698,6 +1698,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
 // lower-half thread adds it during step i+1 and does the read-modify-write of grad_offset (whose read was issued a step earlier).
 // gcol(i+1) and the dW product do not touch the staged region, so the pipeline runs through the chunk boundaries; only the
 // re-staging itself (all 1024 threads) is bracketed by barriers.
+#ifdef DPF_STAMPS
+__device__ unsigned long long g_stamps[16 * 128 * 2];
+#define DPF_STAMP(step, slot)                                                                                          \
+  if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_stamps[(wave_u * 128 + (step)) * 2 + (slot)] = __builtin_readcyclecounter();
+#else
+#define DPF_STAMP(step, slot)
+#endif
 constexpr int XS = 260;    // padded row of a rotating tile (wgrad B reads: rows l15, 4 consecutive voxels per lane group)
 
 // one sampler step of half H: partial coordinate gradient (gd, gh, gw) over this half's channels; the samples replace the gcol column.
@@ -1828,6 +1835,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
         else { atomicAdd(dqp, a0); atomicAdd(dqp + p.P, a1); atomicAdd(dqp + 2 * p.P, a2); }
       }
       if (i == NS) break;
+      DPF_STAMP(i, 0)
       first_chunk = c0 == 0;
       const Off3 ocur = onext;
       const bool last_tap = t + 1 == p.T;
@@ -1848,6 +1856,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
         pp[0] = gd; pp[256] = gh; pp[512] = gw;
       }
       tap_next(p, it);
+      DPF_STAMP(i, 1)
       __syncthreads();                                 // step barrier
       if (last_tap) {
         t = 0; c0 += CH; it = TapIt{0, 0, 0};
@@ -1888,6 +1897,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
     for (int j = 0; j <= NS; ++j) {                    // iteration j writes gcol(j) during step j - 1 (j = 0: the prologue)
       int tn = tj + 1, cn0 = cj;                       // step j + 1
       if (tn == p.T) { tn = 0; cn0 += CH; }
+      DPF_STAMP(j, 0)
       if (j < NS) {
         float a[16];
 #pragma unroll
@@ -1915,6 +1925,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
               if (CH == 16 || 4 * lg + r < CH) dst[(4 * lg + r) * XS + (2 * sp2 + u) * 16] = acc[u][r];   // D row = channel, col = voxel
         }
       }
+      DPF_STAMP(j, 1)
       __syncthreads();                                 // j = 0: prologue barrier; else the barrier of step j - 1
       tj = tn; cj = cn0;                               // now (tap, chunk) of step j + 1
       if (j >= 1 && j < NS && (j % p.T) == 0) {        // step j - 1 was the last tap of its chunk: help re-staging the region for step j
@@ -1942,6 +1953,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
     int ts = 0, cs = 0;                                // (tap, chunk index) of the step whose samples are contracted next
 #pragma unroll 1
     for (int i = 0; i <= NS; ++i) {                    // iteration i contracts S(i - 1) during step i (i = NS: after the last barrier)
+      DPF_STAMP(i, 0)
       if (i >= 1) {
         const float* src = s_x + ((i - 1) % 3) * XT + brow;
         f32x4 wacc[4];
@@ -1960,6 +1972,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
         }
         if (++ts == p.T) { ts = 0; ++cs; }
       }
+      DPF_STAMP(i, 1)
       if (i < NS) {
         __syncthreads();                               // barrier of step i
         if (i + 1 < NS && (i + 1) % p.T == 0) {        // step i was the last tap of its chunk
@@ -2433,5 +2446,11 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   }
   return dpf_check_launch();
 }
+
+#ifdef DPF_STAMPS
+int dpf_debug_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16 * 128 * 2) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

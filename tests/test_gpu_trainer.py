@@ -64,7 +64,9 @@ def test_entry_point_smoke():
     ws = os.path.join(ROOT, 'workspace', 'stereodpnet', 'pytest_smoke')
     assert os.path.exists(os.path.join(ws, 'checkpoint_epoch=00.ckpt')) and os.path.exists(os.path.join(ws, 'log.jsonl'))
     ck = torch.load(os.path.join(ws, 'checkpoint_epoch=00.ckpt'), map_location='cpu', weights_only=False)
-    assert ck['global_step'] == 2 and len(ck['state_dict']) == 512      # the reference's 511 keys + the lazy normal_estimator.grid (Q9)
+    # PL 1.4.9 dump_checkpoint convention: global_step + 1 (two optimizer steps -> 3), flagged by 'dpf_ckpt_version'
+    assert ck['global_step'] == 3 and ck['dpf_ckpt_version'] == 2
+    assert len(ck['state_dict']) == 512      # the reference's 511 keys + the lazy normal_estimator.grid (Q9)
 
 
 def test_training_from_a_facedp_dataset_on_disk(tmp_path, monkeypatch):

@@ -63,6 +63,22 @@ def test_checkpoint_every_epoch_and_resume(tmp_path):
     assert torch.equal(m2.w.data, m.w.data) and m2._adam['step'] == 12 and torch.equal(m2._adam['m'], m._adam['m'])
     ck = torch.load(tr.checkpoint_path(2), weights_only=False)
     assert set(ck['state_dict']) == {'w', 'running'} and ck['optimizer_states'][0]['kind'] == 'flat_adam'
+    # file conventions: ours (versioned) stores PL's epoch + 1 / global_step + 1; a round-1 file (no version key, no PL key) stored the
+    # FINISHED epoch and the plain step count; a PL file is taken as PL restores it
+    assert ck['dpf_ckpt_version'] == 2 and ck['epoch'] == 3 and ck['global_step'] == 13
+    ck1 = torch.load(tr.checkpoint_path(1), weights_only=False)
+    legacy = dict(ck1, epoch=1, global_step=8)
+    del legacy['dpf_ckpt_version']
+    torch.save(legacy, str(tmp_path / 'legacy.ckpt'))
+    tr3 = Trainer(opt, str(tmp_path / 'legacy'), rank=0, world_size=1)
+    tr3.load_checkpoint(_Stub(), str(tmp_path / 'legacy.ckpt'))
+    assert tr3.epoch == 2 and tr3.global_step == 8
+    pl = dict(legacy, epoch=2, global_step=9)
+    pl['pytorch-lightning_version'] = '1.4.9'
+    torch.save(pl, str(tmp_path / 'pl.ckpt'))
+    tr4 = Trainer(opt, str(tmp_path / 'pl'), rank=0, world_size=1)
+    tr4.load_checkpoint(_Stub(), str(tmp_path / 'pl.ckpt'))
+    assert tr4.epoch == 2 and tr4.global_step == 9
 
 
 def test_sample_sharding_equal_steps_on_every_rank():
