@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
 // channel of 4 voxels (D row = voxel, col = channel), adds the 8 corner contributions with conflict-free LDS atomics
 // (16 consecutive channels per voxel) and flushes the region once with row-contiguous global atomics.  Samples that leave
 // the region (|offset| >~ 2) fall back to a direct global atomic.
-constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8, GI_CS = 8;   // 8 channels per pass; cell stride 64 B: the cells of 4 x-adjacent voxels tile the 256-B bank row (GI_CS = 9 measured 59 % conflict cycles)
+constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8;   // tile 4 x 2 x 32 outputs, halo 3; GI_CH: granularity of the per-chunk max |W| table
 
 struct GiP {
   int TZ, RZmax, RY, RX;     // tile depth, region dims
@@ -347,232 +347,9 @@ struct GiP {
   int CG;                    // grad_input is produced for channels [0, CG) only
 };
 
-// Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 sustains 0.33 lanes/clk/CU whatever the address pattern,
-// ds_add_f64 3.1 and ds_add_u64 4.8-5.4.  The region therefore accumulates in fp64 (also the more accurate sum); it is
-// converted to fp32 once, at the flush.
-// NW waves per workgroup, NST position sub-tiles of 16 per wave (positions per block = 16 * NST * NW).  NW = 8 runs two waves per
-// SIMD on the same LDS footprint: every phase has twice the threads (each voxel's eight table corners are split between a
-// thread pair), so the issue-bound table / scatter streams of the two waves interleave.
-// FX: the region accumulates in 64-bit FIXED POINT with ds_add_u64 (4.8-5.4 lanes/clk/CU against 3.1 for ds_add_f64,
-// tools/lds_atomic_bench.hip).  The conversion that made an earlier fixed-point variant a net loss is moved out of the per-corner
-// path: a gcol value is quantised ONCE (27 bits against a per-workgroup bound max_p sum_k |go| * max |W|), the 8 corner weights of a
-// (voxel, tap) are quantised once in the table phase (23 bits, shared by all channels), and a contribution is one v_mad_i64_i32.
-// 2^26 * 2^23 * (6912 units of weight mass a tile can put into one cell) < 2^63: no overflow for ANY offsets; integer sums are order
-// independent, so this half of grad_input is also bitwise reproducible.
-template <int NST, int NW, bool FX>
-__global__ __launch_bounds__(64 * NW) void dcn_bwd_input_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
-                                                            const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT,
-                                                            const float* __restrict__ wmaxv /*[chunks of GI_CH] max |W|, FX only*/) {
-  extern __shared__ __align__(16) double smem_d[];
-  constexpr int NT = 64 * NW;
-  constexpr int npos = 16 * NST * NW;
-  constexpr bool HALVES = NW == 8;   // thread pair per voxel in the table phase
-  double* s_reg = smem_d;                                      // [RZ*RY*RX][GI_CS]
-  const int regvox = q.RZmax * q.RY * q.RX;
-  int* s_lidx = (int*)(s_reg + ((regvox * GI_CS + GI_CS + 1) & ~1));   // [npos][8] local voxel index or -1 (16-B aligned); GI_CS dummy doubles before it
-  int* s_vox = s_lidx + npos * 8;                              // [npos][8] global voxel index or -1
-  float* s_w = (float*)(s_vox + npos * 8);                     // [npos][8] corner weight, 0 outside the region
-  float* s_wfar = s_w + npos * 8;                              // [npos][8] corner weight (far pass)
-  int* s_far = (int*)(s_wfar + npos * 8);                         // [4] per-tap flag: some corner left the region
-  int* s_farm = s_far + 4;                                      // [2][npos] per-voxel flag (one row per thread of a pair)
-  float* s_gmax = (float*)(s_farm + 2 * npos);                  // [NW] per-wave max_p sum_k |go[k][p]|  (FX)
-  long long* s_regq = reinterpret_cast<long long*>(s_reg);      // the same region viewed as int64 (FX)
-  int* s_wq = reinterpret_cast<int*>(s_w);                      // table weights as 23-bit fixed point (FX)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int lc = l15 & 7;            // channel within the chunk; lanes 8..15 of a group mirror lanes 0..7 ...
-  const int jb = (l15 >> 3) * 4;     // ... and scatter corners 4..7 instead of 0..3
-
-  int bb = blockIdx.x;
-  const int tx = bb % q.tilesX; bb /= q.tilesX;
-  const int ty = bb % q.tilesY; bb /= q.tilesY;
-  const int tz = bb % q.tilesZ;
-  const int b = bb / q.tilesZ;
-  const int z0 = tz * q.TZ, y0 = ty * GI_TY, x0 = tx * GI_TX;
-  const int rz0u = z0 * p.sd - p.pd - GI_R, ry0 = y0 * p.sh - p.ph - GI_R, rx0 = x0 * p.sw - p.pw - GI_R;
-  const int rz0 = rz0u < 0 ? 0 : rz0u;
-  int rz1 = rz0u + (q.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * GI_R;
-  if (rz1 > p.D) rz1 = p.D;
-  int RZ = rz1 - rz0;
-  if (RZ > q.RZmax) RZ = q.RZmax;
-
-  const long long chan = (long long)p.D * p.H * p.W;
-  const float* off_b = offset + (long long)b * 3 * p.T * p.P;
-  float* dxb = dx + (long long)b * p.C * chan;
-
-  const int vox = HALVES ? (tid & (npos - 1)) : tid;       // this thread's voxel in the table phase
-  const int half = HALVES ? tid / npos : 0;
-  const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
-  const int zo = z0 + pdz, yo = y0 + pdy, xo = x0 + pdx;
-  const bool pvalid = (HALVES || tid < npos) && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
-  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
-
-  // A fragments: go[k][voxel] for this wave's NST sub-tiles, all k (K <= 64 -> 16 k-steps of 4), kept in registers
-  float afrag[NST][16];
-#pragma unroll
-  for (int st = 0; st < NST; ++st) {
-    const int pl = (wave * NST + st) * 16 + l15;
-    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
-    const int gz = z0 + az, gy = y0 + ay, gx = x0 + ax;
-    const bool ok = az < q.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
-    const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int k = 4 * ks + lg;
-      afrag[st][ks] = (ok && k < p.K) ? go[((long long)b * p.K + k) * p.P + gpos] : 0.f;
-    }
-  }
-
-  float gbound = 0.f;
-  if (FX) {   // max over this workgroup's voxels of sum_k |go[k][voxel]|
-    float m = 0.f;
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-      float sa = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) sa += fabsf(afrag[st][ks]);
-      sa += __shfl_xor(sa, 16, 64);
-      sa += __shfl_xor(sa, 32, 64);
-      m = fmaxf(m, sa);
-    }
-    m = dpf_wave_max(m);
-    if (lane == 0) s_gmax[wave] = m;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < NW; ++w) gbound = fmaxf(gbound, s_gmax[w]);
-  }
-
-  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
-  const float* offp0 = off_b + (pvalid ? ppos : 0);
-  for (int c0 = 0; c0 < q.CG; c0 += GI_CH) {      // only the channels whose gradient the caller needs
-    __syncthreads();                                            // previous chunk flushed
-    // |gcol| <= gbound * max|W| of this channel chunk: quantisation step of the 27-bit gcol values, and its inverse for the flush
-    float qscale = 0.f, qinv = 0.f;
-    if (FX) {
-      const float B = gbound * wmaxv[c0 / GI_CH];
-      if (B > 0.f) { qscale = 67108864.f / B; qinv = B * (1.f / 67108864.f) * (1.f / 8388608.f); }
-    }
-    for (int i = tid; i < regvox * GI_CS + GI_CS; i += NT) s_reg[i] = 0.0;
-    if (tid == 0) s_far[0] = 0;
-    const int cc = c0 + lc;
-    const bool cok = cc < q.CG;
-    const float* offp = offp0;
-    Off3 onext = load_off_ptr(offp, p.P, pvalid);
-    TapIt it = {0, 0, 0};
-    float bnext[16];
-    const float* wtn = wt2 + (long long)lg * CT + cc;      // rows k >= K of the repacked tensor are zero; cc < CT always
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
-    for (int t = 0; t < p.T; ++t) {
-      __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
-      if (tid == 0) s_far[(t + 1) & 1] = 0;                     // the flag alternates between two slots: no extra barrier to reset it
-      const Off3 ocur = onext;
-      offp += 3 * p.P;
-      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch: consumed one barrier-to-barrier phase later
-      const TapIt itc = it;
-      tap_next(p, it);
-      if (HALVES || tid < npos) {
-        const Corner cn = corner_at(p, pvalid, zb, yb, xbase, itc, ocur);
-        int anyfar = 0;
-#pragma unroll
-        for (int jj = 0; jj < (HALVES ? 4 : 8); ++jj) {
-          const int j = HALVES ? 4 * half + jj : jj;
-          float wg;
-          const int v = corner_index32(p, cn, j, wg);
-          // element index of the corner's cell in the region; corners outside the region (or the volume) point at the dummy
-          // cell behind it with weight 0, so the scatter below needs no select
-          int li = regvox * GI_CS;
-          bool in = false;
-          if (v >= 0) {
-            const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
-            const int lz = cn.d0 + jd - rz0, ly = cn.h0 + jh - ry0, lx = cn.w0 + jw - rx0;
-            if (lz >= 0 && lz < RZ && ly >= 0 && ly < q.RY && lx >= 0 && lx < q.RX) {
-              li = ((lz * q.RY + ly) * q.RX + lx) * GI_CS;
-              in = true;
-            }
-          }
-          s_lidx[vox * 8 + j] = li;
-          s_vox[vox * 8 + j] = (in || v < 0) ? -1 : (int)v;      // >= 0 only for far corners (second pass)
-          if (FX) s_wq[vox * 8 + j] = in ? __float2int_rn(wg * 8388608.f) : 0;
-          else s_w[vox * 8 + j] = in ? wg : 0.f;
-          s_wfar[vox * 8 + j] = wg;
-          if (!in && v >= 0) anyfar = 1;
-        }
-        s_farm[half * npos + vox] = anyfar;
-        if (anyfar) s_far[t & 1] = 1;
-      }
-      // B fragments: W[k][c0 + lc][t] (both lane halves of a group hold the same 8 channels); next tap's are prefetched
-      float bfrag[16];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) bfrag[ks] = bnext[ks];
-      if (t + 1 < p.T) {
-        wtn += 64 * CT;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
-      }
-      __syncthreads();                                          // tables visible
-#pragma unroll
-      for (int st = 0; st < NST; ++st) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
-        if (cok) {
-          // straight-line scatter: corners outside the region (or invalid) add 0.0 to a dummy slot, so no branch (and no
-          // LDS wait) separates the eight ds_add_f64 of a voxel; the rare far corners are handled in a second, branchy pass
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int pl = (wave * NST + st) * 16 + 4 * lg + r;   // D row = voxel
-            const float g = acc[r];
-            const int4 la = *reinterpret_cast<const int4*>(&s_lidx[pl * 8 + jb]);
-            const int li[4] = {la.x, la.y, la.z, la.w};
-            if (FX) {
-              const int4 wa = *reinterpret_cast<const int4*>(&s_wq[pl * 8 + jb]);
-              const int wq[4] = {wa.x, wa.y, wa.z, wa.w};
-              const long long G = (long long)__float2int_rn(g * qscale);
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                atomicAdd(reinterpret_cast<unsigned long long*>(&s_regq[li[j] + lc]), (unsigned long long)(G * (long long)wq[j]));
-            } else {
-              const float4 wa = *reinterpret_cast<const float4*>(&s_w[pl * 8 + jb]);
-              const float wv[4] = {wa.x, wa.y, wa.z, wa.w};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) atomicAdd(&s_reg[li[j] + lc], (double)(wv[j] * g));
-            }
-          }
-          if (s_far[t & 1] != 0) {                                     // block-uniform: some corner of this tap left the region
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int pl = (wave * NST + st) * 16 + 4 * lg + r;
-              if ((s_farm[pl] | (HALVES ? s_farm[npos + pl] : 0)) == 0) continue;
-              const float g = acc[r];
-              for (int j = 0; j < 4; ++j) {
-                const int v = s_vox[pl * 8 + jb + j];
-                if (v >= 0) atomicAdd(&dxb[(long long)cc * chan + v], s_wfar[pl * 8 + jb + j] * g);   // direct scatter
-              }
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // flush: lanes along x (row-contiguous global atomics); odd channel stride keeps the LDS reads conflict-light
-    const int rowlen = q.RX;
-    const int nrows = RZ * q.RY * GI_CH;
-    for (int row = wave; row < nrows; row += NW) {
-      const int c = row % GI_CH;
-      const int zy = row / GI_CH;
-      const int ly = zy % q.RY, lz = zy / q.RY;
-      const int gz = rz0 + lz, gy = ry0 + ly;
-      if (c0 + c >= q.CG || gy < 0 || gy >= p.H) continue;
-      float* dst = dxb + (long long)(c0 + c) * chan + ((long long)gz * p.H + gy) * p.W;
-      for (int lx = lane; lx < rowlen; lx += 64) {
-        const int gx = rx0 + lx;
-        const int cell = ((lz * q.RY + ly) * q.RX + lx) * GI_CS + c;
-        const float v = FX ? (float)((double)s_regq[cell] * (double)qinv) : (float)s_reg[cell];
-        if (v != 0.f && gx >= 0 && gx < p.W) atomicAdd(&dst[gx], v);
-      }
-    }
-  }
-}
+// Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 sustains 0.33 lanes/clk/CU whatever the address pattern, ds_add_f64 3.1
+// and ds_add_u64 4.8-5.4: the region accumulates in 64-bit FIXED POINT (dcn_bwd_input_pk_kernel below; rounds 1-2 used fp64, then one
+// 64-bit fixed-point value per channel -- 8 channels per pass, 17.9 ms per launch where the packed-pair kernel takes 10.0).
 
 // wmax[ch] = max over taps, k and the GI_CH channels of chunk ch of |wt2[t][k][c]|   (one workgroup per chunk)
 __global__ __launch_bounds__(256) void dcn_wmax_kernel(const float* __restrict__ wt2, float* __restrict__ wmax, int T, int CT, int C) {
@@ -605,9 +382,17 @@ __global__ __launch_bounds__(256) void dcn_wmax_kernel(const float* __restrict__
 // measured bound -- far-corner global atomics are emitted on the first attempt only.  Later passes use the measured bound.
 // Error per contribution <= 0.5 unit, unit = gbound * wmax * mass / 2^30: ~1e-6 of the tensor scale at MASS0, deterministic
 // (integer adds commute).
+#ifdef DPF_STAMPS
+__device__ unsigned long long g_stamps[16 * 128 * 2];
+#define DPF_STAMP(step, slot)                                                                                          \
+  if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_stamps[(DPF_STAMP_WAVE * 128 + (step)) * 2 + (slot)] = __builtin_readcyclecounter();
+#else
+#define DPF_STAMP(step, slot)
+#endif
 constexpr int PK_CH = 16, PK_CS = 8;
 constexpr float PK_MASS0 = 128.f, PK_MASS_Q = 131072.f;   // first-pass mass bound; fixed-point scale of the mass counters (6912 * 2^17 < 2^30)
 
+#define DPF_STAMP_WAVE wave
 template <int NST, int NW>
 __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
                                                                    const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT,
@@ -618,19 +403,20 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   constexpr bool HALVES = NW == 8;   // thread pair per voxel in the table phase
   const int regvox = q.RZmax * q.RY * q.RX;
   long long* s_regq = smem_q;                                    // [regvox + 1][PK_CS]: cell = 8 packed channel pairs; last cell = dummy
-  int* s_lidx = (int*)(s_regq + (size_t)(regvox + 1) * PK_CS);   // [npos][8] u64 index of the corner's cell (dummy cell when outside)
-  int* s_vox = s_lidx + npos * 8;                                // [npos][8] global voxel index, >= 0 only for far corners
-  float* s_w = (float*)(s_vox + npos * 8);                       // [npos][8] corner weight, 0 outside the region
-  float* s_wfar = s_w + npos * 8;                                // [npos][8] corner weight (far pass)
-  unsigned* s_mass = (unsigned*)(s_wfar + npos * 8);             // [regvox + 4] weight mass per cell, PK_MASS_Q fixed point
-  int* s_far = (int*)(s_mass + ((regvox + 4) & ~3));             // [4] per-tap flag: some corner left the region
-  int* s_farm = s_far + 4;                                       // [2][npos] per-voxel flag (one row per thread of a pair)
-  float* s_gmax = (float*)(s_farm + 2 * npos);                   // [NW]
+  int* s_lidx = (int*)(s_regq + (size_t)(regvox + 1) * PK_CS);   // [2][npos][8] u64 index of the corner's cell (dummy cell when outside)
+  float* s_w = (float*)(s_lidx + 2 * npos * 8);                  // [2][npos][8] corner weight, 0 outside the region
+  unsigned* s_mass = (unsigned*)(s_w + 2 * npos * 8);            // [regvox + 4] weight mass per cell, PK_MASS_Q fixed point
+  int* s_far = (int*)(s_mass + ((regvox + 4) & ~3));             // [4] flag of tap t in slot t % 3: some corner left the region
+  int* s_farm = s_far + 4;                                       // [2][2][npos] per-voxel flag (one row per thread of a pair)
+  float* s_gmax = (float*)(s_farm + 4 * npos);                   // [NW]
   unsigned* s_mmax = (unsigned*)(s_gmax + NW);                   // [NW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int pr = l15 >> 1;           // channel pair within the 16-channel chunk
   const int jb = (l15 & 1) * 4;      // this lane's corners: 0-3 (even lane) or 4-7 (odd lane)
   const bool odd = (l15 & 1) != 0;
+  // the two waves that share a SIMD (wave, wave + 4) run the two halves of a tap step in opposite order: one builds the next tap's
+  // tables (vector ALU) while the other feeds the LDS atomic unit and the matrix pipe
+  const bool tables_first = __builtin_amdgcn_readfirstlane(NW == 8 ? (wave >> 2) & 1 : wave & 1) != 0;
 
   int bb = blockIdx.x;
   const int tx = bb % q.tilesX; bb /= q.tilesX;
@@ -697,6 +483,62 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   float massb = PK_MASS0;      // bound on the weight mass of a cell that the current pass is scaled for
   bool need_mass = true;       // the running pass also measures the mass
   int attempt = 0;             // 1: this pass is a repeat (far corners already emitted)
+
+  // corner tables of one tap for this thread's voxel (its 4 or 8 corners) into table buffer `buf`.  Separable: per axis and side
+  // (low / high corner) the in-volume flag, the in-region flag, the cell-index term and the linear weight; a corner is then two
+  // adds, two multiplies and two mask ANDs (cuh:43-68 for the index / weight, cuh:248 for `valid`)
+  const int RYX = q.RY * q.RX * PK_CS, RXC = q.RX * PK_CS;
+  auto build_table = [&](int t, int buf, const TapIt& itc, const Off3& ocur) {
+    if (HALVES || tid < npos) {
+      const Corner cn = corner_at(p, pvalid, zb, yb, xbase, itc, ocur);
+      bool okz[2], oky[2], okx[2], inz[2], iny[2], inx[2];
+      int cz[2], cy[2], cx[2];
+      float wz[2], wy[2], wx[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int d = cn.d0 + e, h = cn.h0 + e, w = cn.w0 + e;
+        const int lz = d - rz0, ly = h - ry0, lx = w - rx0;
+        okz[e] = cn.valid && d >= 0 && d <= p.D - 1;
+        oky[e] = h >= 0 && h <= p.H - 1;
+        okx[e] = w >= 0 && w <= p.W - 1;
+        inz[e] = lz >= 0 && lz < RZ;
+        iny[e] = ly >= 0 && ly < q.RY;
+        inx[e] = lx >= 0 && lx < q.RX;
+        cz[e] = lz * RYX; cy[e] = ly * RXC; cx[e] = lx * PK_CS;
+        wz[e] = e ? cn.ld : 1.f - cn.ld;
+        wy[e] = e ? cn.lh : 1.f - cn.lh;
+        wx[e] = e ? cn.lw : 1.f - cn.lw;
+      }
+      bool anyfar = false;
+      int liv[HALVES ? 4 : 8];
+      float wv[HALVES ? 4 : 8];
+#pragma unroll
+      for (int jj = 0; jj < (HALVES ? 4 : 8); ++jj) {
+        const int jd = HALVES ? -1 : (jj >> 2) & 1, jh = (jj >> 1) & 1, jw = jj & 1;
+        // HALVES: this thread's z side is `half` (a run-time value): select the z terms once, outside (below)
+        const bool ok = (HALVES ? (half ? okz[1] : okz[0]) : okz[jd]) && oky[jh] && okx[jw];
+        const bool in = ok && (HALVES ? (half ? inz[1] : inz[0]) : inz[jd]) && iny[jh] && inx[jw];
+        const int zc = HALVES ? (half ? cz[1] : cz[0]) : cz[jd];
+        const float zw = HALVES ? (half ? wz[1] : wz[0]) : wz[jd];
+        const float wg = zw * wy[jh] * wx[jw];
+        liv[jj] = in ? zc + cy[jh] + cx[jw] : dummy;
+        wv[jj] = in ? wg : 0.f;
+        anyfar |= ok && !in;
+        if (need_mass && in) atomicAdd(&s_mass[liv[jj] / PK_CS], (unsigned)__float2int_rn(wg * PK_MASS_Q));
+      }
+      int* lp = &s_lidx[(buf * npos + vox) * 8 + 4 * half];
+      float* wp = &s_w[(buf * npos + vox) * 8 + 4 * half];
+      *reinterpret_cast<int4*>(lp) = make_int4(liv[0], liv[1], liv[2], liv[3]);
+      *reinterpret_cast<float4*>(wp) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      if (!HALVES) {
+        *reinterpret_cast<int4*>(lp + 4) = make_int4(liv[4], liv[5], liv[6], liv[7]);
+        *reinterpret_cast<float4*>(wp + 4) = make_float4(wv[4], wv[5], wv[6], wv[7]);
+      }
+      s_farm[(buf * 2 + half) * npos + vox] = anyfar ? 1 : 0;
+      if (anyfar) s_far[t % 3] = 1;
+    }
+  };
+
   for (int c0 = 0; c0 < q.CG;) {      // only the channels whose gradient the caller needs
     __syncthreads();                                            // previous pass flushed
     float qscale = 0.f, qinv = 0.f;
@@ -709,7 +551,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
     for (int i = tid; i < (regvox + 1) * PK_CS; i += NT) s_regq[i] = 0;
     if (need_mass)
       for (int i = tid; i < regvox + 1; i += NT) s_mass[i] = 0u;
-    if (tid == 0) s_far[0] = 0;
+    if (tid < 3) s_far[tid] = 0;
     const int cc = c0 + l15;                                    // this lane's gcol column (B fragment); < CT always
     const int ce = c0 + 2 * pr;                                 // even channel of the pair this lane scatters
     const float* offp = offp0;
@@ -719,42 +561,21 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
     const float* wtn = wt2 + (long long)lg * CT + cc;           // rows k >= K of the repacked tensor are zero
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
-    for (int t = 0; t < p.T; ++t) {
-      __syncthreads();                                          // tables of the previous tap consumed (and region zeroed)
-      if (tid == 0) s_far[(t + 1) & 1] = 0;
-      const Off3 ocur = onext;
+    __syncthreads();                                            // region / flags cleared
+    {                                                           // tables of tap 0
+      const Off3 o0 = onext;
       offp += 3 * p.P;
-      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);
-      const TapIt itc = it;
-      tap_next(p, it);
-      if (HALVES || tid < npos) {
-        const Corner cn = corner_at(p, pvalid, zb, yb, xbase, itc, ocur);
-        int anyfar = 0;
-#pragma unroll
-        for (int jj = 0; jj < (HALVES ? 4 : 8); ++jj) {
-          const int j = HALVES ? 4 * half + jj : jj;
-          float wg;
-          const int v = corner_index32(p, cn, j, wg);
-          int li = dummy;
-          bool in = false;
-          if (v >= 0) {
-            const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
-            const int lz = cn.d0 + jd - rz0, ly = cn.h0 + jh - ry0, lx = cn.w0 + jw - rx0;
-            if (lz >= 0 && lz < RZ && ly >= 0 && ly < q.RY && lx >= 0 && lx < q.RX) {
-              li = ((lz * q.RY + ly) * q.RX + lx) * PK_CS;
-              in = true;
-            }
-          }
-          s_lidx[vox * 8 + j] = li;
-          s_vox[vox * 8 + j] = (in || v < 0) ? -1 : (int)v;
-          s_w[vox * 8 + j] = in ? wg : 0.f;
-          s_wfar[vox * 8 + j] = wg;
-          if (need_mass && in) atomicAdd(&s_mass[li / PK_CS], (unsigned)__float2int_rn(wg * PK_MASS_Q));
-          if (!in && v >= 0) anyfar = 1;
-        }
-        s_farm[half * npos + vox] = anyfar;
-        if (anyfar) s_far[t & 1] = 1;
-      }
+      onext = load_off_ptr(offp, p.P, pvalid && 1 < p.T);
+      build_table(0, 0, it, o0);
+    }
+    TapIt it_cur = it;                                          // tap t; `it` runs one tap ahead (the tables being built)
+    tap_next(p, it);
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t) {
+      const int cur = t & 1;
+      if (c0 == PK_CH) { DPF_STAMP(2 * t, 0) }
+      if (tid == 0) s_far[(t + 2) % 3] = 0;                     // slot of tap t + 2: nobody reads or sets it during this step
+      // B fragments: W[k][c0 + l15][t]; the next tap's are prefetched
       float bfrag[16];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) bfrag[ks] = bnext[ks];
@@ -763,16 +584,28 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
       }
-      __syncthreads();                                          // tables visible
+      const Off3 ocur = onext;                                  // offsets of tap t + 1
+      offp += 3 * p.P;
+      onext = load_off_ptr(offp, p.P, pvalid && t + 2 < p.T);
+      if (tables_first && t + 1 < p.T) build_table(t + 1, cur ^ 1, it, ocur);
+      if (c0 == PK_CH) { DPF_STAMP(2 * t, 1) }
+      // ---- scatter of tap t
+      const int* lidx = s_lidx + cur * npos * 8;
+      const float* wtab = s_w + cur * npos * 8;
+      f32x4 acc[NST];
+#pragma unroll
+      for (int st = 0; st < NST; ++st) acc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int st = 0; st < NST; ++st) acc[st] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc[st], 0, 0, 0);
+      const bool far_tap = attempt == 0 && s_far[t % 3] != 0;   // block-uniform: some corner of this tap left the region
 #pragma unroll
       for (int st = 0; st < NST; ++st) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc, 0, 0, 0);
         float ge[4], gd[4];    // gcol of the pair's even / odd channel for the 4 voxels (D rows) of this lane group
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float mine = acc[r];
+          const float mine = acc[st][r];
           const float other = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]: lane ^ 1
           ge[r] = odd ? other : mine;
           gd[r] = odd ? mine : other;
@@ -780,8 +613,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pl = (wave * NST + st) * 16 + 4 * lg + r;   // D row = voxel
-          const int4 la = *reinterpret_cast<const int4*>(&s_lidx[pl * 8 + jb]);
-          const float4 wa = *reinterpret_cast<const float4*>(&s_w[pl * 8 + jb]);
+          const int4 la = *reinterpret_cast<const int4*>(&lidx[pl * 8 + jb]);
+          const float4 wa = *reinterpret_cast<const float4*>(&wtab[pl * 8 + jb]);
           const int li[4] = {la.x, la.y, la.z, la.w};
           const float wv[4] = {wa.x, wa.y, wa.z, wa.w};
           const float es = ge[r] * qscale, os = gd[r] * qscale;
@@ -792,24 +625,39 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
             atomicAdd(reinterpret_cast<unsigned long long*>(&s_regq[li[j] + pr]), (unsigned long long)pk);
           }
         }
-        if (attempt == 0 && s_far[t & 1] != 0) {                      // block-uniform: some corner of this tap left the region
-#pragma unroll
+        if (far_tap) {
+          // rare: corners outside the staged box go straight to global memory; their tables are not kept -- the corner is recomputed
+          // from the voxel's offsets
+#pragma unroll 1
           for (int r = 0; r < 4; ++r) {
             const int pl = (wave * NST + st) * 16 + 4 * lg + r;
-            if ((s_farm[pl] | (HALVES ? s_farm[npos + pl] : 0)) == 0) continue;
+            if ((s_farm[(cur * 2) * npos + pl] | (HALVES ? s_farm[(cur * 2 + 1) * npos + pl] : 0)) == 0) continue;
+            const int fx = pl & 31, fy = (pl >> 5) & 1, fz = pl >> 6;
+            const int fzo = z0 + fz, fyo = y0 + fy, fxo = x0 + fx;
+            const long long fpos = ((long long)fzo * p.Ho + fyo) * p.Wo + fxo;
+            const Off3 fo = load_off_ptr(off_b + (long long)(3 * t) * p.P + fpos, p.P, true);
+            const Corner cn = corner_at(p, true, fzo * p.sd - p.pd, fyo * p.sh - p.ph, fxo * p.sw - p.pw, it_cur, fo);
+#pragma unroll 1
             for (int j = 0; j < 4; ++j) {
-              const int v = s_vox[pl * 8 + jb + j];
-              if (v >= 0) {
-                const float wf = s_wfar[pl * 8 + jb + j];
-                if (ce < q.CG) atomicAdd(&dxb[(long long)ce * chan + v], wf * ge[r]);       // direct scatter
-                if (ce + 1 < q.CG) atomicAdd(&dxb[(long long)(ce + 1) * chan + v], wf * gd[r]);
-              }
+              float wg;
+              const int v = corner_index32(p, cn, jb + j, wg);
+              if (v < 0) continue;
+              const int jd = ((jb + j) >> 2) & 1, jh = ((jb + j) >> 1) & 1, jw = (jb + j) & 1;
+              const int lz = cn.d0 + jd - rz0, ly = cn.h0 + jh - ry0, lx = cn.w0 + jw - rx0;
+              if (lz >= 0 && lz < RZ && ly >= 0 && ly < q.RY && lx >= 0 && lx < q.RX) continue;   // went into the region
+              if (ce < q.CG) atomicAdd(&dxb[(long long)ce * chan + v], wg * ge[r]);
+              if (ce + 1 < q.CG) atomicAdd(&dxb[(long long)(ce + 1) * chan + v], wg * gd[r]);
             }
           }
         }
       }
+      if (c0 == PK_CH) { DPF_STAMP(2 * t + 1, 0) }
+      if (!tables_first && t + 1 < p.T) build_table(t + 1, cur ^ 1, it, ocur);
+      it_cur = it;
+      tap_next(p, it);
+      if (c0 == PK_CH) { DPF_STAMP(2 * t + 1, 1) }
+      __syncthreads();                                          // tables of tap t + 1 complete, those of tap t consumed
     }
-    __syncthreads();
     if (need_mass) {      // was the pass scaled for enough mass?
       unsigned m = 0u;
       for (int i = tid; i < regvox; i += NT) m = max(m, s_mass[i]);
@@ -1389,6 +1237,64 @@ __global__ __launch_bounds__(512) void dcn_fwd_region8_kernel(const float* __res
 // samplers build tap t+1 while the MFMA waves consume tap t: one barrier per tap instead of two, and the vector / LDS pipes and the
 // matrix pipe of every SIMD (which hosts one wave of each role) run concurrently.  The 4- and 8-wave kernels above alternate the
 // two phases with every wave in lockstep at one workgroup per CU (LDS), which leaves each pipe idle for the other's phase.
+// half-chunk sampler of the 16-wave forward kernel: writes its NC samples straight into the tile column `dst` (row stride STR).  Fast
+// path: two straight-line groups of 4 corners (8 ds_read_b128 in flight); slow path (a corner outside the staged box): channel by
+// channel from global memory, rolled -- it costs the fast path no registers.
+template <int CH, int H, int ROWS>
+__device__ __forceinline__ void fwd_sample_half_store(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
+                                                      const float* __restrict__ xb, int c0, long long chan, float* dst) {
+  constexpr int NC = CH / 2;
+  float* dh = dst + H * NC * ROWS;
+  if (!sp.valid) {
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) dh[ch * ROWS] = 0.f;
+    return;
+  }
+  if (sp.fast) {
+    float val[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) val[ch] = 0.f;
+#pragma unroll
+    for (int jd = 0; jd < 2; ++jd) {
+      float v[4][NC];
+#pragma unroll
+      for (int jy = 0; jy < 4; ++jy) corner_half<CH, H>(g, sp, s_reg, jd, jy >> 1, jy & 1, v[jy]);
+#pragma unroll
+      for (int jy = 0; jy < 4; ++jy) {
+        const float wj = sp.wz[jd] * sp.wy[jy >> 1] * sp.wx[jy & 1];
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) val[ch] = fmaf(wj, v[jy][ch], val[ch]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) dh[ch * ROWS] = val[ch];
+  } else {
+    int vx[8];
+    float wj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+      const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
+      const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
+      vx[j] = in ? (d * p.H + h) * p.W + w : -1;
+      wj[j] = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+    }
+#pragma unroll 1
+    for (int ch = 0; ch < NC; ++ch) {
+      const int cg = c0 + H * NC + ch;
+      const float* xc = xb + (long long)(cg < p.C ? cg : p.C - 1) * chan;
+      float sv = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = (vx[j] >= 0 && cg < p.C) ? xc[vx[j]] : 0.f;
+        sv = fmaf(wj[j], xv, sv);
+      }
+      dh[ch * ROWS] = sv;
+    }
+  }
+}
+
 constexpr int STR = 256;   // row of the [CH][256] sample tile (lane-consecutive writes and reads: no padding needed)
 // NW = 8: 4 sampler waves (a voxel per thread, all CH channels) + 4 MFMA waves (64 voxels each).
 // NW = 16: 8 sampler waves (a thread PAIR per voxel, half the channels each) + 8 MFMA waves (32 voxels each): four waves per SIMD --
@@ -1401,43 +1307,35 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
   constexpr int KT = 32 * MT;
   constexpr int NS = NW / 2;                          // sampler waves = MFMA waves
   constexpr int NTW = 8 / NS;                         // 32-voxel column tiles per MFMA wave (2 or 1)
-  constexpr int NC = CH / 2;
   float* s_reg = smem;                                // [RV][VS]
   float* s_S = s_reg + RegCfg<CH>::VS * g.RV;         // [2][CH][STR]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool sampler = wave_u < NS;
-  const int mw = wave_u - NS;                          // MFMA wave index
-  const int half = wave_u >> 2;                        // NW = 16: sampler waves 0-3 take channels [0, CH/2), 4-7 the rest
-  const int vox = tid & 255;
   const RegCtx c = region_ctx(p, g, blockIdx.x);
   const long long chan = (long long)p.D * p.H * p.W;
   const float* xb = x + (long long)c.b * p.C * chan;
-  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
-  const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
-  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
-  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
-  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
-
-  f32x16 acc[MT][NTW];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
-
-  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
-  const int Cpad = (p.C + CH - 1) / CH * CH;
-  const float* offp0 = off_b + (pvalid ? ppos : 0);
-  for (int c0 = 0; c0 < p.C; c0 += CH) {
-    __syncthreads();                                   // samplers are done with the previous chunk's region
-    stage_region_any<CH>(p, g, c, xb, c0, s_reg, tid, 64 * NW, vec != 0);
-    __syncthreads();
-    if (sampler) {
+  // The role branch is the OUTERMOST construct: each role owns its chunk / tap loops, so no value of one role is live through the
+  // other's code (with the branch inside the chunk loop the 16-wave variant spilled 45 registers in its MFMA loop).
+  if (wave_u < NS) {
+    // ------------------------------------------------------------------------------------------------ samplers
+    const int half = wave_u >> 2;                      // NW = 16: sampler waves 0-3 take channels [0, CH/2), 4-7 the rest
+    const int vox = tid & 255;
+    const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
+    const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
+    const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
+    const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+    const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
+    const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
+    const float* offp0 = off_b + (pvalid ? ppos : 0);
+#pragma unroll 1
+    for (int c0 = 0; c0 < p.C; c0 += CH) {
+      __syncthreads();                                 // samplers are done with the previous chunk's region
+      stage_region_any<CH>(p, g, c, xb, c0, s_reg, tid, 64 * NW, vec != 0);
       const float* offp = offp0;
       Off3 onext = load_off_ptr(offp, p.P, pvalid);
       TapIt it = {0, 0, 0};
+      __syncthreads();
+#pragma unroll 1
       for (int t = 0; t < p.T; ++t) {
         const Off3 ocur = onext;
         offp += 3 * p.P;
@@ -1452,15 +1350,28 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
 #pragma unroll
           for (int ch = 0; ch < CH; ++ch) dst[ch * STR] = val[ch];
         } else {
-          float val[NC];
-          if (half == 0) sample_half<CH, 0>(p, g, sp, cn, s_reg, xb, c0, chan, val);
-          else sample_half<CH, 1>(p, g, sp, cn, s_reg, xb, c0, chan, val);
-#pragma unroll
-          for (int ch = 0; ch < NC; ++ch) dst[(half * NC + ch) * STR] = val[ch];
+          if (half == 0) fwd_sample_half_store<CH, 0, 256>(p, g, sp, cn, s_reg, xb, c0, chan, dst);
+          else fwd_sample_half_store<CH, 1, 256>(p, g, sp, cn, s_reg, xb, c0, chan, dst);
         }
         __syncthreads();                               // barrier t: S[t&1] is complete; the MFMA waves have finished reading S[(t-1)&1]
       }
-    } else {
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ MFMA waves
+    const int mw = wave_u - NS;
+    const int Cpad = (p.C + CH - 1) / CH * CH;
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < p.C; c0 += CH) {
+      __syncthreads();
+      stage_region_any<CH>(p, g, c, xb, c0, s_reg, tid, 64 * NW, vec != 0);
+      __syncthreads();
       // weight fragments of tap t are fetched (L2) one tap ahead
       float aN[CH / 2][MT];
       {
@@ -1470,6 +1381,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
 #pragma unroll
           for (int m = 0; m < MT; ++m) aN[sx][m] = wtt[(2 * sx) * KT + m * 32];
       }
+#pragma unroll 1
       for (int t = 0; t < p.T; ++t) {
         float a[CH / 2][MT];
 #pragma unroll
@@ -1497,8 +1409,6 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
         }
       }
     }
-  }
-  if (!sampler) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       const int pl = mw * (32 * NTW) + nt * 32 + l31;
@@ -1698,13 +1608,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float*
 // lower-half thread adds it during step i+1 and does the read-modify-write of grad_offset (whose read was issued a step earlier).
 // gcol(i+1) and the dW product do not touch the staged region, so the pipeline runs through the chunk boundaries; only the
 // re-staging itself (all 1024 threads) is bracketed by barriers.
-#ifdef DPF_STAMPS
-__device__ unsigned long long g_stamps[16 * 128 * 2];
-#define DPF_STAMP(step, slot)                                                                                          \
-  if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_stamps[(wave_u * 128 + (step)) * 2 + (slot)] = __builtin_readcyclecounter();
-#else
-#define DPF_STAMP(step, slot)
-#endif
 constexpr int XS = 260;    // padded row of a rotating tile (wgrad B reads: rows l15, 4 consecutive voxels per lane group)
 
 // one sampler step of half H: partial coordinate gradient (gd, gh, gw) over this half's channels; the samples replace the gcol column.
@@ -1783,6 +1686,8 @@ __device__ __forceinline__ void rs_sample_half(const DcnP& p, const RegGeo& g, c
   }
 }
 
+#undef DPF_STAMP_WAVE
+#define DPF_STAMP_WAVE wave_u
 template <int CH>
 __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                  const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
@@ -1801,8 +1706,6 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
   const float* xb = x + (long long)c.b * p.C * chan;
   const int NS = nchunk * p.T;
   constexpr int XT = CH * XS;
-  const int dbg = vec >> 1;   // TEMP ablation switches
-  vec &= 1;
 
   if (role == 0) {
     // ------------------------------------------------------------------------------------------------ samplers
@@ -1828,7 +1731,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
     bool first_chunk = true;
 #pragma unroll 1
     for (int i = 0; i <= NS; ++i) {
-      if (half == 0 && i >= 1 && pvalid && !(dbg & 1)) {      // finish step i - 1: both halves of the channel chunk
+      if (half == 0 && i >= 1 && pvalid) {      // finish step i - 1: both halves of the channel chunk
         const float* pp = s_part + ((i - 1) & 1) * 768 + vox;
         const float a0 = pg[0] + pp[0], a1 = pg[1] + pp[256], a2 = pg[2] + pp[512];
         if (first_chunk) { dqp[0] = a0; dqp[p.P] = a1; dqp[2 * p.P] = a2; }
@@ -1843,8 +1746,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
       onext = load_off_ptr(offp, p.P, pvalid && i + 1 < NS);   // next step's offsets (tap 0 again after the last tap of a chunk)
       dqp = doff_b + (long long)(3 * t) * p.P + ppos;
       const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
-      Samp sp = make_samp(p, g, c, cn);
-      if (dbg & 2) sp.valid = false;
+      const Samp sp = make_samp(p, g, c, cn);
       float* col = s_x + (i % 3) * XT + vox;
       float gd, gh, gw;
       if (half == 0) {
@@ -1913,7 +1815,6 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
           f32x4 acc[2];
           acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
           acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (!(dbg & 16))
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
@@ -1959,12 +1860,11 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
         f32x4 wacc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) wacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 8))
 #pragma unroll
         for (int ks = 0; ks < 64; ks += 4)
 #pragma unroll
           for (int u = 0; u < 4; ++u) wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[ks + u], src[4 * (ks + u)], wacc[u], 0, 0, 0);
-        if (l15 < CH && cs * CH + l15 < p.C && !(dbg & 4)) {
+        if (l15 < CH && cs * CH + l15 < p.C) {
           float* dst = rep + ((long long)(ts * nchunk + cs) * 64 + 16 * rw + 4 * lg) * 16 + l15;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -2268,55 +2168,30 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     q.tilesX = dpf_div_up(p.Wo, GI_TX);
     q.CG = grad_input_channels < C ? (grad_input_channels < 0 ? 0 : grad_input_channels) : C;
     const int npos = 64 * q.TZ;
-    const size_t lds = sizeof(double) * ((((size_t)q.RZmax * q.RY * q.RX * GI_CS + GI_CS + 1) & ~(size_t)1)) + sizeof(float) * ((size_t)npos * 34 + 4 + 16);
+    // region (8 packed pairs per cell + dummy cell), 2 x (lidx, w) tables, far flags, mass counters
+    const size_t lds = sizeof(long long) * (size_t)(q.RZmax * q.RY * q.RX + 1) * PK_CS + sizeof(float) * ((size_t)npos * 36 + 4 + 32) +
+                       sizeof(unsigned) * (size_t)((q.RZmax * q.RY * q.RX + 4) & ~3);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
-    if (lds <= 150 * 1024 && blocks < 0x7fffffffLL && (long long)D * H * W < 0x7fffffffLL) {
+    if (lds <= 160 * 1024 && blocks < 0x7fffffffLL && (long long)D * H * W < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
       hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * 64 * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1,
                          64);
-      // fixed-point region (ds_add_u64): per-chunk max |W| for the quantisation bound, kept behind the grad_weight scratch in ws
-      static const int use_fx = getenv("DPF_DCN_GI_FX") ? atoi(getenv("DPF_DCN_GI_FX")) : 1;
+      // packed fixed-point region (two channels per ds_add_u64): per-chunk max |W| for the quantisation bound, kept behind the
+      // grad_weight scratch in ws
       float* wmaxv = ws + dpf_deform_conv3d_workspace_floats(C, K, p.T) - 64;
-      if (use_fx) hipLaunchKernelGGL(dcn_wmax_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, ws, wmaxv, p.T, CT, C);
-#define DPF_GI(NS, NWv)                                                                                                        \
-  {                                                                                                                            \
-    if (use_fx) {                                                                                                              \
-      if (set_lds(dcn_bwd_input_kernel<NS, NWv, true>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                  \
-      hipLaunchKernelGGL((dcn_bwd_input_kernel<NS, NWv, true>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
-    } else {                                                                                                                   \
-      if (set_lds(dcn_bwd_input_kernel<NS, NWv, false>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                 \
-      hipLaunchKernelGGL((dcn_bwd_input_kernel<NS, NWv, false>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
-    }                                                                                                                          \
-  }
-      // packed pairs (two channels per ds_add_u64, 16 channels per pass) unless DPF_DCN_GI_PK=0; needs the per-chunk max |W| too
-      static const int use_pk = getenv("DPF_DCN_GI_PK") ? atoi(getenv("DPF_DCN_GI_PK")) : 1;
-      const size_t lds_pk = sizeof(long long) * (size_t)(q.RZmax * q.RY * q.RX + 1) * PK_CS + sizeof(float) * ((size_t)npos * 34 + 4 + 32) +
-                            sizeof(unsigned) * (size_t)((q.RZmax * q.RY * q.RX + 4) & ~3);
-      if (use_pk && lds_pk <= 160 * 1024) {
-        if (!use_fx) hipLaunchKernelGGL(dcn_wmax_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, ws, wmaxv, p.T, CT, C);
+      hipLaunchKernelGGL(dcn_wmax_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, ws, wmaxv, p.T, CT, C);
 #define DPF_GIP(NS, NWv)                                                                                                       \
   {                                                                                                                            \
-    if (set_lds(dcn_bwd_input_pk_kernel<NS, NWv>, lds_pk) != DPF_OK) return DPF_ERR_LAUNCH;                                    \
-    hipLaunchKernelGGL((dcn_bwd_input_pk_kernel<NS, NWv>), grid, dim3(64 * NWv), lds_pk, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
+    if (set_lds(dcn_bwd_input_pk_kernel<NS, NWv>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                       \
+    hipLaunchKernelGGL((dcn_bwd_input_pk_kernel<NS, NWv>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
   }
-        switch (q.TZ) {
-          case 1: DPF_GIP(1, 4); break;
-          case 2: DPF_GIP(2, 4); break;
-          case 3: DPF_GIP(3, 4); break;
-          default: DPF_GIP(2, 8); break;
-        }
-#undef DPF_GIP
-      } else {
-        switch (q.TZ) {
-          case 1: DPF_GI(1, 4); break;
-          case 2: DPF_GI(2, 4); break;
-          case 3: DPF_GI(3, 4); break;
-          default:
-            if (getenv("DPF_DCN_GI4")) DPF_GI(4, 4) else DPF_GI(2, 8)   // 256 voxels: 8 waves (two per SIMD)
-            break;
-        }
+      switch (q.TZ) {
+        case 1: DPF_GIP(1, 4); break;
+        case 2: DPF_GIP(2, 4); break;
+        case 3: DPF_GIP(3, 4); break;
+        default: DPF_GIP(2, 8); break;   // 256 voxels: 8 waves (two per SIMD)
       }
-#undef DPF_GI
+#undef DPF_GIP
       dx_done = true;
     }
   }
@@ -2370,7 +2245,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   {                                                                                                                            \
     if (set_lds(dcn_bwd_offset_rs_kernel<Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                           \
     hipLaunchKernelGGL((dcn_bwd_offset_rs_kernel<Cw>), grid, dim3(1024), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, p, gr, \
-                       CT, nchunk, vec_rs | ((getenv("DPF_DBG") ? atoi(getenv("DPF_DBG")) : 0) << 1));                                                                                    \
+                       CT, nchunk, vec_rs);                                                                                    \
   }
       if (CHb == 16) DPF_OFFRS(16) else DPF_OFFRS(12)
 #undef DPF_OFFRS
