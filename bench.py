@@ -7,7 +7,10 @@ A step = forward + loss + backward + gradient all-reduce (RCCL, N > 1) + fused A
 `--batch` dual-pixel pairs of `--height` x `--width` per GPU (weak scaling), inputs resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line (contract in the task description) including
   "roofline":     the dominant kernel (implicit-GEMM convolution on the fp32 matrix cores) -- algorithmic FLOPs per
-                  launch / average launch duration, measured live with HIP events on the launch stream;
+                  launch / average launch duration, measured live with HIP events on the launch stream; "families" lists every timed
+                  family (dense conv fwd/dgrad, weight gradient, 1x1 convs as their own HBM-bound family, small-K, deformable conv
+                  forward / backward) with TFLOP/s or GB/s and, from the committed PMC passes, HBM bytes per step;
+  "roofline_hbm": the largest HBM-bound family (normalisation + activation), algorithmic GB/s against 8 TB/s;
   "cpu_baseline": the CPU oracle (oracle/, a PyTorch-CPU restatement of the reference) timed on this host's cores on a
                   bounded sample (one 1x512x768 train step = BASELINE configs[1]'s shape, 16 threads), scaled to 1024x1536
                   samples/s by pixel count (kind "port").
@@ -129,6 +132,7 @@ def main():
     ap.add_argument('--sync-bn', action='store_true',
                     help='BatchNorm statistics over the global batch (what the reference does under DDP); default per-rank statistics')
     ap.add_argument('--shapes', default=None, help='write a per-convolution-shape timing table to this file')
+    ap.add_argument('--no-detail', action='store_true', help='skip the two extra untimed steps that time the normalisation / activation launches')
     ap.add_argument('--workload', default='train', choices=['train', 'psm_volume', 'cost_volume', 'cost_volume_fix'],
                     help="'train' = the BASELINE metric; the other two time one HBM-bound stage in isolation (BASELINE configs[3], SURVEY a2-a4)")
     args = ap.parse_args()
@@ -193,45 +197,90 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # a few extra, UNTIMED steps with the detail timers on: the 744 normalisation / activation launches of a step are timed here so that
+    # their event records cannot perturb the headline number
+    prof_detail, detail_steps = [], 0
+    if not args.no_detail:
+        ops.PROFILE, ops.PROFILE_DETAIL, detail_steps = [], True, 2
+        for _ in range(detail_steps):
+            model.train_step(batch, reducer)
+        sync()
+        prof_detail, ops.PROFILE, ops.PROFILE_DETAIL = ops.PROFILE, None, False
+    ranks_seen = world
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                  # every rank contributes 1: the sum is the number of ranks RCCL really joined
+        ranks_seen = int(round(float(ones.item())))
+
     if rank == 0:
         global_batch = args.batch * world
         value = global_batch * args.steps / elapsed
-        fam = {}
-        shapes = {}
-        for family, flops, e0, e1, tag, nbytes in prof:
-            secs = e0.elapsed_time(e1) * 1e-3
-            f = fam.setdefault(family, [0.0, 0.0, 0, 0.0])
-            f[0] += flops
-            f[1] += secs
-            f[2] += 1
-            f[3] += nbytes
-            g = shapes.setdefault(tag, [0.0, 0.0, 0])
-            g[0] += flops
-            g[1] += secs
-            g[2] += 1
+
+        def families(records, steps):
+            fam, shapes = {}, {}
+            for family, flops, e0, e1, tag, nbytes in records:
+                secs = e0.elapsed_time(e1) * 1e-3
+                f = fam.setdefault(family, [0.0, 0.0, 0, 0.0])
+                f[0] += flops; f[1] += secs; f[2] += 1; f[3] += nbytes
+                g = shapes.setdefault(tag, [0.0, 0.0, 0])
+                g[0] += flops; g[1] += secs; g[2] += 1
+            return fam, shapes
+        fam, shapes = families(prof, args.steps)
+        fam_d, _ = families([r for r in prof_detail if r[0] == 'norm_act'], detail_steps)
         if args.shapes:
             with open(args.shapes, 'w') as fh:
                 for tag, (fl, se, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                     fh.write('%-60s calls %4d  ms/step %8.3f  TFLOP/s %6.1f\n' % (tag, n, se / args.steps * 1e3, fl / se / 1e12))
-        dom = max(fam, key=lambda k: fam[k][1]) if fam else None
+        # HBM bytes per step and family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_profiles.sh)
+        tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r03_pmc_traffic.json')
+        pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        same_workload = args.model == 'stereodpnet' and (args.batch, args.height, args.width) == (4, 1024, 1536)
+
+        def hbm_per_step(*keys):
+            recs = [pmc[k] for k in keys if k in pmc]
+            return sum(r['hbm_bytes_per_step'] for r in recs) if (recs and same_workload) else None
+        PMC_KEYS = {'conv_igemm': ('igemm2',), 'conv_wgrad': ('wgrad2',), 'conv_pointwise': ('pointwise',), 'conv_smallk': ('smallk',),
+                    'dcn_fwd': ('dcn_fwd',), 'dcn_bwd': ('dcn_bwd_input', 'dcn_bwd_offset'), 'norm_act': ('bn_',)}
+        MFMA_FAMILIES = ('conv_igemm', 'conv_wgrad', 'conv_bf16', 'dcn_fwd', 'dcn_bwd')
+        fam_out = {}
+        for k, (flops, secs, n, nbytes) in list(fam.items()) + list(fam_d.items()):
+            steps = detail_steps if k == 'norm_act' else args.steps
+            rec = {'ms_per_step': secs / steps * 1e3, 'launches_per_step': n / steps}
+            if k in MFMA_FAMILIES or k == 'conv_smallk':
+                rec['tflops'] = flops / secs / 1e12
+            if nbytes > 0:
+                rec['algorithmic_gbs'] = nbytes / secs / 1e9
+                rec['algorithmic_bytes_per_step'] = nbytes / steps
+            hb = hbm_per_step(*PMC_KEYS.get(k, ()))
+            if hb is not None:
+                rec['hbm_bytes_per_step'] = hb
+                if nbytes > 0:
+                    rec['traffic_over_algorithmic'] = hb / (nbytes / steps)
+            fam_out[k] = rec
+        dom = 'conv_igemm' if 'conv_igemm' in fam else (max(fam, key=lambda k: fam[k][1]) if fam else None)
         roof = None
         if dom:
             flops, secs, n, alg_bytes = fam[dom]
             ach = flops / secs / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r02_pmc_traffic.json')
-            if os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                fam_key = {'conv_igemm': 'igemm2', 'conv_wgrad': 'wgrad2'}.get(dom)
-                rec = json.load(open(tpath)).get(fam_key)
-                if rec:
-                    traffic = rec['hbm_bytes_per_launch']
+            hb = hbm_per_step(*PMC_KEYS.get(dom, ()))
             # the dense conv kernels contract on the bf16 matrix cores in --precision bf16: price them against THAT peak (they are then
             # staging-bound -- LDS-DMA / LDS reads of the fp32 patch -- far below it)
             peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                    'traffic': traffic, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n, 'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed,
-                    'families': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3} for k, v in fam.items()}}
+                    'traffic': (hb / (n / args.steps)) if hb is not None else None, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n,
+                    'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed, 'families': fam_out}
+        roof_hbm = None
+        if 'norm_act' in fam_d:      # the largest HBM-bound family: BatchNorm / InstanceNorm / activations / residual adds
+            flops, secs, n, nbytes = fam_d['norm_act']
+            gbs = nbytes / secs / 1e9
+            hb = hbm_per_step('bn_')
+            roof_hbm = {'bound': 'hbm', 'kernel': 'norm_act', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
+                        'traffic': (hb / (n / detail_steps)) if hb is not None else None, 'algorithmic_bytes_per_launch': nbytes / n,
+                        'launches': n, 'avg_launch_ms': secs / n * 1e3, 'ms_per_step': secs / detail_steps * 1e3,
+                        'note': 'a launch = one normalisation+activation op (forward: statistics unless the conv epilogue made them + apply; '
+                                'backward: reduce + apply), timed in %d extra untimed steps' % detail_steps}
         pixels = args.height * args.width
+        executed = sum(v[0] for k, v in fam.items()) / args.steps       # FLOPs the kernels really ran per step (GEMM parts; compat mode runs 2 of the 16 attention calls)
         line = {
             'metric': 'train samples/sec, %s %dx%d DP pair' % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.height, args.width), 'value': value, 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
@@ -244,8 +293,14 @@ def main():
                        'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics',
                        'weight_gradients': 'side stream' if ops.WGRAD_ASYNC else 'in line'},
             'final_loss': loss,
+            'rccl_ranks_seen': ranks_seen,
+            # whole-model fractions of the fp32 peak: against the reference's algorithmic FLOPs (SURVEY section 8d counts all 16 attention
+            # calls) and against the FLOPs the kernels executed (compat mode computes 2 of the 16: identical results)
             'flop_frac_of_f32_peak': (value * FLOP_PER_PIXEL_FWD_BWD * pixels / (world * PEAK_F32_TFLOPS * 1e12)) if args.model == 'stereodpnet' else None,
+            'flop_frac_executed': executed * args.steps / elapsed / (PEAK_F32_TFLOPS * 1e12),
+            'executed_tflop_per_step': executed / 1e12,
             'roofline': roof,
+            'roofline_hbm': roof_hbm,
         }
         if world == 1 and not args.no_cpu_baseline:
             # 16 threads: the oracle's small-tensor PyTorch-CPU ops scale badly beyond that (256 threads on the 128-core

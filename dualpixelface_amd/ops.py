@@ -21,6 +21,9 @@ _scratch = {}
 # Optional live kernel timing (bench.py): a list that receives (family, algorithmic_flops, start_event, end_event) for
 # every dense-convolution launch; events are recorded on the stream the kernels are launched on.
 PROFILE = None
+# bench.py sets this for a few extra (untimed) steps: the HBM-bound normalisation / activation launches are timed too (744 per step --
+# kept out of the timed region so that their event records cannot perturb the headline number)
+PROFILE_DETAIL = False
 
 
 class _Timed(object):
@@ -39,6 +42,17 @@ class _Timed(object):
             self.e1.record()
             PROFILE.append((self.family, self.flops, self.e0, self.e1, self.tag, self.nbytes))
         return False
+
+
+class _Off(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_Timed.OFF = _Off()
 
 
 def _ptr(t):
@@ -158,7 +172,7 @@ def _conv_fwd_raw(x, w, bias, stride, pad, dil, stats=None):
                    _stream())
         return out
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
-    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * od * oh * ow,
+    with _Timed('conv_pointwise' if kd * kh * kw == 1 else 'conv_igemm', 2.0 * N * K * C * kd * kh * kw * od * oh * ow,
                 'fwd N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
                 4.0 * (x.numel() + out.numel() + w.numel())):
         if stats is not None and FUSE_BN_STATS and K <= 128 and IW % 4 == 0 and kd * kh * kw > 1:
@@ -205,7 +219,7 @@ def _conv_transpose_raw(x, w, bias, out_dims, ksize, stride, pad, dil, k_needed=
                    kd, kh, kw, *stride, *pad, *dil, _stream())
         return out
     ws = scratch(L.call('dpf_conv_workspace_floats', kd * kh * kw, C, K), x.device, 'convw')
-    with _Timed('conv_igemm', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW,
+    with _Timed('conv_pointwise' if kd * kh * kw == 1 else 'conv_igemm', 2.0 * N * K * C * kd * kh * kw * ID * IH * IW,
                 'tr  N%d C%d K%d in%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
                 4.0 * (x.numel() + out.numel() + w.numel())):
         L.call('dpf_conv_transpose', _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, C, ID, IH, IW, K, *out_dims, kd, kh, kw,
@@ -224,7 +238,7 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
         with _Timed('conv_smallk', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW, 'skw N%d C%d K%d x%dx%dx%d' % (N, C, K, ID, IH, IW)):
             lib().call('dpf_conv_smallk_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, kd, kh, kw, *stride, *pad, *dil, _stream())
         return dw
-    with _Timed('conv_wgrad', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW,
+    with _Timed('conv_pointwise' if kd * kh * kw == 1 else 'conv_wgrad', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW,
                 'wg  N%d C%d K%d x%dx%dx%d k%d%d%d s%d d%d' % (N, C, K, ID, IH, IW, kd, kh, kw, stride[2], dil[2]),
                 4.0 * (x.numel() + g.numel() + dw.numel())):
         L = lib()
@@ -455,6 +469,11 @@ class NormActFn(torch.autograd.Function):
         L = lib()
         mean = invstd = None
         n_, c_, wmod = N, C, C
+        fused_stats = mode == 1 and exchange is None and bool(stats) and stats.get('ptr') == x.data_ptr()
+        # algorithmic bytes: statistics pass (unless the conv epilogue made them) + apply (x and residuals in, y out)
+        nb = 4.0 * x.numel() * ((0 if (mode in (0, 2) or fused_stats) else 1) + 2 + (res is not None) + (res2 is not None))
+        timer = _Timed('norm_act', 0.0, 'naf', nb) if PROFILE_DETAIL else _Timed.OFF
+        timer.__enter__()
         if mode == 1 and exchange is not None:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
@@ -493,6 +512,7 @@ class NormActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         L.call('dpf_norm_act_forward', _ptr(x), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), wmod, _ptr(res), _ptr(res2), act,
                _ptr(slope), float(slope_const), _ptr(y), n_, c_, S, _stream())
+        timer.__exit__()
         ctx.save_for_backward(x, weight, bias, slope, res, mean, invstd)
         ctx.cfg = (mode, act, float(slope_const), n_, c_, S, wmod, res2 is not None)
         ctx.exchange = exchange if mode == 1 else None
@@ -514,6 +534,9 @@ class NormActFn(torch.autograd.Function):
         training = 1 if mode in (1, 3) else 0
         args = (_ptr(x), _ptr(gy), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), wmod, _ptr(res), act, _ptr(slope), slope_const,
                 training, _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), _ptr(dslope))
+        # algorithmic bytes: reduce pass (x, gy) when the norm trains + apply pass (x, gy in; dx, dres out)
+        timer = _Timed('norm_act', 0.0, 'nab', 4.0 * x.numel() * ((2 if training else 0) + 2 + (dx is not None) + (dres is not None))) if PROFILE_DETAIL else _Timed.OFF
+        timer.__enter__()
         if ctx.exchange is not None:
             # SyncBatchNorm: local reductions, sum over the ranks, then dx with the global element count
             # ws[3C] carries this rank's element count through the same all-reduce: uneven per-rank batches need no extra
@@ -526,6 +549,7 @@ class NormActFn(torch.autograd.Function):
         else:
             ws = zero_slot(3 * c_, x.device)                               # pre-zeroed: phase 3 skips the per-layer memset
             L.call('dpf_norm_act_backward_ex', *args, _ptr(ws), n_, c_, S, 3, 0.0, _stream())
+        timer.__exit__()
         dres2 = gy if (has_res2 and ctx.needs_input_grad[5]) else None
         return dx, dweight, dbias, dslope, dres, dres2, None, None, None, None, None, None, None
 
@@ -555,6 +579,8 @@ class NormActCatFn(torch.autograd.Function):
         cat = torch.empty((N, Ctot) + tuple(xs[0].shape[2:]), dtype=torch.float32, device=xs[0].device)
         L = lib()
         saved, c0 = [], 0
+        timer = _Timed('norm_act', 0.0, 'ncf', 4.0 * sum(x.numel() for x in xs) * 2) if PROFILE_DETAIL else _Timed.OFF
+        timer.__enter__()
         for i in range(n):
             x, C = xs[i], Cs[i]
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -574,6 +600,7 @@ class NormActCatFn(torch.autograd.Function):
                    _ptr(cat), Ctot, c0, N, C, S, _stream())
             saved += [x, ws[i], bs[i], mean, invstd]
             c0 += C
+        timer.__exit__()
         ctx.save_for_backward(*saved)
         ctx.cfg = (mode, act, n, N, tuple(Cs), S, Ctot)
         return cat
@@ -585,6 +612,8 @@ class NormActCatFn(torch.autograd.Function):
         sv = ctx.saved_tensors
         L = lib()
         grads, c0 = [], 0
+        timer = _Timed('norm_act', 0.0, 'ncb', 4.0 * gcat.numel() * 5) if PROFILE_DETAIL else _Timed.OFF
+        timer.__enter__()
         for i in range(n):
             x, w, b, mean, invstd = sv[5 * i:5 * i + 5]
             C = Cs[i]
@@ -596,6 +625,7 @@ class NormActCatFn(torch.autograd.Function):
                    None, 0.0, 1 if mode == 1 else 0, _ptr(dx), None, _ptr(dw), _ptr(db), None, _ptr(wsb), N, C, S, _stream())
             grads += [dx, dw, db, None, None]
             c0 += C
+        timer.__exit__()
         return (None, None, None) + tuple(grads)
 
 
@@ -1090,8 +1120,11 @@ def deform_conv_forward_raw(x, weight, bias, offset, stride, pad, dil, group=1, 
     wo = _out_dim(W, kw, stride[2], pad[2], dil[2])
     out = torch.empty((B, K, do, ho, wo), dtype=torch.float32, device=x.device)
     ws = scratch(L.call('dpf_deform_conv3d_workspace_floats', C, K, kd * kh * kw), x.device, 'convw')
-    L.call('dpf_deform_conv3d_forward', _ptr(x), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(out), _ptr(ws), B, C, D, H, W, K, kd, kh, kw,
-           *stride, *pad, *dil, group, dgroup, step, _stream())
+    # algorithmic work: the GEMM part 2 B P K C T FLOP (the 8 C T sample FMAs per voxel are not counted); bytes = x + offset + out once
+    with _Timed('dcn_fwd', 2.0 * B * K * C * kd * kh * kw * do * ho * wo, 'dcnf C%d K%d %dx%dx%d' % (C, K, D, H, W),
+                4.0 * (x.numel() + offset.numel() + out.numel())):
+        L.call('dpf_deform_conv3d_forward', _ptr(x), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(out), _ptr(ws), B, C, D, H, W, K, kd, kh, kw,
+               *stride, *pad, *dil, group, dgroup, step, _stream())
     return out
 
 
@@ -1104,9 +1137,13 @@ def deform_conv_backward_raw(x, weight, bias, offset, go, stride, pad, dil, grou
     gw = torch.empty_like(weight)
     gb = torch.empty_like(bias)
     ws = scratch(L.call('dpf_deform_conv3d_workspace_floats', C, K, kd * kh * kw), x.device, 'convw')
-    L.call('dpf_deform_conv3d_backward_ex', _ptr(x), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(go), _ptr(gi), _ptr(goff), _ptr(gw), _ptr(gb),
-           _ptr(ws), B, C, D, H, W, K, kd, kh, kw, *stride, *pad, *dil, group, dgroup, step, C if gi_channels is None else int(gi_channels),
-           _stream())
+    cg = C if gi_channels is None else int(gi_channels)
+    # algorithmic work: gcol GEMM for grad_offset (all C) + grad_weight GEMM + gcol GEMM for the cg channels of grad_input; bytes = x, offset,
+    # grad_output read, grad_input (cg channels) and grad_offset written, once each
+    with _Timed('dcn_bwd', 2.0 * B * K * (2 * C + cg) * kd * kh * kw * go.numel() / (B * K), 'dcnb C%d K%d %dx%dx%d' % (C, K, D, H, W),
+                4.0 * (x.numel() + 2 * offset.numel() + go.numel() + gi.numel() * cg // C)):
+        L.call('dpf_deform_conv3d_backward_ex', _ptr(x), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(go), _ptr(gi), _ptr(goff), _ptr(gw), _ptr(gb),
+               _ptr(ws), B, C, D, H, W, K, kd, kh, kw, *stride, *pad, *dil, group, dgroup, step, cg, _stream())
     return gi, goff, gw, gb
 
 

@@ -1,6 +1,6 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel-family HBM traffic per launch.
 
-usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json]
+usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json] [train steps in each pass]
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (MI355X_MICROARCH.md: hbm_bytes = (FETCH + WRITE) * 1024); on gfx950
 FETCH_SIZE under-counts wide coalesced reads by 2x -- the raw value is kept and the corrected one (x2) reported beside it.
 """
@@ -41,6 +41,7 @@ def agg(path, counter):
 def main():
     fetch, nf = agg(sys.argv[1], 'FETCH_SIZE')
     write, nw = agg(sys.argv[2], 'WRITE_SIZE')
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else None
     out = {}
     for fam in sorted(set(fetch) | set(write)):
         launches = max(nf.get(fam, 0), nw.get(fam, 0), 1)
@@ -48,6 +49,9 @@ def main():
         w = write.get(fam, 0.0) * 1024.0 / max(nw.get(fam, 1), 1)
         out[fam] = {'launches': launches, 'fetch_bytes_per_launch_raw': f, 'fetch_bytes_per_launch_x2': 2 * f,
                     'write_bytes_per_launch': w, 'hbm_bytes_per_launch': 2 * f + w}
+        if steps:      # all dispatches of the family (helpers included) per train step
+            out[fam]['hbm_bytes_per_step'] = (2 * fetch.get(fam, 0.0) + write.get(fam, 0.0)) * 1024.0 / steps
+            out[fam]['launches_per_step'] = launches / steps
     json.dump(out, open(sys.argv[3], 'w') if len(sys.argv) > 3 else sys.stdout, indent=1)
 
 
