@@ -120,9 +120,10 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--wgrad-async', action='store_true',
-                    help='weight gradients on a side stream (faster step; per-kernel durations then overlap, so the roofline '
-                         'attribution of this run is not per kernel -- see DESIGN.md)')
+    ap.add_argument('--wgrad-inline', action='store_true',
+                    help='weight gradients in line on the main stream in the timed region too (default: on a side stream, where they '
+                         'overlap the HBM-bound kernels of the main chain; the per-kernel roofline block is always measured in line)')
+    ap.add_argument('--wgrad-async', action='store_true', help='(default behaviour; kept for older command lines)')
     ap.add_argument('--cpu-baseline-only', default=None, metavar='HxW:threads[,threads...]',
                     help='time only the CPU oracle at the given size for each thread count (e.g. 1024x1536:16,128) and exit')
     ap.add_argument('--model', default='stereodpnet', choices=['stereodpnet', 'psmnet', 'nnet', 'stereonet'],
@@ -179,8 +180,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.wgrad_async:
-        ops.WGRAD_ASYNC = True
+    ops.WGRAD_ASYNC = not args.wgrad_inline
     for _ in range(args.warmup):
         model.train_step(batch, reducer)
     sync()
@@ -199,13 +199,24 @@ def main():
 
     # a few extra, UNTIMED steps with the detail timers on: the 744 normalisation / activation launches of a step are timed here so that
     # their event records cannot perturb the headline number
+    # Per-kernel attribution: with the weight gradients on a side stream (the default, and what `value` is measured on) kernels of the
+    # two streams overlap and an event pair no longer brackets ONE kernel's undisturbed run.  The roofline block is therefore measured
+    # on `detail_steps` further steps of the same model / batch with the weight gradients IN LINE (no overlap: event time == kernel
+    # time, equal to the rocprofv3 averages in profiles/), which also carry the detail timers of the 744 normalisation launches.
+    prof_timed, timed_async = prof, ops.WGRAD_ASYNC
     prof_detail, detail_steps = [], 0
     if not args.no_detail:
-        ops.PROFILE, ops.PROFILE_DETAIL, detail_steps = [], True, 2
+        ops.WGRAD_ASYNC = False
+        model.train_step(batch, reducer)                          # one settling step in the in-line mode
+        ops.PROFILE, ops.PROFILE_DETAIL, detail_steps = [], True, 3
         for _ in range(detail_steps):
             model.train_step(batch, reducer)
         sync()
         prof_detail, ops.PROFILE, ops.PROFILE_DETAIL = ops.PROFILE, None, False
+        ops.WGRAD_ASYNC = timed_async
+        prof, prof_steps = [r for r in prof_detail if r[0] != 'norm_act'], detail_steps
+    else:
+        prof_steps = args.steps
     ranks_seen = world
     if world > 1:
         ones = torch.ones(1, device=dev)
@@ -225,12 +236,13 @@ def main():
                 g = shapes.setdefault(tag, [0.0, 0.0, 0])
                 g[0] += flops; g[1] += secs; g[2] += 1
             return fam, shapes
-        fam, shapes = families(prof, args.steps)
+        fam, shapes = families(prof, prof_steps)
+        fam_t, _ = families(prof_timed, args.steps)
         fam_d, _ = families([r for r in prof_detail if r[0] == 'norm_act'], detail_steps)
         if args.shapes:
             with open(args.shapes, 'w') as fh:
                 for tag, (fl, se, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                    fh.write('%-60s calls %4d  ms/step %8.3f  TFLOP/s %6.1f\n' % (tag, n, se / args.steps * 1e3, fl / se / 1e12))
+                    fh.write('%-60s calls %4d  ms/step %8.3f  TFLOP/s %6.1f\n' % (tag, n, se / prof_steps * 1e3, fl / se / 1e12))
         # HBM bytes per step and family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_profiles.sh)
         tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r03_pmc_traffic.json')
         pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -244,7 +256,7 @@ def main():
         MFMA_FAMILIES = ('conv_igemm', 'conv_wgrad', 'conv_bf16', 'dcn_fwd', 'dcn_bwd')
         fam_out = {}
         for k, (flops, secs, n, nbytes) in list(fam.items()) + list(fam_d.items()):
-            steps = detail_steps if k == 'norm_act' else args.steps
+            steps = detail_steps if k == 'norm_act' else prof_steps
             rec = {'ms_per_step': secs / steps * 1e3, 'launches_per_step': n / steps}
             if k in MFMA_FAMILIES or k == 'conv_smallk':
                 rec['tflops'] = flops / secs / 1e12
@@ -266,9 +278,16 @@ def main():
             # the dense conv kernels contract on the bf16 matrix cores in --precision bf16: price them against THAT peak (they are then
             # staging-bound -- LDS-DMA / LDS reads of the fp32 patch -- far below it)
             peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+            inline_ms = sum(v[1] for v in fam.values()) / prof_steps * 1e3
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                    'traffic': (hb / (n / args.steps)) if hb is not None else None, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n,
-                    'avg_launch_ms': secs / n * 1e3, 'time_share_of_step': secs / elapsed, 'families': fam_out}
+                    'traffic': (hb / (n / prof_steps)) if hb is not None else None, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n,
+                    'avg_launch_ms': secs / n * 1e3, 'ms_per_step': secs / prof_steps * 1e3,
+                    'measured_in': ('%d steps after the timed region, weight gradients in line (kernels do not overlap: event time = kernel time)' % prof_steps)
+                                   if not args.no_detail else 'the timed region', 'families': fam_out}
+            if dom in fam_t and timed_async and not args.no_detail:      # the same family as the timed region saw it (overlapped by the side stream)
+                f2 = fam_t[dom]
+                roof['timed_region_overlapped'] = {'achieved': f2[0] / f2[1] / 1e12, 'frac': f2[0] / f2[1] / 1e12 / peak, 'avg_launch_ms': f2[1] / f2[2] * 1e3,
+                                                   'note': 'event pairs of the timed region: side-stream weight gradients share the chip with these launches'}
         roof_hbm = None
         if 'norm_act' in fam_d:      # the largest HBM-bound family: BatchNorm / InstanceNorm / activations / residual adds
             flops, secs, n, nbytes = fam_d['norm_act']
@@ -280,7 +299,7 @@ def main():
                         'note': 'a launch = one normalisation+activation op (forward: statistics unless the conv epilogue made them + apply; '
                                 'backward: reduce + apply), timed in %d extra untimed steps' % detail_steps}
         pixels = args.height * args.width
-        executed = sum(v[0] for k, v in fam.items()) / args.steps       # FLOPs the kernels really ran per step (GEMM parts; compat mode runs 2 of the 16 attention calls)
+        executed = sum(v[0] for k, v in fam.items()) / prof_steps       # FLOPs the kernels really ran per step (GEMM parts; compat mode runs 2 of the 16 attention calls)
         line = {
             'metric': 'train samples/sec, %s %dx%d DP pair' % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.height, args.width), 'value': value, 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
@@ -291,7 +310,7 @@ def main():
                                    % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.batch, args.height, args.width),
                        'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,
                        'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics',
-                       'weight_gradients': 'side stream' if ops.WGRAD_ASYNC else 'in line'},
+                       'weight_gradients': 'side stream' if timed_async else 'in line'},
             'final_loss': loss,
             'rccl_ranks_seen': ranks_seen,
             # whole-model fractions of the fp32 peak: against the reference's algorithmic FLOPs (SURVEY section 8d counts all 16 attention

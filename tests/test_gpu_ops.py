@@ -741,6 +741,76 @@ def test_full_size_properties():
     assert abs(fd - an) <= 5e-2 * abs(an) + 50 * tol, (fd, an, tol)
 
 
+def test_full_size_properties_2d_head_norm_bf16():
+    """More BASELINE-size launches through reference-free properties: the dilated 2-D conv of the normal head's stack
+    (16 x 96 x 256 x 384, dilation 2: adjoints), the soft-argmin head (4 x 1 x 8 x 256 x 384 -> 1024 x 1536: the probabilities sum to 1,
+    the prediction is their expectation, the gradient matches a central difference), BatchNorm forward / backward at the hourglass
+    shape (4 x 32 x 8 x 256 x 384: zero mean, unit variance, sum dx = sum dx * xhat = 0 per channel), and the bf16-operand 3x3x3 kernel,
+    which must equal the exact-fp32 kernel run on bf16-rounded operands (same accumulation type, only the summation order differs)."""
+    ops = _ops()
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    scale = lambda a, b: (dot(a, a) * dot(b, b)) ** 0.5
+    # ---- dilated 2-D conv (normal head, n_convs.1: 96 -> 96, dilation 2)
+    x = r(16, 96, 256, 384).requires_grad_()
+    w = (r(96, 96, 3, 3) * 0.03).requires_grad_()
+    out = ops.conv2d(x, w, None, 1, 2, 2)
+    g = r(*out.shape)
+    gx, gw = torch.autograd.grad(out, (x, w), g)
+    a0, tol = dot(out.detach(), g), 2e-6 * scale(out.detach(), g)
+    assert abs(a0 - dot(x.detach(), gx)) <= tol and abs(a0 - dot(w.detach(), gw)) <= tol, (a0, dot(x.detach(), gx), dot(w.detach(), gw), tol)
+    del x, out, g, gx
+    # ---- soft-argmin head
+    disp = [-4 + 0.5 * i for i in range(32)]
+    lg = (r(4, 1, 8, 256, 384) * 2.0).requires_grad_()
+    pred, prob = ops.softargmin(lg, disp, 4, True)
+    assert pred.shape == (4, 1024, 1536) and prob.shape == (4, 32, 1024, 1536)
+    ps = prob.sum(1)
+    assert float((ps - 1).abs().max()) <= 1e-5
+    ex = (prob * torch.tensor(disp, device=DEV).view(1, -1, 1, 1)).sum(1)
+    assert float((ex - pred.detach()).abs().max()) <= 1e-4
+    assert float(pred.min()) >= -4.0 - 1e-4 and float(pred.max()) <= 11.5 + 1e-4
+    gp = r(*pred.shape)
+    (gl,) = torch.autograd.grad(pred, lg, gp)
+    d = r(*lg.shape)
+    eps = 1e-2
+    with torch.no_grad():
+        pp = ops.softargmin(lg.detach() + eps * d, disp, 4, False)[0]
+        pm = ops.softargmin(lg.detach() - eps * d, disp, 4, False)[0]
+    fd, an = dot(pp - pm, gp) / (2 * eps), dot(gl, d)
+    assert abs(fd - an) <= 2e-2 * abs(an) + 1e-4 * scale(gl, d), (fd, an)
+    del prob, ps, ex, pred, gp, gl, pp, pm
+    # ---- BatchNorm (training) forward / backward
+    xb = (r(4, 32, 8, 256, 384) * 3.0 + 1.5).requires_grad_()
+    wb, bb = torch.ones(32, device=DEV, requires_grad=True), torch.zeros(32, device=DEV, requires_grad=True)
+    rm, rv = torch.zeros(32, device=DEV), torch.ones(32, device=DEV)
+    yb = ops.norm_act(xb, wb, bb, running_mean=rm, running_var=rv, mode=1, act=0)
+    m = yb.detach().double().mean((0, 2, 3, 4))
+    v = yb.detach().double().var((0, 2, 3, 4), unbiased=False)
+    assert float(m.abs().max()) <= 1e-5 and float((v - 1).abs().max()) <= 1e-4, (float(m.abs().max()), float((v - 1).abs().max()))
+    assert float((rm - 0.1 * xb.detach().double().mean((0, 2, 3, 4)).float()).abs().max()) <= 1e-5
+    gb_ = r(*yb.shape)
+    dxb, dwb, dbb = torch.autograd.grad(yb, (xb, wb, bb), gb_)
+    n = xb.numel() // 32
+    s1 = dxb.double().sum((0, 2, 3, 4)).abs().max()
+    s2 = (dxb.double() * yb.detach().double()).sum((0, 2, 3, 4)).abs().max()
+    bound = float(dxb.double().abs().sum((0, 2, 3, 4)).max())
+    assert float(s1) <= 2e-5 * bound and float(s2) <= 2e-5 * bound * 3, (float(s1), float(s2), bound)
+    assert float((dbb.double() - gb_.double().sum((0, 2, 3, 4))).abs().max()) <= 1e-5 * float(gb_.double().abs().sum((0, 2, 3, 4)).max())
+    assert float((dwb.double() - (gb_.double() * yb.detach().double()).sum((0, 2, 3, 4))).abs().max()) <= 1e-5 * float(gb_.double().abs().sum((0, 2, 3, 4)).max()) * 4
+    del yb, gb_, dxb
+    # ---- bf16-operand 3x3x3 kernel == exact kernel on bf16-rounded operands (sample 0)
+    xc = xb.detach()
+    wc = r(32, 32, 3, 3, 3) * 0.05
+    with ops.conv_operands(True):
+        ob = ops.conv3d(xc, wc, None, 1, 1, 1)
+    oe = ops.conv3d(xc[:1].bfloat16().float(), wc.bfloat16().float(), None, 1, 1, 1)
+    assert float((ob[:1] - oe).abs().max()) <= 1e-5 * float(oe.abs().max()), float((ob[:1] - oe).abs().max())
+    of = ops.conv3d(xc[:1], wc, None, 1, 1, 1)
+    assert float((ob[:1] - of).abs().max()) > 1e-4 * float(of.abs().max())        # and it is NOT the exact kernel (the mode engaged)
+
+
 @pytest.mark.parametrize('shape', [
     # N, C, K, D, H, W, kernel, stride, bias
     (2, 8, 32, 1, 20, 36, (1, 3, 3), 1, False),          # ragged tiles in H and W

@@ -13,7 +13,7 @@ run() { "$@" 2>> "$O/bench.err"; }
 pmc_pass() {   # <dir> <counter> <bench args...>
   local d=$1 c=$2; shift 2
   rm -rf "gpurun_out/$d"
-  rocprofv3 --kernel-trace --pmc "$c" --output-format csv -d "gpurun_out/$d" -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-detail "$@" > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc "$c" --output-format csv -d "gpurun_out/$d" -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline "$@" > /dev/null 2>&1
 }
 pmc_pass pmc_f FETCH_SIZE; pmc_pass pmc_w WRITE_SIZE
 python3 tools/pmc_traffic.py gpurun_out/pmc_f/p_counter_collection.csv gpurun_out/pmc_w/p_counter_collection.csv "$O/${R}_pmc_traffic.json" 3
@@ -23,7 +23,7 @@ run python bench.py --steps 10 --warmup 3 --shapes "$O/${R}_conv_shape_table.txt
 bash tools/gpu_prof.sh "$R" > "$O/${R}_bench_family_ms.txt" 2>&1
 cp "gpurun_out/prof_${R}_kernel_stats.csv" "$O/${R}_bench_kernel_stats.csv"
 export PMC_FILTER="igemm2 wgrad2 dcn_ pointwise bn_"
-bash tools/gpu_pmc.sh ${R}sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-detail > "$O/${R}_sq_counters.txt" 2>&1
+bash tools/gpu_pmc.sh ${R}sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline > "$O/${R}_sq_counters.txt" 2>&1
 if [ -z "$QUICK" ]; then
   pmc_pass pmc_f3 FETCH_SIZE --precision bf16; pmc_pass pmc_w3 WRITE_SIZE --precision bf16
   python3 tools/pmc_traffic.py gpurun_out/pmc_f3/p_counter_collection.csv gpurun_out/pmc_w3/p_counter_collection.csv "$O/${R}_pmc_traffic_bf16.json" 3
@@ -32,7 +32,7 @@ if [ -z "$QUICK" ]; then
   run python bench.py --model psmnet --batch 2 --no-cpu-baseline > "$O/${R}_bench_c4_psmnet_train.json"
   run python bench.py --precision bf16 --no-cpu-baseline --shapes "$O/${R}_conv_shape_table_bf16.txt" > "$O/${R}_bench_c5_bf16_b4.json"
   run python bench.py --precision bf16 --batch 8 --no-cpu-baseline > "$O/${R}_bench_c5_bf16_b8.json"
-  run python bench.py --wgrad-async --no-cpu-baseline > "$O/${R}_bench_wgrad_async.json"
+  run python bench.py --wgrad-inline --no-cpu-baseline > "$O/${R}_bench_wgrad_inline.json"
   run python bench.py --model nnet --batch 2 --no-cpu-baseline > "$O/${R}_bench_nnet_train.json"
   run python bench.py --model stereonet --no-cpu-baseline > "$O/${R}_bench_stereonet_train.json"
   run python bench.py --workload cost_volume --no-cpu-baseline > "$O/${R}_bench_cost_volume_stage.json"
