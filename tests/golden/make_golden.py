@@ -164,7 +164,9 @@ def checksum(t):
 
 
 # ----------------------------------------------------------------------------- fixtures
-def gen_e2e(tag, B, H, W, train, mask_mode, stages, prepare=None):
+def gen_e2e(tag, B, H, W, train, mask_mode, stages, prepare=None, compact=False):
+    """compact: large fixture (c1's 256x256) -- the inputs are not stored (synthetic_batch(B, H, W, seed=0, mask_mode) regenerates them bit
+    for bit) and the predictions are kept as every-other-pixel samples plus fp64 checksums."""
     torch.manual_seed(1)
     model, opt = build_reference()
     fill_by_recipe(model)
@@ -203,11 +205,18 @@ def gen_e2e(tag, B, H, W, train, mask_mode, stages, prepare=None):
         h.remove()
 
     out = {}
-    for k, v in batch.items():
-        out['in_' + k] = f32(v)
-    out['pred_depth'] = f32(res['pred_depth'])
-    out['pred_normal'] = f32(res['pred_normal'])
-    out['ref_feature'] = f32(res['ref_feature'])
+    if compact:
+        out['batch_args'] = np.array([B, H, W, 0])                       # synthetic_batch(B, H, W, seed=0, mask_mode=...)
+        out['mask_mode'] = np.array(mask_mode)
+        for k in ('pred_depth', 'pred_normal', 'ref_feature'):
+            out[k + '_s'] = f32(res[k][..., ::2, ::2])
+            out[k + '_cs'] = checksum(res[k])
+    else:
+        for k, v in batch.items():
+            out['in_' + k] = f32(v)
+        out['pred_depth'] = f32(res['pred_depth'])
+        out['pred_normal'] = f32(res['pred_normal'])
+        out['ref_feature'] = f32(res['ref_feature'])
     out['prob_depth_cs'] = checksum(res['prob_depth'])
     out['prob_depth_s'] = f32(res['prob_depth'][:, :, ::4, ::8, ::8])
     if stages:
@@ -323,3 +332,4 @@ if __name__ == '__main__':
     gen_e2e('eval_32x48_b2', 2, 32, 48, False, 'ones', stages=False)
     gen_e2e('train_64x96_b1', 1, 64, 96, True, 'ones', stages=False)
     gen_e2e('train_128x128_b2', 2, 128, 128, True, 'bern', stages=False)      # better conditioned BatchNorm: gradient / Adam-step pin
+    gen_e2e('train_256x256_b1', 1, 256, 256, True, 'bern', stages=False, compact=True)   # BASELINE configs[0]'s size: full 32-wide tiles

@@ -770,7 +770,7 @@ def test_full_size_properties_2d_head_norm_bf16():
     assert float((ps - 1).abs().max()) <= 1e-5
     ex = (prob * torch.tensor(disp, device=DEV).view(1, -1, 1, 1)).sum(1)
     assert float((ex - pred.detach()).abs().max()) <= 1e-4
-    assert float(pred.min()) >= -4.0 - 1e-4 and float(pred.max()) <= 11.5 + 1e-4
+    assert float(pred.detach().min()) >= -4.0 - 1e-4 and float(pred.detach().max()) <= 11.5 + 1e-4
     gp = r(*pred.shape)
     (gl,) = torch.autograd.grad(pred, lg, gp)
     d = r(*lg.shape)

@@ -87,6 +87,27 @@ def test_eval_and_second_size(golden_dir):
     _close(res['final_loss'], g['final_loss'], 1e-5, '64x96 final_loss')
 
 
+def test_oracle_at_256x256_vs_reference(golden_dir):
+    """BASELINE configs[0]'s size: the oracle against the imported reference's 256 x 256 run (tests/golden/make_golden_256.py; inputs are
+    regenerated, predictions compared on the stored every-other-pixel samples).  Same op order on the same CPU backend: 1e-4."""
+    from dualpixelface_amd.recipe import synthetic_batch
+    g = np.load(golden_dir + '/e2e_train_256x256_b1.npz')
+    B, H, W, seed = (int(v) for v in g['batch_args'])
+    batch = synthetic_batch(B, H, W, seed=seed, mask_mode=str(g['mask_mode']))
+    st = recipe_state()
+    orc = StereoDPNetOracle(st, training=True)
+    res = orc.forward(batch)
+    _close(res['pred_depth'][..., ::2, ::2], g['pred_depth_s'], 1e-4, '256 pred_depth')
+    _close(res['pred_normal'][..., ::2, ::2], g['pred_normal_s'], 1e-4, '256 pred_normal')
+    _close(res['final_loss'], g['final_loss'], 1e-5, '256 final_loss')
+    res['final_loss'].backward()
+    for k in g.files:
+        if k.startswith('grad::') and np.linalg.norm(g[k]) > 1e-6:
+            ref = torch.from_numpy(g[k]).double()
+            rel = ((st[k[6:]].grad.double() - ref).norm() / ref.norm()).item()
+            assert rel <= 1e-3, (k, rel)
+
+
 def test_losses_fixture(golden_dir):
     g = np.load(golden_dir + '/loss.npz')
     orc = StereoDPNetOracle({}, training=True)
