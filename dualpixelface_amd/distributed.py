@@ -112,6 +112,34 @@ class FlatGradReducer(object):
             for w in work:
                 w.wait()
 
+    # ---- staged exchange for the gather scheme (plugin.train_step): the backward pass tells the reducer when a bucket's gradients
+    # all exist (tensor hooks at the bucket boundaries of the network, see StereoDPNetCore._network); the bucket is gathered into the
+    # arena and its all-reduce enqueued right away, overlapping the rest of the backward pass.
+    def stage_begin(self):
+        self._staged = set()
+        self._work = []
+        self.log = []                                     # ('launch', bucket) / ('backward_done',) in host order (tests)
+
+    def bucket_of(self, p):
+        return self._param_bucket.get(id(p))
+
+    def stage_launch(self, bi):
+        """Bucket bi sits complete in the arena: enqueue its all-reduce (asynchronous; stage_finish waits)."""
+        if bi in self._staged:
+            return
+        self._staged.add(bi)
+        self.log.append(('launch', bi))
+        self._launch(bi)
+
+    def stage_finish(self):
+        self.log.append(('backward_done',))
+        for bi in range(len(self.buckets)):
+            if bi not in self._staged:
+                self.stage_launch(bi)
+        for w in self._work:
+            w.wait()
+        self._work = []
+
     def remove(self):
         for h in self._hooks:
             h.remove()

@@ -266,6 +266,16 @@ def wgrad_async_begin(params):
     del _wgrad_pending[:]
 
 
+def wgrad_async_take(want):
+    """Mid-backward hand-over (bucketed gradient exchange): join the side stream and return the deferred [(parameter, gradient)] for
+    which ``want(parameter)`` holds; the others stay pending."""
+    taken = [pg for pg in _wgrad_pending if want(pg[0])]
+    if taken:
+        _wgrad_pending[:] = [pg for pg in _wgrad_pending if not want(pg[0])]
+        torch.cuda.current_stream().wait_stream(_wgrad_side[taken[0][1].device])
+    return taken
+
+
 def wgrad_async_finish():
     """Join the side stream and return [(parameter, gradient)] in launch order."""
     global _wgrad_registry

@@ -105,22 +105,48 @@ class _PluginHooks(object):
             for p, _ in pairs:
                 p.grad = None
             ops.wgrad_async_begin([p for p, _ in pairs])
-            results = self.forward(batch)
-            results['final_loss'].backward()
+
+            def gather(sel):
+                """Copy the gradients of the selected (parameter, arena view) pairs into the arena; afterwards .grad IS the view."""
+                views, grads = [], []
+                for p, v in sel:
+                    if p.grad is v:
+                        continue
+                    if p.grad is None:
+                        v.zero_()
+                    else:
+                        views.append(v)
+                        grads.append(p.grad)
+                if views:
+                    torch._foreach_copy_(views, grads)
+                for p, v in sel:
+                    p.grad = v
+
+            staged = reducer is not None and reducer.world_size > 1 and getattr(self, 'stage_grads', True)
+            if staged:
+                # Data-parallel: the network fires self._grad_stage(bucket) from tensor hooks at its bucket boundaries (normal head done;
+                # aggregation + cost volume done); that bucket is gathered and its all-reduce enqueued while the backward pass continues.
+                reducer.stage_begin()
+
+                def on_stage(bi):
+                    for p, g in ops.wgrad_async_take(lambda q: reducer.bucket_of(q) == bi):
+                        p.grad = g if p.grad is None else p.grad + g
+                    gather([(p, v) for p, v in pairs if reducer.bucket_of(p) == bi])
+                    reducer.stage_launch(bi)
+                self._grad_stage = on_stage
+            try:
+                results = self.forward(batch)
+                results['final_loss'].backward()
+            finally:
+                self._grad_stage = None
             for p, g in ops.wgrad_async_finish():
                 p.grad = g if p.grad is None else p.grad + g
-            views, grads = [], []
-            for p, v in pairs:
-                if p.grad is None:
-                    v.zero_()
-                else:
-                    views.append(v)
-                    grads.append(p.grad)
-            torch._foreach_copy_(views, grads)
-            for p, v in pairs:
-                p.grad = v
+            gather(pairs)
             if reducer is not None:
-                reducer.reduce_all()
+                if staged:
+                    reducer.stage_finish()
+                else:
+                    reducer.reduce_all()
                 gscale = 1.0 / reducer.world_size
         else:
             flat_g = self.flat_gradients(zero=True)

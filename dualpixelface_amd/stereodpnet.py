@@ -566,11 +566,26 @@ class StereoDPNetCore(_Base):
             a, b = 'right', 'left'
         ref = self._features(batch[a])
         tar = self._features(batch[b])
+        stage = getattr(self, '_grad_stage', None)          # data-parallel step: gradient buckets are exchanged as they complete
+        if stage is not None and ref.requires_grad:
+            # bucket 1 (cost volume + aggregation) is complete once the gradients of BOTH feature maps exist
+            left = [2]
+
+            def feat_hook(g):
+                left[0] -= 1
+                if left[0] == 0:
+                    stage(1)
+                return g
+            ref.register_hook(feat_hook)
+            tar.register_hook(feat_hook)
         vol = self._cost_volume(ref, tar)
         logits, costs = self._aggregate(vol)
         preds, pred_all, prob_all = ops.softargmin_heads(logits, self.disp_values, 4, True)
         normal = None
         if opt.model.predict_normal:
+            if stage is not None and costs[0].requires_grad:
+                # bucket 2 (normal head): done when the (summed) gradient of its input reaches the aggregation stack
+                costs[0].register_hook(lambda g: (stage(2), g)[1])
             normal, _, _ = self._normals(costs[0], preds[0], batch)
         return {'pred_depth': pred_all, 'prob_depth': prob_all,
                 'pred_normal': normal.unsqueeze(1) if normal is not None else None,

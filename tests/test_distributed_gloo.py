@@ -39,7 +39,18 @@ def _worker(rank, world, port, out):
         loss = (params[0] @ x).sum() * (rank + 1) + params[1].sum() * 2 + (params[2] ** 2).sum()
         loss.backward()
         red.finish()
-    out[rank] = (flat.clone(), flat_g.clone())
+    hooked = flat_g.clone()
+    # the staged scheme of plugin.train_step: the caller says when a bucket is complete in the arena; every bucket is exchanged once,
+    # the ones nobody announced at stage_finish
+    g = torch.Generator().manual_seed(100 + rank)
+    flat_g.copy_(torch.randn(n, generator=g))
+    local = flat_g.clone()
+    red.stage_begin()
+    red.stage_launch(1)
+    red.stage_launch(1)                  # idempotent
+    red.stage_finish()
+    assert red.log == [('launch', 1), ('backward_done',), ('launch', 0)] and red.bucket_of(params[3]) == 1
+    out[rank] = (flat.clone(), hooked, local, flat_g.clone())
     dist.destroy_process_group()
 
 
@@ -48,8 +59,9 @@ def test_flat_grad_reducer_world2():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    p0, g0 = out[0]
-    p1, g1 = out[1]
+    p0, g0, l0, s0 = out[0]
+    p1, g1, l1, s1 = out[1]
+    assert torch.equal(s0, s1) and torch.allclose(s0, l0 + l1), 'staged exchange: every bucket summed exactly once'
     assert torch.equal(p0, p1), 'parameters must be broadcast from rank 0'
     assert torch.equal(g0, g1), 'both ranks must hold the same summed gradient'
     # expected SUM over ranks: d/dW0 = (rank+1) * x_rank broadcast over rows

@@ -47,10 +47,24 @@ def _worker(rank, world, port, sync_bn, out):
         model.enable_sync_batchnorm()
     full = _full_batch()
     batch = {k: v[2 * rank:2 * rank + 2].cuda() for k, v in full.items()}
+    # count the collectives of the step
+    counts = {'all_reduce': 0, 'all_gather': 0}
+    real_ar, real_ag = dist.all_reduce, dist.all_gather_into_tensor
+
+    def ar(*a, **k):
+        counts['all_reduce'] += 1
+        return real_ar(*a, **k)
+
+    def ag(*a, **k):
+        counts['all_gather'] += 1
+        return real_ag(*a, **k)
+    dist.all_reduce, dist.all_gather_into_tensor = ar, ag
     res = model.train_step(batch, reducer, lr=1e-3)
+    dist.all_reduce, dist.all_gather_into_tensor = real_ar, real_ag
     torch.cuda.synchronize()
     out[rank] = (model.flat_parameters().detach().cpu(), model.flat_gradients(zero=False).detach().cpu(), float(res['final_loss']),
                  model.state_dict()['feature_extraction.firstconv.0.1.running_mean'].cpu())
+    out['log%d' % rank] = (list(reducer.log), dict(counts))
     dist.destroy_process_group()
 
 
@@ -59,6 +73,7 @@ def _run(sync_bn):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, sync_bn, out), nprocs=2, join=True)
+    _run.logs = (out['log0'], out['log1'])
     return out[0], out[1]
 
 
@@ -78,6 +93,11 @@ def test_two_ranks_per_rank_batchnorm():
         ref += m.flat_gradients(zero=False).detach().cpu()
     scale = ref.abs().max().item()
     assert (g0 - ref).abs().max().item() <= 2e-3 * scale
+    # the exchange overlaps the backward pass: the normal head's bucket (2) and the aggregation + cost-volume bucket (1) are
+    # all-reduced from tensor hooks BEFORE backward() returns, the feature extractor's (0) after it; 3 collectives per step in all
+    for log, counts in _run.logs:
+        assert log == [('launch', 2), ('launch', 1), ('backward_done',), ('launch', 0)], log
+        assert counts == {'all_reduce': 3, 'all_gather': 0}, counts
 
 
 def test_two_ranks_sync_batchnorm_equals_single_process_full_batch():
@@ -96,6 +116,13 @@ def test_two_ranks_sync_batchnorm_equals_single_process_full_batch():
     assert rel <= 1e-1, rel            # a broken exchange (per-rank statistics) gives O(1)
     # Adam normalises the step: parameters move by <= lr, identically up to that tolerance
     assert (p0 - ref_p).abs().max().item() <= 2.5e-3
+    # collectives of a SyncBatchNorm step: one [2C+1] all-gather per training BatchNorm call in forward (45 per feature pass x 2, 2
+    # attention calls, 25 in the aggregation stack, 2 in the normal head = 119) and one [3C+1] all-reduce each in backward, plus the 3
+    # gradient buckets.  A BatchNorm's statistics are needed before the next layer can run and its gradient sums before its dx, so
+    # exchanges of consecutive layers cannot be merged; what could be (the two feature passes in lockstep: -45, the three dilated
+    # branches of a DPBlock: -20) is listed in DESIGN.md section 5.
+    for log, counts in _run.logs:
+        assert counts == {'all_gather': 119, 'all_reduce': 122}, counts
 
 
 def test_bench_under_torchrun_two_ranks():
