@@ -13,6 +13,15 @@
 
 namespace {
 
+// In-kernel s_memtime stamps of one workgroup (-DDPF_STAMPS builds only; tools/debug/dcn_stamps_*.py read them back)
+#ifdef DPF_STAMPS
+__device__ unsigned long long g_stamps[16 * 128 * 2];
+#define DPF_STAMP(step, slot)                                                                                          \
+  if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_stamps[(DPF_STAMP_WAVE * 128 + (step)) * 2 + (slot)] = __builtin_readcyclecounter();
+#else
+#define DPF_STAMP(step, slot)
+#endif
+
 constexpr int TP = 64;          // output voxels per workgroup
 constexpr int SP = TP + 1;      // padded LDS row
 constexpr int MAXC = 128;
@@ -382,13 +391,6 @@ __global__ __launch_bounds__(256) void dcn_wmax_kernel(const float* __restrict__
 // measured bound -- far-corner global atomics are emitted on the first attempt only.  Later passes use the measured bound.
 // Error per contribution <= 0.5 unit, unit = gbound * wmax * mass / 2^30: ~1e-6 of the tensor scale at MASS0, deterministic
 // (integer adds commute).
-#ifdef DPF_STAMPS
-__device__ unsigned long long g_stamps[16 * 128 * 2];
-#define DPF_STAMP(step, slot)                                                                                          \
-  if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_stamps[(DPF_STAMP_WAVE * 128 + (step)) * 2 + (slot)] = __builtin_readcyclecounter();
-#else
-#define DPF_STAMP(step, slot)
-#endif
 constexpr int PK_CH = 16, PK_CS = 8;
 constexpr float PK_MASS0 = 128.f, PK_MASS_Q = 131072.f;   // first-pass mass bound; fixed-point scale of the mass counters (6912 * 2^17 < 2^30)
 
@@ -795,6 +797,7 @@ struct RegGeo {
   int RXL;                 // left halo along x (>= R; chosen so that the region's first column is 16-byte aligned in global memory)
   int TZ, RZmax, RY, RX, RV;
   int tilesZ, tilesY, tilesX;
+  int TX;                  // tile width in output voxels (32; 16 for the half-width forward tile)
 };
 
 struct RegCtx {
@@ -808,7 +811,7 @@ __device__ __forceinline__ RegCtx region_ctx(const DcnP& p, const RegGeo& g, int
   const int ty = blk % g.tilesY; blk /= g.tilesY;
   const int tz = blk % g.tilesZ;
   c.b = blk / g.tilesZ;
-  c.z0 = tz * g.TZ; c.y0 = ty * RG_TY; c.x0 = tx * RG_TX;
+  c.z0 = tz * g.TZ; c.y0 = ty * RG_TY; c.x0 = tx * g.TX;
   const int rz0u = c.z0 * p.sd - p.pd - g.R;
   c.rz0 = rz0u < 0 ? 0 : rz0u;
   int rz1 = rz0u + (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * g.R;
@@ -1295,20 +1298,84 @@ __device__ __forceinline__ void fwd_sample_half_store(const DcnP& p, const RegGe
   }
 }
 
+// full-chunk sampler of the 8-wave (4-wave at TXV = 16) forward kernel: all CH channels of one voxel, written straight into the tile
+// column `dst`.  Same structure as the half sampler: straight-line fast path in two groups of 4 corners, rolled slow path.
+template <int CH, int ROWS>
+__device__ __forceinline__ void fwd_sample_store(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
+                                                 const float* __restrict__ xb, int c0, long long chan, float* dst) {
+  if (!sp.valid) {
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) dst[ch * ROWS] = 0.f;
+    return;
+  }
+  if (sp.fast) {
+    float val[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) val[ch] = 0.f;
+#pragma unroll
+    for (int jd = 0; jd < 2; ++jd) {
+      float v[4][CH];
+#pragma unroll
+      for (int jy = 0; jy < 4; ++jy) corner_vec<CH>(g, sp, s_reg, jd, jy >> 1, jy & 1, v[jy]);
+#pragma unroll
+      for (int jy = 0; jy < 4; ++jy) {
+        const float wj = sp.wz[jd] * sp.wy[jy >> 1] * sp.wx[jy & 1];
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) val[ch] = fmaf(wj, v[jy][ch], val[ch]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) dst[ch * ROWS] = val[ch];
+  } else {
+    int vx[8];
+    float wj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+      const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
+      const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
+      vx[j] = in ? (d * p.H + h) * p.W + w : -1;
+      wj[j] = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
+    }
+#pragma unroll 1
+    for (int ch = 0; ch < CH; ++ch) {
+      const int cg = c0 + ch;
+      const float* xc = xb + (long long)(cg < p.C ? cg : p.C - 1) * chan;
+      float sv = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = (vx[j] >= 0 && cg < p.C) ? xc[vx[j]] : 0.f;
+        sv = fmaf(wj[j], xv, sv);
+      }
+      dst[ch * ROWS] = sv;
+    }
+  }
+}
+
 constexpr int STR = 256;   // row of the [CH][256] sample tile (lane-consecutive writes and reads: no padding needed)
 // NW = 8: 4 sampler waves (a voxel per thread, all CH channels) + 4 MFMA waves (64 voxels each).
 // NW = 16: 8 sampler waves (a thread PAIR per voxel, half the channels each) + 8 MFMA waves (32 voxels each): four waves per SIMD --
 //          the kernel is latency bound at one LDS-limited workgroup per CU (measured: MFMA 25 %, VALU 17 %, LDS 20 % busy with 8 waves).
-template <int MT, int CH, int NW>
+#undef DPF_STAMP_WAVE
+#define DPF_STAMP_WAVE wave_u
+// TXV: tile width (32: 4 x 2 x 32 = 256 voxels per workgroup; 16: 128 voxels, half the LDS image at the same halo ratio -- two workgroups
+// per CU, out of phase with each other).  Samplers cover the tile once (a voxel per thread, all CH channels) or twice (thread pair
+// per voxel, half the channels each) depending on NW.
+template <int MT, int CH, int NW, int TXV>
 __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                              const float* __restrict__ wt /*[T][Cpad][KT], zero rows beyond C*/,
                                                              const float* __restrict__ bias, float* __restrict__ out, DcnP p, RegGeo g, int vec) {
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32 * MT;
   constexpr int NS = NW / 2;                          // sampler waves = MFMA waves
-  constexpr int NTW = 8 / NS;                         // 32-voxel column tiles per MFMA wave (2 or 1)
+  constexpr int NVOX = 8 * TXV;                       // output voxels per workgroup
+  constexpr int NTW = NVOX / (32 * NS);               // 32-voxel column tiles per MFMA wave (2 or 1)
+  constexpr bool HALF = NS * 64 == 2 * NVOX;          // thread pair per voxel
+  constexpr int STRV = NVOX;                          // row of the [CH][NVOX] sample tile
+  static_assert(NTW == 1 || NTW == 2, "tile / wave split");
   float* s_reg = smem;                                // [RV][VS]
-  float* s_S = s_reg + RegCfg<CH>::VS * g.RV;         // [2][CH][STR]
+  float* s_S = s_reg + RegCfg<CH>::VS * g.RV;         // [2][CH][STRV]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const RegCtx c = region_ctx(p, g, blockIdx.x);
@@ -1318,10 +1385,10 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
   // other's code (with the branch inside the chunk loop the 16-wave variant spilled 45 registers in its MFMA loop).
   if (wave_u < NS) {
     // ------------------------------------------------------------------------------------------------ samplers
-    const int half = wave_u >> 2;                      // NW = 16: sampler waves 0-3 take channels [0, CH/2), 4-7 the rest
-    const int vox = tid & 255;
+    const int vox = tid % NVOX;
+    const int half = tid / NVOX;                       // HALF: the first NVOX threads take channels [0, CH/2), the others the rest
     const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
-    const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
+    const int pdx = vox % TXV, pdy = (vox / TXV) & 1, pdz = vox / (2 * TXV);
     const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
     const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
     const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
@@ -1337,22 +1404,21 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
       __syncthreads();
 #pragma unroll 1
       for (int t = 0; t < p.T; ++t) {
+        if (c0 == CH) { DPF_STAMP(t, 0) }
         const Off3 ocur = onext;
         offp += 3 * p.P;
         onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);
         const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
         tap_next(p, it);
         const Samp sp = make_samp(p, g, c, cn);
-        float* dst = s_S + (t & 1) * (CH * STR) + vox;
-        if (NW == 8) {
-          float val[CH];
-          sample_chunk<CH>(p, g, sp, cn, s_reg, xb, c0, chan, val);
-#pragma unroll
-          for (int ch = 0; ch < CH; ++ch) dst[ch * STR] = val[ch];
+        float* dst = s_S + (t & 1) * (CH * STRV) + vox;
+        if (!HALF) {
+          fwd_sample_store<CH, STRV>(p, g, sp, cn, s_reg, xb, c0, chan, dst);
         } else {
-          if (half == 0) fwd_sample_half_store<CH, 0, 256>(p, g, sp, cn, s_reg, xb, c0, chan, dst);
-          else fwd_sample_half_store<CH, 1, 256>(p, g, sp, cn, s_reg, xb, c0, chan, dst);
+          if (half == 0) fwd_sample_half_store<CH, 0, STRV>(p, g, sp, cn, s_reg, xb, c0, chan, dst);
+          else fwd_sample_half_store<CH, 1, STRV>(p, g, sp, cn, s_reg, xb, c0, chan, dst);
         }
+        if (c0 == CH) { DPF_STAMP(t, 1) }
         __syncthreads();                               // barrier t: S[t&1] is complete; the MFMA waves have finished reading S[(t-1)&1]
       }
     }
@@ -1396,23 +1462,25 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
             for (int m = 0; m < MT; ++m) aN[sx][m] = wtt[(2 * sx) * KT + m * 32];
         }
         __syncthreads();                               // barrier t
-        const float* src = s_S + (t & 1) * (CH * STR) + mw * (32 * NTW) + l31;
+        if (c0 == CH) { DPF_STAMP(t, 0) }
+        const float* src = s_S + (t & 1) * (CH * STRV) + mw * (32 * NTW) + l31;
 #pragma unroll
         for (int sx = 0; sx < CH / 2; ++sx) {
           float bv[NTW];
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) bv[nt] = src[(2 * sx + hh) * STR + nt * 32];
+          for (int nt = 0; nt < NTW; ++nt) bv[nt] = src[(2 * sx + hh) * STRV + nt * 32];
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sx][m], bv[nt], acc[m][nt], 0, 0, 0);
         }
+        if (c0 == CH) { DPF_STAMP(t, 1) }
       }
     }
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       const int pl = mw * (32 * NTW) + nt * 32 + l31;
-      const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+      const int ax = pl % TXV, ay = (pl / TXV) & 1, az = pl / (2 * TXV);
       const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
       if (az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo) {
         const long long pos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
@@ -1962,8 +2030,9 @@ __global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __
 
 size_t region_lds(const RegGeo& g, int CH) { return sizeof(float) * ((size_t)CH * g.RV + (size_t)16 * ST); }
 
-int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, int RYH = -1) {
+int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, int RYH = -1, int TX = RG_TX) {
   g.R = R;
+  g.TX = TX;
   g.RXL = R;
   g.RYH = RYH < R ? R : RYH;
   g.TZ = p.Do < 4 ? p.Do : 4;
@@ -1971,15 +2040,15 @@ int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, in
   if (RZ > p.D) RZ = p.D;
   g.RZmax = RZ;
   g.RY = (RG_TY - 1) * p.sh + (p.kh - 1) * p.dh + 1 + 2 * g.RYH;
-  g.RX = (RG_TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + 2 * R;
+  g.RX = (TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + 2 * R;
   if (aligned) {   // first region column = x0*sw - pw - RXL on a 16-byte boundary (x0*sw is a multiple of 32), RX a multiple of 4
     while ((p.pw + g.RXL) & 3) ++g.RXL;
-    g.RX = ((g.RXL + (RG_TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + R + 3) / 4) * 4;
+    g.RX = ((g.RXL + (TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + R + 3) / 4) * 4;
   }
   g.RV = g.RZmax * g.RY * g.RX;
   g.tilesZ = dpf_div_up(p.Do, g.TZ);
   g.tilesY = dpf_div_up(p.Ho, RG_TY);
-  g.tilesX = dpf_div_up(p.Wo, RG_TX);
+  g.tilesX = dpf_div_up(p.Wo, TX);
   const long long blocks = (long long)p.B * g.tilesZ * g.tilesY * g.tilesX;
   if (g.RX > 64 || region_lds(g, CH) > 160 * 1024 || blocks >= 0x7fffffffLL || p.K > 128) return DPF_ERR_UNSUPPORTED;
   return DPF_OK;
@@ -2057,26 +2126,36 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
     if (use_rs && MT <= 2) {
       RegGeo ga{};
       const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2 && !getenv("DPF_DCN_NOVEC");
-      auto lds_of = [&](const RegGeo& q) { return sizeof(float) * ((size_t)CH * q.RV + (size_t)2 * CH * STR); };
+      // half-width tile (4 x 2 x 16 voxels, 4 waves, image under 80 KB: two workgroups per CU) for 16-channel chunks: 6.45 vs 6.78 ms on
+      // the 64-channel layer; 12-channel chunks (35-channel layer) are faster on the full tile (4.28 vs 4.48).  DPF_DCN_FWD_TX=16|32 forces one.
+      static const int fwd_tx = getenv("DPF_DCN_FWD_TX") ? atoi(getenv("DPF_DCN_FWD_TX")) : 0;
+      const int TXv = fwd_tx == 16 ? 16 : (fwd_tx == 32 ? 32 : (CH == 16 ? 16 : 32));
+      auto lds_of = [&](const RegGeo& q) { return sizeof(float) * ((size_t)CH * q.RV + (size_t)2 * CH * 8 * TXv); };
+      const size_t lds_cap = TXv == 16 ? 80 * 1024 : 160 * 1024;
       int vec = 0;
       bool ok = false;
       if (can_vec) {
-        static const int rs_default = 8;
-        (void)rs_default;
         const int cand[6][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}};     // (x/z halo, y halo), widest first
         for (int i = 0; i < 6 && !ok; ++i)
-          if (region_geo(ga, p, CH, cand[i][0], true, cand[i][1]) == DPF_OK && lds_of(ga) <= 160 * 1024) { ok = true; vec = 1; }
+          if (region_geo(ga, p, CH, cand[i][0], true, cand[i][1], TXv) == DPF_OK && lds_of(ga) <= lds_cap) { ok = true; vec = 1; }
       }
-      if (!ok) { ga = g; ok = lds_of(ga) <= 160 * 1024; }
+      if (!ok) {
+        for (int R = 4; R >= 3 && !ok; --R)
+          if (region_geo(ga, p, CH, R, false, -1, TXv) == DPF_OK && lds_of(ga) <= lds_cap) ok = true;
+      }
       if (ok) {
         const size_t lds_rs = lds_of(ga);
         const dim3 grid_rs((unsigned)((long long)B * ga.tilesZ * ga.tilesY * ga.tilesX));
-#define DPF_RS(M, Cw, Nw)                                                                                                  \
+#define DPF_RS(M, Cw, Nw, Tx)                                                                                              \
   {                                                                                                                        \
-    if (set_lds(dcn_fwd_rs_kernel<M, Cw, Nw>, lds_rs) != DPF_OK) return DPF_ERR_LAUNCH;                                    \
-    hipLaunchKernelGGL((dcn_fwd_rs_kernel<M, Cw, Nw>), grid_rs, dim3(64 * Nw), lds_rs, st, input, offset, ws, bias, output, p, ga, vec); \
+    if (set_lds(dcn_fwd_rs_kernel<M, Cw, Nw, Tx>, lds_rs) != DPF_OK) return DPF_ERR_LAUNCH;                                \
+    hipLaunchKernelGGL((dcn_fwd_rs_kernel<M, Cw, Nw, Tx>), grid_rs, dim3(64 * Nw), lds_rs, st, input, offset, ws, bias, output, p, ga, vec); \
   }
-#define DPF_RSN(M, Cw) { if (use_rs == 8) DPF_RS(M, Cw, 8) else DPF_RS(M, Cw, 16) }
+#define DPF_RSN(M, Cw)                                                                                                     \
+  {                                                                                                                        \
+    if (TXv == 16) { if (use_rs == 8) DPF_RS(M, Cw, 4, 16) else DPF_RS(M, Cw, 8, 16) }                                     \
+    else { if (use_rs == 8) DPF_RS(M, Cw, 8, 32) else DPF_RS(M, Cw, 16, 32) }                                              \
+  }
         if (MT == 1) { if (CH == 16) DPF_RSN(1, 16) else DPF_RSN(1, 12) } else { if (CH == 16) DPF_RSN(2, 16) else DPF_RSN(2, 12) }
 #undef DPF_RSN
 #undef DPF_RS
