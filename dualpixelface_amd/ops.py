@@ -99,14 +99,15 @@ _zero_arena = {}
 def zero_slot(nfloats, device):
     """A zero-filled scratch slot that is handed out once per zeroing: slots are carved from a large arena that is cleared by ONE fill
     when it runs out, instead of one memset per BatchNorm backward (121 tiny memsets per step).  Stream-ordered like `scratch`."""
-    st = _zero_arena.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)       # one arena per stream: a fill never races another stream's slots
+    st = _zero_arena.get(key)
     n = (int(nfloats) + 31) & ~31
     if st is None or st[1] + n > st[0].numel():
         size = max(1 << 20, 4 * n)
         buf = st[0] if st is not None and st[0].numel() >= size else torch.empty(size, dtype=torch.float32, device=device)
         buf.zero_()
         st = [buf, 0]
-        _zero_arena[device] = st
+        _zero_arena[key] = st
     slot = st[0][st[1]:st[1] + n]
     st[1] += n
     return slot
@@ -463,6 +464,26 @@ def depthwise_conv3x3(x, w):
 
 
 # ----------------------------------------------------------------------------------------------- norm + activation
+# Two passes of a shared module on two streams (StereoDPNetCore._network: left / right feature extraction): the running-statistics
+# updates of a BatchNorm layer must happen in the reference's order (first pass, then second).  BN_ORDER = ('record', events) makes
+# every training statistics launch leave an event keyed by its running_mean buffer; ('wait', events) makes it wait for that event first.
+BN_ORDER = None
+
+
+def _bn_order_before(running_mean):
+    if BN_ORDER is not None and BN_ORDER[0] == 'wait' and running_mean is not None:
+        ev = BN_ORDER[1].get(running_mean.data_ptr())
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
+def _bn_order_after(running_mean):
+    if BN_ORDER is not None and BN_ORDER[0] == 'record' and running_mean is not None:
+        ev = torch.cuda.Event()
+        ev.record()
+        BN_ORDER[1][running_mean.data_ptr()] = ev
+
+
 class NormActFn(torch.autograd.Function):
     """y = act(norm(x) * w + b + res) + res2 with norm = batch norm (training/eval) or instance norm, or no norm."""
 
@@ -484,6 +505,8 @@ class NormActFn(torch.autograd.Function):
         nb = 4.0 * x.numel() * ((0 if (mode in (0, 2) or fused_stats) else 1) + 2 + (res is not None) + (res2 is not None))
         timer = _Timed('norm_act', 0.0, 'naf', nb) if PROFILE_DETAIL else _Timed.OFF
         timer.__enter__()
+        if mode == 1:
+            _bn_order_before(running_mean)
         if mode == 1 and exchange is not None:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
@@ -519,6 +542,8 @@ class NormActFn(torch.autograd.Function):
             invstd = torch.empty_like(mean)
             ws = scratch(2 * c_, x.device)
             L.call('dpf_bn_stats', _ptr(x), n_, c_, S, BN_EPS, 0.0, None, None, _ptr(mean), _ptr(invstd), _ptr(ws), _stream())
+        if mode == 1:
+            _bn_order_after(running_mean)
         y = torch.empty_like(x)
         L.call('dpf_norm_act_forward', _ptr(x), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), wmod, _ptr(res), _ptr(res2), act,
                _ptr(slope), float(slope_const), _ptr(y), n_, c_, S, _stream())
@@ -596,6 +621,8 @@ class NormActCatFn(torch.autograd.Function):
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
             st = holders[i] if holders else None
+            if mode == 1:
+                _bn_order_before(rms[i])
             if mode == 1 and st and st.get('ptr') == x.data_ptr() and st['channels'] == C and st['count'] == N * S:
                 L.call('dpf_bn_finalize_partials', _ptr(st['slab']), st['parts'], C, N * S, BN_EPS, BN_MOMENTUM, _ptr(rms[i]), _ptr(rvs[i]),
                        _ptr(mean), _ptr(invstd), _stream())
@@ -606,6 +633,8 @@ class NormActCatFn(torch.autograd.Function):
                        _stream())
             else:
                 L.call('dpf_bn_eval_stats', _ptr(rms[i]), _ptr(rvs[i]), C, BN_EPS, _ptr(mean), _ptr(invstd), _stream())
+            if mode == 1:
+                _bn_order_after(rms[i])
             L.call('dpf_norm_act_forward_slice', _ptr(x), _ptr(mean), _ptr(invstd), _ptr(ws[i]), _ptr(bs[i]), C, None, None, act, None, 0.0,
                    _ptr(cat), Ctot, c0, N, C, S, _stream())
             saved += [x, ws[i], bs[i], mean, invstd]

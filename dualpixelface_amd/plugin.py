@@ -2,6 +2,8 @@
 (src/model/model_selector.py:11-15 -> src/model/stereodpnet/mainmodel.py:21), with the same methods PL / main.py call
 (mainmodel.py:67-177) plus an MI355X-native ``train_step`` (flat-arena gradients, fused Adam, optional RCCL all-reduce).
 """
+import contextlib
+
 import torch
 
 from . import ops
@@ -127,18 +129,28 @@ class _PluginHooks(object):
                 # Data-parallel: the network fires self._grad_stage(bucket) from tensor hooks at its bucket boundaries (normal head done;
                 # aggregation + cost volume done); that bucket is gathered and its all-reduce enqueued while the backward pass continues.
                 reducer.stage_begin()
+                main = torch.cuda.current_stream() if flat_g.is_cuda else None
 
                 def on_stage(bi):
-                    for p, g in ops.wgrad_async_take(lambda q: reducer.bucket_of(q) == bi):
-                        p.grad = g if p.grad is None else p.grad + g
-                    gather([(p, v) for p, v in pairs if reducer.bucket_of(p) == bi])
-                    reducer.stage_launch(bi)
+                    # The hook may fire on another stream than the step's (the second feature pass has its own): the bucket's gradients
+                    # were produced on the main stream (and the weight-gradient side stream), and Adam will read the arena there -- so the
+                    # gather and the collective are enqueued on the main stream, after whatever the hook's stream has produced so far.
+                    cur = torch.cuda.current_stream() if main is not None else None
+                    if main is not None and cur != main:
+                        main.wait_stream(cur)
+                    with (torch.cuda.stream(main) if main is not None else contextlib.nullcontext()):
+                        for p, g in ops.wgrad_async_take(lambda q: reducer.bucket_of(q) == bi):
+                            p.grad = g if p.grad is None else p.grad + g
+                        gather([(p, v) for p, v in pairs if reducer.bucket_of(p) == bi])
+                        reducer.stage_launch(bi)
                 self._grad_stage = on_stage
+            self._two_streams_ok = True            # see StereoDPNetCore._network
             try:
                 results = self.forward(batch)
                 results['final_loss'].backward()
             finally:
                 self._grad_stage = None
+                self._two_streams_ok = False
             for p, g in ops.wgrad_async_finish():
                 p.grad = g if p.grad is None else p.grad + g
             gather(pairs)

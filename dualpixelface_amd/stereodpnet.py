@@ -177,6 +177,13 @@ def build_spec(opt):
     return s
 
 
+# left / right feature passes on two HIP streams in training (224.1 -> 221.5 ms per step); DPF_FEATURES_TWO_STREAMS=0: one after the other
+FEATURES_TWO_STREAMS = os.environ.get('DPF_FEATURES_TWO_STREAMS', '1') == '1'
+if FEATURES_TWO_STREAMS and hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+    # the shared feature extractor's parameters receive gradients from both streams: intended
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+
 class StereoDPNetCore(_Base):
     """Parameters (flat arena) + the straight-line HIP forward.  ``STEREODPNET`` below adds the plugin hooks."""
 
@@ -564,8 +571,32 @@ class StereoDPNetCore(_Base):
                 a, b = 'right', 'left'
         elif opt.dataset.flip_lr:
             a, b = 'right', 'left'
-        ref = self._features(batch[a])
-        tar = self._features(batch[b])
+        if FEATURES_TWO_STREAMS and getattr(self, '_two_streams_ok', False) and self.training and self.stat_exchange is None and batch[a].is_cuda:
+            # (only inside train_step's gather scheme, which sets _two_streams_ok: there every parameter gradient is a fresh tensor and the
+            # shared extractor's weight gradients are serialised on the weight-gradient stream; a plain loss.backward() into preset
+            # .grad arena views was measured to corrupt the LAST gradient of the pass -- firstconv.0.0.weight -- when two streams
+            # accumulate into it, tools/debug/two_rank_probe.py)
+            # the two feature passes are independent (Q8): the second one runs on its own HIP stream, so that its HBM-bound normalisation
+            # kernels overlap the first one's MFMA-bound convolutions (and the other way round); autograd runs each pass's backward on
+            # the stream of its forward.  Running statistics stay in the reference's order: every BatchNorm of the second pass waits
+            # for the first pass's update of the same layer (ops.BN_ORDER).
+            main = torch.cuda.current_stream()
+            side = self._feature_stream = getattr(self, '_feature_stream', None) or torch.cuda.Stream(device=batch[a].device)
+            events = {}
+            side.wait_stream(main)
+            ops.BN_ORDER = ('record', events)
+            try:
+                ref = self._features(batch[a])
+                ops.BN_ORDER = ('wait', events)
+                with torch.cuda.stream(side):
+                    tar = self._features(batch[b])
+            finally:
+                ops.BN_ORDER = None
+            main.wait_stream(side)
+            tar.record_stream(main)
+        else:
+            ref = self._features(batch[a])
+            tar = self._features(batch[b])
         stage = getattr(self, '_grad_stage', None)          # data-parallel step: gradient buckets are exchanged as they complete
         if stage is not None and ref.requires_grad:
             # bucket 1 (cost volume + aggregation) is complete once the gradients of BOTH feature maps exist

@@ -1,0 +1,64 @@
+"""2 ranks (gloo, one GPU): which combination of {two feature streams, staged exchange, side-stream weight gradients} breaks the summed gradient."""
+import os, sys
+import torch
+import torch.multiprocessing as mp
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+H, W = 32, 48
+
+def _model():
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.plugin import STEREODPNET
+    from dualpixelface_amd.recipe import fill_by_recipe
+    m = STEREODPNET(load_option()); fill_by_recipe(m)
+    return m.to('cuda').train()
+
+def _worker(rank, world, port, two, staged, asyncw, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch.distributed as dist
+    from dualpixelface_amd import ops
+    import dualpixelface_amd.stereodpnet as sd
+    from dualpixelface_amd.distributed import init_from_env, make_reducer, broadcast_flat
+    from dualpixelface_amd.recipe import synthetic_batch
+    sd.FEATURES_TWO_STREAMS = two
+    ops.WGRAD_ASYNC = asyncw
+    torch.cuda.set_device(0)
+    init_from_env('gloo')
+    model = _model()
+    model.stage_grads = staged
+    if rank == 1 and os.environ.get('PROBE_MUL'):
+        with torch.no_grad():
+            model.flat_parameters().mul_(1.5)
+    broadcast_flat(model.flat_parameters(), 0)
+    reducer = make_reducer(model)
+    full = synthetic_batch(4, H, W, seed=11)
+    batch = {k: v[2 * rank:2 * rank + 2].cuda() for k, v in full.items()}
+    model.train_step(batch, reducer, lr=1e-3)
+    torch.cuda.synchronize()
+    out[rank] = model.flat_gradients(zero=False).detach().cpu()
+    dist.destroy_process_group()
+
+if __name__ == '__main__':
+    from dualpixelface_amd.recipe import synthetic_batch
+    import dualpixelface_amd.stereodpnet as sd
+    sd.FEATURES_TWO_STREAMS = bool(os.environ.get('PROBE_REF_TWO'))
+    full = synthetic_batch(4, H, W, seed=11)
+    ref = None
+    for r in range(2):
+        m = _model(); m.flat_gradients(zero=True)
+        m.forward({k: v[2 * r:2 * r + 2].cuda() for k, v in full.items()})['final_loss'].backward()
+        if os.environ.get('PROBE_SYNC'):
+            torch.cuda.synchronize()
+        g = m.flat_gradients(zero=False).detach().cpu()
+        ref = g if ref is None else ref + g
+    n = 0
+    for two in (True,):
+        for staged in (True,):
+            for asyncw in (True,):
+                mgr = mp.Manager(); out = mgr.dict()
+                mp.spawn(_worker, args=(2, 36000 + n, two, staged, asyncw, out), nprocs=2, join=True); n += 1
+                d = (out[0] - ref).abs()
+                bad = (d > 2e-3 * ref.abs().max()).nonzero().flatten()
+                print('two_streams %5s staged %5s async_wgrad %5s: max diff %.3e, %d bad entries, first bad %s last bad %s, ranks equal %s' % (
+                    two, staged, asyncw, d.max().item(), bad.numel(), bad[0].item() if bad.numel() else None, bad[-1].item() if bad.numel() else None, torch.equal(out[0], out[1])))
