@@ -572,10 +572,7 @@ class StereoDPNetCore(_Base):
         elif opt.dataset.flip_lr:
             a, b = 'right', 'left'
         if FEATURES_TWO_STREAMS and getattr(self, '_two_streams_ok', False) and self.training and self.stat_exchange is None and batch[a].is_cuda:
-            # (only inside train_step's gather scheme, which sets _two_streams_ok: there every parameter gradient is a fresh tensor and the
-            # shared extractor's weight gradients are serialised on the weight-gradient stream; a plain loss.backward() into preset
-            # .grad arena views was measured to corrupt the LAST gradient of the pass -- firstconv.0.0.weight -- when two streams
-            # accumulate into it, tools/debug/two_rank_probe.py)
+            # (enabled by train_step, which sets _two_streams_ok; plain forward() callers stay on one stream)
             # the two feature passes are independent (Q8): the second one runs on its own HIP stream, so that its HBM-bound normalisation
             # kernels overlap the first one's MFMA-bound convolutions (and the other way round); autograd runs each pass's backward on
             # the stream of its forward.  Running statistics stay in the reference's order: every BatchNorm of the second pass waits
@@ -588,6 +585,10 @@ class StereoDPNetCore(_Base):
             try:
                 ref = self._features(batch[a])
                 ops.BN_ORDER = ('wait', events)
+                # the image was allocated on the caller's stream and is read on `side` -- in forward and again by the first conv's weight
+                # gradient in backward: tell the caching allocator, or a caller that drops its batch early gets the block back while that
+                # kernel still reads it (seen as a corrupted firstconv.0.0.weight gradient, tools/debug/two_rank_probe.py)
+                batch[b].record_stream(side)
                 with torch.cuda.stream(side):
                     tar = self._features(batch[b])
             finally:

@@ -47,6 +47,7 @@ if __name__ == '__main__':
     ref = None
     for r in range(2):
         m = _model(); m.flat_gradients(zero=True)
+        m._two_streams_ok = bool(os.environ.get('PROBE_REF_TWO'))
         m.forward({k: v[2 * r:2 * r + 2].cuda() for k, v in full.items()})['final_loss'].backward()
         if os.environ.get('PROBE_SYNC'):
             torch.cuda.synchronize()
