@@ -7,7 +7,11 @@ A step = forward + loss + backward + gradient all-reduce (RCCL, N > 1) + fused A
 `--batch` dual-pixel pairs of `--height` x `--width` per GPU (weak scaling), inputs resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line (contract in the task description) including
   "roofline":     the dominant kernel (implicit-GEMM convolution on the fp32 matrix cores) -- algorithmic FLOPs per
-                  launch / average launch duration, measured live with HIP events on the launch stream; "families" lists every timed
+                  launch / average launch duration, measured live with HIP events on the launch stream.  `value` is timed with the step's
+                  stream overlap on (weight gradients on a side stream, the two feature passes on two streams); kernels of different
+                  streams then share the chip, so this block is measured on 3 further steps of the same model run on ONE stream, where an
+                  event pair brackets one kernel's undisturbed run (`measured_in`; `--single-stream` times `value` that way too);
+                  "families" lists every timed
                   family (dense conv fwd/dgrad, weight gradient, 1x1 convs as their own HBM-bound family, small-K, deformable conv
                   forward / backward) with TFLOP/s or GB/s and, from the committed PMC passes, HBM bytes per step;
   "roofline_hbm": the largest HBM-bound family (normalisation + activation), algorithmic GB/s against 8 TB/s;
@@ -120,9 +124,10 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--wgrad-inline', action='store_true',
-                    help='weight gradients in line on the main stream in the timed region too (default: on a side stream, where they '
-                         'overlap the HBM-bound kernels of the main chain; the per-kernel roofline block is always measured in line)')
+    ap.add_argument('--wgrad-inline', '--single-stream', dest='wgrad_inline', action='store_true',
+                    help='everything on ONE stream in the timed region too (default: weight gradients on a side stream and the two feature '
+                         'passes on two streams, where MFMA-bound and HBM-bound kernels overlap; the per-kernel roofline block is always '
+                         'measured on one stream)')
     ap.add_argument('--wgrad-async', action='store_true', help='(default behaviour; kept for older command lines)')
     ap.add_argument('--cpu-baseline-only', default=None, metavar='HxW:threads[,threads...]',
                     help='time only the CPU oracle at the given size for each thread count (e.g. 1024x1536:16,128) and exit')
@@ -180,7 +185,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.WGRAD_ASYNC = not args.wgrad_inline
+    import dualpixelface_amd.stereodpnet as sdn
+
+    def set_streams(on):
+        ops.WGRAD_ASYNC = bool(on) and os.environ.get('DPF_WGRAD_ASYNC', '1') == '1'
+        sdn.FEATURES_TWO_STREAMS = bool(on) and os.environ.get('DPF_FEATURES_TWO_STREAMS', '1') == '1'
+    set_streams(not args.wgrad_inline)
     for _ in range(args.warmup):
         model.train_step(batch, reducer)
     sync()
@@ -203,17 +213,17 @@ def main():
     # two streams overlap and an event pair no longer brackets ONE kernel's undisturbed run.  The roofline block is therefore measured
     # on `detail_steps` further steps of the same model / batch with the weight gradients IN LINE (no overlap: event time == kernel
     # time, equal to the rocprofv3 averages in profiles/), which also carry the detail timers of the 744 normalisation launches.
-    prof_timed, timed_async = prof, ops.WGRAD_ASYNC
+    prof_timed, timed_async = prof, (ops.WGRAD_ASYNC or sdn.FEATURES_TWO_STREAMS)
     prof_detail, detail_steps = [], 0
     if not args.no_detail:
-        ops.WGRAD_ASYNC = False
-        model.train_step(batch, reducer)                          # one settling step in the in-line mode
+        set_streams(False)
+        model.train_step(batch, reducer)                          # one settling step in the one-stream mode
         ops.PROFILE, ops.PROFILE_DETAIL, detail_steps = [], True, 3
         for _ in range(detail_steps):
             model.train_step(batch, reducer)
         sync()
         prof_detail, ops.PROFILE, ops.PROFILE_DETAIL = ops.PROFILE, None, False
-        ops.WGRAD_ASYNC = timed_async
+        set_streams(not args.wgrad_inline)
         prof, prof_steps = [r for r in prof_detail if r[0] != 'norm_act'], detail_steps
     else:
         prof_steps = args.steps
@@ -282,12 +292,12 @@ def main():
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                     'traffic': (hb / (n / prof_steps)) if hb is not None else None, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n,
                     'avg_launch_ms': secs / n * 1e3, 'ms_per_step': secs / prof_steps * 1e3,
-                    'measured_in': ('%d steps after the timed region, weight gradients in line (kernels do not overlap: event time = kernel time)' % prof_steps)
+                    'measured_in': ('%d steps after the timed region on ONE stream (weight gradients in line, feature passes one after the other: kernels do not overlap, event time = kernel time)' % prof_steps)
                                    if not args.no_detail else 'the timed region', 'families': fam_out}
             if dom in fam_t and timed_async and not args.no_detail:      # the same family as the timed region saw it (overlapped by the side stream)
                 f2 = fam_t[dom]
                 roof['timed_region_overlapped'] = {'achieved': f2[0] / f2[1] / 1e12, 'frac': f2[0] / f2[1] / 1e12 / peak, 'avg_launch_ms': f2[1] / f2[2] * 1e3,
-                                                   'note': 'event pairs of the timed region: side-stream weight gradients share the chip with these launches'}
+                                                   'note': 'event pairs of the timed region: kernels of the other streams share the chip with these launches'}
         roof_hbm = None
         if 'norm_act' in fam_d:      # the largest HBM-bound family: BatchNorm / InstanceNorm / activations / residual adds
             flops, secs, n, nbytes = fam_d['norm_act']
@@ -310,7 +320,7 @@ def main():
                                    % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.batch, args.height, args.width),
                        'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,
                        'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics',
-                       'weight_gradients': 'side stream' if timed_async else 'in line'},
+                       'streams': ('weight gradients on a side stream, left / right feature passes on two streams' if timed_async else 'one stream')},
             'final_loss': loss,
             'rccl_ranks_seen': ranks_seen,
             # whole-model fractions of the fp32 peak: against the reference's algorithmic FLOPs (SURVEY section 8d counts all 16 attention

@@ -523,6 +523,16 @@ int dpf_norm_act_backward_slice(const float* x, const float* dy, int dy_channels
                                 dweight, dbias, dslope, ws, N, C, S, 0, 0.0, stream);
 }
 
+// the same with the phases of dpf_norm_act_backward_ex (SyncBatchNorm of a branch that wrote a channel slice of a concatenation)
+int dpf_norm_act_backward_slice_ex(const float* x, const float* dy, int dy_channels, int dy_c0, const float* mean, const float* invstd,
+                                   const float* w, const float* b, int wmod, const float* res, int act, const float* slope, float slope_const,
+                                   int training, float* dx, float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C,
+                                   long long S, int phase, double count, void* stream) {
+  if (dy_c0 < 0 || dy_c0 + C > dy_channels) return DPF_ERR_INVALID_ARG;
+  return norm_act_backward_impl(x, dy, dy_channels, dy_c0, mean, invstd, w, b, wmod, res, act, slope, slope_const, training, dx, dres,
+                                dweight, dbias, dslope, ws, N, C, S, phase, count, stream);
+}
+
 int dpf_norm_act_backward(const float* x, const float* dy, const float* mean, const float* invstd, const float* w, const float* b,
                           int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
                           float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, void* stream) {

@@ -599,7 +599,7 @@ class NormActCatFn(torch.autograd.Function):
     slice of the concatenated tensor, the backward reads its slice of the incoming gradient (dpf_norm_act_*_slice)."""
 
     @staticmethod
-    def forward(ctx, mode, act, holders, *tensors):
+    def forward(ctx, mode, act, holders, exchange, *tensors):
         n = len(tensors) // 5
         xs = [_c(tensors[5 * i]) for i in range(n)]
         ws = [tensors[5 * i + 1] for i in range(n)]
@@ -616,11 +616,36 @@ class NormActCatFn(torch.autograd.Function):
         saved, c0 = [], 0
         timer = _Timed('norm_act', 0.0, 'ncf', 4.0 * sum(x.numel() for x in xs) * 2) if PROFILE_DETAIL else _Timed.OFF
         timer.__enter__()
+        sync = exchange if mode == 1 else None
+        if sync is not None:
+            # SyncBatchNorm: the branches are independent, so their {mean, M2, count} vectors travel in ONE all-gather
+            offs, tot = [], 0
+            for C in Cs:
+                offs.append(tot)
+                tot += 2 * C + 1
+            packed = torch.empty(tot, dtype=torch.float32, device=xs[0].device)
+            for i in range(n):
+                wsb = scratch(2 * Cs[i], xs[i].device)
+                L.call('dpf_bn_local_moments', _ptr(xs[i]), N, Cs[i], S, _ptr(packed[offs[i]:]), _ptr(wsb), _stream())
+                packed[offs[i] + 2 * Cs[i]] = float(N * S)
+            gathered = sync.all_gather(packed)                               # [W, tot]
         for i in range(n):
             x, C = xs[i], Cs[i]
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
             st = holders[i] if holders else None
+            if sync is not None:
+                _bn_order_before(rms[i])
+                moments = gathered[:, offs[i]:offs[i] + 2 * C].contiguous()
+                counts = gathered[:, offs[i] + 2 * C].contiguous()
+                L.call('dpf_bn_merge_moments', _ptr(moments), _ptr(counts), gathered.shape[0], C, BN_EPS, BN_MOMENTUM, _ptr(rms[i]), _ptr(rvs[i]),
+                       _ptr(mean), _ptr(invstd), _stream())
+                _bn_order_after(rms[i])
+                L.call('dpf_norm_act_forward_slice', _ptr(x), _ptr(mean), _ptr(invstd), _ptr(ws[i]), _ptr(bs[i]), C, None, None, act, None, 0.0,
+                       _ptr(cat), Ctot, c0, N, C, S, _stream())
+                saved += [x, ws[i], bs[i], mean, invstd]
+                c0 += C
+                continue
             if mode == 1:
                 _bn_order_before(rms[i])
             if mode == 1 and st and st.get('ptr') == x.data_ptr() and st['channels'] == C and st['count'] == N * S:
@@ -642,6 +667,7 @@ class NormActCatFn(torch.autograd.Function):
         timer.__exit__()
         ctx.save_for_backward(*saved)
         ctx.cfg = (mode, act, n, N, tuple(Cs), S, Ctot)
+        ctx.exchange = sync
         return cat
 
     @staticmethod
@@ -653,19 +679,46 @@ class NormActCatFn(torch.autograd.Function):
         grads, c0 = [], 0
         timer = _Timed('norm_act', 0.0, 'ncb', 4.0 * gcat.numel() * 5) if PROFILE_DETAIL else _Timed.OFF
         timer.__enter__()
+        outs = []
         for i in range(n):
             x, w, b, mean, invstd = sv[5 * i:5 * i + 5]
-            C = Cs[i]
-            dx = torch.empty_like(x) if ctx.needs_input_grad[3 + 5 * i] else None
-            dw = torch.empty_like(w) if ctx.needs_input_grad[3 + 5 * i + 1] else None
-            db = torch.empty_like(b) if ctx.needs_input_grad[3 + 5 * i + 2] else None
-            wsb = scratch(3 * C, x.device)
-            L.call('dpf_norm_act_backward_slice', _ptr(x), _ptr(gcat), Ctot, c0, _ptr(mean), _ptr(invstd), _ptr(w), _ptr(b), C, None, act,
-                   None, 0.0, 1 if mode == 1 else 0, _ptr(dx), None, _ptr(dw), _ptr(db), None, _ptr(wsb), N, C, S, _stream())
+            outs.append((torch.empty_like(x) if ctx.needs_input_grad[4 + 5 * i] else None,
+                         torch.empty_like(w) if ctx.needs_input_grad[4 + 5 * i + 1] else None,
+                         torch.empty_like(b) if ctx.needs_input_grad[4 + 5 * i + 2] else None))
+        if ctx.exchange is not None:
+            # SyncBatchNorm: local reductions of every branch, ONE all-reduce of the packed [3 C_i + 1] vectors (the last slot of each
+            # carries this rank's element count), then dx with the global counts
+            offs, tot = [], 0
+            for C in Cs:
+                offs.append(tot)
+                tot += 3 * C + 1
+            ws_all = torch.empty(tot, dtype=torch.float32, device=gcat.device)
+            for phase in (1, 2):
+                c0 = 0
+                for i in range(n):
+                    x, w, b, mean, invstd = sv[5 * i:5 * i + 5]
+                    dx, dw, db = outs[i]
+                    L.call('dpf_norm_act_backward_slice_ex', _ptr(x), _ptr(gcat), Ctot, c0, _ptr(mean), _ptr(invstd), _ptr(w), _ptr(b), Cs[i], None,
+                           act, None, 0.0, 1, _ptr(dx), None, _ptr(dw), _ptr(db), None, _ptr(ws_all[offs[i]:]), N, Cs[i], S, phase,
+                           0.0 if phase == 1 else -1.0, _stream())
+                    if phase == 1:
+                        ws_all[offs[i] + 3 * Cs[i]] = float(N) * float(S)
+                    c0 += Cs[i]
+                if phase == 1:
+                    ctx.exchange.all_reduce_sum_(ws_all)
+        else:
+            for i in range(n):
+                x, w, b, mean, invstd = sv[5 * i:5 * i + 5]
+                C = Cs[i]
+                dx, dw, db = outs[i]
+                wsb = scratch(3 * C, x.device)
+                L.call('dpf_norm_act_backward_slice', _ptr(x), _ptr(gcat), Ctot, c0, _ptr(mean), _ptr(invstd), _ptr(w), _ptr(b), C, None, act,
+                       None, 0.0, 1 if mode == 1 else 0, _ptr(dx), None, _ptr(dw), _ptr(db), None, _ptr(wsb), N, C, S, _stream())
+                c0 += C
+        for dx, dw, db in outs:
             grads += [dx, dw, db, None, None]
-            c0 += C
         timer.__exit__()
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 def _conv_transpose_acc(x, w, out, ksize, stride, pad, dil):
@@ -776,13 +829,14 @@ def conv_bn_concat(x, branches, dilations, training):
     return ConvBnCatFn.apply(1 if training else 2, tuple(int(d) for d in dilations), x, *flat)
 
 
-def norm_act_concat(branches, mode, act=ACT_NONE):
+def norm_act_concat(branches, mode, act=ACT_NONE, exchange=None):
     """branches: list of (x, weight, bias, running_mean, running_var, stats holder or None) with equal batch / spatial shape;
-    mode 1 = training batch norm (per-rank statistics), 2 = eval.  -> [N, sum C_i, ...]."""
+    mode 1 = training batch norm (per-rank statistics, or global-batch statistics through ``exchange`` -- one collective for all
+    branches), 2 = eval.  -> [N, sum C_i, ...]."""
     flat = []
     for x, w, b, rm, rv, _ in branches:
         flat += [x, w, b, rm, rv]
-    return NormActCatFn.apply(mode, act, [br[5] for br in branches], *flat)
+    return NormActCatFn.apply(mode, act, [br[5] for br in branches], exchange, *flat)
 
 
 # ----------------------------------------------------------------------------------------------- resampling

@@ -349,9 +349,16 @@ class StereoDPNetCore(_Base):
     def _convbn2_concat(self, x, prefixes, dilations):
         """torch.cat([convbn(x; dilation d) for d], 1) (DPBlock.conv_dilate, modules.py:43-45): every branch's BatchNorm writes its
         channel slice of the concatenated tensor directly."""
-        if self.training and self.stat_exchange is not None:      # SyncBatchNorm exchanges {mean, M2}: the plain path
-            return ops.concat_channels([self._convbn2(x, q, 1, d, d) for q, d in zip(prefixes, dilations)])
         P, B = self._P, self._B
+        if self.training and self.stat_exchange is not None:
+            # SyncBatchNorm: the three independent branches exchange their statistics in ONE all-gather (and one all-reduce in backward)
+            branches = []
+            for q, d in zip(prefixes, dilations):
+                y = ops.conv2d(x, P[q + '.0.weight'], None, 1, d if d > 1 else 1, d, bf16=self.bf16_2d)
+                key = q + '.1.num_batches_tracked'
+                self._pending_counts[key] = self._pending_counts.get(key, 0) + 1
+                branches.append((y, P[q + '.1.weight'], P[q + '.1.bias'], B[q + '.1.running_mean'], B[q + '.1.running_var'], None))
+            return ops.norm_act_concat(branches, 1, ACT_NONE, exchange=self.stat_exchange)
         # DPF_CONV_BN_CAT=1: conv + BatchNorm + cat as ONE autograd node whose backward sums the three data gradients in the transposed-conv
         # epilogue (ops.ConvBnCatFn).  Measured +0.2 % on the step (the epilogue's read-modify-write costs what the two add passes cost), so
         # the default keeps the convolutions as plain launches and only fuses BatchNorm + cat.

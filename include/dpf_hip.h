@@ -138,6 +138,12 @@ int dpf_norm_act_backward_ex(const float* x, const float* dy, const float* mean,
                              int wmod, const float* res, int act, const float* slope, float slope_const, int training, float* dx,
                              float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C, long long S, int phase,
                              double count, void* stream);
+/* dpf_norm_act_backward_slice with the phases of dpf_norm_act_backward_ex: SyncBatchNorm of branches that wrote channel slices of one
+ * concatenated tensor (DPBlock.conv_dilate, modules.py:43-45) -- their exchanges travel in one collective */
+int dpf_norm_act_backward_slice_ex(const float* x, const float* dy, int dy_channels, int dy_c0, const float* mean, const float* invstd,
+                                   const float* w, const float* b, int wmod, const float* res, int act, const float* slope, float slope_const,
+                                   int training, float* dx, float* dres, float* dweight, float* dbias, float* dslope, float* ws, int N, int C,
+                                   long long S, int phase, double count, void* stream);
 int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void* stream);
 
 /* ---- resampling: F.interpolate(bilinear, align_corners=True) (modules.py:127-128, normal_module.py:22-29), FPN's

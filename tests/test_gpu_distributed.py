@@ -116,13 +116,13 @@ def test_two_ranks_sync_batchnorm_equals_single_process_full_batch():
     assert rel <= 1e-1, rel            # a broken exchange (per-rank statistics) gives O(1)
     # Adam normalises the step: parameters move by <= lr, identically up to that tolerance
     assert (p0 - ref_p).abs().max().item() <= 2.5e-3
-    # collectives of a SyncBatchNorm step: one [2C+1] all-gather per training BatchNorm call in forward (45 per feature pass x 2, 2
-    # attention calls, 25 in the aggregation stack, 2 in the normal head = 119) and one [3C+1] all-reduce each in backward, plus the 3
-    # gradient buckets.  A BatchNorm's statistics are needed before the next layer can run and its gradient sums before its dx, so
-    # exchanges of consecutive layers cannot be merged; what could be (the two feature passes in lockstep: -45, the three dilated
-    # branches of a DPBlock: -20) is listed in DESIGN.md section 5.
+    # collectives of a SyncBatchNorm step: one all-gather per training BatchNorm exchange in forward and one all-reduce each in backward,
+    # plus the 3 gradient buckets.  119 BatchNorm calls per step (45 per feature pass x 2, 2 attention calls, 25 in the aggregation
+    # stack, 2 in the normal head); the three dilated branches of a DPBlock are independent and travel in ONE packed exchange (10
+    # DPBlock calls: -20) -> 99.  A BatchNorm's statistics are needed before the next layer can run and its gradient sums before its dx,
+    # so exchanges of consecutive layers cannot be merged.
     for log, counts in _run.logs:
-        assert counts == {'all_gather': 119, 'all_reduce': 122}, counts
+        assert counts == {'all_gather': 99, 'all_reduce': 102}, counts
 
 
 def test_bench_under_torchrun_two_ranks():
