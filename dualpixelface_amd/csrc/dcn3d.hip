@@ -391,6 +391,14 @@ __global__ __launch_bounds__(256) void dcn_wmax_kernel(const float* __restrict__
 // measured bound -- far-corner global atomics are emitted on the first attempt only.  Later passes use the measured bound.
 // Error per contribution <= 0.5 unit, unit = gbound * wmax * mass / 2^30: ~1e-6 of the tensor scale at MASS0, deterministic
 // (integer adds commute).
+// floor(x + 0.5) in ONE instruction (__float2int_rn is v_rndne_f32 + v_cvt_i32_f32): the quantiser of the packed scatter runs 64 times per
+// (wave, tap); ties round up instead of to even -- the same 0.5-unit bound
+__device__ __forceinline__ int cvt_rpi(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 constexpr int PK_CH = 16, PK_CS = 8;
 constexpr float PK_MASS0 = 128.f, PK_MASS_Q = 131072.f;   // first-pass mass bound; fixed-point scale of the mass counters (6912 * 2^17 < 2^30)
 
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
           const float es = ge[r] * qscale, os = gd[r] * qscale;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int qe = __float2int_rn(es * wv[j]), qo = __float2int_rn(os * wv[j]);
+            const int qe = cvt_rpi(es * wv[j]), qo = cvt_rpi(os * wv[j]);
             const long long pk = ((long long)qe << 32) + (long long)qo;
             atomicAdd(reinterpret_cast<unsigned long long*>(&s_regq[li[j] + pr]), (unsigned long long)pk);
           }
