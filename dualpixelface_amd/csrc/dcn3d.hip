@@ -596,7 +596,10 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
       }
       const Off3 ocur = onext;                                  // offsets of tap t + 1
       offp += 3 * p.P;
-      onext = load_off_ptr(offp, p.P, pvalid && t + 2 < p.T);
+      {
+        const float* np = t + 2 < p.T ? offp : offp0;             // always inside the tensor: unconditional loads
+        onext = Off3{np[0], np[p.P], np[2 * p.P]};
+      }
       if (tables_first && t + 1 < p.T) build_table(t + 1, cur ^ 1, it, ocur);
       if (c0 == PK_CH) { DPF_STAMP(2 * t, 1) }
       // ---- scatter of tap t
@@ -1415,7 +1418,10 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
         if (c0 == CH) { DPF_STAMP(t, 0) }
         const Off3 ocur = onext;
         offp += 3 * p.P;
-        onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);
+        {   // always-valid pointer, unconditional loads (a conditional load is a branch in the tap loop)
+          const float* np = t + 1 < p.T ? offp : offp0;
+          onext = Off3{np[0], np[p.P], np[2 * p.P]};
+        }
         const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
         tap_next(p, it);
         const Samp sp = make_samp(p, g, c, cn);
@@ -1819,7 +1825,9 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
       const Off3 ocur = onext;
       const bool last_tap = t + 1 == p.T;
       offp = last_tap ? offp0 : offp + 3 * p.P;
-      onext = load_off_ptr(offp, p.P, pvalid && i + 1 < NS);   // next step's offsets (tap 0 again after the last tap of a chunk)
+      // next step's offsets (tap 0 again after the last tap of a chunk).  The pointer is always inside the tensor (voxels outside the
+      // volume read voxel 0 and are masked by pvalid later): unconditional loads -- a conditional one is a branch in the step loop
+      onext = Off3{offp[0], offp[p.P], offp[2 * p.P]};
       dqp = doff_b + (long long)(3 * t) * p.P + ppos;
       const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
       const Samp sp = make_samp(p, g, c, cn);
