@@ -944,6 +944,33 @@ __device__ __forceinline__ Samp make_samp(const DcnP& p, const RegGeo& g, const 
   return s;
 }
 
+// Branch-free variant for the role-split samplers: a sample outside the volume (or a voxel outside the tile) is a FAST sample with all
+// masks -- hence all weights and derivative factors -- zero that reads region cell 0: one exec-mask branch less in the step loop.
+__device__ __forceinline__ Samp make_samp_nb(const DcnP& p, const RegGeo& g, const RegCtx& c, const Corner& cn) {
+  Samp s;
+  const bool v = cn.valid != 0;
+  const bool zl = v && cn.d0 >= 0 && cn.d0 <= p.D - 1, zh = v && cn.d0 + 1 >= 0 && cn.d0 + 1 <= p.D - 1;
+  const bool yl = v && cn.h0 >= 0 && cn.h0 <= p.H - 1, yh = v && cn.h0 + 1 >= 0 && cn.h0 + 1 <= p.H - 1;
+  const bool xl = v && cn.w0 >= 0 && cn.w0 <= p.W - 1, xh = v && cn.w0 + 1 >= 0 && cn.w0 + 1 <= p.W - 1;
+  s.mz[0] = zl ? 1.f : 0.f; s.mz[1] = zh ? 1.f : 0.f;
+  s.my[0] = yl ? 1.f : 0.f; s.my[1] = yh ? 1.f : 0.f;
+  s.mx[0] = xl ? 1.f : 0.f; s.mx[1] = xh ? 1.f : 0.f;
+  s.wz[0] = (1.f - cn.ld) * s.mz[0]; s.wz[1] = cn.ld * s.mz[1];
+  s.wy[0] = (1.f - cn.lh) * s.my[0]; s.wy[1] = cn.lh * s.my[1];
+  s.wx[0] = (1.f - cn.lw) * s.mx[0]; s.wx[1] = cn.lw * s.mx[1];
+  const int lz = cn.d0 - c.rz0, ly = cn.h0 - c.ry0, lx = cn.w0 - c.rx0;
+  const bool yx_in = ly >= 0 && ly + 1 < g.RY && lx >= 0 && lx + 1 < g.RX;
+  const bool zlo_in = lz >= 0 && lz < c.RZ, zhi_in = lz + 1 >= 0 && lz + 1 < c.RZ;
+  const bool inreg = v && yx_in && (zlo_in || !zl) && (zhi_in || !zh);
+  const int iz0 = zlo_in ? lz : (zhi_in ? lz + 1 : 0);
+  const int iz1 = zhi_in ? lz + 1 : iz0;
+  s.base = inreg ? (iz0 * g.RY + ly) * g.RX + lx : 0;
+  s.dzs = inreg ? (iz1 - iz0) * g.RY * g.RX : 0;
+  s.valid = true;
+  s.fast = inreg || !v;
+  return s;
+}
+
 // 16 channels of corner (jd, jh, jw): 4 x ds_read_b128 from the channel-last image (fast path)
 template <int CH>
 __device__ __forceinline__ void corner_vec(const RegGeo& g, const Samp& s, const float* s_reg, int jd, int jh, int jw, float v[CH]) {
@@ -1259,12 +1286,7 @@ __device__ __forceinline__ void fwd_sample_half_store(const DcnP& p, const RegGe
                                                       const float* __restrict__ xb, int c0, long long chan, float* dst) {
   constexpr int NC = CH / 2;
   float* dh = dst + H * NC * ROWS;
-  if (!sp.valid) {
-#pragma unroll
-    for (int ch = 0; ch < NC; ++ch) dh[ch * ROWS] = 0.f;
-    return;
-  }
-  if (sp.fast) {
+  if (sp.fast) {      // (samples outside the volume arrive as fast samples with zero weights: make_samp_nb)
     float val[NC];
 #pragma unroll
     for (int ch = 0; ch < NC; ++ch) val[ch] = 0.f;
@@ -1314,12 +1336,7 @@ __device__ __forceinline__ void fwd_sample_half_store(const DcnP& p, const RegGe
 template <int CH, int ROWS>
 __device__ __forceinline__ void fwd_sample_store(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
                                                  const float* __restrict__ xb, int c0, long long chan, float* dst) {
-  if (!sp.valid) {
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) dst[ch * ROWS] = 0.f;
-    return;
-  }
-  if (sp.fast) {
+  if (sp.fast) {      // (samples outside the volume arrive as fast samples with zero weights: make_samp_nb)
     float val[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) val[ch] = 0.f;
@@ -1424,7 +1441,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
         }
         const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
         tap_next(p, it);
-        const Samp sp = make_samp(p, g, c, cn);
+        const Samp sp = make_samp_nb(p, g, c, cn);
         float* dst = s_S + (t & 1) * (CH * STRV) + vox;
         if (!HALF) {
           fwd_sample_store<CH, STRV>(p, g, sp, cn, s_reg, xb, c0, chan, dst);
@@ -1701,11 +1718,7 @@ __device__ __forceinline__ void rs_sample_half(const DcnP& p, const RegGeo& g, c
   constexpr int NC = CH / 2;
   gd = gh = gw = 0.f;
   float* colh = col + H * NC * XS;
-  if (!sp.valid) {
-#pragma unroll
-    for (int ch = 0; ch < NC; ++ch) colh[ch * XS] = 0.f;
-    return;
-  }
+  // (samples outside the volume arrive as fast samples with zero weights and masks: make_samp_nb)
   // dot_j = sum_ch gcol[ch] * x[corner j][ch]; the three coordinate derivatives weight it with the other two trilinear factors and the
   // signed in-volume mask of their own axis (cuh:131-187)
   float dots[8];
@@ -1830,7 +1843,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
       onext = Off3{offp[0], offp[p.P], offp[2 * p.P]};
       dqp = doff_b + (long long)(3 * t) * p.P + ppos;
       const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
-      const Samp sp = make_samp(p, g, c, cn);
+      const Samp sp = make_samp_nb(p, g, c, cn);
       float* col = s_x + (i % 3) * XT + vox;
       float gd, gh, gw;
       if (half == 0) {
