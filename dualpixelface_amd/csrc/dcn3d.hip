@@ -1772,12 +1772,22 @@ __device__ __forceinline__ void rs_sample_half(const DcnP& p, const RegGeo& g, c
       colh[ch * XS] = sv;
     }
   }
+  // d/d(coord) of the trilinear sample, factored (34 instead of 72 operations): dots[4 jd + 2 jh + jw]
+  {
+    float A[2][2], E[2][2];      // A[jd][jh] = sum_jw wx dot;  E[jd][jw] = sum_jh wy dot
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-    gd += (jd ? sp.mz[1] : -sp.mz[0]) * sp.wy[jh] * sp.wx[jw] * dots[j];
-    gh += (jh ? sp.my[1] : -sp.my[0]) * sp.wz[jd] * sp.wx[jw] * dots[j];
-    gw += (jw ? sp.mx[1] : -sp.mx[0]) * sp.wz[jd] * sp.wy[jh] * dots[j];
+    for (int jd = 0; jd < 2; ++jd)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        A[jd][u] = fmaf(sp.wx[1], dots[4 * jd + 2 * u + 1], sp.wx[0] * dots[4 * jd + 2 * u]);
+        E[jd][u] = fmaf(sp.wy[1], dots[4 * jd + 2 + u], sp.wy[0] * dots[4 * jd + u]);
+      }
+    const float B0 = fmaf(sp.wy[1], A[0][1], sp.wy[0] * A[0][0]), B1 = fmaf(sp.wy[1], A[1][1], sp.wy[0] * A[1][0]);
+    gd = fmaf(sp.mz[1], B1, -sp.mz[0] * B0);
+    const float C0 = fmaf(sp.wz[1], A[1][0], sp.wz[0] * A[0][0]), C1 = fmaf(sp.wz[1], A[1][1], sp.wz[0] * A[0][1]);
+    gh = fmaf(sp.my[1], C1, -sp.my[0] * C0);
+    const float F0 = fmaf(sp.wz[1], E[1][0], sp.wz[0] * E[0][0]), F1 = fmaf(sp.wz[1], E[1][1], sp.wz[0] * E[0][1]);
+    gw = fmaf(sp.mx[1], F1, -sp.mx[0] * F0);
   }
 }
 
