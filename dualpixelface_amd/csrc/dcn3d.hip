@@ -410,15 +410,19 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   extern __shared__ __align__(16) long long smem_q[];
   constexpr int NT = 64 * NW;
   constexpr int npos = 16 * NST * NW;
-  constexpr bool HALVES = NW == 8;   // thread pair per voxel in the table phase
+  constexpr bool HALVES = NW >= 8;   // thread pair per voxel in the table phase (4 corners each: one z side)
+  constexpr int FR = HALVES ? 2 : 1; // table threads per voxel = rows of the per-voxel far flags
+  // threads that build tables: with 16 waves the first 8 (four threads per voxel -- two corners each -- measured slower, 8.86 vs 8.48 ms:
+  // the per-voxel part of the corner arithmetic and the offset loads are repeated in every thread of a voxel)
+  constexpr int TBL_T = FR * npos;
   const int regvox = q.RZmax * q.RY * q.RX;
   long long* s_regq = smem_q;                                    // [regvox + 1][PK_CS]: cell = 8 packed channel pairs; last cell = dummy
   int* s_lidx = (int*)(s_regq + (size_t)(regvox + 1) * PK_CS);   // [2][npos][8] u64 index of the corner's cell (dummy cell when outside)
   float* s_w = (float*)(s_lidx + 2 * npos * 8);                  // [2][npos][8] corner weight, 0 outside the region
   unsigned* s_mass = (unsigned*)(s_w + 2 * npos * 8);            // [regvox + 4] weight mass per cell, PK_MASS_Q fixed point
   int* s_far = (int*)(s_mass + ((regvox + 4) & ~3));             // [4] flag of tap t in slot t % 3: some corner left the region
-  int* s_farm = s_far + 4;                                       // [2][2][npos] per-voxel flag (one row per thread of a pair)
-  float* s_gmax = (float*)(s_farm + 4 * npos);                   // [NW]
+  int* s_farm = s_far + 4;                                       // [2][FR][npos] per-voxel flag (one row per table thread of a voxel)
+  float* s_gmax = (float*)(s_farm + 2 * FR * npos);              // [NW]
   unsigned* s_mmax = (unsigned*)(s_gmax + NW);                   // [NW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int pr = l15 >> 1;           // channel pair within the 16-channel chunk
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   const bool odd = (l15 & 1) != 0;
   // the two waves that share a SIMD (wave, wave + 4) run the two halves of a tap step in opposite order: one builds the next tap's
   // tables (vector ALU) while the other feeds the LDS atomic unit and the matrix pipe
-  const bool tables_first = __builtin_amdgcn_readfirstlane(NW == 8 ? (wave >> 2) & 1 : wave & 1) != 0;
+  const bool tables_first = __builtin_amdgcn_readfirstlane(NW >= 8 ? (wave >> 2) & 1 : wave & 1) != 0;
 
   int bb = blockIdx.x;
   const int tx = bb % q.tilesX; bb /= q.tilesX;
@@ -445,11 +449,12 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   const float* off_b = offset + (long long)b * 3 * p.T * p.P;
   float* dxb = dx + (long long)b * p.C * chan;
 
-  const int vox = HALVES ? (tid & (npos - 1)) : tid;       // this thread's voxel in the table phase
-  const int half = HALVES ? tid / npos : 0;
+  const int vox = FR > 1 ? (tid & (npos - 1)) : tid;       // this thread's voxel in the table phase
+  const int half = FR > 1 ? (tid / npos) & 1 : 0;          // its z side
+  const bool tbl_thread = tid < TBL_T;                     // wave-uniform
   const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
   const int zo = z0 + pdz, yo = y0 + pdy, xo = x0 + pdx;
-  const bool pvalid = (HALVES || tid < npos) && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
+  const bool pvalid = tbl_thread && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
   const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
 
   // A fragments: go[k][voxel] for this wave's NST sub-tiles, all k (K <= 64 -> 16 k-steps of 4), kept in registers
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   // adds, two multiplies and two mask ANDs (cuh:43-68 for the index / weight, cuh:248 for `valid`)
   const int RYX = q.RY * q.RX * PK_CS, RXC = q.RX * PK_CS;
   auto build_table = [&](int t, int buf, const TapIt& itc, const Off3& ocur) {
-    if (HALVES || tid < npos) {
+    if (tbl_thread) {
       const Corner cn = corner_at(p, pvalid, zb, yb, xbase, itc, ocur);
       bool okz[2], oky[2], okx[2], inz[2], iny[2], inx[2];
       int cz[2], cy[2], cx[2];
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
         *reinterpret_cast<int4*>(lp + 4) = make_int4(liv[4], liv[5], liv[6], liv[7]);
         *reinterpret_cast<float4*>(wp + 4) = make_float4(wv[4], wv[5], wv[6], wv[7]);
       }
-      s_farm[(buf * 2 + half) * npos + vox] = anyfar ? 1 : 0;
+      s_farm[(buf * FR + half) * npos + vox] = anyfar ? 1 : 0;
       if (anyfar) s_far[t % 3] = 1;
     }
   };
@@ -585,18 +590,9 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
       const int cur = t & 1;
       if (c0 == PK_CH) { DPF_STAMP(2 * t, 0) }
       if (tid == 0) s_far[(t + 2) % 3] = 0;                     // slot of tap t + 2: nobody reads or sets it during this step
-      // B fragments: W[k][c0 + l15][t]; the next tap's are prefetched
-      float bfrag[16];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) bfrag[ks] = bnext[ks];
-      if (t + 1 < p.T) {
-        wtn += 64 * CT;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
-      }
       const Off3 ocur = onext;                                  // offsets of tap t + 1
       offp += 3 * p.P;
-      {
+      if (tbl_thread) {
         const float* np = t + 2 < p.T ? offp : offp0;             // always inside the tensor: unconditional loads
         onext = Off3{np[0], np[p.P], np[2 * p.P]};
       }
@@ -608,10 +604,17 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
       f32x4 acc[NST];
 #pragma unroll
       for (int st = 0; st < NST; ++st) acc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // B fragments: W[k][c0 + l15][t], prefetched one tap ahead; the next tap's loads are issued once the chain has consumed these
+      // (the registers are reused: the 16-wave variant has 128)
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
-        for (int st = 0; st < NST; ++st) acc[st] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bfrag[ks], acc[st], 0, 0, 0);
+        for (int st = 0; st < NST; ++st) acc[st] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bnext[ks], acc[st], 0, 0, 0);
+      if (t + 1 < p.T) {
+        wtn += 64 * CT;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
+      }
       const bool far_tap = attempt == 0 && s_far[t % 3] != 0;   // block-uniform: some corner of this tap left the region
 #pragma unroll
       for (int st = 0; st < NST; ++st) {
@@ -644,7 +647,10 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
 #pragma unroll 1
           for (int r = 0; r < 4; ++r) {
             const int pl = (wave * NST + st) * 16 + 4 * lg + r;
-            if ((s_farm[(cur * 2) * npos + pl] | (HALVES ? s_farm[(cur * 2 + 1) * npos + pl] : 0)) == 0) continue;
+            int anyf = 0;
+#pragma unroll
+            for (int fr = 0; fr < FR; ++fr) anyf |= s_farm[(cur * FR + fr) * npos + pl];
+            if (anyf == 0) continue;
             const int fx = pl & 31, fy = (pl >> 5) & 1, fz = pl >> 6;
             const int fzo = z0 + fz, fyo = y0 + fy, fxo = x0 + fx;
             const long long fpos = ((long long)fzo * p.Ho + fyo) * p.Wo + fxo;
@@ -1943,19 +1949,21 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
     }
   } else {
     // ------------------------------------------------------------------------------------------------ dW partial = go . S^T
-    // A fragments: go[k = 16 rw + l15][voxel 4 ks + lg], 64 k-steps over the 256 voxels of the tile
+    // A fragments: go[k = 16 rw + l15][voxel], 64 k-steps over the 256 voxels of the tile.  The contraction order is free: k-step ks = 4 q + u
+    // pairs matrix row lg with voxel 16 q + 4 lg + u, so the four B operands of steps 4 q .. 4 q + 3 are ONE ds_read_b128 per lane (64
+    // single-dword reads per step left this role waiting on the LDS queue behind the samplers: 7.9 k of a 9.4 k-clock step busy)
     float wfrag[64];
     const int kk = 16 * rw + l15;
 #pragma unroll
     for (int ks = 0; ks < 64; ++ks) {
-      const int pl = 4 * ks + lg;
+      const int pl = 16 * (ks >> 2) + 4 * lg + (ks & 3);
       const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
       const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
       const bool ok = kk < p.K && az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
       wfrag[ks] = ok ? go[((long long)c.b * p.K + kk) * p.P + ((long long)gz * p.Ho + gy) * p.Wo + gx] : 0.f;
     }
     float* rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
-    const int brow = (l15 < CH ? l15 : CH - 1) * XS + lg;      // B operand: S[channel l15][voxel 4 ks + lg]; rows beyond CH are masked below
+    const int brow = (l15 < CH ? l15 : CH - 1) * XS + 4 * lg;  // B operand: S[channel l15][voxels 16 q + 4 lg ..+3]; rows beyond CH are masked below
     stage_region_any<CH>(p, g, c, xb, 0, s_reg, tid - 256, 768, vec != 0);
     __syncthreads();                                   // prologue barrier
     int ts = 0, cs = 0;                                // (tap, chunk index) of the step whose samples are contracted next
@@ -1968,9 +1976,13 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < 4; ++u) wacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 64; ks += 4)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[ks + u], src[4 * (ks + u)], wacc[u], 0, 0, 0);
+        for (int qq = 0; qq < 16; ++qq) {
+          const float4 bv = *reinterpret_cast<const float4*>(src + 16 * qq);
+          wacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[4 * qq + 0], bv.x, wacc[0], 0, 0, 0);
+          wacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[4 * qq + 1], bv.y, wacc[1], 0, 0, 0);
+          wacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[4 * qq + 2], bv.z, wacc[2], 0, 0, 0);
+          wacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[4 * qq + 3], bv.w, wacc[3], 0, 0, 0);
+        }
         if (l15 < CH && cs * CH + l15 < p.C) {
           float* dst = rep + ((long long)(ts * nchunk + cs) * 64 + 16 * rw + 4 * lg) * 16 + l15;
 #pragma unroll
@@ -2307,7 +2319,12 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
         case 1: DPF_GIP(1, 4); break;
         case 2: DPF_GIP(2, 4); break;
         case 3: DPF_GIP(3, 4); break;
-        default: DPF_GIP(2, 8); break;   // 256 voxels: 8 waves (two per SIMD)
+        default:                         // 256 voxels: 8 waves (two per SIMD) or 16 (four per SIMD, one 16-voxel sub-tile each)
+          {
+            static const int pk16 = getenv("DPF_DCN_PK16") ? atoi(getenv("DPF_DCN_PK16")) : 1;
+            if (pk16) { DPF_GIP(1, 16); } else { DPF_GIP(2, 8); }
+          }
+          break;
       }
 #undef DPF_GIP
       dx_done = true;

@@ -18,7 +18,8 @@ L = lib()
 buf = (ctypes.c_ulonglong * (16 * 128 * 2))()
 h = L._dll if hasattr(L, '_dll') else None
 import glob
-dll = ctypes.CDLL(glob.glob('dualpixelface_amd/libdpf_hip.so')[0])
+import os
+dll = ctypes.CDLL(os.environ.get('DPF_LIB_PATH') or glob.glob('dualpixelface_amd/libdpf_hip.so')[0])
 assert dll.dpf_debug_stamps(buf) == 0
 import numpy as np
 a = np.array(buf, dtype=np.uint64).reshape(16, 128, 2).astype(np.int64)
