@@ -2173,7 +2173,10 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
     const dim3 grid((unsigned)((long long)B * g.tilesZ * g.tilesY * g.tilesX));
     // role-split pipeline (sampler waves + MFMA waves, double-buffered sample tile) where its LDS image fits; with 16-byte aligned
     // rows the region gets an aligned x-origin and is staged with float4 loads
-    static const int use_rs = getenv("DPF_DCN_FWD_RS") ? atoi(getenv("DPF_DCN_FWD_RS")) : 8;   // 0 off, 8 or 16 waves (8 measured faster: 12.3 vs 13.2 ms)
+    // DPF_DCN_FWD_RS: 0 off, 8 or 16 = waves per CU.  Default: 16 for 16-channel chunks (two half-width workgroups of 8 waves: 5.75 vs
+    // 6.13 ms on the 64-channel layer), 8 for 12-channel chunks (4.24 vs 4.77 ms on the 35-channel layer)
+    static const int use_rs_env = getenv("DPF_DCN_FWD_RS") ? atoi(getenv("DPF_DCN_FWD_RS")) : -1;
+    const int use_rs = use_rs_env >= 0 ? use_rs_env : (CH == 16 ? 16 : 8);
     if (use_rs && MT <= 2) {
       RegGeo ga{};
       const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2 && !getenv("DPF_DCN_NOVEC");
