@@ -39,6 +39,7 @@ struct W2P {
   int ID, IH, IW, QD, QH, QW;
   int sd, sh, sw, pd, ph, pw;
   int kd, kh, kw, dd, dh, dw, T;
+  int rstep, dhl;              // row step of a tile (dilated rows, below) and the tap-row distance inside the LDS image (dh / rstep)
   int ext_d, ext_h, RS, SR, PS, CS, PSseg, CSseg, colshift;   // x image: row / plane / channel strides (floats, segments)
   int CCW, cchunks, kslices, groups, nxseg;
   int tilesH, tilesW, nchunk;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
     const int cc = cn / p.T;
     const int tap = cn - cc * p.T;
     const int tw_ = tap % p.kw, th_ = (tap / p.kw) % p.kh, td_ = tap / (p.kw * p.kh);
-    colbase[t] = cc * p.CS + td_ * p.dd * p.PS + (th_ * p.dh + wave * p.sh) * p.RS + tw_ * p.dw + p.colshift + 4 * hh * p.sw;
+    colbase[t] = cc * p.CS + td_ * p.dd * p.PS + (th_ * p.dhl + wave * p.sh) * p.RS + tw_ * p.dw + p.colshift + 4 * hh * p.sw;
   }
 
   // ---- x-patch DMA descriptors: flat segment f -> (cc, plane, row, seg); tile independent
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
     const unsigned seg = r2 - rr * p.SR;
     const bool ok = (int)f < p.nxseg && (int)cc < ncc && (int)pl < p.ext_d && (int)rr < p.ext_h;
     xmeta[j] = ok ? (int)((pl << 16) | (rr << 8) | seg) : -1;
-    xoff[j] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + rr) * p.IW + 4 * seg);
+    xoff[j] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + rr * p.rstep) * p.IW + 4 * seg);
   }
   // ---- g-tile DMA descriptors: physical slot P = k*SPR + sp (P = tid + 256 j) holds the logical slot sp ^ (k & 15) of row k;
   //      k = tid/SPR + 8 j, so the permutation depends on j only through its parity (two variants), the row advances by a scalar
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
   for (int v = 0; v < 2; ++v) {
     const int lg = (tid % SPR) ^ ((gk0 + v * KSTEP) & 15);
     glg[v] = lg;
-    goff[v] = (int)((long long)gk0 * g_chan + (long long)(lg >> 3) * p.QW + 4 * (lg & 7));
+    goff[v] = (int)((long long)gk0 * g_chan + (long long)(lg >> 3) * p.rstep * p.QW + 4 * (lg & 7));
   }
 
   // tile cursor (depth fastest): decoded once, then advanced by one per issued tile -- no integer division in the tile loop
@@ -148,7 +149,10 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
   }
 
   auto issue = [&](int buf) {
-    const int n = cur_n, qd = cur_qd, q0h = cur_th * WTH, q0w = cur_tw * 32;
+    // rstep > 1 (rows dilated by dh, stride 1): tile rows are q0h + w * dh -- the rows of one dilation phase -- so the patch is kh + 3
+    // image rows fetched dh apart instead of 3 + (kh - 1) * dh + 1 consecutive ones
+    const int n = cur_n, qd = cur_qd, q0w = cur_tw * 32;
+    const int q0h = p.rstep == 1 ? cur_th * WTH : (cur_th / p.rstep) * (WTH * p.rstep) + cur_th % p.rstep;
     if (++cur_qd == p.QD) {
       cur_qd = 0;
       if (++cur_tw == p.tilesW) {
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
       if (j * 256 < p.nxseg) {                                   // wave-uniform
         const int m = xmeta[j];
         if (m >= 0) {
-          const int id = i0d + (m >> 16), ih = i0h + ((m >> 8) & 0xff), iw = a0 + 4 * (m & 0xff);
+          const int id = i0d + (m >> 16), ih = i0h + ((m >> 8) & 0xff) * p.rstep, iw = a0 + 4 * (m & 0xff);
           const bool ok = id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
           glds16(ok ? xt + xoff[j] : zero, dbase + (j * 256 + wave * 64) * 4);
         }
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
     float* gbase = dbase + xFloats;
     bool gok[2];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) gok[v] = q0h + (glg[v] >> 3) < p.QH && q0w + 4 * (glg[v] & 7) < p.QW;
+    for (int v = 0; v < 2; ++v) gok[v] = q0h + (glg[v] >> 3) * p.rstep < p.QH && q0w + 4 * (glg[v] & 7) < p.QW;
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const bool ok = gk0 + j * KSTEP < krows && gok[j & 1];
@@ -341,14 +345,14 @@ int env_int(const char* name, int dflt) {
 }
 
 // bank conflicts of the B-operand gather for one candidate (PS, CS): sum over the 32-lane column windows of the extra LDS cycles
-int gather_conflicts(const DpfWgradDesc& d, int T, int ncolmax, int RS, int PS, int CS) {
+int gather_conflicts(const DpfWgradDesc& d, int T, int ncolmax, int RS, int PS, int CS, int dhl) {
   int total = 0;
   for (int c0 = 0; c0 < ncolmax; c0 += 32) {
     int cnt[32] = {0};
     for (int l = 0; l < 32 && c0 + l < ncolmax; ++l) {
       const int col = c0 + l, cc = col / T, tap = col % T;
       const int tw = tap % d.kw, th = (tap / d.kw) % d.kh, td = tap / (d.kw * d.kh);
-      ++cnt[(cc * CS + td * d.dd * PS + th * d.dh * RS + tw * d.dw) & 31];
+      ++cnt[(cc * CS + td * d.dd * PS + th * dhl * RS + tw * d.dw) & 31];
     }
     int worst = 0;
     for (int b = 0; b < 32; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
@@ -404,7 +408,12 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.QD = d.QD; p.QH = d.QH; p.QW = d.QW;
   p.sd = d.sd; p.sh = d.sh; p.sw = d.sw; p.pd = d.pd; p.ph = d.ph; p.pw = d.pw;
   p.kd = d.kd; p.kh = d.kh; p.kw = d.kw; p.dd = d.dd; p.dh = d.dh; p.dw = d.dw; p.T = T;
-  p.ext_d = (d.kd - 1) * d.dd + 1; p.ext_h = (WTH - 1) * d.sh + (d.kh - 1) * d.dh + 1;
+  // rows dilated by dh at stride 1: a tile takes the 4 rows of ONE dilation phase (dh apart), so its patch is kh + 3 image rows instead
+  // of 4 + (kh - 1) * dh (20 rows at dilation 8: a fifth of the channels per LDS buffer, 44.7 TFLOP/s on the 64 -> 64 dilation-8 layer)
+  static const int rstep_on = env_int("DPF_W2_RSTEP", 1);
+  p.rstep = (rstep_on && d.sh == 1 && d.dh > 1 && d.kh > 1) ? d.dh : 1;
+  p.dhl = d.dh / p.rstep;
+  p.ext_d = (d.kd - 1) * d.dd + 1; p.ext_h = (WTH - 1) * d.sh + (d.kh - 1) * p.dhl + 1;
   const int ext_w = 31 * d.sw + (d.kw - 1) * d.dw + 1;
   p.colshift = (((-d.pw) % 4) + 4) % 4;
   p.RS = ((p.colshift + ext_w + 3) / 4) * 4;
@@ -425,7 +434,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
     for (int pp = 0; pp < 8; ++pp)
       for (int cp = 0; cp < 8; ++cp) {
         const int PS = p.ext_h * p.RS + 4 * pp, CS = p.ext_d * PS + 4 * cp;
-        const int c = gather_conflicts(d, T, CCW * T, p.RS, PS, CS) * 64 + pp * p.ext_d + cp;
+        const int c = gather_conflicts(d, T, CCW * T, p.RS, PS, CS, p.dhl) * 64 + pp * p.ext_d + cp;
         if (c < bestc) { bestc = c; p.PS = PS; p.CS = CS; }
       }
     const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
@@ -441,7 +450,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   p.CCW = CCW; p.nxseg = CCW * p.CS / 4;
   p.cchunks = dpf_div_up(d.C, CCW);
   p.kslices = dpf_div_up(d.K, 32);
-  p.tilesH = dpf_div_up(d.QH, WTH); p.tilesW = dpf_div_up(d.QW, 32);
+  p.tilesH = dpf_div_up(d.QH, WTH * p.rstep) * p.rstep; p.tilesW = dpf_div_up(d.QW, 32);
   p.ntiles = (long long)d.N * d.QD * p.tilesH * p.tilesW;
   p.mCS = magic20(p.CSseg); p.mPS = magic20(p.PSseg); p.mSR = magic20(p.SR);
   // as many position chunks as fit the chip at once: (workgroups resident per CU by registers and LDS) x 256 CUs / groups

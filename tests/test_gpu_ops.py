@@ -64,6 +64,7 @@ CONV_CASES = [
     (1, 96, 1, 17, 36, 32, (1, 3, 3), (1, 1, 1), (0, 5, 5), (1, 5, 5)),
     (1, 32, 2, 40, 72, 32, (1, 3, 3), (1, 1, 1), (0, 4, 4), (1, 4, 4)),
     (2, 32, 1, 19, 40, 32, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 3, 3)),
+    (2, 64, 1, 45, 48, 64, (1, 3, 3), (1, 1, 1), (0, 8, 8), (1, 8, 8)),      # weight gradient on row-dilated tiles: two blocks of 4 * 8 rows, the second ragged
     (1, 40, 2, 5, 8, 160, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     (2, 33, 1, 20, 36, 96, (1, 3, 3), (1, 1, 1), (0, 0, 0), (1, 1, 1)),      # no padding: the data gradient's patch starts outside the tensor
     (1, 192, 1, 9, 12, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
