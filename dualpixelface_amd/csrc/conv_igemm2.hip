@@ -30,6 +30,8 @@ struct G2P {
   int sxd, sxh, sxw;            // input step per output step
   int e0d, e0h, e0w;            // input coordinate of output 0 at the minimal tap: i = q * sx + e0
   int ext_d, ext_h;             // patch planes, rows per plane
+  int pz, thp, thp_shift, odt;  // a tile = pz output planes x thp rows (pz * thp = 4 * NT position rows); odt = depth tiles
+  int planeStride;              // floats between patch planes (ext_h * RS)
   int RS, SR;                   // patch row stride in floats (multiple of 4), 16-byte segments per row
   int colshift;                 // patch column of the first needed input column (alignment slack, 0..3)
   int rpc, chanStride;          // rows per channel, floats per channel
@@ -98,11 +100,11 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
   int b = (blockIdx.x & 7) * p.cpx + (blockIdx.x >> 3);
   if (b >= p.ntiles) return;
   const int tile_id = b;
-  const int qd = b % p.OD; b /= p.OD;
+  const int qd = (b % p.odt) * p.pz; b /= p.odt;       // first output plane of the tile
   const int tw = b % p.tilesW; b /= p.tilesW;
   const int th = b % p.tilesH;
   const int n = b / p.tilesH;
-  const int q0h = th * TH, q0w = tw * 32;
+  const int q0h = th * p.thp, q0w = tw * 32;
   const int i0d = qd * p.sxd + p.e0d, i0h = q0h * p.sxh + p.e0h;
   const int a0 = q0w * p.sxw + p.e0w - p.colshift;     // 16-byte aligned first staged column
 
@@ -160,7 +162,11 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
 
   int lanebase[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) lanebase[t] = ((wave * NT + t) * p.sxh) * p.RS + l31 * p.sxw + p.colshift + hh * (BF ? 4 : 1) * p.chanStride;
+  for (int t = 0; t < NT; ++t) {
+    // position row r of the tile = (plane r / thp, row r % thp): depth tiles share the kd - 1 halo planes between their output planes
+    const int r = wave * NT + t, rz = r >> p.thp_shift, ry = r & (p.thp - 1);
+    lanebase[t] = rz * p.sxd * p.planeStride + ry * p.sxh * p.RS + l31 * p.sxw + p.colshift + hh * (BF ? 4 : 1) * p.chanStride;
+  }
   const int abase = hh * KT + l31;
 
   issue(0, 0);
@@ -296,8 +302,15 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
   const int ow = q0w + l31;
   const long long out_plane = (long long)p.OH * p.OW;
   const long long kstride = (long long)p.OD * out_plane;
-  const int oh0 = q0h + wave * NT;
-  float* op = out + ((long long)n * p.Ktot + p.k0) * kstride + ((long long)qd * p.OH + oh0) * p.OW + ow;
+  float* op = out + ((long long)n * p.Ktot + p.k0) * kstride + ow;
+  long long orow[NT];      // offset of position row t of this wave inside a channel
+  bool rok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r = wave * NT + t, oz = qd + (r >> p.thp_shift), oy = q0h + (r & (p.thp - 1));
+    rok[t] = oz < p.OD && oy < p.OH;
+    orow[t] = ((long long)oz * p.OH + oy) * p.OW;
+  }
   if (ow < p.OW && !p.accum) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
           const float bv = bias ? bias[p.k0 + k] : 0.f;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            if (oh0 + t < p.OH) op[(long long)k * kstride + t * p.OW] = acc[m][t][j] + bv;
+            if (rok[t]) op[(long long)k * kstride + orow[t]] = acc[m][t][j] + bv;
         }
       }
     }
@@ -322,8 +335,8 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
           const float bv = bias ? bias[p.k0 + k] : 0.f;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            if (oh0 + t < p.OH) {
-              float* o = op + (long long)k * kstride + t * p.OW;
+            if (rok[t]) {
+              float* o = op + (long long)k * kstride + orow[t];
               *o += acc[m][t][j] + bv;
             }
         }
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
         double d1 = 0.0, d2 = 0.0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const double v = (colok && oh0 + t < p.OH) ? (double)(acc[m][t][j] + bv) : 0.0;
+          const double v = (colok && rok[t]) ? (double)(acc[m][t][j] + bv) : 0.0;
           d1 += v;
           d2 += v * v;                                           // exact product, fp64 accumulation
         }
@@ -864,11 +877,32 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
     p.sxd = p.sxh = p.sxw = 1;
     p.e0d = d.pd - (d.kd - 1) * d.dd; p.e0h = d.ph - (d.kh - 1) * d.dh; p.e0w = d.pw - (d.kw - 1) * d.dw;
   }
-  p.ext_d = (d.kd - 1) * d.dd + 1;
-  p.ext_h = (TH - 1) * p.sxh + (d.kh - 1) * d.dh + 1;
   ext_w = 31 * p.sxw + (d.kw - 1) * d.dw + 1;
   p.colshift = ((p.e0w % 4) + 4) % 4;
   p.RS = ((p.colshift + ext_w + 3) / 4) * 4;
+  // depth tiles: pz output planes x TH / pz rows.  A 3-plane kernel stages kd - 1 halo planes per tile, so one output plane per tile
+  // fetches every input plane three times (16 x 32 tile: 3 x 18 = 54 patch rows per 16 position rows; 4 planes x 4 rows: 6 x 6 = 36).
+  // The split with the fewest staged rows per position row wins; DPF_G2_PZ = 1 | 2 | 4 forces one.
+  {
+    static const int pz_over = env_int("DPF_G2_PZ", 0);
+    auto pz_ok = [&](int pz) { return pz == 1 || (d.kd > 1 && pz <= TH / 2 && pz <= d.OD); };
+    auto pz_cost = [&](int pz) {
+      const int thp = TH / pz;
+      return (double)((pz - 1) * p.sxd + (d.kd - 1) * d.dd + 1) * ((thp - 1) * p.sxh + (d.kh - 1) * d.dh + 1) / (double)(pz * thp);
+    };
+    int best_pz = 1;
+    for (int pz : {2, 4})
+      if (pz_ok(pz) && pz_cost(pz) < pz_cost(best_pz) - 1e-9) best_pz = pz;
+    if ((pz_over == 1 || pz_over == 2 || pz_over == 4) && pz_ok(pz_over)) best_pz = pz_over;
+    p.pz = best_pz;
+    p.thp = TH / p.pz;
+    p.thp_shift = 0;
+    while ((1 << p.thp_shift) < p.thp) ++p.thp_shift;
+    p.odt = dpf_div_up(d.OD, p.pz);
+  }
+  p.ext_d = (p.pz - 1) * p.sxd + (d.kd - 1) * d.dd + 1;
+  p.ext_h = (p.thp - 1) * p.sxh + (d.kh - 1) * d.dh + 1;
+  p.planeStride = p.ext_h * p.RS;
   p.SR = p.RS / 4;
   p.rpc = p.ext_d * p.ext_h;
   p.chanStride = p.rpc * p.RS;
@@ -892,7 +926,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   // Launches that fill the chip several times over run best with the smallest chunk (more resident workgroups hide the DMA
   // latency: +1..5 % on every large shape, tools/conv_shape_bench.py sweep); small launches (< 2 tiles per CU) keep the larger
   // chunks, which shorten their few workgroups' barrier chains.
-  const long long ntiles_est = (long long)d.N * d.OD * dpf_div_up(d.OH, TH) * dpf_div_up(d.OW, 32);
+  const long long ntiles_est = (long long)d.N * p.odt * dpf_div_up(d.OH, p.thp) * dpf_div_up(d.OW, 32);
   int CC = 0;
   if (ntiles_est >= 512 && 2 * buf_bytes(2) <= (size_t)lds_target && nseg_of(2) <= NLD * 256) CC = 2;
   if (!CC)
@@ -907,11 +941,11 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   p.nseg = nseg_of(CC);
   p.nwseg = bf ? T * KT : T * CC * KT / 4;
   p.nchunks = (d.C + CC - 1) / CC;
-  p.tilesH = dpf_div_up(d.OH, TH);
+  p.tilesH = dpf_div_up(d.OH, p.thp);
   p.tilesW = dpf_div_up(d.OW, 32);
   p.mSR = magic20(p.SR); p.mRPC = magic20(p.rpc); p.mEH = magic20(p.ext_h);
   if ((long long)(bf ? 2 : 1) * NLD * 256 * (p.SR > p.rpc ? p.SR : p.rpc) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
-  const long long ntiles = (long long)d.N * d.OD * p.tilesH * p.tilesW;
+  const long long ntiles = (long long)d.N * p.odt * p.tilesH * p.tilesW;
   if (ntiles <= 0 || ntiles > 0x3fffffffLL) return DPF_ERR_INVALID_ARG;
   p.ntiles = (int)ntiles;
   p.cpx = (int)((ntiles + 7) / 8);
