@@ -1,0 +1,35 @@
+"""The alternative kernel paths behind the DPF_* switches (README "Environment switches") are live code: unaligned shapes, LDS images
+that do not fit and A/B measurements reach them.  The switches are read once per process, so each set runs the relevant parity tests
+in a child interpreter."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SETS = [
+    # 8-wave packed grad_input kernel, fused (not role-split) grad_offset kernel, 8 waves per CU in the forward
+    ({'DPF_DCN_PK16': '0', 'DPF_DCN_OFF_RS': '0', 'DPF_DCN_FWD_RS': '8'}, 'test_deform_conv and not full_size'),
+    # role-split forward off (region kernels), half-width tile off
+    ({'DPF_DCN_FWD_RS': '0'}, 'test_deform_conv and not full_size'),
+    # consecutive-row weight-gradient tiles for dilated layers, one output plane per forward tile
+    ({'DPF_W2_RSTEP': '0', 'DPF_G2_PZ': '1'}, 'test_conv_forward_backward'),
+    # four output planes per tile wherever the geometry allows it
+    ({'DPF_G2_PZ': '4'}, 'test_conv_forward_backward'),
+    # first-generation dense conv kernels (what unaligned shapes fall back to)
+    ({'DPF_IGEMM2': '0', 'DPF_WGRAD2': '0', 'DPF_IGEMM2_TR2': '0'}, 'test_conv_forward_backward'),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env_set,select', SETS, ids=['+'.join('%s=%s' % kv for kv in s[0].items()) for s in SETS])
+def test_parity_on_the_alternative_paths(env_set, select):
+    env = dict(os.environ)
+    env.update(env_set)
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_ops.py'), '-m', 'gpu', '-x', '-q', '-k', select, '-p', 'no:cacheprovider']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    tail = (r.stdout or '')[-1500:] + (r.stderr or '')[-500:]
+    assert r.returncode == 0, tail
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, tail
