@@ -348,7 +348,14 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
 // channel of 4 voxels (D row = voxel, col = channel), adds the 8 corner contributions with conflict-free LDS atomics
 // (16 consecutive channels per voxel) and flushes the region once with row-contiguous global atomics.  Samples that leave
 // the region (|offset| >~ 2) fall back to a direct global atomic.
-constexpr int GI_TY = 2, GI_TX = 32, GI_R = 3, GI_CH = 8;   // tile 4 x 2 x 32 outputs, halo 3; GI_CH: granularity of the per-chunk max |W| table
+// grad_input tile: 4 x 8 x 8 output voxels.  With the halo of 3 its LDS region is 4 x 14 x 14 cells = 3.1 per output voxel; the 4 x 2 x 32 tile of
+// the other deformable-conv kernels needs 4 x 10 x 40 = 6.25 (twice the region fills, flushes and global float atomics): 8.48 -> 7.97 ms per
+// 64-channel launch (4 x 4 x 16: 8.01).  -DDPF_GI_TX=32|16|8 selects the shape at compile time.
+#ifndef DPF_GI_TX
+#define DPF_GI_TX 8
+#endif
+constexpr int GI_TX = DPF_GI_TX, GI_TY = 64 / GI_TX, GI_R = 3, GI_CH = 8;   // tile 4 x GI_TY x GI_TX outputs (64 per plane), halo 3; GI_CH: granularity of the per-chunk max |W| table
+constexpr int GI_TXS = GI_TX == 32 ? 5 : (GI_TX == 16 ? 4 : 3);
 
 struct GiP {
   int TZ, RZmax, RY, RX;     // tile depth, region dims
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   const int vox = FR > 1 ? (tid & (npos - 1)) : tid;       // this thread's voxel in the table phase
   const int half = FR > 1 ? (tid / npos) & 1 : 0;          // its z side
   const bool tbl_thread = tid < TBL_T;                     // wave-uniform
-  const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
+  const int pdx = vox & (GI_TX - 1), pdy = (vox >> GI_TXS) & (GI_TY - 1), pdz = vox >> 6;
   const int zo = z0 + pdz, yo = y0 + pdy, xo = x0 + pdx;
   const bool pvalid = tbl_thread && pdz < q.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
   const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
 #pragma unroll
   for (int st = 0; st < NST; ++st) {
     const int pl = (wave * NST + st) * 16 + l15;
-    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+    const int ax = pl & (GI_TX - 1), ay = (pl >> GI_TXS) & (GI_TY - 1), az = pl >> 6;
     const int gz = z0 + az, gy = y0 + ay, gx = x0 + ax;
     const bool ok = az < q.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
     const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
 #pragma unroll
             for (int fr = 0; fr < FR; ++fr) anyf |= s_farm[(cur * FR + fr) * npos + pl];
             if (anyf == 0) continue;
-            const int fx = pl & 31, fy = (pl >> 5) & 1, fz = pl >> 6;
+            const int fx = pl & (GI_TX - 1), fy = (pl >> GI_TXS) & (GI_TY - 1), fz = pl >> 6;
             const int fzo = z0 + fz, fyo = y0 + fy, fxo = x0 + fx;
             const long long fpos = ((long long)fzo * p.Ho + fyo) * p.Wo + fxo;
             const Off3 fo = load_off_ptr(off_b + (long long)(3 * t) * p.P + fpos, p.P, true);
