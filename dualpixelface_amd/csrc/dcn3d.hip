@@ -821,7 +821,8 @@ struct RegGeo {
   int RXL;                 // left halo along x (>= R; chosen so that the region's first column is 16-byte aligned in global memory)
   int TZ, RZmax, RY, RX, RV;
   int tilesZ, tilesY, tilesX;
-  int TX;                  // tile width in output voxels (32; 16 for the half-width forward tile)
+  int TX;                  // tile width in output voxels (32; 16 for the half-width forward tile; 8 for the compact 4 x 8 x 8 tile)
+  int TY, TXS;             // tile rows (2; 8 for the compact tile) and log2(TX)
 };
 
 struct RegCtx {
@@ -835,7 +836,7 @@ __device__ __forceinline__ RegCtx region_ctx(const DcnP& p, const RegGeo& g, int
   const int ty = blk % g.tilesY; blk /= g.tilesY;
   const int tz = blk % g.tilesZ;
   c.b = blk / g.tilesZ;
-  c.z0 = tz * g.TZ; c.y0 = ty * RG_TY; c.x0 = tx * g.TX;
+  c.z0 = tz * g.TZ; c.y0 = ty * g.TY; c.x0 = tx * g.TX;
   const int rz0u = c.z0 * p.sd - p.pd - g.R;
   c.rz0 = rz0u < 0 ? 0 : rz0u;
   int rz1 = rz0u + (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * g.R;
@@ -1429,7 +1430,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
     const int vox = tid % NVOX;
     const int half = tid / NVOX;                       // HALF: the first NVOX threads take channels [0, CH/2), the others the rest
     const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
-    const int pdx = vox % TXV, pdy = (vox / TXV) & 1, pdz = vox / (2 * TXV);
+    const int pdx = vox & (g.TX - 1), pdy = (vox >> g.TXS) & (g.TY - 1), pdz = vox / (2 * TXV);   // g.TX * g.TY = 2 * TXV voxels per plane
     const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
     const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
     const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
@@ -1524,7 +1525,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       const int pl = mw * (32 * NTW) + nt * 32 + l31;
-      const int ax = pl % TXV, ay = (pl / TXV) & 1, az = pl / (2 * TXV);
+      const int ax = pl & (g.TX - 1), ay = (pl >> g.TXS) & (g.TY - 1), az = pl / (2 * TXV);
       const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
       if (az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo) {
         const long long pos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
@@ -1830,7 +1831,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
     const int vox = tid & 255, half = wave_u >> 2;
     const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
     float* doff_b = doff + (long long)c.b * 3 * p.T * p.P;
-    const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
+    const int pdx = vox & (g.TX - 1), pdy = (vox >> g.TXS) & (g.TY - 1), pdz = vox >> 6;     // 64 voxels per plane: TX * TY = 64
     const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
     const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
     const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
@@ -1897,7 +1898,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int pl = rw * 64 + st * 16 + l15;
-      const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+      const int ax = pl & (g.TX - 1), ay = (pl >> g.TXS) & (g.TY - 1), az = pl >> 6;
       const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
       const bool ok = az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
       const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
@@ -1964,7 +1965,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
 #pragma unroll
     for (int ks = 0; ks < 64; ++ks) {
       const int pl = 16 * (ks >> 2) + 4 * lg + (ks & 3);
-      const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
+      const int ax = pl & (g.TX - 1), ay = (pl >> g.TXS) & (g.TY - 1), az = pl >> 6;
       const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
       const bool ok = kk < p.K && az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
       wfrag[ks] = ok ? go[((long long)c.b * p.K + kk) * p.P + ((long long)gz * p.Ho + gy) * p.Wo + gx] : 0.f;
@@ -2088,16 +2089,19 @@ __global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __
 
 size_t region_lds(const RegGeo& g, int CH) { return sizeof(float) * ((size_t)CH * g.RV + (size_t)16 * ST); }
 
-int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, int RYH = -1, int TX = RG_TX) {
+int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, int RYH = -1, int TX = RG_TX, int TY = RG_TY) {
   g.R = R;
   g.TX = TX;
+  g.TY = TY;
+  g.TXS = 0;
+  while ((1 << g.TXS) < TX) ++g.TXS;
   g.RXL = R;
   g.RYH = RYH < R ? R : RYH;
   g.TZ = p.Do < 4 ? p.Do : 4;
   int RZ = (g.TZ - 1) * p.sd + (p.kd - 1) * p.dd + 1 + 2 * R;
   if (RZ > p.D) RZ = p.D;
   g.RZmax = RZ;
-  g.RY = (RG_TY - 1) * p.sh + (p.kh - 1) * p.dh + 1 + 2 * g.RYH;
+  g.RY = (TY - 1) * p.sh + (p.kh - 1) * p.dh + 1 + 2 * g.RYH;
   g.RX = (TX - 1) * p.sw + (p.kw - 1) * p.dw + 1 + 2 * R;
   if (aligned) {   // first region column = x0*sw - pw - RXL on a 16-byte boundary (x0*sw is a multiple of 32), RX a multiple of 4
     while ((p.pw + g.RXL) & 3) ++g.RXL;
@@ -2105,7 +2109,7 @@ int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, in
   }
   g.RV = g.RZmax * g.RY * g.RX;
   g.tilesZ = dpf_div_up(p.Do, g.TZ);
-  g.tilesY = dpf_div_up(p.Ho, RG_TY);
+  g.tilesY = dpf_div_up(p.Ho, TY);
   g.tilesX = dpf_div_up(p.Wo, TX);
   const long long blocks = (long long)p.B * g.tilesZ * g.tilesY * g.tilesX;
   if (g.RX > 64 || region_lds(g, CH) > 160 * 1024 || blocks >= 0x7fffffffLL || p.K > 128) return DPF_ERR_UNSUPPORTED;
@@ -2193,16 +2197,19 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
       const int TXv = fwd_tx == 16 ? 16 : (fwd_tx == 32 ? 32 : (CH == 16 ? 16 : 32));
       auto lds_of = [&](const RegGeo& q) { return sizeof(float) * ((size_t)CH * q.RV + (size_t)2 * CH * 8 * TXv); };
       const size_t lds_cap = TXv == 16 ? 80 * 1024 : 160 * 1024;
+      // shape of the 2 * TXv voxels of a tile plane: DPF_DCN_FWD_TY = 2 (TXv wide), 4 or 8 rows
+      static const int fwd_ty = getenv("DPF_DCN_FWD_TY") ? atoi(getenv("DPF_DCN_FWD_TY")) : 2;
+      const int TYg = (fwd_ty == 4 || (fwd_ty == 8 && TXv == 32)) ? fwd_ty : 2, TXg = 2 * TXv / TYg;
       int vec = 0;
       bool ok = false;
       if (can_vec) {
         const int cand[6][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}};     // (x/z halo, y halo), widest first
         for (int i = 0; i < 6 && !ok; ++i)
-          if (region_geo(ga, p, CH, cand[i][0], true, cand[i][1], TXv) == DPF_OK && lds_of(ga) <= lds_cap) { ok = true; vec = 1; }
+          if (region_geo(ga, p, CH, cand[i][0], true, cand[i][1], TXg, TYg) == DPF_OK && lds_of(ga) <= lds_cap) { ok = true; vec = 1; }
       }
       if (!ok) {
         for (int R = 4; R >= 3 && !ok; --R)
-          if (region_geo(ga, p, CH, R, false, -1, TXv) == DPF_OK && lds_of(ga) <= lds_cap) ok = true;
+          if (region_geo(ga, p, CH, R, false, -1, TXg, TYg) == DPF_OK && lds_of(ga) <= lds_cap) ok = true;
       }
       if (ok) {
         const size_t lds_rs = lds_of(ga);
@@ -2375,9 +2382,14 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     bool ok = false;
     int vec_rs = 0;
     if (can_vec) {
-      const int cand[6][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}};
-      for (int i = 0; i < 6 && !ok; ++i)
-        if (region_geo(gr, p, CHb, cand[i][0], true, cand[i][1]) == DPF_OK && lds_of(gr) <= 160 * 1024) { ok = true; vec_rs = 1; }
+      // compact 4 x 4 x 16 tile (DPF_DCN_OFF_TX=16, default; 8 = 4 x 8 x 8, 32 = 4 x 2 x 32): the same 256 voxels need a smaller haloed
+      // region, so a wider halo fits next to the three rotating tiles -- less staging per tile and fewer samples on the global slow path.
+      // Per launch (tools/dcn_bench.py): 12-channel chunks 7.37 (32) / 6.88 (16) / 7.06 (8) ms, 16-channel chunks 9.20 / 9.20 / 9.50
+      static const int off_tx = getenv("DPF_DCN_OFF_TX") ? atoi(getenv("DPF_DCN_OFF_TX")) : 16;
+      const int TXo = (off_tx == 8 || off_tx == 16) ? off_tx : 32, TYo = 64 / TXo;
+      const int cand[8][2] = {{5, 6}, {4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}, {3, 3}};
+      for (int i = 0; i < 7 && !ok; ++i)
+        if (region_geo(gr, p, CHb, cand[i][0], true, cand[i][1], TXo, TYo) == DPF_OK && lds_of(gr) <= 160 * 1024) { ok = true; vec_rs = 1; }
     }
     if (!ok) {
       for (int R = 4; R >= 3 && !ok; --R)
