@@ -348,13 +348,18 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
 // channel of 4 voxels (D row = voxel, col = channel), adds the 8 corner contributions with conflict-free LDS atomics
 // (16 consecutive channels per voxel) and flushes the region once with row-contiguous global atomics.  Samples that leave
 // the region (|offset| >~ 2) fall back to a direct global atomic.
-// grad_input tile: 4 x 8 x 8 output voxels.  With the halo of 3 its LDS region is 4 x 14 x 14 cells = 3.1 per output voxel; the 4 x 2 x 32 tile of
-// the other deformable-conv kernels needs 4 x 10 x 40 = 6.25 (twice the region fills, flushes and global float atomics): 8.48 -> 7.97 ms per
+// grad_input tile: 4 x 8 x 8 output voxels.  With a halo of 3 its LDS region is 4 x 14 x 14 cells = 3.1 per output voxel; the 4 x 2 x 32 tile
+// needs 4 x 10 x 40 = 6.25 (twice the region fills, flushes and global float atomics): 8.48 -> 7.97 ms per
 // 64-channel launch (4 x 4 x 16: 8.01).  -DDPF_GI_TX=32|16|8 selects the shape at compile time.
 #ifndef DPF_GI_TX
 #define DPF_GI_TX 8
 #endif
-constexpr int GI_TX = DPF_GI_TX, GI_TY = 64 / GI_TX, GI_R = 3, GI_CH = 8;   // tile 4 x GI_TY x GI_TX outputs (64 per plane), halo 3; GI_CH: granularity of the per-chunk max |W| table
+// halo of the grad_input region: 4 (the compact tile leaves the LDS for it): at the bench model's offsets (p99 3.7 voxels in the first
+// layer) fewer corners take the global far path -- backward 30.7 -> 30.1 ms per step (halo 5: 29.9, with 1.6x the region cells to flush)
+#ifndef DPF_GI_R
+#define DPF_GI_R 4
+#endif
+constexpr int GI_TX = DPF_GI_TX, GI_TY = 64 / GI_TX, GI_R = DPF_GI_R, GI_CH = 8;   // tile 4 x GI_TY x GI_TX outputs (64 per plane), halo 3; GI_CH: granularity of the per-chunk max |W| table
 constexpr int GI_TXS = GI_TX == 32 ? 5 : (GI_TX == 16 ? 4 : 3);
 
 struct GiP {
