@@ -22,6 +22,15 @@ __device__ unsigned long long g_stamps[16 * 128 * 2];
 #define DPF_STAMP(step, slot)
 #endif
 
+// XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (blockIdx % 8 labels the XCD and its L2), so with
+// the plain blockIdx -> tile map x-neighbouring tiles -- which share halo rows, offset / grad_output cache lines -- sit behind eight
+// different L2s and every line is fetched from HBM several times.  Here each label walks a CONTIGUOUS range of tiles (x fastest):
+// a bijection of [0, n) for any n.
+__device__ __forceinline__ int dpf_xcd_tile(int blk, int n) {
+  const int q = n >> 3, r = n & 7, x = blk & 7, i = blk >> 3;
+  return x * q + (x < r ? x : r) + i;
+}
+
 constexpr int TP = 64;          // output voxels per workgroup
 constexpr int SP = TP + 1;      // padded LDS row
 constexpr int MAXC = 128;
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   // tables (vector ALU) while the other feeds the LDS atomic unit and the matrix pipe
   const bool tables_first = __builtin_amdgcn_readfirstlane(NW >= 8 ? (wave >> 2) & 1 : wave & 1) != 0;
 
-  int bb = blockIdx.x;
+  int bb = dpf_xcd_tile(blockIdx.x, gridDim.x);
   const int tx = bb % q.tilesX; bb /= q.tilesX;
   const int ty = bb % q.tilesY; bb /= q.tilesY;
   const int tz = bb % q.tilesZ;
@@ -837,6 +846,7 @@ struct RegCtx {
 
 __device__ __forceinline__ RegCtx region_ctx(const DcnP& p, const RegGeo& g, int blk) {
   RegCtx c;
+  blk = dpf_xcd_tile(blk, gridDim.x);
   const int tx = blk % g.tilesX; blk /= g.tilesX;
   const int ty = blk % g.tilesY; blk /= g.tilesY;
   const int tz = blk % g.tilesZ;
