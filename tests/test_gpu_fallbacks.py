@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SETS = [
     # 8-wave packed grad_input kernel, fused (not role-split) grad_offset kernel, 8 waves per CU in the forward
     ({'DPF_DCN_PK16': '0', 'DPF_DCN_OFF_RS': '0', 'DPF_DCN_FWD_RS': '8'}, 'test_deform_conv and not full_size'),
+    # 4 x 2 x 32 tile in the role-split grad_offset kernel, 4-row forward tile planes
+    ({'DPF_DCN_OFF_TX': '32', 'DPF_DCN_FWD_TY': '4'}, 'test_deform_conv and not full_size'),
     # role-split forward off (region kernels), half-width tile off
     ({'DPF_DCN_FWD_RS': '0'}, 'test_deform_conv and not full_size'),
     # consecutive-row weight-gradient tiles for dilated layers, one output plane per forward tile
@@ -21,6 +23,24 @@ SETS = [
     # first-generation dense conv kernels (what unaligned shapes fall back to)
     ({'DPF_IGEMM2': '0', 'DPF_WGRAD2': '0', 'DPF_IGEMM2_TR2': '0'}, 'test_conv_forward_backward'),
 ]
+
+
+# whole-model steps on ONE stream (weight gradients in line, feature passes one after the other) against the reference fixtures
+E2E_SETS = [
+    ({'DPF_FEATURES_TWO_STREAMS': '0', 'DPF_WGRAD_ASYNC': '0'}, 'test_gradients_and_adam_step_vs_reference_fixture or test_train_step_with_flat_grad_reducer_single_rank'),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env_set,select', E2E_SETS, ids=['+'.join('%s=%s' % kv for kv in s[0].items()) for s in E2E_SETS])
+def test_whole_model_parity_on_one_stream(env_set, select):
+    env = dict(os.environ)
+    env.update(env_set)
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_e2e.py'), '-m', 'gpu', '-x', '-q', '-k', select, '-p', 'no:cacheprovider']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
+    tail = (r.stdout or '')[-1500:] + (r.stderr or '')[-500:]
+    assert r.returncode == 0, tail
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, tail
 
 
 @pytest.mark.gpu
