@@ -9,6 +9,7 @@
 // matrix cores against the [K x C] weight slice of that tap, so columns never reach HBM.
 #include "dpf_common.h"
 #include "dpf_repack.h"
+#include "dcn_internal.h"
 #include <cstdlib>
 
 namespace {
@@ -2172,7 +2173,8 @@ int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void*
 
 // workspace floats for dpf_deform_conv3d_forward / _backward (repacked weights)
 long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
-  const long long repack = (long long)T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);   // either repack, reduce index padded
+  long long repack = (long long)T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);   // either repack, reduce index padded
+  if (T == 27 && dcn_lean_workspace_floats(C, K) > repack) repack = dcn_lean_workspace_floats(C, K);
   return repack + (long long)WG_NREP * T * ((C + 11) / 12) * 64 * 16 + 64;   // + grad_weight scratch replicas (chunks of >= 12 channels) + max|W| per channel chunk
 }
 
@@ -2192,6 +2194,12 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
   const int MT = (K + 31) / 32, KT = 32 * MT;
   RegGeo g{};
   const int CH = region_chunk(C);
+  // the configuration the model runs (3x3x3, stride 1, padding 1, dilation 1, depth <= 4, aligned rows): lean-sampler kernels of dcn_lean.hip
+  if (kd == 3 && kh == 3 && kw == 3 && sd == 1 && sh == 1 && sw == 1 && pd == 1 && ph == 1 && pw == 1 && dd == 1 && dh == 1 && dw == 1 &&
+      !getenv("DPF_DCN_V1")) {
+    rc = dcn_lean_forward(input, offset, weight, bias, output, ws, B, C, D, H, W, K, st);
+    if (rc != DPF_ERR_UNSUPPORTED) return rc;
+  }
   if (!getenv("DPF_DCN_V1") && region_pick(g, p, CH) == DPF_OK) {
     const int Cpad = (C + CH - 1) / CH * CH;
     hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * Cpad * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0,

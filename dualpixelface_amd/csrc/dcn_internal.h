@@ -1,0 +1,13 @@
+// Internal (non-ABI) interface between the deformable-convolution translation units.
+#pragma once
+#include "dpf_common.h"
+
+// "Lean" kernels (dcn_lean.hip) for the configuration StereoDPNet uses: 3x3x3 taps, stride 1, padding 1, dilation 1, depth <= 4,
+// rows 16-byte aligned (W % 4 == 0), K <= 64.  Each returns DPF_ERR_UNSUPPORTED when the shape is not eligible (the caller then uses the
+// generic region kernels of dcn3d.hip), DPF_OK when it launched.
+//
+// weight: the caller's [K][C][27] tensor; ws: workspace of at least dcn_lean_workspace_floats(C, K) floats (weights repacked into the
+// matrix waves' fragment order).
+long long dcn_lean_workspace_floats(int C, int K);
+int dcn_lean_forward(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, int B, int C, int D, int H,
+                     int W, int K, hipStream_t st);

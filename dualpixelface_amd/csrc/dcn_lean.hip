@@ -1,0 +1,476 @@
+// Deformable 3-D convolution, "lean sampler" kernels for the configuration StereoDPNet runs (normal_module.py:14-19: 3x3x3 taps,
+// stride 1, padding 1, dilation 1, depth 4): same arithmetic as dcn3d.hip (reference: src/module/dcn3d/src/cuda/deform_im2col_cuda.cuh:26-72
+// sampler, :192-265 im2col + validity rule :248; deform_conv_cuda.cu:93-123 GEMM + bias), different instruction budget.
+//
+// What round 3 measured: the role-split kernels are bound by the SAMPLER's instruction stream -- ~700 vector
+// instructions per (64 voxels x 16 channels x 1 tap), 128 of them the essential FMAs -- while the matrix waves need 2048 clocks for the
+// same step.  The diet here:
+//   * quad-planar LDS image  region[q][cell][4 channels]  (q = channel quad): the 16 lanes of a ds_read_b128 group read 16 consecutive
+//     cells = 256 contiguous bytes (conflict free without a swizzle), and because RY / RX are template constants every corner of every
+//     quad is  base + immediate offset : two address registers per tap instead of 32 computed addresses;
+//   * the region is staged WITH its out-of-volume cells as zeros, so corners outside the volume along y / x read zeros and need no masks
+//     (cuh:43-65 returns 0 for them); only z (whole depth staged, D <= 4) keeps its two masks;
+//   * the lane -> voxel map is permuted so that each lane group of a ds_read_b128 holds 16 x-consecutive voxels;
+//   * trilinear weights and the 8 x CH multiply-adds on v_pk_mul_f32 / v_pk_fma_f32 with op_sel broadcasting the weight (no splat moves);
+//   * samples are written as one ds_write_b128 per quad into a quad-planar tile  S[q][voxel][4]  that the matrix waves read as b128;
+//   * a sample whose corner block leaves the staged box is redone by the whole wave (lane = channel x corner pair: two global loads per
+//     lane, one round trip) instead of 16 serial channel round trips in the one slow lane.
+#include "dcn_internal.h"
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct LeanP {
+  int B, C, K, D, H, W;
+  int Cpad, KT;
+  long long P;          // D * H * W (= output voxels per channel: stride 1, padding 1)
+  int tilesY, tilesX;   // a tile spans the whole depth
+  int nchunk;           // channel chunks
+};
+
+// XCD-aware tile order (see dcn3d.hip: dpf_xcd_tile)
+__device__ __forceinline__ int lean_xcd_tile(int blk, int n) {
+  const int q = n >> 3, r = n & 7, x = blk & 7, i = blk >> 3;
+  return x * q + (x < r ? x : r) + i;
+}
+
+template <int CH_, int TY_, int TX_, int RYH_, int RXL_, int RXR_>
+struct Geo {
+  static constexpr int CH = CH_, NQ = CH_ / 4, TY = TY_, TX = TX_, RYH = RYH_, RXL = RXL_;
+  static constexpr int NV = 4 * TY * TX;                       // output voxels per workgroup (4 depth planes)
+  static constexpr int RY = TY + 2 + 2 * RYH;
+  static constexpr int RX = (TX + 2 + RXL + RXR_ + 3) / 4 * 4;
+  static constexpr int ZS = RY * RX * 16;                      // bytes between depth planes of a quad plane
+  static constexpr int PLANE = 4 * ZS;                         // bytes of one quad plane of the region image
+  static constexpr int SQ = NV * 16;                           // bytes of one quad plane of the sample tile
+  static constexpr int SBUF = NQ * SQ;                         // one sample tile
+  static constexpr int LDS = NQ * PLANE + 2 * SBUF;
+  static constexpr int NS = NV / 64;                           // sampler waves (= matrix waves)
+  static_assert((1 + RXL) % 4 == 0 && TX % 16 == 0 && NV % 64 == 0, "aligned region origin / whole waves");
+};
+
+// lane (0..31) -> position (0..31) such that the two 16-lane groups ds_read_b128 services together ({0-3,12-15,20-27}, {4-11,16-19,28-31}:
+// MI355X_MICROARCH.md, LDS table) hold positions 0..15 and 16..31
+__device__ __forceinline__ int lane_pos32(int l) { return (int)((0x73261540u >> (4 * (l >> 2))) & 7u) * 4 + (l & 3); }
+
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 w, f32x2 v) {   // w.x * v
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(v));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_mul_hi(f32x2 w, f32x2 v) {   // w.y * v
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "v"(v));
+  return r;
+}
+__device__ __forceinline__ void pk_fma_lo(f32x2& acc, f32x2 w, f32x2 v) {   // acc += w.x * v
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(v));
+}
+__device__ __forceinline__ void pk_fma_hi(f32x2& acc, f32x2 w, f32x2 v) {   // acc += w.y * v
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(v));
+}
+
+// Stage x[b, c0 .. c0 + CH) over the region rows [ry0, ry0 + RY) x columns [rx0, rx0 + RX) x all D planes into region[q][cell][4];
+// cells outside the volume and channels beyond C are zeros.  A unit = 4 channels x 4 consecutive x: four float4 loads, a register
+// transpose, four ds_write_b128 into 64 consecutive bytes.
+template <class G>
+__device__ __forceinline__ void lean_stage(const LeanP& p, const float* __restrict__ xb, int c0, char* region, int ry0, int rx0, int tid,
+                                           int nthreads) {
+  constexpr int SR = G::RX / 4;
+  const long long chan = p.P;
+  const int units = p.D * G::RY * G::NQ * SR;
+  for (int u = tid; u < units; u += nthreads) {
+    const int seg = u % SR;
+    const int it = u / SR;
+    const int cg = it % G::NQ;
+    const int row = it / G::NQ;
+    const int lz = row / G::RY, ly = row - lz * G::RY;
+    const int gy = ry0 + ly, gx = rx0 + 4 * seg;
+    const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    const float* src = xb + (long long)(c0 + 4 * cg) * chan + ((long long)lz * p.H + gy) * p.W + gx;
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (ok && c0 + 4 * cg + q < p.C) ? *reinterpret_cast<const f32x4*>(src + q * chan) : f32x4{0.f, 0.f, 0.f, 0.f};
+    char* dst = region + cg * G::PLANE + (row * G::RX + 4 * seg) * 16;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0].x, v[1].x, v[2].x, v[3].x};
+    *reinterpret_cast<f32x4*>(dst + 16) = f32x4{v[0].y, v[1].y, v[2].y, v[3].y};
+    *reinterpret_cast<f32x4*>(dst + 32) = f32x4{v[0].z, v[1].z, v[2].z, v[3].z};
+    *reinterpret_cast<f32x4*>(dst + 48) = f32x4{v[0].w, v[1].w, v[2].w, v[3].w};
+  }
+}
+
+// channel (within the chunk) that lane half hh contracts in k-step s of the matrix waves: the B operand of step s is component s & 3 of
+// the b128 read of quad 2 * (s >> 2) + hh (CH = 16; first 4 steps of CH = 12), or component s & 1 of the b64 read at quad 2 + 8 * hh bytes
+template <int CH>
+__device__ __forceinline__ int lean_kstep_channel(int s, int hh) {
+  if (CH == 16 || s < 4) return 4 * (2 * (s >> 2) + hh) + (s & 3);
+  return 8 + 2 * hh + (s & 1);
+}
+
+#ifdef DPF_STAMPS
+__device__ unsigned long long g_lean_stamps[16 * 128 * 4];
+#define LEAN_STAMP(step, slot)                                                                                          \
+  if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_lean_stamps[(wave_u * 128 + (step)) * 4 + (slot)] = __builtin_readcyclecounter();
+#else
+#define LEAN_STAMP(step, slot)
+#endif
+
+// Per (voxel, tap) table of the sampler: where the 2 x 2 x 2 corner block sits in the staged region and the eight trilinear weights.
+struct LeanTab {
+  int a0, a1;                   // byte offsets of the (low y, low x) corner cell on the low / high depth plane
+  f32x2 w00, w01, w10, w11;     // weights of (jd, jh) = (0,0), (0,1), (1,0), (1,1), each as the pair (jw = 0, jw = 1)
+  int d0, h0, w0;               // kept for the rare sample that leaves the staged box
+  float ld, lh, lw;
+  bool inreg;
+};
+
+template <class G>
+__device__ __forceinline__ LeanTab lean_tab(const LeanP& p, bool pvalid, int ry0, int rx0, float fd, float fh, float fw) {
+  LeanTab t;
+  const float d0f = floorf(fd), h0f = floorf(fh), w0f = floorf(fw);
+  t.ld = fd - d0f; t.lh = fh - h0f; t.lw = fw - w0f;
+  t.d0 = (int)d0f; t.h0 = (int)h0f; t.w0 = (int)w0f;
+  const int ly = t.h0 - ry0, lx = t.w0 - rx0;
+  t.inreg = (unsigned)ly < (unsigned)(G::RY - 1) && (unsigned)lx < (unsigned)(G::RX - 1);
+  const bool ok = t.inreg && pvalid;
+  // z: the whole depth is staged; planes outside the volume get weight 0 and a clamped index
+  const bool mz0 = (unsigned)t.d0 < (unsigned)p.D, mz1 = (unsigned)(t.d0 + 1) < (unsigned)p.D;
+  f32x2 wz, wy, wx;
+  wz.x = (ok && mz0) ? 1.f - t.ld : 0.f;
+  wz.y = (ok && mz1) ? t.ld : 0.f;
+  wy.x = 1.f - t.lh; wy.y = t.lh;
+  wx.x = 1.f - t.lw; wx.y = t.lw;
+  const int Dm1 = p.D - 1;
+  const int iz0 = min(max(t.d0, 0), Dm1), iz1 = min(max(t.d0 + 1, 0), Dm1);
+  const int cell = ok ? __mul24(__mul24(iz0, G::RY) + ly, G::RX) + lx : 0;
+  t.a0 = cell * 16;
+  t.a1 = t.a0 + __mul24(iz1 - iz0, G::ZS);
+  const f32x2 zy0 = pk_mul_lo(wz, wy), zy1 = pk_mul_hi(wz, wy);          // (wz0 wy0, wz0 wy1), (wz1 wy0, wz1 wy1)
+  t.w00 = pk_mul_lo(zy0, wx); t.w01 = pk_mul_hi(zy0, wx);
+  t.w10 = pk_mul_lo(zy1, wx); t.w11 = pk_mul_hi(zy1, wx);
+  return t;
+}
+
+#define LEAN_LOAD8(dst, q)                                                                        \
+  dst[0] = *reinterpret_cast<const f32x4*>(r0 + (q) * G::PLANE);                                  \
+  dst[1] = *reinterpret_cast<const f32x4*>(r0 + (q) * G::PLANE + 16);                             \
+  dst[2] = *reinterpret_cast<const f32x4*>(r0 + (q) * G::PLANE + G::RX * 16);                     \
+  dst[3] = *reinterpret_cast<const f32x4*>(r0 + (q) * G::PLANE + G::RX * 16 + 16);                \
+  dst[4] = *reinterpret_cast<const f32x4*>(r1 + (q) * G::PLANE);                                  \
+  dst[5] = *reinterpret_cast<const f32x4*>(r1 + (q) * G::PLANE + 16);                             \
+  dst[6] = *reinterpret_cast<const f32x4*>(r1 + (q) * G::PLANE + G::RX * 16);                     \
+  dst[7] = *reinterpret_cast<const f32x4*>(r1 + (q) * G::PLANE + G::RX * 16 + 16);
+
+// Trilinear samples of the CH staged channels for one (voxel, tap), written to this lane's cell of the sample tile; samples whose corner
+// block leaves the staged box are redone by the whole wave from global memory (see the file header).  The corner reads of two quads are
+// in flight while a third is accumulated; `between` runs right after the first reads were issued (the caller builds the next tap's table
+// there, under the LDS latency).
+template <class G, class F>
+__device__ __forceinline__ void lean_gather(const LeanP& p, const char* region, char* s_tile, int vox, int lane, bool pvalid, const LeanTab& tb,
+                                            const float* __restrict__ xb, int c0, F between) {
+  constexpr int CH = G::CH, NQ = G::NQ;
+  const char* r0 = region + tb.a0;
+  const char* r1 = region + tb.a1;
+  char* sdst = s_tile + vox * 16;
+  f32x4 cr[3][8];
+  LEAN_LOAD8(cr[0], 0)
+  if (NQ > 1) { LEAN_LOAD8(cr[1], 1) }
+  between();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (q + 2 < NQ) { LEAN_LOAD8(cr[(q + 2) % 3], q + 2) }
+    const f32x4* c = cr[q % 3];
+    f32x2 lo = pk_mul_lo(tb.w00, c[0].xy), hi = pk_mul_lo(tb.w00, c[0].zw);
+    pk_fma_hi(lo, tb.w00, c[1].xy); pk_fma_hi(hi, tb.w00, c[1].zw);
+    pk_fma_lo(lo, tb.w01, c[2].xy); pk_fma_lo(hi, tb.w01, c[2].zw);
+    pk_fma_hi(lo, tb.w01, c[3].xy); pk_fma_hi(hi, tb.w01, c[3].zw);
+    pk_fma_lo(lo, tb.w10, c[4].xy); pk_fma_lo(hi, tb.w10, c[4].zw);
+    pk_fma_hi(lo, tb.w10, c[5].xy); pk_fma_hi(hi, tb.w10, c[5].zw);
+    pk_fma_lo(lo, tb.w11, c[6].xy); pk_fma_lo(hi, tb.w11, c[6].zw);
+    pk_fma_hi(lo, tb.w11, c[7].xy); pk_fma_hi(hi, tb.w11, c[7].zw);
+    *reinterpret_cast<f32x4*>(sdst + q * G::SQ) = f32x4{lo.x, lo.y, hi.x, hi.y};
+  }
+  // ---- samples whose corner block leaves the staged box (rare): the wave redoes them together from global memory.  Lane l takes
+  // channel l & 15 and the corner pair (jd, jh) = (l >> 5, (l >> 4) & 1): two loads (jw = 0, 1), then the four pairs are summed
+  // across lanes.  (cuh:248: a sample outside (-1, D) x (-1, H) x (-1, W) is zero -- it stays with the zero the fast path wrote.)
+  unsigned long long slow = __ballot(pvalid && !tb.inreg);
+  if (slow) {
+    const bool vvalid = (unsigned)(tb.d0 + 1) <= (unsigned)p.D && (unsigned)(tb.h0 + 1) <= (unsigned)p.H && (unsigned)(tb.w0 + 1) <= (unsigned)p.W;
+    slow = __ballot(pvalid && !tb.inreg && vvalid);
+  }
+  while (slow) {
+    const int L = __builtin_ctzll(slow);
+    slow &= slow - 1;
+    const int sd0 = __builtin_amdgcn_readlane(tb.d0, L), sh0 = __builtin_amdgcn_readlane(tb.h0, L), sw0 = __builtin_amdgcn_readlane(tb.w0, L);
+    const float sld = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.ld), L));
+    const float slh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.lh), L));
+    const float slw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.lw), L));
+    const int svox = __builtin_amdgcn_readlane(vox, L);
+    const int ch = lane & 15, jd = lane >> 5, jh = (lane >> 4) & 1;
+    const int dz = sd0 + jd, hy = sh0 + jh;
+    const int cgl = c0 + ch;
+    const bool rowin = ch < CH && cgl < p.C && (unsigned)dz < (unsigned)p.D && (unsigned)hy < (unsigned)p.H;
+    const bool in0 = rowin && (unsigned)sw0 < (unsigned)p.W, in1 = rowin && (unsigned)(sw0 + 1) < (unsigned)p.W;
+    const float* xr = xb + (long long)(cgl < p.C ? cgl : 0) * p.P + ((long long)(rowin ? dz : 0) * p.H + (rowin ? hy : 0)) * p.W;
+    const float v0 = in0 ? xr[sw0] : 0.f, v1 = in1 ? xr[sw0 + 1] : 0.f;
+    const float wzy = (jd ? sld : 1.f - sld) * (jh ? slh : 1.f - slh);
+    float part = fmaf(wzy * slw, v1, (wzy * (1.f - slw)) * v0);
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (lane < CH) *reinterpret_cast<float*>(s_tile + (lane >> 2) * G::SQ + svox * 16 + (lane & 3) * 4) = part;
+  }
+}
+
+// Role-split forward: waves [0, NS) sample (a voxel per lane, all CH channels of the staged chunk), waves [NS, 2 NS) contract 64 voxels
+// each against the [K x CH] weight slice of the tap on v_mfma_f32_32x32x2_f32 (exact fp32).  The sample tile is double buffered: one
+// barrier per tap.  Latencies are taken out of the step: the samplers fetch a tap's offsets three taps ahead (a first-touch HBM read
+// each: the offset tensor is 0.5 GB), the matrix waves copy tile t into registers right after barrier t and meanwhile contract tile
+// t - 1, whose weight fragments were fetched (L2) during the step before.
+template <class G, int MT>
+__global__ __launch_bounds__(128 * G::NS) void dcn_lean_fwd_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                                  const float* __restrict__ wt, const float* __restrict__ bias,
+                                                                  float* __restrict__ out, LeanP p) {
+  extern __shared__ __align__(16) char smem[];
+  constexpr int CH = G::CH, NQ = G::NQ, NS = G::NS, KSTEPS = CH / 2, T = 27;
+  char* region = smem;
+  char* s_S = smem + NQ * G::PLANE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int blk = lean_xcd_tile(blockIdx.x, gridDim.x);
+  const int tx = blk % p.tilesX; blk /= p.tilesX;
+  const int ty = blk % p.tilesY;
+  const int b = blk / p.tilesY;
+  const int y0 = ty * G::TY, x0 = tx * G::TX;
+  const int ry0 = y0 - 1 - G::RYH, rx0 = x0 - 1 - G::RXL;
+  const float* xb = x + (long long)b * p.C * p.P;
+  if (wave_u < NS) {
+    // ------------------------------------------------------------------------------------------------------------ samplers
+    const int vox = wave_u * 64 + (lane & 32) + lane_pos32(lane & 31);
+    const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+    const int zo = pz, yo = y0 + py, xo = x0 + px;
+    const bool pvalid = zo < p.D && yo < p.H && xo < p.W;
+    const long long ppos = pvalid ? ((long long)zo * p.H + yo) * p.W + xo : 0;
+    const float* offp0 = offset + (long long)b * 3 * T * p.P + ppos;
+    const float zbf = (float)(zo - 1), ybf = (float)(yo - 1), xbf = (float)(xo - 1);
+    const long long P3 = 3 * p.P;
+    // Offsets are fetched four taps ahead of their use (first-touch HBM reads): slot (u % 3) of the ring holds tap u's three components.
+    // The table of tap t + 1 is built while tap t's first corner reads are in flight.
+    float od[3], oh[3], ow[3];
+    LeanTab tab = lean_tab<G>(p, pvalid, ry0, rx0, zbf + offp0[0], ybf + offp0[p.P], xbf + offp0[2 * p.P]);
+#pragma unroll
+    for (int u = 1; u <= 3; ++u) { od[u % 3] = offp0[u * P3]; oh[u % 3] = offp0[u * P3 + p.P]; ow[u % 3] = offp0[u * P3 + 2 * p.P]; }
+#pragma unroll 1
+    for (int c0 = 0; c0 < p.C; c0 += CH) {
+      __syncthreads();                                 // everybody is done with the previous chunk's region
+      lean_stage<G>(p, xb, c0, region, ry0, rx0, tid, 128 * NS);
+      __syncthreads();
+#pragma unroll 1
+      for (int g = 0; g < 9; ++g) {                    // tap row (ti, tj) = (g / 3, g % 3); the three tk are unrolled
+        const int gn = g < 8 ? g + 1 : 0;              // row of the tap after this row's last one (the next chunk starts over)
+        const int ti = g / 3, tj = g - 3 * ti, tin = gn / 3, tjn = gn - 3 * tin;
+        const float fz_same = zbf + (float)ti, fy_same = ybf + (float)tj, fz_next = zbf + (float)tin, fy_next = ybf + (float)tjn;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int t = 3 * g + r;
+          LEAN_STAMP(t, 0)
+          const int sl = (r + 1) % 3;                  // ring slot of tap t + 1
+          const float fdn = (r < 2 ? fz_same : fz_next) + od[sl], fhn = (r < 2 ? fy_same : fy_next) + oh[sl];
+          const float fwn = (xbf + (float)((r + 1) % 3)) + ow[sl];
+          {
+            int u = t + 4;                             // refill the slot with the tap three further on
+            if (u >= T) u -= T;
+            const float* np = offp0 + (long long)u * P3;
+            od[sl] = np[0]; oh[sl] = np[p.P]; ow[sl] = np[2 * p.P];
+          }
+          LeanTab tabn;
+#ifdef LEAN_NO_SAMPLE
+          tabn = lean_tab<G>(p, pvalid, ry0, rx0, fdn, fhn, fwn);
+#else
+          lean_gather<G>(p, region, s_S + ((g + r) & 1) * G::SBUF, vox, lane, pvalid, tab, xb, c0,
+                         [&]() { tabn = lean_tab<G>(p, pvalid, ry0, rx0, fdn, fhn, fwn); });
+#endif
+          tab = tabn;
+          LEAN_STAMP(t, 1)
+          __syncthreads();                             // barrier t: S[t & 1] is complete; the matrix waves hold S[(t - 1) & 1] in registers
+          LEAN_STAMP(t, 2)
+        }
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------------------ matrix waves
+    const int mw = wave_u - NS, l31 = lane & 31, hh = lane >> 5;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[m][nt][j] = 0.f;
+    const unsigned sb = (unsigned)(NQ * G::PLANE + (mw * 64 + l31) * 16 + hh * G::SQ);              // quad hh of voxel mw*64 + l31 (LDS byte address)
+    const unsigned sb2 = (unsigned)(NQ * G::PLANE + (mw * 64 + l31) * 16 + 2 * G::SQ + hh * 8);     // CH = 12: this lane half's half of quad 2
+    const unsigned wlane = (unsigned)lane * 32u;       // this lane's 8 fragments of a (tap, chunk, m) block of the repacked weights
+    // one step: fetch the weight fragments of tile t (used in the NEXT step), pass barrier t, copy tile t from LDS into registers and meanwhile
+    // contract tile t - 1.  Two register sets alternate (the tap loop is unrolled by two), so nothing is copied.
+    auto step = [&](int t, int chunk, f32x4 (&aU)[MT][2], f32x4 (&bU)[2][2], f32x4 (&aL)[MT][2], f32x4 (&bL)[2][2]) {
+      // aU / bU: in use (tile t - 1);  aL / bL: being loaded (tile t)
+      if (t < T) {
+        const char* wb = reinterpret_cast<const char*>(wt) + ((long long)(t * p.nchunk + chunk) * MT) * 2048;   // uniform
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          aL[m][0] = *reinterpret_cast<const f32x4*>(wb + wlane + m * 2048);
+          aL[m][1] = *reinterpret_cast<const f32x4*>(wb + wlane + m * 2048 + 16);
+        }
+        __syncthreads();                               // barrier t
+        LEAN_STAMP(t, 0)
+        const unsigned so = (t & 1) * G::SBUF;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          bL[nt][0] = *reinterpret_cast<const f32x4*>(smem + sb + so + nt * 512);
+          if constexpr (CH == 16) {
+            bL[nt][1] = *reinterpret_cast<const f32x4*>(smem + sb + so + nt * 512 + 2 * G::SQ);
+          } else {
+            const f32x2 f1 = *reinterpret_cast<const f32x2*>(smem + sb2 + so + nt * 512);
+            bL[nt][1] = f32x4{f1.x, f1.y, 0.f, 0.f};
+          }
+        }
+      }
+#ifndef LEAN_NO_MFMA
+      if (t > 0) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[m][s >> 2][s & 3], bU[nt][s >> 2][s & 3], acc[m][nt], 0, 0, 0);
+      }
+#endif
+      LEAN_STAMP(t, 1)
+    };
+    f32x4 aA[MT][2], aB[MT][2], bA[2][2], bB[2][2];
+    int chunk = 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < p.C; c0 += CH, ++chunk) {
+      __syncthreads();
+      lean_stage<G>(p, xb, c0, region, ry0, rx0, tid, 128 * NS);
+      __syncthreads();
+#pragma unroll 1
+      for (int t = 0; t <= T; t += 2) {                // T + 1 = 28 steps: tile t is loaded in step t and contracted in step t + 1
+        step(t, chunk, aB, bB, aA, bA);
+        step(t + 1, chunk, aA, bA, aB, bB);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int vox = mw * 64 + nt * 32 + l31;
+      const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+      const int gz = pz, gy = y0 + py, gx = x0 + px;
+      if (gz < p.D && gy < p.H && gx < p.W) {
+        const long long pos = ((long long)gz * p.H + gy) * p.W + gx;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+            if (k < p.K) out[((long long)b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
+          }
+      }
+    }
+  }
+}
+
+// Weight fragments in the order the matrix waves consume them: wl[tap][chunk][m][lane][8] with fragment s of lane (l31, hh) =
+// W[k = 32 m + l31][c = chunk * CH + lean_kstep_channel(s, hh)][tap] (zero beyond K / C; CH = 12 uses s < 6), so that a lane fetches its 8
+// fragments of a (tap, chunk, m) block as two 16-byte loads from one uniform base + 32 * lane.
+template <int CH>
+__global__ void lean_repack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wl, int K, int C, int MT, int nchunk) {
+  const int total = 27 * nchunk * MT * 512;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int s = i & 7, lane = (i >> 3) & 63;
+    int r = i >> 9;
+    const int m = r % MT; r /= MT;
+    const int chunk = r % nchunk;
+    const int t = r / nchunk;
+    const int k = 32 * m + (lane & 31);
+    float v = 0.f;
+    if (s < CH / 2) {
+      const int c = chunk * CH + lean_kstep_channel<CH>(s, lane >> 5);
+      if (k < K && c < C) v = w[((long long)k * C + c) * 27 + t];
+    }
+    wl[i] = v;
+  }
+}
+
+template <typename F>
+int lean_set_lds(F f, size_t lds) {
+  if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DPF_ERR_LAUNCH;
+  return DPF_OK;
+}
+
+template <class G>
+int lean_launch_fwd(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, LeanP p, hipStream_t st) {
+  p.tilesY = dpf_div_up(p.H, G::TY);
+  p.tilesX = dpf_div_up(p.W, G::TX);
+  const long long blocks = (long long)p.B * p.tilesY * p.tilesX;
+  if (blocks >= 0x7fffffffLL) return DPF_ERR_UNSUPPORTED;
+  const int MT = p.KT / 32;
+  hipLaunchKernelGGL((lean_repack_fwd_kernel<G::CH>), dim3(dpf_ew_grid(27LL * p.nchunk * MT * 512)), dim3(256), 0, st, weight, ws, p.K, p.C, MT, p.nchunk);
+  const dim3 grid((unsigned)blocks), block(128 * G::NS);
+  if (MT == 1) {
+    if (lean_set_lds(dcn_lean_fwd_kernel<G, 1>, G::LDS) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL((dcn_lean_fwd_kernel<G, 1>), grid, block, G::LDS, st, x, offset, ws, bias, out, p);
+  } else {
+    if (lean_set_lds(dcn_lean_fwd_kernel<G, 2>, G::LDS) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL((dcn_lean_fwd_kernel<G, 2>), grid, block, G::LDS, st, x, offset, ws, bias, out, p);
+  }
+  return dpf_check_launch();
+}
+
+//                  CH TY  TX RYH RXL RXR      voxels  region cells    LDS
+typedef Geo<16, 2, 32, 3, 3, 3> G16a;   //   256     4 x 10 x 40    135 168   one workgroup per CU
+typedef Geo<16, 2, 16, 3, 3, 3> G16b;   //   128     4 x 10 x 24     77 824   two per CU
+typedef Geo<16, 4, 16, 3, 3, 3> G16c;   //   256     4 x 12 x 24    106 496
+typedef Geo<12, 2, 32, 5, 7, 4> G12a;   //   256     4 x 14 x 48    153 600   the first layer's offsets are wider (p99 3.7 voxels): halo 4-7 / 5
+typedef Geo<12, 2, 16, 4, 3, 3> G12b;   //   128     4 x 12 x 24     67 584   two per CU
+typedef Geo<12, 4, 16, 5, 7, 4> G12c;   //   256     4 x 16 x 32    122 880
+
+}  // namespace
+
+#ifdef DPF_STAMPS
+extern "C" int dpf_debug_lean_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lean_stamps), sizeof(unsigned long long) * 16 * 128 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// chunk width: 12 where it pads the channel count less than 16 does (35 -> 36 instead of 48)
+int dcn_lean_chunk(int C) { return ((C + 11) / 12 * 12 < (C + 15) / 16 * 16) ? 12 : 16; }
+
+long long dcn_lean_workspace_floats(int C, int K) {
+  const int CH = dcn_lean_chunk(C);
+  return 27LL * ((C + CH - 1) / CH) * ((K + 31) / 32) * 512;
+}
+
+int dcn_lean_forward(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, int B, int C, int D, int H,
+                     int W, int K, hipStream_t st) {
+  static const int lean_env = getenv("DPF_DCN_LEAN") ? atoi(getenv("DPF_DCN_LEAN")) : 1;
+  if (!lean_env || D > 4 || D < 1 || (W & 3) || K > 64 || (reinterpret_cast<uintptr_t>(x) & 15)) return DPF_ERR_UNSUPPORTED;
+  if ((long long)D * H * W >= 0x7fffffffLL / 4) return DPF_ERR_UNSUPPORTED;
+  const int CH = dcn_lean_chunk(C);
+  LeanP p{};
+  p.B = B; p.C = C; p.K = K; p.D = D; p.H = H; p.W = W;
+  p.Cpad = (C + CH - 1) / CH * CH;
+  p.nchunk = p.Cpad / CH;
+  p.KT = 32 * ((K + 31) / 32);
+  p.P = (long long)D * H * W;
+  // tile variant: DPF_DCN_LEAN_FWD = a | b | c (default: c)
+  static const char tile = getenv("DPF_DCN_LEAN_FWD") ? getenv("DPF_DCN_LEAN_FWD")[0] : 'c';
+  if (CH == 16) {
+    if (tile == 'b') return lean_launch_fwd<G16b>(x, offset, weight, bias, out, ws, p, st);
+    if (tile == 'a') return lean_launch_fwd<G16a>(x, offset, weight, bias, out, ws, p, st);
+    return lean_launch_fwd<G16c>(x, offset, weight, bias, out, ws, p, st);
+  }
+  if (tile == 'b') return lean_launch_fwd<G12b>(x, offset, weight, bias, out, ws, p, st);
+  if (tile == 'a') return lean_launch_fwd<G12a>(x, offset, weight, bias, out, ws, p, st);
+  return lean_launch_fwd<G12c>(x, offset, weight, bias, out, ws, p, st);
+}

@@ -18,6 +18,7 @@ flat arenas that a generic trainer would not know how to checkpoint, so this mod
 import json
 import math
 import os
+import re
 import time
 
 import torch
@@ -92,7 +93,22 @@ class Trainer(object):
             if int(ckpt.get('dpf_ckpt_version', 0)) >= 2:
                 self.global_step = max(self.global_step - 1, 0)               # our own files: undo dump_checkpoint's + 1 exactly
             elif 'pytorch-lightning_version' not in ckpt and 'epoch' in ckpt:
-                self.epoch += 1                                               # legacy file: 'epoch' = the epoch that had finished
+                # Unversioned files of this trainer exist in two generations that no key tells apart: round 1 stored the FINISHED epoch,
+                # later revisions the NEXT epoch to run (and the plain global_step).  save_checkpoint names the file after the finished
+                # epoch (checkpoint_epoch=NN.ckpt), so the name decides; without it the caller has to say (option.legacy_ckpt_epoch =
+                # 'finished' | 'next') -- never guess: a wrong guess silently skips or repeats an epoch and shifts the LR schedule.
+                m = re.search(r'checkpoint_epoch=(\d+)\.ckpt$', os.path.basename(path))
+                conv = getattr(self.option, 'legacy_ckpt_epoch', None)
+                if conv is None and m is not None:
+                    if self.epoch == int(m.group(1)):
+                        conv = 'finished'
+                    elif self.epoch == int(m.group(1)) + 1:
+                        conv = 'next'
+                if conv not in ('finished', 'next'):
+                    raise ValueError("unversioned checkpoint %r: cannot tell whether its 'epoch' = %d is the finished epoch or the next one to "
+                                     "run; set option.legacy_ckpt_epoch to 'finished' or 'next'" % (path, self.epoch))
+                if conv == 'finished':
+                    self.epoch += 1
             states = ckpt.get('optimizer_states') or []
             if states and states[0].get('kind') == 'flat_adam' and states[0].get('m') is not None:
                 dev = model.flat_parameters().device

@@ -1,6 +1,8 @@
 """Trainer logic that needs no GPU: the reference's schedules and the checkpoint round trip on a stand-in model."""
 import os
 
+import pytest
+
 import torch
 
 from dualpixelface_amd.config import load_option
@@ -69,10 +71,29 @@ def test_checkpoint_every_epoch_and_resume(tmp_path):
     ck1 = torch.load(tr.checkpoint_path(1), weights_only=False)
     legacy = dict(ck1, epoch=1, global_step=8)
     del legacy['dpf_ckpt_version']
-    torch.save(legacy, str(tmp_path / 'legacy.ckpt'))
+    # the two unversioned generations are told apart by the file name save_checkpoint gives (NN = the finished epoch) -- never guessed
+    os.makedirs(str(tmp_path / 'r1'))
+    torch.save(legacy, str(tmp_path / 'r1' / 'checkpoint_epoch=01.ckpt'))             # round 1: 'epoch' = finished epoch
     tr3 = Trainer(opt, str(tmp_path / 'legacy'), rank=0, world_size=1)
-    tr3.load_checkpoint(_Stub(), str(tmp_path / 'legacy.ckpt'))
+    tr3.load_checkpoint(_Stub(), str(tmp_path / 'r1' / 'checkpoint_epoch=01.ckpt'))
     assert tr3.epoch == 2 and tr3.global_step == 8
+    base = dict(legacy, epoch=2, global_step=8)                                       # later revisions: 'epoch' = next epoch, plain step
+    os.makedirs(str(tmp_path / 'r2'))
+    torch.save(base, str(tmp_path / 'r2' / 'checkpoint_epoch=01.ckpt'))
+    tr5 = Trainer(opt, str(tmp_path / 'legacy2'), rank=0, world_size=1)
+    tr5.load_checkpoint(_Stub(), str(tmp_path / 'r2' / 'checkpoint_epoch=01.ckpt'))
+    assert tr5.epoch == 2 and tr5.global_step == 8
+    torch.save(legacy, str(tmp_path / 'legacy.ckpt'))                                 # renamed file: refuse to guess ...
+    tr6 = Trainer(opt, str(tmp_path / 'legacy3'), rank=0, world_size=1)
+    with pytest.raises(ValueError):
+        tr6.load_checkpoint(_Stub(), str(tmp_path / 'legacy.ckpt'))
+    opt.legacy_ckpt_epoch = 'finished'                                                # ... unless the caller says which
+    tr6.load_checkpoint(_Stub(), str(tmp_path / 'legacy.ckpt'))
+    assert tr6.epoch == 2
+    opt.legacy_ckpt_epoch = 'next'
+    tr6.load_checkpoint(_Stub(), str(tmp_path / 'legacy.ckpt'))
+    assert tr6.epoch == 1
+    del opt.legacy_ckpt_epoch
     pl = dict(legacy, epoch=2, global_step=9)
     pl['pytorch-lightning_version'] = '1.4.9'
     torch.save(pl, str(tmp_path / 'pl.ckpt'))
