@@ -139,6 +139,9 @@ def main():
                     help='BatchNorm statistics over the global batch (what the reference does under DDP); default per-rank statistics')
     ap.add_argument('--shapes', default=None, help='write a per-convolution-shape timing table to this file')
     ap.add_argument('--no-detail', action='store_true', help='skip the two extra untimed steps that time the normalisation / activation launches')
+    ap.add_argument('--force-dist', action='store_true',
+                    help="with --gpus 1: still create a (world-size-1) 'nccl' process group and send every gradient bucket through it -- the "
+                         "staged reducer (tensor-hook launches, side-stream joins, stage_finish, fused Adam) runs through RCCL's stream handling")
     ap.add_argument('--workload', default='train', choices=['train', 'psm_volume', 'cost_volume', 'cost_volume_fix'],
                     help="'train' = the BASELINE metric; the other two time one HBM-bound stage in isolation (BASELINE configs[3], SURVEY a2-a4)")
     args = ap.parse_args()
@@ -162,6 +165,13 @@ def main():
         return stage_bench(args)
     # test hooks (tests/test_gpu_distributed.py): DPF_DIST_BACKEND=gloo and DPF_ONE_DEVICE=1 let two ranks share the one GPU of a test box
     rank, world, local = init_from_env(os.environ.get('DPF_DIST_BACKEND'))
+    if args.force_dist and world == 1 and not dist.is_initialized():
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        torch.cuda.set_device(0)
+        dist.init_process_group(os.environ.get('DPF_DIST_BACKEND') or 'nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or without RANK set)' % (args.gpus, world, args.gpus)
     if os.environ.get('DPF_ONE_DEVICE'):
         local = 0
@@ -175,7 +185,7 @@ def main():
     model = {'psmnet': PSMNET, 'nnet': NNET, 'stereonet': STEREONET}.get(args.model, STEREODPNET)(opt)     # reference initialisation scheme, random weights
     model.to(dev)
     broadcast_flat(model.flat_parameters(), 0)
-    reducer = make_reducer(model) if world > 1 else None
+    reducer = make_reducer(model, force_collectives=args.force_dist) if (world > 1 or args.force_dist) else None
     if args.sync_bn and world > 1:
         model.enable_sync_batchnorm()
     batch = {k: v.to(dev) for k, v in synthetic_batch(args.batch, args.height, args.width, seed=rank).items()}
@@ -228,7 +238,7 @@ def main():
     else:
         prof_steps = args.steps
     ranks_seen = world
-    if world > 1:
+    if world > 1 or (args.force_dist and dist.is_initialized()):
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                                  # every rank contributes 1: the sum is the number of ranks RCCL really joined
         ranks_seen = int(round(float(ones.item())))
@@ -323,6 +333,8 @@ def main():
                        'streams': ('weight gradients on a side stream, left / right feature passes on two streams' if timed_async else 'one stream')},
             'final_loss': loss,
             'rccl_ranks_seen': ranks_seen,
+            'collective_backend': (dist.get_backend() if dist.is_initialized() else None),
+            'gradient_collectives_per_step': (reducer.collective_calls / float(args.warmup + args.steps + (0 if args.no_detail else 4))) if reducer is not None else 0,
             # whole-model fractions of the fp32 peak: against the reference's algorithmic FLOPs (SURVEY section 8d counts all 16 attention
             # calls) and against the FLOPs the kernels executed (compat mode computes 2 of the 16: identical results)
             'flop_frac_of_f32_peak': (value * FLOP_PER_PIXEL_FWD_BWD * pixels / (world * PEAK_F32_TFLOPS * 1e12)) if args.model == 'stereodpnet' else None,

@@ -2399,7 +2399,14 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   // the three tiles; DPF_DCN_OFF_RS=0 selects the fused 4-wave kernel
   static const int use_off_rs = getenv("DPF_DCN_OFF_RS") ? atoi(getenv("DPF_DCN_OFF_RS")) : 1;
   bool rs_done = false;
-  if (region_ok && dx_done && fuse_wg && use_off_rs) {
+  // the model's configuration: lean-sampler kernel of dcn_lean.hip (same dwtmp layout and chunk width as the role-split kernel below)
+  if (region_ok && dx_done && fuse_wg && kd == 3 && kh == 3 && kw == 3 && sd == 1 && sh == 1 && sw == 1 && pd == 1 && ph == 1 && pw == 1 &&
+      dd == 1 && dh == 1 && dw == 1 && CHb == dcn_lean_chunk(C)) {
+    rc = dcn_lean_bwd_offset(input, offset, weight, grad_output, grad_offset, dwtmp, ws, B, C, D, H, W, K, st);
+    if (rc == DPF_OK) rs_done = true;
+    else if (rc != DPF_ERR_UNSUPPORTED) return rc;
+  }
+  if (!rs_done && region_ok && dx_done && fuse_wg && use_off_rs) {
     RegGeo gr{};
     auto lds_of = [&](const RegGeo& qq) { return sizeof(float) * ((size_t)CHb * qq.RV + (size_t)3 * CHb * XS + 2 * 3 * 256); };
     bool ok = false;

@@ -8,6 +8,10 @@
 //
 // weight: the caller's [K][C][27] tensor; ws: workspace of at least dcn_lean_workspace_floats(C, K) floats (weights repacked into the
 // matrix waves' fragment order).
+int dcn_lean_chunk(int C);                              // channel-chunk width (12 or 16) the lean kernels run with
 long long dcn_lean_workspace_floats(int C, int K);
 int dcn_lean_forward(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, int B, int C, int D, int H,
                      int W, int K, hipStream_t st);
+// grad_offset + grad_weight partials: dwtmp[8][27][nchunk][64][16] (zero-initialised by the caller; chunk width dcn_lean_chunk(C)).
+int dcn_lean_bwd_offset(const float* x, const float* offset, const float* weight, const float* go, float* doff, float* dwtmp, float* ws, int B, int C,
+                        int D, int H, int W, int K, hipStream_t st);

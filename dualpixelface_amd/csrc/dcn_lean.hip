@@ -123,7 +123,10 @@ struct LeanTab {
   f32x2 w00, w01, w10, w11;     // weights of (jd, jh) = (0,0), (0,1), (1,0), (1,1), each as the pair (jw = 0, jw = 1)
   int d0, h0, w0;               // kept for the rare sample that leaves the staged box
   float ld, lh, lw;
-  bool inreg;
+  bool inreg;                   // corner block inside the staged box
+  bool slow;                    // a sample the fast path cannot serve: voxel inside the tile's volume part, sample valid (cuh:248), box left
+  f32x2 wz, wy, wx;             // axis factors (low, high); wz carries the in-volume mask of its plane and the validity of the sample
+  f32x2 mz;                     // 1 / 0: depth plane inside the volume and sample usable (coordinate derivative along z)
 };
 
 template <class G>
@@ -134,7 +137,11 @@ __device__ __forceinline__ LeanTab lean_tab(const LeanP& p, bool pvalid, int ry0
   t.d0 = (int)d0f; t.h0 = (int)h0f; t.w0 = (int)w0f;
   const int ly = t.h0 - ry0, lx = t.w0 - rx0;
   t.inreg = (unsigned)ly < (unsigned)(G::RY - 1) && (unsigned)lx < (unsigned)(G::RX - 1);
-  const bool ok = t.inreg && pvalid;
+  // cuh:248: a sample outside (-1, D) x (-1, H) x (-1, W) contributes nothing, not even through its coordinate derivative (the zero-padded
+  // image alone would still hand a derivative to a sample sitting exactly on -1)
+  const bool valid = pvalid && fd > -1.f && fh > -1.f && fw > -1.f && fd < (float)p.D && fh < (float)p.H && fw < (float)p.W;
+  const bool ok = t.inreg && valid;
+  t.slow = valid && !t.inreg;
   // z: the whole depth is staged; planes outside the volume get weight 0 and a clamped index
   const bool mz0 = (unsigned)t.d0 < (unsigned)p.D, mz1 = (unsigned)(t.d0 + 1) < (unsigned)p.D;
   f32x2 wz, wy, wx;
@@ -142,6 +149,8 @@ __device__ __forceinline__ LeanTab lean_tab(const LeanP& p, bool pvalid, int ry0
   wz.y = (ok && mz1) ? t.ld : 0.f;
   wy.x = 1.f - t.lh; wy.y = t.lh;
   wx.x = 1.f - t.lw; wx.y = t.lw;
+  t.wz = wz; t.wy = wy; t.wx = wx;
+  t.mz.x = (ok && mz0) ? 1.f : 0.f; t.mz.y = (ok && mz1) ? 1.f : 0.f;
   const int Dm1 = p.D - 1;
   const int iz0 = min(max(t.d0, 0), Dm1), iz1 = min(max(t.d0 + 1, 0), Dm1);
   const int cell = ok ? __mul24(__mul24(iz0, G::RY) + ly, G::RX) + lx : 0;
@@ -195,11 +204,7 @@ __device__ __forceinline__ void lean_gather(const LeanP& p, const char* region, 
   // ---- samples whose corner block leaves the staged box (rare): the wave redoes them together from global memory.  Lane l takes
   // channel l & 15 and the corner pair (jd, jh) = (l >> 5, (l >> 4) & 1): two loads (jw = 0, 1), then the four pairs are summed
   // across lanes.  (cuh:248: a sample outside (-1, D) x (-1, H) x (-1, W) is zero -- it stays with the zero the fast path wrote.)
-  unsigned long long slow = __ballot(pvalid && !tb.inreg);
-  if (slow) {
-    const bool vvalid = (unsigned)(tb.d0 + 1) <= (unsigned)p.D && (unsigned)(tb.h0 + 1) <= (unsigned)p.H && (unsigned)(tb.w0 + 1) <= (unsigned)p.W;
-    slow = __ballot(pvalid && !tb.inreg && vvalid);
-  }
+  unsigned long long slow = __ballot(tb.slow);
   while (slow) {
     const int L = __builtin_ctzll(slow);
     slow &= slow - 1;
@@ -380,6 +385,292 @@ __global__ __launch_bounds__(128 * G::NS) void dcn_lean_fwd_kernel(const float* 
   }
 }
 
+// ====================================================================================================================================
+// grad_offset + grad_weight (reference: deformable_col2im_coord, deform_im2col_cuda.cuh:111-190,336-405; the grad_weight GEMM,
+// deform_conv_cuda.cu:220-279).  Per (chunk, tap) step:
+//   gcol[c][v] = sum_k W[k][c][t] go[k][v]                      (matrix waves, v_mfma_f32_16x16x4_f32: rows = channels)
+//   S[c][v]    = trilinear sample of x[c] at (v, t);  grad_offset[3t + axis][v] += sum_c gcol[c][v] dS[c][v] / d(coord)     (samplers)
+//   dW[k][c][t] += sum_v go[k][v] S[c][v]                        (matrix waves)
+// Eight waves: 4 samplers (a voxel per lane, all CH channels -- the lean sampler of the forward kernel plus one dot product per corner)
+// and 4 matrix waves that each run BOTH products (on this chip a wave issuing fp32 MFMAs back to back starves the other waves of its
+// SIMD of vector and LDS issue -- tools/lean_probe.hip -- so the two matrix roles of round 3, one wave each, were serialised anyway).
+// Tiles: G[2][q][voxel][4] (gcol, quad planar: the 16x16 MFMA result of a lane IS one quad of one voxel -> one ds_write_b128; the sampler
+// reads its voxel's CH values as NQ ds_read_b128) and S[2][CH][260] (channel major: the weight-gradient B operands of 4 consecutive voxels
+// are one ds_read_b128).  Step i: matrix waves write G(i + 1) and contract S(i - 1); samplers read G(i), write S(i); one barrier.
+constexpr int LEAN_SS = 260;          // padded row of the S tile (floats)
+constexpr int LEAN_NREP = 8;          // replicas of the grad_weight scratch tensor (same layout as dcn3d.hip: [rep][T][nchunk][64][16])
+
+template <class G>
+struct BwdLds {
+  static constexpr int GT = G::NQ * G::SQ;                     // one gcol tile (bytes)
+  static constexpr int ST = G::CH * LEAN_SS * 4;               // one sample tile (bytes)
+  static constexpr int OFF_G = G::NQ * G::PLANE;
+  static constexpr int OFF_S = OFF_G + 2 * GT;
+  static constexpr int LDS = OFF_S + 2 * ST;
+  static_assert(G::NV == 256, "4 sampler waves + 4 matrix waves of 64 voxels");
+};
+
+template <class G>
+__global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                                  const float* __restrict__ wg /*[T][nchunk][64 lanes][16]*/,
+                                                                  const float* __restrict__ go, float* __restrict__ doff, float* __restrict__ dwtmp,
+                                                                  LeanP p) {
+  extern __shared__ __align__(16) char smem[];
+  constexpr int CH = G::CH, NQ = G::NQ, T = 27;
+  typedef BwdLds<G> L;
+  char* region = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int blk = lean_xcd_tile(blockIdx.x, gridDim.x);
+  const int tx = blk % p.tilesX; blk /= p.tilesX;
+  const int ty = blk % p.tilesY;
+  const int b = blk / p.tilesY;
+  const int y0 = ty * G::TY, x0 = tx * G::TX;
+  const int ry0 = y0 - 1 - G::RYH, rx0 = x0 - 1 - G::RXL;
+  const float* xb = x + (long long)b * p.C * p.P;
+  const float* gob = go + (long long)b * p.K * p.P;
+  const int NS = p.nchunk * T;
+  if (wave_u < 4) {
+    // ------------------------------------------------------------------------------------------------------------ samplers
+    const int vox = wave_u * 64 + (lane & 32) + lane_pos32(lane & 31);
+    const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+    const int zo = pz, yo = y0 + py, xo = x0 + px;
+    const bool pvalid = zo < p.D && yo < p.H && xo < p.W;
+    const long long ppos = pvalid ? ((long long)zo * p.H + yo) * p.W + xo : 0;
+    const float* offp0 = offset + (long long)b * 3 * T * p.P + ppos;
+    float* doffp0 = doff + (long long)b * 3 * T * p.P + ppos;
+    const float zbf = (float)(zo - 1), ybf = (float)(yo - 1), xbf = (float)(xo - 1);
+    const long long P3 = 3 * p.P;
+    float od[3], oh[3], ow[3];
+    LeanTab tab = lean_tab<G>(p, pvalid, ry0, rx0, zbf + offp0[0], ybf + offp0[p.P], xbf + offp0[2 * p.P]);
+#pragma unroll
+    for (int u = 1; u <= 3; ++u) { od[u % 3] = offp0[u * P3]; oh[u % 3] = offp0[u * P3 + p.P]; ow[u % 3] = offp0[u * P3 + 2 * p.P]; }
+    lean_stage<G>(p, xb, 0, region, ry0, rx0, tid, 512);
+    __syncthreads();                                   // prologue: region of chunk 0 staged, gcol(0) written
+    int i = 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < p.C; c0 += CH) {
+      if (c0 > 0) {
+        lean_stage<G>(p, xb, c0, region, ry0, rx0, tid, 512);
+        __syncthreads();
+      }
+#pragma unroll 1
+      for (int g = 0; g < 9; ++g) {
+        const int gn = g < 8 ? g + 1 : 0;
+        const int ti = g / 3, tj = g - 3 * ti, tin = gn / 3, tjn = gn - 3 * tin;
+        const float fz_same = zbf + (float)ti, fy_same = ybf + (float)tj, fz_next = zbf + (float)tin, fy_next = ybf + (float)tjn;
+#pragma unroll
+        for (int r = 0; r < 3; ++r, ++i) {
+          const int t = 3 * g + r;
+          const int sl = (r + 1) % 3;
+          const float fdn = (r < 2 ? fz_same : fz_next) + od[sl], fhn = (r < 2 ? fy_same : fy_next) + oh[sl];
+          const float fwn = (xbf + (float)((r + 1) % 3)) + ow[sl];
+          {
+            int u = t + 4;
+            if (u >= T) u -= T;
+            const float* np = offp0 + (long long)u * P3;
+            od[sl] = np[0]; oh[sl] = np[p.P]; ow[sl] = np[2 * p.P];
+          }
+          const char* gt = smem + L::OFF_G + (i & 1) * L::GT + vox * 16;
+          float* st = reinterpret_cast<float*>(smem + L::OFF_S + (i & 1) * L::ST);
+          const char* r0 = region + tab.a0;
+          const char* r1 = region + tab.a1;
+          const f32x2 w00 = pk_mul_lo(pk_mul_lo(tab.wz, tab.wy), tab.wx), w01 = pk_mul_hi(pk_mul_lo(tab.wz, tab.wy), tab.wx);
+          const f32x2 w10 = pk_mul_lo(pk_mul_hi(tab.wz, tab.wy), tab.wx), w11 = pk_mul_hi(pk_mul_hi(tab.wz, tab.wy), tab.wx);
+          f32x4 cr[2][8], gq[2];
+          LEAN_LOAD8(cr[0], 0)
+          gq[0] = *reinterpret_cast<const f32x4*>(gt);
+          LeanTab tabn = lean_tab<G>(p, pvalid, ry0, rx0, fdn, fhn, fwn);      // next tap's table, under the LDS latency
+          f32x2 dot[8];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) {
+              LEAN_LOAD8(cr[(q + 1) & 1], q + 1)
+              gq[(q + 1) & 1] = *reinterpret_cast<const f32x4*>(gt + (q + 1) * G::SQ);
+            }
+            const f32x4* c = cr[q & 1];
+            const f32x2 glo = gq[q & 1].xy, ghi = gq[q & 1].zw;
+            // sample of the quad's 4 channels
+            f32x2 lo = pk_mul_lo(w00, c[0].xy), hi = pk_mul_lo(w00, c[0].zw);
+            pk_fma_hi(lo, w00, c[1].xy); pk_fma_hi(hi, w00, c[1].zw);
+            pk_fma_lo(lo, w01, c[2].xy); pk_fma_lo(hi, w01, c[2].zw);
+            pk_fma_hi(lo, w01, c[3].xy); pk_fma_hi(hi, w01, c[3].zw);
+            pk_fma_lo(lo, w10, c[4].xy); pk_fma_lo(hi, w10, c[4].zw);
+            pk_fma_hi(lo, w10, c[5].xy); pk_fma_hi(hi, w10, c[5].zw);
+            pk_fma_lo(lo, w11, c[6].xy); pk_fma_lo(hi, w11, c[6].zw);
+            pk_fma_hi(lo, w11, c[7].xy); pk_fma_hi(hi, w11, c[7].zw);
+            st[(4 * q + 0) * LEAN_SS + vox] = lo.x; st[(4 * q + 1) * LEAN_SS + vox] = lo.y;
+            st[(4 * q + 2) * LEAN_SS + vox] = hi.x; st[(4 * q + 3) * LEAN_SS + vox] = hi.y;
+            // dot_j += sum over the quad's channels of gcol * corner j (two channels per lane of the packed multiply-add)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (q == 0) dot[j] = glo * c[j].xy; else dot[j] = __builtin_elementwise_fma(glo, c[j].xy, dot[j]);
+              dot[j] = __builtin_elementwise_fma(ghi, c[j].zw, dot[j]);
+            }
+          }
+          // d sample / d coord, factored: A[jd][jh] = sum_jw wx dot, E[jd][jw] = sum_jh wy dot  (dots of corners outside the volume are
+          // zero along y / x because the staged image is; the depth planes carry their masks in wz / mz)
+          float gd, gh, gw;
+          {
+            float d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = dot[j].x + dot[j].y;            // index 4 jd + 2 jh + jw
+            const float wx0 = tab.wx.x, wx1 = tab.wx.y, wy0 = tab.wy.x, wy1 = tab.wy.y, wz0 = tab.wz.x, wz1 = tab.wz.y;
+            const float A00 = fmaf(wx1, d[1], wx0 * d[0]), A01 = fmaf(wx1, d[3], wx0 * d[2]);
+            const float A10 = fmaf(wx1, d[5], wx0 * d[4]), A11 = fmaf(wx1, d[7], wx0 * d[6]);
+            const float E00 = fmaf(wy1, d[2], wy0 * d[0]), E01 = fmaf(wy1, d[3], wy0 * d[1]);
+            const float E10 = fmaf(wy1, d[6], wy0 * d[4]), E11 = fmaf(wy1, d[7], wy0 * d[5]);
+            const float B0 = fmaf(wy1, A01, wy0 * A00), B1 = fmaf(wy1, A11, wy0 * A10);
+            gd = fmaf(tab.mz.y, B1, -tab.mz.x * B0);
+            gh = fmaf(wz1, A11 - A10, wz0 * (A01 - A00));
+            gw = fmaf(wz1, E11 - E10, wz0 * (E01 - E00));
+          }
+          // ---- samples that leave the staged box: the wave redoes them from global memory (lane = channel x corner pair (jd, jh))
+          unsigned long long slow = __ballot(tab.slow);
+          while (slow) {
+            const int Lq = __builtin_ctzll(slow);
+            slow &= slow - 1;
+            const int sd0 = __builtin_amdgcn_readlane(tab.d0, Lq), sh0 = __builtin_amdgcn_readlane(tab.h0, Lq), sw0 = __builtin_amdgcn_readlane(tab.w0, Lq);
+            const float sld = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tab.ld), Lq));
+            const float slh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tab.lh), Lq));
+            const float slw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tab.lw), Lq));
+            const int svox = __builtin_amdgcn_readlane(vox, Lq);
+            const int ch = lane & 15, jd = lane >> 5, jh = (lane >> 4) & 1;
+            const int dz = sd0 + jd, hy = sh0 + jh;
+            const int cgl = c0 + ch;
+            const bool rowin = ch < CH && cgl < p.C && (unsigned)dz < (unsigned)p.D && (unsigned)hy < (unsigned)p.H;
+            const bool in0 = rowin && (unsigned)sw0 < (unsigned)p.W, in1 = rowin && (unsigned)(sw0 + 1) < (unsigned)p.W;
+            const float* xr = xb + (long long)(cgl < p.C ? cgl : 0) * p.P + ((long long)(rowin ? dz : 0) * p.H + (rowin ? hy : 0)) * p.W;
+            const float v0 = in0 ? xr[sw0] : 0.f, v1 = in1 ? xr[sw0 + 1] : 0.f;
+            const float gch = ch < CH ? *reinterpret_cast<const float*>(smem + L::OFF_G + (i & 1) * L::GT + (ch >> 2) * G::SQ + svox * 16 + (ch & 3) * 4) : 0.f;
+            const float wzj = jd ? sld : 1.f - sld, wyj = jh ? slh : 1.f - slh;
+            float part = (wzj * wyj) * fmaf(slw, v1, (1.f - slw) * v0);
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (lane < CH) st[lane * LEAN_SS + svox] = part;
+            float e0 = gch * v0, e1 = gch * v1;          // this channel's share of dot(jd, jh, 0 / 1); summed over the 16 channels of the row
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { e0 += __shfl_xor(e0, m, 64); e1 += __shfl_xor(e1, m, 64); }
+            // every lane of row (jd, jh) now holds that corner pair's two dots; the three derivatives are sums over the four rows
+            const float ex = fmaf(slw, e1, (1.f - slw) * e0);                     // sum_jw wx dot
+            float sgd = (jd ? 1.f : -1.f) * wyj * ex;                              // d/dz: sign of the plane, other factors wy wx
+            float sgh = (jh ? 1.f : -1.f) * wzj * ex;
+            float sgw = wzj * wyj * (e1 - e0);
+            sgd += __shfl_xor(sgd, 16, 64); sgd += __shfl_xor(sgd, 32, 64);
+            sgh += __shfl_xor(sgh, 16, 64); sgh += __shfl_xor(sgh, 32, 64);
+            sgw += __shfl_xor(sgw, 16, 64); sgw += __shfl_xor(sgw, 32, 64);
+            if (lane == Lq) { gd = sgd; gh = sgh; gw = sgw; }
+          }
+          if (pvalid) {
+            float* dq = doffp0 + (long long)(3 * t) * p.P;
+            if (c0 == 0) { dq[0] = gd; dq[p.P] = gh; dq[2 * p.P] = gw; }
+            else { atomicAdd(dq, gd); atomicAdd(dq + p.P, gh); atomicAdd(dq + 2 * p.P, gw); }
+          }
+          tab = tabn;
+          __syncthreads();                             // step barrier
+        }
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------------------ matrix waves
+    const int mw = wave_u - 4, l15 = lane & 15, lg = lane >> 4;
+    // gcol B fragments: go[k = 4 ks + lg][voxel] for this wave's 4 sub-tiles of 16 voxels
+    float bfrag[4][16];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int vox = mw * 64 + s4 * 16 + l15;
+      const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+      const bool ok = pz < p.D && y0 + py < p.H && x0 + px < p.W;
+      const long long gpos = ok ? ((long long)pz * p.H + y0 + py) * p.W + x0 + px : 0;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int k = 4 * ks + lg;
+        bfrag[s4][ks] = (ok && k < p.K) ? gob[(long long)k * p.P + gpos] : 0.f;
+      }
+    }
+    // grad_weight A fragments: go[k = 16 mw + l15][voxel 16 q + 4 lg + u] for k-step 4 q + u
+    float wfrag[64];
+    {
+      const int kk = 16 * mw + l15;
+#pragma unroll
+      for (int ks = 0; ks < 64; ++ks) {
+        const int vox = 16 * (ks >> 2) + 4 * lg + (ks & 3);
+        const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+        const bool ok = kk < p.K && pz < p.D && y0 + py < p.H && x0 + px < p.W;
+        wfrag[ks] = ok ? gob[(long long)kk * p.P + ((long long)pz * p.H + y0 + py) * p.W + x0 + px] : 0.f;
+      }
+    }
+    float* rep = dwtmp + (long long)(blockIdx.x % LEAN_NREP) * T * p.nchunk * 64 * 16;
+    const int brow = (l15 < CH ? l15 : CH - 1) * LEAN_SS + 4 * lg;
+    const unsigned wlane = (unsigned)lane * 64u;
+    auto gcol = [&](int j) {                           // gcol(j) -> G[j & 1]
+      const int chunk = j / T, t = j - chunk * T;
+      const char* wb = reinterpret_cast<const char*>(wg) + (long long)(t * p.nchunk + chunk) * 4096;
+      f32x4 a4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a4[u] = *reinterpret_cast<const f32x4*>(wb + wlane + 16 * u);
+      char* dst = smem + L::OFF_G + (j & 1) * L::GT + lg * G::SQ + (mw * 64 + l15) * 16;
+#pragma unroll
+      for (int sp2 = 0; sp2 < 2; ++sp2) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[ks >> 2][ks & 3], bfrag[2 * sp2 + u][ks], acc[u], 0, 0, 0);
+        if (lg < NQ) {
+          *reinterpret_cast<f32x4*>(dst + (2 * sp2) * 256) = acc[0];            // D rows 4 lg .. 4 lg + 3 = quad lg of voxel (col)
+          *reinterpret_cast<f32x4*>(dst + (2 * sp2 + 1) * 256) = acc[1];
+        }
+      }
+    };
+    gcol(0);
+    lean_stage<G>(p, xb, 0, region, ry0, rx0, tid, 512);
+    __syncthreads();                                   // prologue barrier
+#pragma unroll 1
+    for (int i = 0; i <= NS; ++i) {
+      if (i + 1 < NS) gcol(i + 1);
+      if (i >= 1) {                                    // contract S(i - 1)
+        const int j = i - 1, cs = j / T, ts = j - cs * T;
+        const float* src = reinterpret_cast<const float*>(smem + L::OFF_S + (j & 1) * L::ST) + brow;
+        f32x4 wacc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(src + 16 * qq);
+          wacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[4 * qq + 0], bv.x, wacc[0], 0, 0, 0);
+          wacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[4 * qq + 1], bv.y, wacc[1], 0, 0, 0);
+          wacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[4 * qq + 2], bv.z, wacc[2], 0, 0, 0);
+          wacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[4 * qq + 3], bv.w, wacc[3], 0, 0, 0);
+        }
+        if (l15 < CH && cs * CH + l15 < p.C) {
+          float* dst = rep + ((long long)(ts * p.nchunk + cs) * 64 + 16 * mw + 4 * lg) * 16 + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * mw + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], (wacc[0][r] + wacc[1][r]) + (wacc[2][r] + wacc[3][r]));
+        }
+      }
+      if (i < NS) {
+        __syncthreads();                               // barrier of step i
+        if (i + 1 < NS && (i + 1) % T == 0) {          // step i was the last tap of its chunk: re-stage the region
+          lean_stage<G>(p, xb, ((i + 1) / T) * CH, region, ry0, rx0, tid, 512);
+          __syncthreads();
+        }
+      }
+    }
+  }
+}
+
+// gcol A fragments: wg[tap][chunk][lane][16] with entry ks of lane (l15, lg) = W[k = 4 ks + lg][c = chunk * CH + l15][tap] (zero beyond K / C / CH)
+__global__ void lean_repack_gcol_kernel(const float* __restrict__ w, float* __restrict__ wg, int K, int C, int CH, int nchunk) {
+  const int total = 27 * nchunk * 1024;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ks = i & 15, lane = (i >> 4) & 63;
+    const int r = i >> 10;
+    const int chunk = r % nchunk, t = r / nchunk;
+    const int k = 4 * ks + (lane >> 4), l15 = lane & 15, c = chunk * CH + l15;
+    wg[i] = (k < K && l15 < CH && c < C) ? w[((long long)k * C + c) * 27 + t] : 0.f;
+  }
+}
+
 // Weight fragments in the order the matrix waves consume them: wl[tap][chunk][m][lane][8] with fragment s of lane (l31, hh) =
 // W[k = 32 m + l31][c = chunk * CH + lean_kstep_channel(s, hh)][tap] (zero beyond K / C; CH = 12 uses s < 6), so that a lane fetches its 8
 // fragments of a (tap, chunk, m) block as two 16-byte loads from one uniform base + 32 * lane.
@@ -435,6 +726,22 @@ typedef Geo<12, 2, 32, 5, 7, 4> G12a;   //   256     4 x 14 x 48    153 600   th
 typedef Geo<12, 2, 16, 4, 3, 3> G12b;   //   128     4 x 12 x 24     67 584   two per CU
 typedef Geo<12, 4, 16, 5, 7, 4> G12c;   //   256     4 x 16 x 32    122 880
 
+typedef Geo<16, 4, 16, 4, 3, 3> B16;    //   256     4 x 14 x 24    152 064   backward tiles: region + 2 gcol tiles + 2 sample tiles
+typedef Geo<12, 4, 16, 5, 7, 4> B12;    //   256     4 x 16 x 32    147 840
+
+template <class G>
+int lean_launch_bwd_offset(const float* x, const float* offset, const float* weight, const float* go, float* doff, float* dwtmp, float* ws, LeanP p,
+                           hipStream_t st) {
+  p.tilesY = dpf_div_up(p.H, G::TY);
+  p.tilesX = dpf_div_up(p.W, G::TX);
+  const long long blocks = (long long)p.B * p.tilesY * p.tilesX;
+  if (blocks >= 0x7fffffffLL) return DPF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(lean_repack_gcol_kernel, dim3(dpf_ew_grid(27LL * p.nchunk * 1024)), dim3(256), 0, st, weight, ws, p.K, p.C, G::CH, p.nchunk);
+  if (lean_set_lds(dcn_lean_bwd_offset_kernel<G>, BwdLds<G>::LDS) != DPF_OK) return DPF_ERR_LAUNCH;
+  hipLaunchKernelGGL((dcn_lean_bwd_offset_kernel<G>), dim3((unsigned)blocks), dim3(512), BwdLds<G>::LDS, st, x, offset, ws, go, doff, dwtmp, p);
+  return dpf_check_launch();
+}
+
 }  // namespace
 
 #ifdef DPF_STAMPS
@@ -473,4 +780,22 @@ int dcn_lean_forward(const float* x, const float* offset, const float* weight, c
   if (tile == 'b') return lean_launch_fwd<G12b>(x, offset, weight, bias, out, ws, p, st);
   if (tile == 'a') return lean_launch_fwd<G12a>(x, offset, weight, bias, out, ws, p, st);
   return lean_launch_fwd<G12c>(x, offset, weight, bias, out, ws, p, st);
+}
+
+// grad_offset (fully written) + grad_weight partials into dwtmp[LEAN_NREP = 8][27][nchunk][64][16] (zero-initialised by the caller, folded by
+// dcn3d.hip's dcn_wgrad_fold_kernel with chunk width dcn_lean_chunk(C)).  ws: >= 27 * nchunk * 1024 floats.
+int dcn_lean_bwd_offset(const float* x, const float* offset, const float* weight, const float* go, float* doff, float* dwtmp, float* ws, int B, int C,
+                        int D, int H, int W, int K, hipStream_t st) {
+  static const int lean_env = getenv("DPF_DCN_LEAN") ? atoi(getenv("DPF_DCN_LEAN")) : 1;
+  if (!lean_env || (lean_env & 4) || D > 4 || D < 1 || (W & 3) || K > 64 || (reinterpret_cast<uintptr_t>(x) & 15)) return DPF_ERR_UNSUPPORTED;
+  if ((long long)D * H * W >= 0x7fffffffLL / 4) return DPF_ERR_UNSUPPORTED;
+  const int CH = dcn_lean_chunk(C);
+  LeanP p{};
+  p.B = B; p.C = C; p.K = K; p.D = D; p.H = H; p.W = W;
+  p.Cpad = (C + CH - 1) / CH * CH;
+  p.nchunk = p.Cpad / CH;
+  p.KT = 32 * ((K + 31) / 32);
+  p.P = (long long)D * H * W;
+  if (CH == 16) return lean_launch_bwd_offset<B16>(x, offset, weight, go, doff, dwtmp, ws, p, st);
+  return lean_launch_bwd_offset<B12>(x, offset, weight, go, doff, dwtmp, ws, p, st);
 }

@@ -26,10 +26,22 @@ def init_from_env(backend=None):
         # default timeout: a dead rank or a mismatched training collective fails fast (the long wait for rank-0 validation has its own
         # group, see wait_for_rank0)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    make_wait_group()
     return rank, world, local
 
 
 _wait_group = None
+
+
+def make_wait_group(hours=4.0):
+    """Create the gloo group of wait_for_rank0 NOW -- right after init_process_group, while the ranks are in lock-step.  new_group is a
+    collective over the default group: created lazily at the end of the first epoch (rank 0 still validating, possibly for hours) its
+    store waits would have had to honour the long timeout, and a rank that died before the first call would have left the others inside
+    group construction instead of inside the monitored barrier that is meant to report it."""
+    global _wait_group
+    if _wait_group is None and dist.is_initialized() and dist.get_world_size() > 1:
+        _wait_group = dist.new_group(backend='gloo', timeout=datetime_timeout(hours))
+    return _wait_group
 
 
 def wait_for_rank0(hours=4.0):
@@ -39,9 +51,7 @@ def wait_for_rank0(hours=4.0):
     global _wait_group
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    if _wait_group is None:
-        import datetime
-        _wait_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=hours))
+    make_wait_group(hours)                               # (normally created in init_from_env / Trainer.fit already)
     dist.monitored_barrier(group=_wait_group, timeout=datetime_timeout(hours), wait_all_ranks=False)
 
 
@@ -57,10 +67,19 @@ class FlatGradReducer(object):
     roughly the reverse order, so buckets are cut from the tail.  ``bucket_bounds``: arena offsets that split it.
     """
 
-    def __init__(self, flat_grad, layout, bucket_bounds=None, group=None):
+    def __init__(self, flat_grad, layout, bucket_bounds=None, group=None, force_collectives=None, stage_of=None):
         self.flat = flat_grad
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        # collectives run when there is somebody to talk to -- or when forced (DPF_FORCE_DIST=1 / bench.py --force-dist: a world-size-1
+        # process group still sends every bucket through the backend's stream handling; a one-rank all-reduce(SUM) is the identity)
+        if force_collectives is None:
+            force_collectives = os.environ.get('DPF_FORCE_DIST', '0') == '1'
+        self.collectives = self.world_size > 1 or (bool(force_collectives) and dist.is_initialized())
+        # named stages of the staged exchange: {'aggregation': bucket, 'normal': bucket} -- only buckets whose slice holds exactly the
+        # parameters the network announces under that name (make_reducer checks the layout); anything else waits for stage_finish
+        self.stage_of = dict(stage_of or {})
+        self.collective_calls = 0
         n = flat_grad.numel()
         bounds = sorted(set([0, n] + list(bucket_bounds or [])))
         self.buckets = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
@@ -84,7 +103,8 @@ class FlatGradReducer(object):
 
     def _launch(self, bi):
         lo, hi = self.buckets[bi]
-        if self.world_size > 1:
+        if self.collectives:
+            self.collective_calls += 1
             self._work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
@@ -107,7 +127,8 @@ class FlatGradReducer(object):
 
     def reduce_all(self):
         """One all-reduce(SUM) per bucket over the (already complete) arena; no hooks involved."""
-        if self.world_size > 1:
+        if self.collectives:
+            self.collective_calls += len(self.buckets)
             work = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in self.buckets]
             for w in work:
                 w.wait()
@@ -124,8 +145,9 @@ class FlatGradReducer(object):
         return self._param_bucket.get(id(p))
 
     def stage_launch(self, bi):
-        """Bucket bi sits complete in the arena: enqueue its all-reduce (asynchronous; stage_finish waits)."""
-        if bi in self._staged:
+        """Bucket bi sits complete in the arena: enqueue its all-reduce (asynchronous; stage_finish waits).  A bucket number outside the
+        reducer's range is refused (ignored: stage_finish exchanges whatever was not staged)."""
+        if bi is None or not (0 <= bi < len(self.buckets)) or bi in self._staged:
             return
         self._staged.add(bi)
         self.log.append(('launch', bi))
@@ -150,8 +172,11 @@ def broadcast_flat(flat, src=0, group=None):
         dist.broadcast(flat, src=src, group=group)
 
 
-def make_reducer(model, nbuckets=3):
-    """Reducer for a StereoDPNetCore: buckets cut at the cost-volume and normal-estimator boundaries."""
+def make_reducer(model, nbuckets=3, force_collectives=None):
+    """Reducer for a StereoDPNetCore: buckets cut at the cost-volume and normal-estimator boundaries.  The staged exchange fires NAMED
+    stages ('aggregation' = cost volume + aggregation stack, 'normal' = normal head); a name maps to a bucket only if that bucket's
+    slice holds exactly the parameters of that part of the network -- with other cuts (nbuckets 1 or 2, custom bounds) the name is
+    absent and its gradients travel with stage_finish."""
     flat_g = model.flat_gradients(zero=True)
     pd = dict(model.named_parameters())
     layout = [(pd[name], off, numel) for name, off, numel, _ in model._layout]
@@ -161,7 +186,29 @@ def make_reducer(model, nbuckets=3):
             offs = [off for name, off, _, _ in model._layout if name.startswith(prefix)]
             if offs:
                 bounds.append(min(offs))
-    return FlatGradReducer(flat_g, layout, bounds[:max(0, nbuckets - 1)])
+    red = FlatGradReducer(flat_g, layout, bounds[:max(0, nbuckets - 1)], force_collectives=force_collectives)
+    red.stage_of = stage_names(model, red)
+    return red
+
+
+def stage_names(model, reducer):
+    """{'aggregation': bucket, 'normal': bucket} for the buckets that hold exactly those parts of the network."""
+    def part(name):
+        if name.startswith('normal_estimator'):
+            return 'normal'
+        if name.startswith('feature_extraction'):
+            return 'features'
+        return 'aggregation'                              # cost volume + aggregation stack + heads
+    members = {}
+    for name, off, _, _ in model._layout:
+        for bi, (lo, hi) in enumerate(reducer.buckets):
+            if lo <= off < hi:
+                members.setdefault(bi, set()).add(part(name))
+    out = {}
+    for bi, parts in members.items():
+        if len(parts) == 1 and next(iter(parts)) in ('aggregation', 'normal'):
+            out[next(iter(parts))] = bi
+    return out
 
 
 class StatExchange(object):

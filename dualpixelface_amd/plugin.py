@@ -12,7 +12,7 @@ from .selectors import metric_selector, optimizer_selector, scheduler_selector
 from .nnet import NNetCore
 from .psmnet import PSMNetCore
 from .stereonet import StereoNetCore
-from .stereodpnet import StereoDPNetCore
+from .stereodpnet import StereoDPNetCore, two_stream_grad_warning_off
 
 
 class _PluginHooks(object):
@@ -124,14 +124,19 @@ class _PluginHooks(object):
                 for p, v in sel:
                     p.grad = v
 
-            staged = reducer is not None and reducer.world_size > 1 and getattr(self, 'stage_grads', True)
+            staged = reducer is not None and getattr(reducer, 'collectives', reducer.world_size > 1) and getattr(self, 'stage_grads', True)
             if staged:
                 # Data-parallel: the network fires self._grad_stage(bucket) from tensor hooks at its bucket boundaries (normal head done;
                 # aggregation + cost volume done); that bucket is gathered and its all-reduce enqueued while the backward pass continues.
                 reducer.stage_begin()
                 main = torch.cuda.current_stream() if flat_g.is_cuda else None
 
-                def on_stage(bi):
+                def on_stage(name):
+                    # `name`: 'aggregation' | 'normal' (StereoDPNetCore._network).  A reducer cut differently has no bucket of that name:
+                    # nothing is staged then and stage_finish exchanges everything after backward().
+                    bi = reducer.stage_of.get(name) if hasattr(reducer, 'stage_of') else None
+                    if bi is None:
+                        return
                     # The hook may fire on another stream than the step's (the second feature pass has its own): the bucket's gradients
                     # were produced on the main stream (and the weight-gradient side stream), and Adam will read the arena there -- so the
                     # gather and the collective are enqueued on the main stream, after whatever the hook's stream has produced so far.
@@ -146,8 +151,9 @@ class _PluginHooks(object):
                 self._grad_stage = on_stage
             self._two_streams_ok = True            # see StereoDPNetCore._network
             try:
-                results = self.forward(batch)
-                results['final_loss'].backward()
+                with two_stream_grad_warning_off():
+                    results = self.forward(batch)
+                    results['final_loss'].backward()
             finally:
                 self._grad_stage = None
                 self._two_streams_ok = False

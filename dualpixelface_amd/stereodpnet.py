@@ -179,9 +179,26 @@ def build_spec(opt):
 
 # left / right feature passes on two HIP streams in training (224.1 -> 221.5 ms per step); DPF_FEATURES_TWO_STREAMS=0: one after the other
 FEATURES_TWO_STREAMS = os.environ.get('DPF_FEATURES_TWO_STREAMS', '1') == '1'
-if FEATURES_TWO_STREAMS and hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
-    # the shared feature extractor's parameters receive gradients from both streams: intended
-    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+
+class two_stream_grad_warning_off(object):
+    """The shared feature extractor's parameters receive gradients from both streams of the two-stream step: intended.  torch's
+    accumulate-grad stream-mismatch warning is switched off only around that step (plugin.train_step) and restored afterwards, so a host
+    application embedding the plugin keeps the diagnostic for its own models."""
+
+    def __enter__(self):
+        self.had = None
+        g = torch.autograd.graph
+        if FEATURES_TWO_STREAMS and hasattr(g, 'set_warn_on_accumulate_grad_stream_mismatch'):
+            probe = getattr(torch._C, '_warn_on_accumulate_grad_stream_mismatch', None)      # the current setting (default: warn)
+            self.had = bool(probe()) if callable(probe) else True
+            g.set_warn_on_accumulate_grad_stream_mismatch(False)
+        return self
+
+    def __exit__(self, *exc):
+        if self.had is not None:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(self.had)
+        return False
 
 
 class StereoDPNetCore(_Base):
@@ -607,13 +624,13 @@ class StereoDPNetCore(_Base):
             tar = self._features(batch[b])
         stage = getattr(self, '_grad_stage', None)          # data-parallel step: gradient buckets are exchanged as they complete
         if stage is not None and ref.requires_grad:
-            # bucket 1 (cost volume + aggregation) is complete once the gradients of BOTH feature maps exist
+            # stage 'aggregation' (cost volume + aggregation stack) is complete once the gradients of BOTH feature maps exist
             left = [2]
 
             def feat_hook(g):
                 left[0] -= 1
                 if left[0] == 0:
-                    stage(1)
+                    stage('aggregation')
                 return g
             ref.register_hook(feat_hook)
             tar.register_hook(feat_hook)
@@ -623,8 +640,8 @@ class StereoDPNetCore(_Base):
         normal = None
         if opt.model.predict_normal:
             if stage is not None and costs[0].requires_grad:
-                # bucket 2 (normal head): done when the (summed) gradient of its input reaches the aggregation stack
-                costs[0].register_hook(lambda g: (stage(2), g)[1])
+                # stage 'normal' (normal head): done when the (summed) gradient of its input reaches the aggregation stack
+                costs[0].register_hook(lambda g: (stage('normal'), g)[1])
             normal, _, _ = self._normals(costs[0], preds[0], batch)
         return {'pred_depth': pred_all, 'prob_depth': prob_all,
                 'pred_normal': normal.unsqueeze(1) if normal is not None else None,

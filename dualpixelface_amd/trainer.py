@@ -175,6 +175,7 @@ class Trainer(object):
                 val_loader = None
         if getattr(opt, 'load_model', None) and getattr(opt, 'mode', 'train') == 'train':
             self.load_checkpoint(model, opt.load_model, resume=bool(getattr(opt, 'load_strict', True)))
+        dd.make_wait_group()                                 # while the ranks are in lock-step (see distributed.make_wait_group)
         dd.broadcast_flat(model.flat_parameters(), 0)
         reducer = dd.make_reducer(model) if self.world_size > 1 else None
         if self.world_size > 1 and getattr(opt, 'sync_batch', False):

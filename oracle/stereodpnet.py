@@ -239,7 +239,15 @@ class StereoDPNetOracle(object):
         disp = F.interpolate(disp_full.unsqueeze(1), scale_factor=0.25, mode='nearest') * 0.25
         cr = torch.tensor(cfg.costrange, dtype=torch.float32).view(1, -1, 1, 1).to(cost.dtype)
         diff = torch.abs(cr - disp)
-        _, idx = torch.topk(1.0 / (diff + 1e-6), k=cfg.dsample_num, dim=1)            # :130-131
+        score = 1.0 / (diff + 1e-6)
+        if getattr(self, 'topk_ties', 'torch') == 'cuda':
+            # torch.topk leaves the choice among EQUAL scores at the k-th place to its backend.  The reference runs on CUDA, whose top-k
+            # (radix select of the k-th value, then everything above it and the elements equal to it in index order) keeps the lowest
+            # indices; the CPU backend (std::nth_element) keeps whatever its partition leaves.  'cuda' states the CUDA rule explicitly
+            # (stable descending sort); away from exact ties the two agree.
+            idx = torch.sort(score, dim=1, descending=True, stable=True)[1][:, :cfg.dsample_num]
+        else:
+            _, idx = torch.topk(score, k=cfg.dsample_num, dim=1)                      # :130-131
         idx = torch.sort(idx, dim=1)[0]
         sq_cost = torch.gather(costv, 1, idx.unsqueeze(2).expand(-1, -1, C, -1, -1))
         sq_disp = torch.gather(cr.expand(B, D, h, w), 1, idx)

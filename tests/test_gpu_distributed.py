@@ -160,3 +160,87 @@ def test_bench_self_launch_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 and d['value'] > 0
+
+
+def _nccl_one_rank_worker(port, out):
+    """One rank, backend 'nccl' (= RCCL): the staged reducer's collectives really go through ProcessGroupNCCL -- its own stream, the
+    event hand-over from the stream the bucket was gathered on, work.wait() before Adam -- next to the weight-gradient side stream and the
+    second feature stream.  A one-rank all-reduce(SUM) is the identity, so every bucket must come back bit for bit."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from dualpixelface_amd.distributed import make_reducer
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    try:
+        from dualpixelface_amd.recipe import synthetic_batch
+        batch = {k: v.cuda() for k, v in synthetic_batch(2, 64, 96, seed=11).items()}
+        model = _model()
+        reducer = make_reducer(model, force_collectives=True)
+        assert reducer.collectives and reducer.world_size == 1 and reducer.stage_of == {'aggregation': 1, 'normal': 2}
+        sent = {}
+        launch = reducer._launch
+
+        def spy(bi):                                   # what the bucket holds when its all-reduce is enqueued (same stream: after the gather)
+            lo, hi = reducer.buckets[bi]
+            sent[bi] = reducer.flat[lo:hi].clone()
+            launch(bi)
+        reducer._launch = spy
+        res = model.train_step(batch, reducer)
+        torch.cuda.synchronize()
+        order = list(reducer.log)
+        flat = model.flat_gradients(zero=False)
+        same = all(torch.equal(flat[lo:hi], sent[bi]) for bi, (lo, hi) in enumerate(reducer.buckets))
+        # the twin without a reducer (no collectives at all): same weights, same batch
+        twin = _model()
+        res2 = twin.train_step(batch)
+        torch.cuda.synchronize()
+        g1, g2 = flat.double().cpu(), twin.flat_gradients(zero=False).double().cpu()
+        p1, p2 = model.flat_parameters().double().cpu(), twin.flat_parameters().double().cpu()
+        ones = torch.ones(1, device='cuda')
+        dist.all_reduce(ones)
+        out.update(order=order, same=bool(same), nsent=len(sent), calls=reducer.collective_calls, backend=dist.get_backend(),
+                   ranks_seen=float(ones.item()), loss=(float(res['final_loss']), float(res2['final_loss'])),
+                   grad_rel=float((g1 - g2).norm() / g2.norm()), grad_finite=bool(torch.isfinite(g1).all()),
+                   param_maxdiff=float((p1 - p2).abs().max()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_nccl_staged_exchange_is_the_identity():
+    """no multi-GPU box exists in the build pool, but a world-size-1 'nccl' group on the one GPU runs exactly the path
+    that had never run -- dist.all_reduce(async_op=True) issued from autograd-thread tensor hooks next to the side streams."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        p = ctx.Process(target=_nccl_one_rank_worker, args=(port, out))
+        p.start()
+        p.join(600)
+        assert p.exitcode == 0, 'nccl worker failed (exit code %r)' % (p.exitcode,)
+        out = dict(out)
+    assert out['backend'] == 'nccl' and out['ranks_seen'] == 1.0
+    assert out['order'] == [('launch', 2), ('launch', 1), ('backward_done',), ('launch', 0)], out['order']
+    assert out['calls'] == 3 and out['nsent'] == 3
+    assert out['same'], 'a bucket changed on its way through the one-rank all-reduce (stream ordering?)'
+    assert out['grad_finite']
+    # against the step without any reducer: equal up to the run-to-run noise of the float atomics (DESIGN section 2)
+    assert abs(out['loss'][0] - out['loss'][1]) <= 1e-5 * abs(out['loss'][1]), out['loss']
+    assert out['grad_rel'] <= 2e-3, out['grad_rel']
+    assert out['param_maxdiff'] <= 2.1e-4, out['param_maxdiff']       # one Adam step moves a parameter by at most lr = 1e-4 either way
+
+
+def test_bench_force_dist_one_rank_nccl():
+    """bench.py --gpus 1 --force-dist: the JSON line reports the backend, the ranks RCCL saw and 3 gradient collectives per step."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '2', '--warmup', '1', '--batch', '1',
+                        '--height', '64', '--width', '96', '--no-cpu-baseline', '--no-detail'], env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['collective_backend'] == 'nccl' and line['rccl_ranks_seen'] == 1 and line['n_gpus'] == 1
+    assert abs(line['gradient_collectives_per_step'] - 3.0) < 1e-9, line['gradient_collectives_per_step']

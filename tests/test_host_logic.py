@@ -148,3 +148,31 @@ def test_reference_style_plugin_entry():
         assert 'COSINELoss' in run_path(os.path.join('src', 'loss', 'normal', 'cosine.py'))
     finally:
         os.chdir(cwd)
+
+
+def test_reducer_stage_names_follow_the_bucket_cut():
+    """The staged gradient exchange fires NAMED stages; a name maps to a bucket only when that bucket holds exactly that part of the network
+    (hard-coded bucket numbers raised IndexError / exchanged half-built buckets with other cuts)."""
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.plugin import STEREODPNET
+    from dualpixelface_amd.distributed import make_reducer, FlatGradReducer, stage_names
+    model = STEREODPNET(load_option())
+    r3 = make_reducer(model, nbuckets=3)
+    assert r3.stage_of == {'aggregation': 1, 'normal': 2} and len(r3.buckets) == 3
+    r3.remove()
+    r2 = make_reducer(model, nbuckets=2)
+    assert r2.stage_of == {} and len(r2.buckets) == 2             # aggregation and normal head share a bucket: nothing is staged early
+    r2.stage_begin()
+    r2.stage_launch(None); r2.stage_launch(7); r2.stage_launch(-1)  # refused, no IndexError
+    assert r2.log == []
+    r2.remove()
+    r1 = make_reducer(model, nbuckets=1)
+    assert r1.stage_of == {} and len(r1.buckets) == 1
+    r1.remove()
+    # a cut INSIDE the feature extractor: bucket 1 would mix feature and aggregation parameters -> unnamed
+    pd = dict(model.named_parameters())
+    layout = [(pd[name], off, numel) for name, off, numel, _ in model._layout]
+    mid = layout[10][1]
+    rc = FlatGradReducer(model.flat_gradients(zero=True), layout, [mid])
+    assert stage_names(model, rc) == {}
+    rc.remove()
