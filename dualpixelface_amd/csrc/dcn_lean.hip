@@ -113,8 +113,11 @@ __device__ __forceinline__ int lean_kstep_channel(int s, int hh) {
 __device__ unsigned long long g_lean_stamps[16 * 128 * 4];
 #define LEAN_STAMP(step, slot)                                                                                          \
   if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_lean_stamps[(wave_u * 128 + (step)) * 4 + (slot)] = __builtin_readcyclecounter();
+#define LEAN_STAMP4(step, slot) \
+  if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_lean_stamps[((wave_u + 8) * 128 + (step)) * 4 + (slot)] = __builtin_readcyclecounter();
 #else
 #define LEAN_STAMP(step, slot)
+#define LEAN_STAMP4(step, slot)
 #endif
 
 // Per (voxel, tap) table of the sampler: where the 2 x 2 x 2 corner block sits in the staged region and the eight trilinear weights.
@@ -381,6 +384,246 @@ __global__ __launch_bounds__(128 * G::NS) void dcn_lean_fwd_kernel(const float* 
             if (k < p.K) out[((long long)b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
           }
       }
+    }
+  }
+}
+
+// ---- forward, second form: every wave samples AND contracts its own 64 voxels.  Measured on this chip (tools/lean_probe.hip,
+// tools/lean_probe2.hip): an fp32 MFMA and vector-ALU work never overlap on a SIMD -- not across waves (a wave issuing MFMAs back to back
+// starves its SIMD partner of vector and LDS issue) and not inside one wave (4 v_pk_fma_f32 behind a 64-clock MFMA cost 34 clocks) -- but
+// LDS reads issued by the SAME wave between its MFMAs are nearly free (2 ds_read_b128 per MFMA: +7 clocks).  So the role split bought no
+// overlap (step = sampler alone + matrix wave alone, stamps in DESIGN section 4) while paying a barrier per tap and an LDS round trip of the
+// samples.  Here a wave issues the corner reads of tap t + 1 in the shadow of its MFMAs of tap t, accumulates them afterwards, and turns
+// its own samples into the B operands of both 32-voxel column tiles with v_permlane32_swap_b32 (channel pair (2s, 2s + 1) of the low half's
+// voxels becomes k-step s of tile 0, of the high half's voxels of tile 1): no sample tile in LDS, no barrier inside a chunk.
+template <int CH>
+__global__ void lean_repack_fwd1_kernel(const float* __restrict__ w, float* __restrict__ wl, int K, int C, int MT, int nchunk) {
+  // wl[tap][chunk][m][lane][8]: fragment s of lane (l31, hh) = W[k = 32 m + l31][c = chunk * CH + 2 s + hh][tap] (zero beyond K / C / CH)
+  const int total = 27 * nchunk * MT * 512;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int s = i & 7, lane = (i >> 3) & 63;
+    int r = i >> 9;
+    const int m = r % MT; r /= MT;
+    const int chunk = r % nchunk;
+    const int t = r / nchunk;
+    const int k = 32 * m + (lane & 31), cl = 2 * s + (lane >> 5), c = chunk * CH + cl;
+    wl[i] = (cl < CH && k < K && c < C) ? w[((long long)k * C + c) * 27 + t] : 0.f;
+  }
+}
+
+template <class G, int MT>
+__global__ __launch_bounds__(256, 2) void dcn_lean_fwd1_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                            const float* __restrict__ wl, const float* __restrict__ bias,
+                                                            float* __restrict__ out, LeanP p) {
+  extern __shared__ __align__(16) char smem[];
+  constexpr int CH = G::CH, NQ = G::NQ, KSTEPS = CH / 2, T = 27;
+  static_assert(G::NV == 256, "four waves of 64 voxels");
+  char* region = smem;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int blk = lean_xcd_tile(blockIdx.x, gridDim.x);
+  const int tx = blk % p.tilesX; blk /= p.tilesX;
+  const int ty = blk % p.tilesY;
+  const int b = blk / p.tilesY;
+  const int y0 = ty * G::TY, x0 = tx * G::TX;
+  const int ry0 = y0 - 1 - G::RYH, rx0 = x0 - 1 - G::RXL;
+  const float* xb = x + (long long)b * p.C * p.P;
+  const int vox = wave_u * 64 + (lane & 32) + lane_pos32(l31);
+  const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+  const int zo = pz, yo = y0 + py, xo = x0 + px;
+  const bool pvalid = zo < p.D && yo < p.H && xo < p.W;
+  const long long ppos = pvalid ? ((long long)zo * p.H + yo) * p.W + xo : 0;
+  const float* offp0 = offset + (long long)b * 3 * T * p.P + ppos;
+  const float zbf = (float)(zo - 1), ybf = (float)(yo - 1), xbf = (float)(xo - 1);
+  const long long P3 = 3 * p.P;
+  const unsigned wlane = (unsigned)lane * 32u;
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][nt][j] = 0.f;
+
+  // accumulate two quads of a tap from their 8 corner reads each into 4 + 4 sample registers (four independent multiply-add chains)
+  auto accum2 = [&](const LeanTab& tb, const f32x4* c, const f32x4* e, float* sv, float* su, bool both) {
+    const f32x2 zy0 = pk_mul_lo(tb.wz, tb.wy), zy1 = pk_mul_hi(tb.wz, tb.wy);
+    const f32x2 w00 = pk_mul_lo(zy0, tb.wx), w01 = pk_mul_hi(zy0, tb.wx), w10 = pk_mul_lo(zy1, tb.wx), w11 = pk_mul_hi(zy1, tb.wx);
+    f32x2 lo = pk_mul_lo(w00, c[0].xy), hi = pk_mul_lo(w00, c[0].zw), l2 = {0.f, 0.f}, h2 = {0.f, 0.f};
+    if (both) { l2 = pk_mul_lo(w00, e[0].xy); h2 = pk_mul_lo(w00, e[0].zw); }
+#define LEAN_ACC(J, W, HL)                                                                    \
+    pk_fma_##HL(lo, W, c[J].xy); pk_fma_##HL(hi, W, c[J].zw);                                 \
+    if (both) { pk_fma_##HL(l2, W, e[J].xy); pk_fma_##HL(h2, W, e[J].zw); }
+    LEAN_ACC(1, w00, hi) LEAN_ACC(2, w01, lo) LEAN_ACC(3, w01, hi) LEAN_ACC(4, w10, lo) LEAN_ACC(5, w10, hi) LEAN_ACC(6, w11, lo) LEAN_ACC(7, w11, hi)
+#undef LEAN_ACC
+    sv[0] = lo.x; sv[1] = lo.y; sv[2] = hi.x; sv[3] = hi.y;
+    if (both) { su[0] = l2.x; su[1] = l2.y; su[2] = h2.x; su[3] = h2.y; }
+  };
+  // samples that leave the staged box: redone by the wave from global memory (lane = channel x corner pair), then handed to the owning lane
+  auto slow_fix = [&](const LeanTab& tb, float* sv, int c0) {
+    unsigned long long slow = __ballot(tb.slow);
+    while (slow) {
+      const int L = __builtin_ctzll(slow);
+      slow &= slow - 1;
+      const int sd0 = __builtin_amdgcn_readlane(tb.d0, L), sh0 = __builtin_amdgcn_readlane(tb.h0, L), sw0 = __builtin_amdgcn_readlane(tb.w0, L);
+      const float sld = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.ld), L));
+      const float slh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.lh), L));
+      const float slw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.lw), L));
+      const int ch = lane & 15, jd = lane >> 5, jh = (lane >> 4) & 1;
+      const int dz = sd0 + jd, hy = sh0 + jh;
+      const int cgl = c0 + ch;
+      const bool rowin = ch < CH && cgl < p.C && (unsigned)dz < (unsigned)p.D && (unsigned)hy < (unsigned)p.H;
+      const bool in0 = rowin && (unsigned)sw0 < (unsigned)p.W, in1 = rowin && (unsigned)(sw0 + 1) < (unsigned)p.W;
+      const float* xr = xb + (long long)(cgl < p.C ? cgl : 0) * p.P + ((long long)(rowin ? dz : 0) * p.H + (rowin ? hy : 0)) * p.W;
+      const float v0 = in0 ? xr[sw0] : 0.f, v1 = in1 ? xr[sw0 + 1] : 0.f;
+      const float wzy = (jd ? sld : 1.f - sld) * (jh ? slh : 1.f - slh);
+      float part = fmaf(wzy * slw, v1, (wzy * (1.f - slw)) * v0);
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);                // lanes 0 .. 15 (and their copies) hold channel `lane & 15` of voxel L
+#pragma unroll
+      for (int ch2 = 0; ch2 < CH; ++ch2) {
+        const float vch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), ch2));
+        if (lane == L) sv[ch2] = vch;
+      }
+    }
+  };
+
+  // offsets ring: slot (u % 3) holds tap u's three components, fetched four taps ahead
+  float od[3], oh[3], ow[3];
+  LeanTab tab = lean_tab<G>(p, pvalid, ry0, rx0, zbf + offp0[0], ybf + offp0[p.P], xbf + offp0[2 * p.P]);
+#pragma unroll
+  for (int u = 1; u <= 3; ++u) { od[u % 3] = offp0[u * P3]; oh[u % 3] = offp0[u * P3 + p.P]; ow[u % 3] = offp0[u * P3 + 2 * p.P]; }
+
+  LeanTab tab1;                                        // tap 1's table while tap 0 is gathered at a chunk's start
+  // one tap: contract tap t (samples in `cur`, weight fragments in `a`) while the corners of tap t + 1 are read; then accumulate tap t + 1
+  // into `nxt`.  `tab` is tap t + 1's table on entry and tap t + 2's on exit.  last: tap t + 1 belongs to the next chunk (nothing to read).
+  auto body = [&](int t, int chunk, int c0, float (&cur)[16], float (&nxt)[16], f32x4 (&a)[MT][2], f32x4 (&an)[MT][2], bool last) {
+    // next tap's weight fragments (L2) and the tap after next's offsets (HBM)
+    {
+      const int tn = t + 1 < T ? t + 1 : 0, cn = t + 1 < T ? chunk : (chunk + 1 < p.nchunk ? chunk + 1 : chunk);
+      const char* wb = reinterpret_cast<const char*>(wl) + ((long long)(tn * p.nchunk + cn) * MT) * 2048;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        an[m][0] = *reinterpret_cast<const f32x4*>(wb + wlane + m * 2048);
+        an[m][1] = *reinterpret_cast<const f32x4*>(wb + wlane + m * 2048 + 16);
+      }
+    }
+    // B operands of both column tiles from this wave's own samples
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(cur[2 * s]), "+v"(cur[2 * s + 1]));
+    const char* r0 = region + tab.a0;
+    const char* r1 = region + tab.a1;
+    f32x4 cr[2][8];
+    auto mfmas = [&](int s0, int s1) {
+#pragma unroll
+      for (int s = s0; s < s1; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s >> 2][s & 3], cur[2 * s + nt], acc[m][nt], 0, 0, 0);
+    };
+    // phase 1: k-steps of quads 0, 1 | corner reads of quads 0, 1 of the next tap
+    __builtin_amdgcn_sched_barrier(0);
+    if (chunk == 1) { LEAN_STAMP4(t, 0) }
+    if (!last) { LEAN_LOAD8(cr[0], 0) LEAN_LOAD8(cr[1], 1) }
+    mfmas(0, 4);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    // (hard fences between the phases: vector-ALU work scheduled in between MFMAs costs a pipe switch each time -- 4 v_pk_fma_f32 behind
+    // an MFMA: +34 clocks, tools/lean_probe2.hip)
+    __builtin_amdgcn_sched_barrier(0);
+    if (chunk == 1) { LEAN_STAMP4(t, 1) }
+    if (!last) accum2(tab, cr[0], cr[1], nxt, nxt + 4, true);
+    __builtin_amdgcn_sched_barrier(0);
+    if (chunk == 1) { LEAN_STAMP4(t, 2) }
+    // phase 2: remaining k-steps | corner reads of the remaining quads
+    if (!last) {
+      LEAN_LOAD8(cr[0], 2)
+      if (NQ > 3) { LEAN_LOAD8(cr[1], 3) }
+    }
+    mfmas(4, KSTEPS);
+#pragma unroll
+    for (int i = 0; i < 4 * (KSTEPS - 4); ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (chunk == 1) { LEAN_STAMP4(t, 3) }
+    if (!last) {
+      accum2(tab, cr[0], cr[1], nxt + 8, nxt + 12, NQ > 3);
+      slow_fix(tab, nxt, c0);
+    }
+    // table of the tap after next (tap t + 2; over the chunk boundary: tap t + 2 - 27 of the next chunk)
+    {
+      int u = t + 2;
+      if (u >= T) u -= T;
+      const int ti = u / 9, tj = (u - 9 * ti) / 3, tk = u - 9 * ti - 3 * tj;
+      const int sl = u % 3;                            // ring slots follow the tap number modulo 3 (27 = 0 mod 3: continuous over chunks)
+      const float fdn = (zbf + (float)ti) + od[sl], fhn = (ybf + (float)tj) + oh[sl], fwn = (xbf + (float)tk) + ow[sl];
+      int v = u + 3;                                   // refill the slot with the tap three further on
+      if (v >= T) v -= T;
+      const float* np = offp0 + (long long)v * P3;
+      od[sl] = np[0]; oh[sl] = np[p.P]; ow[sl] = np[2 * p.P];
+      const LeanTab tn2 = lean_tab<G>(p, pvalid, ry0, rx0, fdn, fhn, fwn);
+      if (last) tab1 = tn2;                            // tap 26: `tab` already is tap 0's table of the next chunk, this one is tap 1's
+      else tab = tn2;
+    }
+  };
+
+  float sA[16], sB[16];
+  f32x4 aA[MT][2], aB[MT][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { sA[i] = 0.f; sB[i] = 0.f; }
+  {
+    const float fd1 = zbf + od[1], fh1 = ybf + oh[1], fw1 = (xbf + 1.f) + ow[1];      // tap 1 = (ti, tj, tk) = (0, 0, 1)
+    const float* np = offp0 + 4 * P3;
+    od[1] = np[0]; oh[1] = np[p.P]; ow[1] = np[2 * p.P];
+    tab1 = lean_tab<G>(p, pvalid, ry0, rx0, fd1, fh1, fw1);
+  }
+  int chunk = 0;
+#pragma unroll 1
+  for (int c0 = 0; c0 < p.C; c0 += CH, ++chunk) {
+    __syncthreads();                                   // every wave is done with the previous chunk's region
+    lean_stage<G>(p, xb, c0, region, ry0, rx0, tid, 256);
+    {                                                  // this chunk's first weight fragments
+      const char* wb = reinterpret_cast<const char*>(wl) + ((long long)chunk * MT) * 2048;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        aA[m][0] = *reinterpret_cast<const f32x4*>(wb + wlane + m * 2048);
+        aA[m][1] = *reinterpret_cast<const f32x4*>(wb + wlane + m * 2048 + 16);
+      }
+    }
+    __syncthreads();
+    {                                                  // tap 0 of the chunk: nothing to contract yet
+      const char* r0 = region + tab.a0;
+      const char* r1 = region + tab.a1;
+      f32x4 cr[2][8];
+      LEAN_LOAD8(cr[0], 0) LEAN_LOAD8(cr[1], 1)
+      accum2(tab, cr[0], cr[1], sA, sA + 4, true);
+      LEAN_LOAD8(cr[0], 2)
+      if (NQ > 3) { LEAN_LOAD8(cr[1], 3) }
+      accum2(tab, cr[0], cr[1], sA + 8, sA + 12, NQ > 3);
+      slow_fix(tab, sA, c0);
+      tab = tab1;
+    }
+#pragma unroll 1
+    for (int t = 0; t < T - 1; t += 2) {               // taps 0 .. 25 in pairs (two register sets alternate), tap 26 below
+      body(t, chunk, c0, sA, sB, aA, aB, false);
+      body(t + 1, chunk, c0, sB, sA, aB, aA, false);
+    }
+    body(T - 1, chunk, c0, sA, sB, aA, aB, true);      // leaves tap 0's table of the next chunk in `tab`, tap 1's in `tab1`
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int vo = wave_u * 64 + nt * 32 + lane_pos32(l31);      // column n of tile nt is the voxel the sampler lane (l31, nt) owns
+    const int qx = vo % G::TX, qy = (vo / G::TX) % G::TY, qz = vo / (G::TX * G::TY);
+    const int gz = qz, gy = y0 + qy, gx = x0 + qx;
+    if (gz < p.D && gy < p.H && gx < p.W) {
+      const long long pos = ((long long)gz * p.H + gy) * p.W + gx;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (k < p.K) out[((long long)b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
+        }
     }
   }
 }
@@ -718,6 +961,26 @@ int lean_launch_fwd(const float* x, const float* offset, const float* weight, co
   return dpf_check_launch();
 }
 
+template <class G>
+int lean_launch_fwd1(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, LeanP p, hipStream_t st) {
+  p.tilesY = dpf_div_up(p.H, G::TY);
+  p.tilesX = dpf_div_up(p.W, G::TX);
+  const long long blocks = (long long)p.B * p.tilesY * p.tilesX;
+  if (blocks >= 0x7fffffffLL) return DPF_ERR_UNSUPPORTED;
+  const int MT = p.KT / 32;
+  constexpr int LDS = G::NQ * G::PLANE;
+  hipLaunchKernelGGL((lean_repack_fwd1_kernel<G::CH>), dim3(dpf_ew_grid(27LL * p.nchunk * MT * 512)), dim3(256), 0, st, weight, ws, p.K, p.C, MT, p.nchunk);
+  const dim3 grid((unsigned)blocks), block(256);
+  if (MT == 1) {
+    if (lean_set_lds(dcn_lean_fwd1_kernel<G, 1>, LDS) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL((dcn_lean_fwd1_kernel<G, 1>), grid, block, LDS, st, x, offset, ws, bias, out, p);
+  } else {
+    if (lean_set_lds(dcn_lean_fwd1_kernel<G, 2>, LDS) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL((dcn_lean_fwd1_kernel<G, 2>), grid, block, LDS, st, x, offset, ws, bias, out, p);
+  }
+  return dpf_check_launch();
+}
+
 //                  CH TY  TX RYH RXL RXR      voxels  region cells    LDS
 typedef Geo<16, 2, 32, 3, 3, 3> G16a;   //   256     4 x 10 x 40    135 168   one workgroup per CU
 typedef Geo<16, 2, 16, 3, 3, 3> G16b;   //   128     4 x 10 x 24     77 824   two per CU
@@ -725,6 +988,7 @@ typedef Geo<16, 4, 16, 3, 3, 3> G16c;   //   256     4 x 12 x 24    106 496
 typedef Geo<12, 2, 32, 5, 7, 4> G12a;   //   256     4 x 14 x 48    153 600   the first layer's offsets are wider (p99 3.7 voxels): halo 4-7 / 5
 typedef Geo<12, 2, 16, 4, 3, 3> G12b;   //   128     4 x 12 x 24     67 584   two per CU
 typedef Geo<12, 4, 16, 5, 7, 4> G12c;   //   256     4 x 16 x 32    122 880
+typedef Geo<12, 4, 16, 5, 3, 3> G12d;   //   256     4 x 16 x 24     73 728 (region only: two all-in-one workgroups per CU)
 
 typedef Geo<16, 4, 16, 4, 3, 3> B16;    //   256     4 x 14 x 24    152 064   backward tiles: region + 2 gcol tiles + 2 sample tiles
 typedef Geo<12, 4, 16, 5, 7, 4> B12;    //   256     4 x 16 x 32    147 840
@@ -770,8 +1034,14 @@ int dcn_lean_forward(const float* x, const float* offset, const float* weight, c
   p.nchunk = p.Cpad / CH;
   p.KT = 32 * ((K + 31) / 32);
   p.P = (long long)D * H * W;
-  // tile variant: DPF_DCN_LEAN_FWD = a | b | c (default: c)
-  static const char tile = getenv("DPF_DCN_LEAN_FWD") ? getenv("DPF_DCN_LEAN_FWD")[0] : 'c';
+  // DPF_DCN_LEAN_FWD = 1: every wave samples and contracts its own voxels; a | b | c: role-split kernel on tile variant a / b / c
+  static const char tile = getenv("DPF_DCN_LEAN_FWD") ? getenv("DPF_DCN_LEAN_FWD")[0] : '1';
+  if (tile == '1') {
+    if (CH == 16) return lean_launch_fwd1<G16c>(x, offset, weight, bias, out, ws, p, st);
+    static const int wide12 = getenv("DPF_DCN_LEAN_WIDE12") ? atoi(getenv("DPF_DCN_LEAN_WIDE12")) : 0;   // 1: wider x halo, one workgroup per CU
+    if (wide12) return lean_launch_fwd1<G12c>(x, offset, weight, bias, out, ws, p, st);
+    return lean_launch_fwd1<G12d>(x, offset, weight, bias, out, ws, p, st);
+  }
   if (CH == 16) {
     if (tile == 'b') return lean_launch_fwd<G16b>(x, offset, weight, bias, out, ws, p, st);
     if (tile == 'a') return lean_launch_fwd<G16a>(x, offset, weight, bias, out, ws, p, st);
