@@ -74,7 +74,10 @@ constexpr int w2_occ() { return w2_occ_of(NCT); }
 // BF = true (operand precision "bf16"): the 4 positions a lane half holds of a group are exactly the 4 reduction indices a lane half
 // feeds to v_mfma_f32_32x32x8_bf16, so a (group, column tile) unit is ONE bf16 MFMA on the RNE-rounded g / x values instead of four
 // exact-f32 ones; staging, fp32 accumulation, slab fold are unchanged.
-template <int NCT, bool BF = false>
+// SW1 = true: column stride 1 known at compile time -- the B-fragment reads s_x[colbase[t] + (8 j + i) * sw] become base + immediate (the
+// 109 v_add_u32 per tile pair that computed those addresses sat between the MFMAs of the loop, and on this chip vector-ALU work and fp32
+// MFMAs never overlap: tools/lean_probe2.hip)
+template <int NCT, bool BF = false, bool SW1 = false>
 __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                      float* __restrict__ slab, W2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
-  const int sw = p.sw;
+  const int sw = SW1 ? 1 : p.sw;
   const int aslot = wave * 8 + hh;               // logical g slot of this lane's half, group 0
   const int arow = l31 * SPR, axor = l31 & 15;
   const long long tbeg = (long long)pchunk * p.per;
@@ -361,16 +364,21 @@ int gather_conflicts(const DpfWgradDesc& d, int T, int ncolmax, int RS, int PS, 
   return total;
 }
 
-template <int NCT, bool BF>
-int launch_w2b(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
+template <int NCT, bool BF, bool SW1>
+int launch_w2c(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
   static bool done = false;
   if (lds > 48 * 1024 && !done) {
-    if (hipFuncSetAttribute((const void*)wgrad2_kernel<NCT, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)wgrad2_kernel<NCT, BF, SW1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return DPF_ERR_LAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((wgrad2_kernel<NCT, BF>), dim3(blocks), dim3(256), lds, st, g, x, slab, p);
+  hipLaunchKernelGGL((wgrad2_kernel<NCT, BF, SW1>), dim3(blocks), dim3(256), lds, st, g, x, slab, p);
   return dpf_check_launch();
+}
+template <int NCT, bool BF>
+int launch_w2b(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
+  static const int sw1 = env_int("DPF_W2_SW1", 1);
+  return (p.sw == 1 && sw1) ? launch_w2c<NCT, BF, true>(g, x, slab, p, lds, blocks, st) : launch_w2c<NCT, BF, false>(g, x, slab, p, lds, blocks, st);
 }
 template <int NCT>
 int launch_w2(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
