@@ -263,10 +263,34 @@ def main():
             with open(args.shapes, 'w') as fh:
                 for tag, (fl, se, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                     fh.write('%-60s calls %4d  ms/step %8.3f  TFLOP/s %6.1f\n' % (tag, n, se / prof_steps * 1e3, fl / se / 1e12))
-        # HBM bytes per step and family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_profiles.sh)
-        tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r03_pmc_traffic.json')
+        # HBM bytes per step and family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_profiles.sh).  The file
+        # carries a hash of the kernel sources it was collected on; the numbers are only reported for the workload, precision, world size
+        # and kernels they were measured with -- otherwise `traffic` is null and `traffic_source` says why.
+        tname = 'r04_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r04_pmc_traffic.json'
+        tpath = os.path.join(ROOT, 'profiles', tname)
         pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        same_workload = args.model == 'stereodpnet' and (args.batch, args.height, args.width) == (4, 1024, 1536)
+        meta = pmc.pop('_meta', {})
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        try:
+            from pmc_traffic import kernel_sources_sha16
+            sha_now = kernel_sources_sha16()
+        except Exception:
+            sha_now = None
+        same_workload = args.model == 'stereodpnet' and (args.batch, args.height, args.width) == (4, 1024, 1536) and world == 1 and not args.sync_bn
+        same_kernels = bool(meta) and meta.get('kernel_sources_sha16') == sha_now
+        if not pmc:
+            why = 'no traffic file'
+        elif not same_workload:
+            why = 'not the workload the counters were collected on (StereoDPNet, 4 x 1024x1536, 1 GPU, per-rank BatchNorm)'
+        elif not same_kernels:
+            why = 'kernel sources changed since the counters were collected'
+        else:
+            why = None
+        traffic_source = {'file': 'profiles/' + tname, 'kernel_sources_sha16': meta.get('kernel_sources_sha16'), 'collected_utc': meta.get('collected_utc'),
+                          'kernel_sources_sha16_now': sha_now, 'used': why is None, 'not_used_because': why}
+        if why is not None:
+            pmc = {}
+            same_workload = False
 
         def hbm_per_step(*keys):
             recs = [pmc[k] for k in keys if k in pmc]
@@ -300,7 +324,7 @@ def main():
             peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
             inline_ms = sum(v[1] for v in fam.values()) / prof_steps * 1e3
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                    'traffic': (hb / (n / prof_steps)) if hb is not None else None, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n,
+                    'traffic': (hb / (n / prof_steps)) if hb is not None else None, 'traffic_source': traffic_source, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n,
                     'avg_launch_ms': secs / n * 1e3, 'ms_per_step': secs / prof_steps * 1e3,
                     'measured_in': ('%d steps after the timed region on ONE stream (weight gradients in line, feature passes one after the other: kernels do not overlap, event time = kernel time)' % prof_steps)
                                    if not args.no_detail else 'the timed region', 'families': fam_out}

@@ -946,34 +946,6 @@ struct Samp {
   bool valid, fast;
 };
 
-__device__ __forceinline__ Samp make_samp(const DcnP& p, const RegGeo& g, const RegCtx& c, const Corner& cn) {
-  Samp s;
-  s.valid = cn.valid != 0;
-  s.fast = false;
-  s.base = 0; s.dzs = 0;
-  const bool zl = cn.d0 >= 0 && cn.d0 <= p.D - 1, zh = cn.d0 + 1 >= 0 && cn.d0 + 1 <= p.D - 1;
-  const bool yl = cn.h0 >= 0 && cn.h0 <= p.H - 1, yh = cn.h0 + 1 >= 0 && cn.h0 + 1 <= p.H - 1;
-  const bool xl = cn.w0 >= 0 && cn.w0 <= p.W - 1, xh = cn.w0 + 1 >= 0 && cn.w0 + 1 <= p.W - 1;
-  s.mz[0] = zl ? 1.f : 0.f; s.mz[1] = zh ? 1.f : 0.f;
-  s.my[0] = yl ? 1.f : 0.f; s.my[1] = yh ? 1.f : 0.f;
-  s.mx[0] = xl ? 1.f : 0.f; s.mx[1] = xh ? 1.f : 0.f;
-  s.wz[0] = (1.f - cn.ld) * s.mz[0]; s.wz[1] = cn.ld * s.mz[1];
-  s.wy[0] = (1.f - cn.lh) * s.my[0]; s.wy[1] = cn.lh * s.my[1];
-  s.wx[0] = (1.f - cn.lw) * s.mx[0]; s.wx[1] = cn.lw * s.mx[1];
-  if (!s.valid) return s;
-  const int lz = cn.d0 - c.rz0, ly = cn.h0 - c.ry0, lx = cn.w0 - c.rx0;
-  const bool yx_in = ly >= 0 && ly + 1 < g.RY && lx >= 0 && lx + 1 < g.RX;
-  const bool zlo_in = lz >= 0 && lz < c.RZ, zhi_in = lz + 1 >= 0 && lz + 1 < c.RZ;
-  if (yx_in && (zlo_in || !zl) && (zhi_in || !zh)) {
-    s.fast = true;
-    const int iz0 = zlo_in ? lz : (zhi_in ? lz + 1 : 0);
-    const int iz1 = zhi_in ? lz + 1 : iz0;
-    s.base = (iz0 * g.RY + ly) * g.RX + lx;
-    s.dzs = (iz1 - iz0) * g.RY * g.RX;
-  }
-  return s;
-}
-
 // Branch-free variant for the role-split samplers: a sample outside the volume (or a voxel outside the tile) is a FAST sample with all
 // masks -- hence all weights and derivative factors -- zero that reads region cell 0: one exec-mask branch less in the step loop.
 __device__ __forceinline__ Samp make_samp_nb(const DcnP& p, const RegGeo& g, const RegCtx& c, const Corner& cn) {
@@ -1012,151 +984,7 @@ __device__ __forceinline__ void corner_vec(const RegGeo& g, const Samp& s, const
   }
 }
 
-// one corner value of channel pointer xc from global memory (slow path); 0 outside the volume
-__device__ __forceinline__ float corner_global(const DcnP& p, const Corner& cn, const float* __restrict__ xc, int jd, int jh, int jw) {
-  const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
-  const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
-  return in ? xc[((long long)d * p.H + h) * p.W + w] : 0.f;
-}
-
-// slow path: the 16 channels of corner (jd, jh, jw) from global memory, issued as 16 independent loads
-template <int CH>
-__device__ __forceinline__ void corner_vec_global(const DcnP& p, const Corner& cn, const float* __restrict__ xb, int c0, long long chan, int jd,
-                                                  int jh, int jw, float v[CH]) {
-  const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
-  const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
-  const long long vox = in ? ((long long)d * p.H + h) * p.W + w : 0;
-#pragma unroll
-  for (int ch = 0; ch < CH; ++ch) {
-    const int c = c0 + ch < p.C ? c0 + ch : p.C - 1;
-    const float x = xb[(long long)c * chan + vox];
-    v[ch] = (in && c0 + ch < p.C) ? x : 0.f;
-  }
-}
-
-// trilinear samples of the 16 channels of the staged chunk at one (voxel, tap)
-template <int CH>
-__device__ __forceinline__ void sample_chunk(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
-                                             const float* __restrict__ xb, int c0, long long chan, float val[CH]) {
-#pragma unroll
-  for (int ch = 0; ch < CH; ++ch) val[ch] = 0.f;
-  if (!sp.valid) return;
-  if (sp.fast) {       // straight-line: the 32 ds_read_b128 of the 8 corners can all be in flight
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-      const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
-      float v[CH];
-      corner_vec<CH>(g, sp, s_reg, jd, jh, jw, v);
-#pragma unroll
-      for (int ch = 0; ch < CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
-    }
-  } else {
-    for (int j = 0; j < 8; ++j) {
-      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-      const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
-      if (wj == 0.f) continue;
-      float v[CH];
-      corner_vec_global<CH>(p, cn, xb, c0, chan, jd, jh, jw, v);
-#pragma unroll
-      for (int ch = 0; ch < CH; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
-    }
-  }
-}
-
 constexpr int ST = 256 + 4;   // padded row of the [16][256] sample / gcol tile
-
-// ---------------------------------------------------------------------------------------------------- forward
-template <int MT, int CH>
-__global__ __launch_bounds__(256) void dcn_fwd_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                             const float* __restrict__ wt /*[T][Cpad][KT], zero rows beyond C*/, const float* __restrict__ bias,
-                                                             float* __restrict__ out, DcnP p, RegGeo g) {
-  extern __shared__ __align__(16) float smem[];
-  constexpr int KT = 32 * MT;
-  float* s_reg = smem;                       // [RV][RegCfg<CH>::VS]
-  float* s_S = s_reg + RegCfg<CH>::VS * g.RV;         // [16][ST]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const RegCtx c = region_ctx(p, g, blockIdx.x);
-  const long long chan = (long long)p.D * p.H * p.W;
-  const float* xb = x + (long long)c.b * p.C * chan;
-  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
-  // this thread's output voxel
-  const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
-  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
-  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
-  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
-
-  f32x16 acc[MT][2];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
-
-  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
-  const int Cpad = (p.C + CH - 1) / CH * CH;
-  const float* offp0 = off_b + (pvalid ? ppos : 0);
-  for (int c0 = 0; c0 < p.C; c0 += CH) {
-    __syncthreads();                                   // previous chunk's region / S tile consumed
-    stage_region<CH>(p, g, c, xb, c0, s_reg, wave_u, lane);
-    const float* offp = offp0;
-    Off3 onext = load_off_ptr(offp, p.P, pvalid);
-    TapIt it = {0, 0, 0};
-    __syncthreads();
-    for (int t = 0; t < p.T; ++t) {
-      const Off3 ocur = onext;
-      offp += 3 * p.P;
-      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch the next tap's offsets
-      // weight fragments of this tap: issue early, consume after the sampling phase
-      float a[CH / 2][MT];
-      const float* wtt = wt + ((long long)t * Cpad + c0 + hh) * KT + l31;
-#pragma unroll
-      for (int sx = 0; sx < CH / 2; ++sx)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a[sx][m] = wtt[(2 * sx) * KT + m * 32];
-      const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
-      tap_next(p, it);
-      const Samp sp = make_samp(p, g, c, cn);
-      if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
-      {
-        float val[CH];
-        sample_chunk<CH>(p, g, sp, cn, s_reg, xb, c0, chan, val);
-#pragma unroll
-        for (int ch = 0; ch < CH; ++ch) s_S[ch * ST + tid] = val[ch];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int sx = 0; sx < CH / 2; ++sx) {
-        float bv[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bv[nt] = s_S[(2 * sx + hh) * ST + wave * 64 + nt * 32 + l31];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sx][m], bv[nt], acc[m][nt], 0, 0, 0);
-      }
-    }
-  }
-  // epilogue: D row = out channel, col = voxel (wave*64 + nt*32 + l31)
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int pl = wave * 64 + nt * 32 + l31;
-    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
-    const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
-    if (az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo) {
-      const long long pos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-          if (k < p.K) out[((long long)c.b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
-        }
-    }
-  }
-}
 
 // ---- 8-wave forward (two waves per SIMD on the same LDS image): a thread pair per voxel, each thread sampling half of the
 // chunk's channels; each wave contracts 32 voxels.
@@ -1176,130 +1004,6 @@ __device__ __forceinline__ void corner_half(const RegGeo& g, const Samp& s, cons
     const float2 a = *reinterpret_cast<const float2*>(r);
     const float4 b = *reinterpret_cast<const float4*>(r + 2);
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = b.z; v[5] = b.w;
-  }
-}
-
-template <int CH, int H>
-__device__ __forceinline__ void sample_half(const DcnP& p, const RegGeo& g, const Samp& sp, const Corner& cn, const float* s_reg,
-                                            const float* __restrict__ xb, int c0, long long chan, float val[CH / 2]) {
-  constexpr int NC = CH / 2;
-#pragma unroll
-  for (int ch = 0; ch < NC; ++ch) val[ch] = 0.f;
-  if (!sp.valid) return;
-  if (sp.fast) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-      const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
-      float v[NC];
-      corner_half<CH, H>(g, sp, s_reg, jd, jh, jw, v);
-#pragma unroll
-      for (int ch = 0; ch < NC; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
-    }
-  } else {
-    for (int j = 0; j < 8; ++j) {
-      const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-      const float wj = sp.wz[jd] * sp.wy[jh] * sp.wx[jw];
-      if (wj == 0.f) continue;
-      const int d = cn.d0 + jd, h = cn.h0 + jh, w = cn.w0 + jw;
-      const bool in = d >= 0 && d <= p.D - 1 && h >= 0 && h <= p.H - 1 && w >= 0 && w <= p.W - 1;
-      const long long vox = in ? ((long long)d * p.H + h) * p.W + w : 0;
-      float v[NC];
-#pragma unroll
-      for (int ch = 0; ch < NC; ++ch) {
-        const int cg = c0 + H * NC + ch;
-        const float x = xb[(long long)(cg < p.C ? cg : p.C - 1) * chan + vox];
-        v[ch] = (in && cg < p.C) ? x : 0.f;
-      }
-#pragma unroll
-      for (int ch = 0; ch < NC; ++ch) val[ch] = fmaf(wj, v[ch], val[ch]);
-    }
-  }
-}
-
-template <int MT, int CH>
-__global__ __launch_bounds__(512) void dcn_fwd_region8_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                              const float* __restrict__ wt /*[T][Cpad][KT], zero rows beyond C*/,
-                                                              const float* __restrict__ bias, float* __restrict__ out, DcnP p, RegGeo g) {
-  extern __shared__ __align__(16) float smem[];
-  constexpr int KT = 32 * MT;
-  constexpr int NC = CH / 2;
-  float* s_reg = smem;                                // [RV][VS]
-  float* s_S = s_reg + RegCfg<CH>::VS * g.RV;         // [CH][ST]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int half = wave_u >> 2;                        // waves 0-3: channels [0, CH/2), waves 4-7: the rest
-  const int vox = tid & 255;
-  const RegCtx c = region_ctx(p, g, blockIdx.x);
-  const long long chan = (long long)p.D * p.H * p.W;
-  const float* xb = x + (long long)c.b * p.C * chan;
-  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
-  const int pdx = vox & 31, pdy = (vox >> 5) & 1, pdz = vox >> 6;
-  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
-  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
-  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
-
-  f32x16 acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[m][j] = 0.f;
-
-  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
-  const int Cpad = (p.C + CH - 1) / CH * CH;
-  const float* offp0 = off_b + (pvalid ? ppos : 0);
-  for (int c0 = 0; c0 < p.C; c0 += CH) {
-    __syncthreads();                                   // previous chunk's region / S tile consumed
-    stage_region<CH>(p, g, c, xb, c0, s_reg, wave_u, lane, 8);
-    const float* offp = offp0;
-    Off3 onext = load_off_ptr(offp, p.P, pvalid);
-    TapIt it = {0, 0, 0};
-    __syncthreads();
-    for (int t = 0; t < p.T; ++t) {
-      const Off3 ocur = onext;
-      offp += 3 * p.P;
-      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);
-      float a[CH / 2][MT];
-      const float* wtt = wt + ((long long)t * Cpad + c0 + hh) * KT + l31;
-#pragma unroll
-      for (int sx = 0; sx < CH / 2; ++sx)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a[sx][m] = wtt[(2 * sx) * KT + m * 32];
-      const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
-      tap_next(p, it);
-      const Samp sp = make_samp(p, g, c, cn);
-      if (t > 0) __syncthreads();                      // MFMAs of the previous tap finished reading s_S
-      {
-        float val[NC];
-        if (half == 0) sample_half<CH, 0>(p, g, sp, cn, s_reg, xb, c0, chan, val);
-        else sample_half<CH, 1>(p, g, sp, cn, s_reg, xb, c0, chan, val);
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) s_S[(half * NC + ch) * ST + vox] = val[ch];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int sx = 0; sx < CH / 2; ++sx) {
-        const float bv = s_S[(2 * sx + hh) * ST + wave * 32 + l31];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sx][m], bv, acc[m], 0, 0, 0);
-      }
-    }
-  }
-  // epilogue: D row = out channel, col = voxel (wave*32 + l31)
-  {
-    const int pl = wave * 32 + l31;
-    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
-    const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
-    if (az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo) {
-      const long long pos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-          if (k < p.K) out[((long long)c.b * p.K + k) * p.P + pos] = acc[m][j] + (bias ? bias[k] : 0.f);
-        }
-    }
   }
 }
 
@@ -1558,170 +1262,6 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
 }
 
 constexpr int WG_NREP = 8;   // replicas of the grad_weight scratch tensor (spreads same-address atomic contention)
-
-// ---------------------------------------------------------------------------------------------------- grad_offset
-// gcol[c][p] = sum_k W[k][c][t] go[k][p] on v_mfma_f32_16x16x4_f32 (D row = channel, col = voxel), then
-// grad_offset[3t+dir][p] = sum_c gcol[c][p] * d sample(c,p,t) / d coord_dir   (cuh:111-190, 336-405)
-// WG = true additionally produces grad_weight in the same pass (the corner values are already in registers): the sampled tile
-// S[16][256] replaces gcol in LDS and each wave contracts it against its 16 output channels of go (see dcn_wgrad_region_kernel)
-template <bool WG, int CH>
-__global__ __launch_bounds__(256) void dcn_bwd_offset_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                                    const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/, const float* __restrict__ go,
-                                                                    float* __restrict__ doff, float* __restrict__ dwtmp, DcnP p, RegGeo g, int CT,
-                                                                    int nchunk, int vec) {
-  extern __shared__ __align__(16) float smem[];
-  float* s_reg = smem;                       // [RV][RegCfg<CH>::VS]
-  float* s_gc = s_reg + RegCfg<CH>::VS * g.RV;        // [16][ST]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const RegCtx c = region_ctx(p, g, blockIdx.x);
-  const long long chan = (long long)p.D * p.H * p.W;
-  const float* xb = x + (long long)c.b * p.C * chan;
-  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
-  float* doff_b = doff + (long long)c.b * 3 * p.T * p.P;
-  const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
-  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
-  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
-  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
-
-  // B fragments: go[k][voxel] for this wave's 4 sub-tiles of 16 voxels, all k (K <= 64)
-  float bfrag[4][16];
-#pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    const int pl = wave * 64 + st * 16 + l15;
-    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
-    const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
-    const bool ok = az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
-    const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int k = 4 * ks + lg;
-      bfrag[st][ks] = (ok && k < p.K) ? go[((long long)c.b * p.K + k) * p.P + gpos] : 0.f;
-    }
-  }
-
-  // grad_weight: A fragments go[k = 16*wave + l15][voxel 4*ks + lg] (64 k-steps over the tile), replica of the scratch tensor
-  float wfrag[WG ? 64 : 1];
-  float* rep = nullptr;
-  if (WG) {
-    const int kk = 16 * wave + l15;
-#pragma unroll
-    for (int ks = 0; ks < 64; ++ks) {
-      const int pl = 4 * ks + lg;
-      const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
-      const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
-      const bool ok = kk < p.K && az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
-      wfrag[ks] = ok ? go[((long long)c.b * p.K + kk) * p.P + ((long long)gz * p.Ho + gy) * p.Wo + gx] : 0.f;
-    }
-    rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
-  }
-
-  const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
-  const float* offp0 = off_b + (pvalid ? ppos : 0);
-  for (int c0 = 0; c0 < p.C; c0 += CH) {
-    __syncthreads();
-    stage_region_any<CH>(p, g, c, xb, c0, s_reg, tid, 256, vec != 0);
-    const float* offp = offp0;
-    Off3 onext = load_off_ptr(offp, p.P, pvalid);
-    TapIt it = {0, 0, 0};
-    for (int t = 0; t < p.T; ++t) {
-      const Off3 ocur = onext;
-      offp += 3 * p.P;
-      onext = load_off_ptr(offp, p.P, pvalid && t + 1 < p.T);   // prefetch the next tap's offsets
-      // running grad_offset of this (tap, voxel) from the previous channel chunks: fetched now, added after the sampling phase
-      float* dq = doff_b + (long long)(3 * t) * p.P + ppos;
-      float dprev[3] = {0.f, 0.f, 0.f};
-      if (pvalid && c0 > 0) { dprev[0] = dq[0]; dprev[1] = dq[p.P]; dprev[2] = dq[2 * p.P]; }
-      // A fragments: W[k][c0 + l15][t] (rows k >= K and columns >= C of the repacked tensor are zero)
-      float afrag[16];
-      const float* wtt = wt2 + ((long long)t * 64 + lg) * CT + c0 + l15;
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) afrag[ks] = wtt[(4 * ks) * CT];
-      const Corner cn = corner_at(p, pvalid, zb, yb, xbase, it, ocur);
-      tap_next(p, it);
-      const Samp sp = make_samp(p, g, c, cn);
-      __syncthreads();                                 // previous tap's s_gc consumed (and region staged)
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], bfrag[st][ks], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_gc[(4 * lg + r) * ST + wave * 64 + st * 16 + l15] = acc[r];   // D row = channel, col = voxel
-      }
-      __syncthreads();
-      float gd = 0.f, gh = 0.f, gw = 0.f;
-      float sval[CH];
-#pragma unroll
-      for (int ch = 0; ch < CH; ++ch) sval[ch] = 0.f;
-      if (sp.valid) {
-        float gcv[CH];
-#pragma unroll
-        for (int ch = 0; ch < CH; ++ch) gcv[ch] = s_gc[ch * ST + tid];   // zero for channels beyond C (zero weight columns)
-        // dot_j = sum_ch gcol[ch] * x[corner j][ch]; the three coordinate derivatives weight it with the other two
-        // trilinear factors and the signed in-volume mask of their own axis (cuh:131-187)
-        float dots[8];
-        if (sp.fast) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float v[CH];
-            corner_vec<CH>(g, sp, s_reg, j >> 2, (j >> 1) & 1, j & 1, v);
-            float dot = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
-            dots[j] = dot;
-            if (WG) {
-              const float wj = sp.wz[j >> 2] * sp.wy[(j >> 1) & 1] * sp.wx[j & 1];
-#pragma unroll
-              for (int ch = 0; ch < CH; ++ch) sval[ch] = fmaf(wj, v[ch], sval[ch]);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float v[CH];
-            corner_vec_global<CH>(p, cn, xb, c0, chan, j >> 2, (j >> 1) & 1, j & 1, v);
-            float dot = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) dot = fmaf(gcv[ch], v[ch], dot);
-            dots[j] = dot;
-            if (WG) {
-              const float wj = sp.wz[j >> 2] * sp.wy[(j >> 1) & 1] * sp.wx[j & 1];
-#pragma unroll
-              for (int ch = 0; ch < CH; ++ch) sval[ch] = fmaf(wj, v[ch], sval[ch]);
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
-          gd += (jd ? sp.mz[1] : -sp.mz[0]) * sp.wy[jh] * sp.wx[jw] * dots[j];
-          gh += (jh ? sp.my[1] : -sp.my[0]) * sp.wz[jd] * sp.wx[jw] * dots[j];
-          gw += (jw ? sp.mx[1] : -sp.mx[0]) * sp.wz[jd] * sp.wy[jh] * dots[j];
-        }
-      }
-      if (pvalid) {   // this thread owns (t, voxel): accumulate over the channel chunks
-        dq[0] = dprev[0] + gd; dq[p.P] = dprev[1] + gh; dq[2 * p.P] = dprev[2] + gw;
-      }
-      if (WG) {
-        // this thread is the only reader of column `tid` of the gcol tile, so it can overwrite it with its samples right away
-#pragma unroll
-        for (int ch = 0; ch < CH; ++ch) s_gc[ch * ST + tid] = sval[ch];
-        __syncthreads();
-        f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 64; ++ks) wacc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[ks], s_gc[l15 * ST + 4 * ks + lg], wacc, 0, 0, 0);
-        if (l15 < CH && c0 + l15 < p.C) {
-          float* dst = rep + ((long long)(t * nchunk + c0 / CH) * 64 + 16 * wave + 4 * lg) * 16 + l15;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (16 * wave + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], wacc[r]);
-        }
-      }
-    }
-  }
-}
-
 
 // ---- role-split grad_offset + grad_weight: 16 waves = 8 SAMPLER waves (a thread PAIR per voxel, each thread half of the chunk's
 // channels: corner reads, coordinate derivatives, samples), 4 GCOL waves (gcol = W^T go for 64 voxels each) and 4 WGRAD waves (dW partial
@@ -2027,71 +1567,6 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
   }
 }
 
-// ---------------------------------------------------------------------------------------------------- grad_weight
-// dW[k][c][t] = sum_{b,p} go[k][p] * S[c][p;t].  Per (chunk, tap) the sampled tile S[16][256] goes to LDS and each wave
-// contracts it against its 16 output channels of go (kept in registers) with v_mfma_f32_16x16x4_f32 (D row = k, col = c);
-// the [64 x 16] partial is added into one of NREP replicas of a [T][chunk][64][16] scratch tensor (64-B contiguous atomics,
-// replicas spread the same-address contention of the 6144 workgroups) that a second kernel folds into dW[k][c][t].
-__global__ __launch_bounds__(256) void dcn_wgrad_region_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                               const float* __restrict__ go, float* __restrict__ dwtmp, DcnP p, RegGeo g,
-                                                               int nchunk) {
-  extern __shared__ __align__(16) float smem[];
-  float* s_reg = smem;                       // [RV][RegCfg<16>::VS]
-  float* s_S = s_reg + RegCfg<16>::VS * g.RV;         // [16][ST]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const RegCtx c = region_ctx(p, g, blockIdx.x);
-  const long long chan = (long long)p.D * p.H * p.W;
-  const float* xb = x + (long long)c.b * p.C * chan;
-  const float* off_b = offset + (long long)c.b * 3 * p.T * p.P;
-  const int pdx = tid & 31, pdy = (tid >> 5) & 1, pdz = tid >> 6;
-  const int zo = c.z0 + pdz, yo = c.y0 + pdy, xo = c.x0 + pdx;
-  const bool pvalid = pdz < g.TZ && zo < p.Do && yo < p.Ho && xo < p.Wo;
-  const long long ppos = pvalid ? ((long long)zo * p.Ho + yo) * p.Wo + xo : p.P;
-
-  // A fragments: go[k = 16*wave + l15][voxel 4*ks + lg], 64 k-steps over the 256 voxels of the tile
-  float afrag[64];
-  const int kk = 16 * wave + l15;
-#pragma unroll
-  for (int ks = 0; ks < 64; ++ks) {
-    const int pl = 4 * ks + lg;
-    const int ax = pl & 31, ay = (pl >> 5) & 1, az = pl >> 6;
-    const int gz = c.z0 + az, gy = c.y0 + ay, gx = c.x0 + ax;
-    const bool ok = kk < p.K && az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
-    afrag[ks] = ok ? go[((long long)c.b * p.K + kk) * p.P + ((long long)gz * p.Ho + gy) * p.Wo + gx] : 0.f;
-  }
-  float* rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
-
-  for (int c0 = 0; c0 < p.C; c0 += 16) {
-    __syncthreads();
-    stage_region<16>(p, g, c, xb, c0, s_reg, wave_u, lane);
-    Off3 onext = load_off(p, off_b, 0, ppos);
-    for (int t = 0; t < p.T; ++t) {
-      const Off3 ocur = onext;
-      onext = load_off(p, off_b, t + 1, ppos);
-      const Corner cn = corner_from(p, t, ppos, ocur);
-      const Samp sp = make_samp(p, g, c, cn);
-      __syncthreads();                                 // region staged / previous tap's s_S consumed
-      {
-        float val[16];
-        sample_chunk<16>(p, g, sp, cn, s_reg, xb, c0, chan, val);
-#pragma unroll
-        for (int ch = 0; ch < 16; ++ch) s_S[ch * ST + tid] = val[ch];
-      }
-      __syncthreads();
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], s_S[l15 * ST + 4 * ks + lg], acc, 0, 0, 0);
-      if (c0 + l15 < p.C) {
-        float* dst = rep + ((long long)(t * nchunk + c0 / 16) * 64 + 16 * wave + 4 * lg) * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (16 * wave + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], acc[r]);
-      }
-    }
-  }
-}
-
 // dW[k][c][t] = sum_rep tmp[rep][t][c/ch][k][c%ch]   (ch = channels per chunk of the producing kernel)
 __global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __restrict__ dw, int K, int C, int T, int nchunk, int ch) {
   const int total = K * C * T;
@@ -2134,12 +1609,6 @@ int region_geo(RegGeo& g, const DcnP& p, int CH, int R, bool aligned = false, in
 
 // chunk width: 12 where it pads the channel count less than 16 does (35 -> 36 vs 48)
 int region_chunk(int C) { return ((C + 11) / 12 * 12 < (C + 15) / 16 * 16) ? 12 : 16; }
-
-// widest halo (4, then 3) whose LDS image fits
-int region_pick(RegGeo& g, const DcnP& p, int CH, bool aligned = false) {
-  if (region_geo(g, p, CH, 4, aligned) == DPF_OK) return DPF_OK;
-  return region_geo(g, p, CH, 3, aligned);
-}
 
 int fill_params(DcnP& p, int B, int C, int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
                 int dd, int dh, int dw) {
@@ -2192,89 +1661,50 @@ int dpf_deform_conv3d_forward(const float* input, const float* weight, const flo
   if (rc != DPF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int MT = (K + 31) / 32, KT = 32 * MT;
-  RegGeo g{};
   const int CH = region_chunk(C);
-  // the configuration the model runs (3x3x3, stride 1, padding 1, dilation 1, depth <= 4, aligned rows): lean-sampler kernels of dcn_lean.hip
+  // (1) the configuration the model runs (3x3x3, stride 1, padding 1, dilation 1, depth <= 4, aligned rows): lean-sampler kernels of dcn_lean.hip
   if (kd == 3 && kh == 3 && kw == 3 && sd == 1 && sh == 1 && sw == 1 && pd == 1 && ph == 1 && pw == 1 && dd == 1 && dh == 1 && dw == 1 &&
       !getenv("DPF_DCN_V1")) {
     rc = dcn_lean_forward(input, offset, weight, bias, output, ws, B, C, D, H, W, K, st);
     if (rc != DPF_ERR_UNSUPPORTED) return rc;
   }
-  if (!getenv("DPF_DCN_V1") && region_pick(g, p, CH) == DPF_OK) {
-    const int Cpad = (C + CH - 1) / CH * CH;
-    hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * Cpad * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0,
-                       Cpad);
-    const dim3 grid((unsigned)((long long)B * g.tilesZ * g.tilesY * g.tilesX));
-    // role-split pipeline (sampler waves + MFMA waves, double-buffered sample tile) where its LDS image fits; with 16-byte aligned
-    // rows the region gets an aligned x-origin and is staged with float4 loads
-    // DPF_DCN_FWD_RS: 0 off, 8 or 16 = waves per CU.  Default: 16 for 16-channel chunks (two half-width workgroups of 8 waves: 5.75 vs
-    // 6.13 ms on the 64-channel layer), 8 for 12-channel chunks (4.24 vs 4.77 ms on the 35-channel layer)
-    static const int use_rs_env = getenv("DPF_DCN_FWD_RS") ? atoi(getenv("DPF_DCN_FWD_RS")) : -1;
-    const int use_rs = use_rs_env >= 0 ? use_rs_env : (CH == 16 ? 16 : 8);
-    if (use_rs && MT <= 2) {
-      RegGeo ga{};
-      const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2 && !getenv("DPF_DCN_NOVEC");
-      // half-width tile (4 x 2 x 16 voxels, 4 waves, image under 80 KB: two workgroups per CU) for 16-channel chunks: 6.45 vs 6.78 ms on
-      // the 64-channel layer; 12-channel chunks (35-channel layer) are faster on the full tile (4.28 vs 4.48).  DPF_DCN_FWD_TX=16|32 forces one.
-      static const int fwd_tx = getenv("DPF_DCN_FWD_TX") ? atoi(getenv("DPF_DCN_FWD_TX")) : 0;
-      const int TXv = fwd_tx == 16 ? 16 : (fwd_tx == 32 ? 32 : (CH == 16 ? 16 : 32));
-      auto lds_of = [&](const RegGeo& q) { return sizeof(float) * ((size_t)CH * q.RV + (size_t)2 * CH * 8 * TXv); };
-      const size_t lds_cap = TXv == 16 ? 80 * 1024 : 160 * 1024;
-      // shape of the 2 * TXv voxels of a tile plane: DPF_DCN_FWD_TY = 2 (TXv wide), 4 or 8 rows
-      static const int fwd_ty = getenv("DPF_DCN_FWD_TY") ? atoi(getenv("DPF_DCN_FWD_TY")) : 2;
-      const int TYg = (fwd_ty == 4 || (fwd_ty == 8 && TXv == 32)) ? fwd_ty : 2, TXg = 2 * TXv / TYg;
-      int vec = 0;
-      bool ok = false;
-      if (can_vec) {
-        const int cand[6][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}};     // (x/z halo, y halo), widest first
-        for (int i = 0; i < 6 && !ok; ++i)
-          if (region_geo(ga, p, CH, cand[i][0], true, cand[i][1], TXg, TYg) == DPF_OK && lds_of(ga) <= lds_cap) { ok = true; vec = 1; }
-      }
-      if (!ok) {
-        for (int R = 4; R >= 3 && !ok; --R)
-          if (region_geo(ga, p, CH, R, false, -1, TXg, TYg) == DPF_OK && lds_of(ga) <= lds_cap) ok = true;
-      }
-      if (ok) {
-        const size_t lds_rs = lds_of(ga);
-        const dim3 grid_rs((unsigned)((long long)B * ga.tilesZ * ga.tilesY * ga.tilesX));
+  // (2) any other geometry whose haloed LDS image fits: role-split region kernel (sampler waves + MFMA waves, double-buffered sample tile);
+  // half-width tile (two workgroups per CU) for 16-channel chunks, full tile for 12-channel ones; with 16-byte aligned rows the region
+  // gets an aligned x-origin and is staged with float4 loads
+  if (!getenv("DPF_DCN_V1") && MT <= 2) {
+    RegGeo ga{};
+    const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2;
+    const int TXv = CH == 16 ? 16 : 32;
+    auto lds_of = [&](const RegGeo& q) { return sizeof(float) * ((size_t)CH * q.RV + (size_t)2 * CH * 8 * TXv); };
+    const size_t lds_cap = TXv == 16 ? 80 * 1024 : 160 * 1024;
+    int vec = 0;
+    bool ok = false;
+    if (can_vec) {
+      const int cand[6][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}};     // (x/z halo, y halo), widest first
+      for (int i = 0; i < 6 && !ok; ++i)
+        if (region_geo(ga, p, CH, cand[i][0], true, cand[i][1], TXv, 2) == DPF_OK && lds_of(ga) <= lds_cap) { ok = true; vec = 1; }
+    }
+    if (!ok) {
+      for (int R = 4; R >= 3 && !ok; --R)
+        if (region_geo(ga, p, CH, R, false, -1, TXv, 2) == DPF_OK && lds_of(ga) <= lds_cap) ok = true;
+    }
+    if (ok) {
+      const int Cpad = (C + CH - 1) / CH * CH;
+      hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * Cpad * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0,
+                         Cpad);
+      const size_t lds_rs = lds_of(ga);
+      const dim3 grid_rs((unsigned)((long long)B * ga.tilesZ * ga.tilesY * ga.tilesX));
 #define DPF_RS(M, Cw, Nw, Tx)                                                                                              \
   {                                                                                                                        \
     if (set_lds(dcn_fwd_rs_kernel<M, Cw, Nw, Tx>, lds_rs) != DPF_OK) return DPF_ERR_LAUNCH;                                \
     hipLaunchKernelGGL((dcn_fwd_rs_kernel<M, Cw, Nw, Tx>), grid_rs, dim3(64 * Nw), lds_rs, st, input, offset, ws, bias, output, p, ga, vec); \
   }
-#define DPF_RSN(M, Cw)                                                                                                     \
-  {                                                                                                                        \
-    if (TXv == 16) { if (use_rs == 8) DPF_RS(M, Cw, 4, 16) else DPF_RS(M, Cw, 8, 16) }                                     \
-    else { if (use_rs == 8) DPF_RS(M, Cw, 8, 32) else DPF_RS(M, Cw, 16, 32) }                                              \
-  }
-        if (MT == 1) { if (CH == 16) DPF_RSN(1, 16) else DPF_RSN(1, 12) } else { if (CH == 16) DPF_RSN(2, 16) else DPF_RSN(2, 12) }
-#undef DPF_RSN
+      if (MT == 1) { if (CH == 16) DPF_RS(1, 16, 8, 16) else DPF_RS(1, 12, 8, 32) } else { if (CH == 16) DPF_RS(2, 16, 8, 16) else DPF_RS(2, 12, 8, 32) }
 #undef DPF_RS
-        return dpf_check_launch();
-      }
+      return dpf_check_launch();
     }
-    const size_t lds = region_lds(g, CH);
-    // 8-wave workgroups measured faster for 16-wide chunks (10.2 vs 10.8 ms, C = 64) and slower for 12-wide ones (8.4 vs 8.15 ms, C = 35)
-    const bool eight = getenv("DPF_DCN_FWD8") ? atoi(getenv("DPF_DCN_FWD8")) != 0 : CH == 16;
-#define DPF_FR2(M, Cw)                                                                                                      \
-  {                                                                                                                         \
-    if (eight) {                                                                                                            \
-      if (set_lds(dcn_fwd_region8_kernel<M, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                     \
-      hipLaunchKernelGGL((dcn_fwd_region8_kernel<M, Cw>), grid, dim3(512), lds, st, input, offset, ws, bias, output, p, g); \
-    } else {                                                                                                                \
-      if (set_lds(dcn_fwd_region_kernel<M, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                      \
-      hipLaunchKernelGGL((dcn_fwd_region_kernel<M, Cw>), grid, dim3(256), lds, st, input, offset, ws, bias, output, p, g);  \
-    }                                                                                                                       \
   }
-#define DPF_FR(M)            \
-  {                          \
-    if (CH == 16) DPF_FR2(M, 16) else DPF_FR2(M, 12) \
-  }
-    switch (MT) { case 1: DPF_FR(1); break; case 2: DPF_FR(2); break; case 3: DPF_FR(3); break; default: DPF_FR(4); break; }
-#undef DPF_FR2
-#undef DPF_FR
-    return dpf_check_launch();
-  }
+  // (3) everything else: one workgroup per 64 output voxels, samples gathered from global memory
   hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * C * KT)), dim3(256), 0, st, weight, ws, K, C, p.T, KT, 0);
   const size_t lds = sizeof(float) * (size_t)p.CP * SP;
   const dim3 grid((unsigned)(B * p.tiles_per_b));
@@ -2359,73 +1789,49 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
         case 1: DPF_GIP(1, 4); break;
         case 2: DPF_GIP(2, 4); break;
         case 3: DPF_GIP(3, 4); break;
-        default:                         // 256 voxels: 8 waves (two per SIMD) or 16 (four per SIMD, one 16-voxel sub-tile each)
-          {
-            static const int pk16 = getenv("DPF_DCN_PK16") ? atoi(getenv("DPF_DCN_PK16")) : 1;
-            if (pk16) { DPF_GIP(1, 16); } else { DPF_GIP(2, 8); }
-          }
-          break;
+        default: DPF_GIP(1, 16); break;   // 256 voxels: 16 waves (four per SIMD, one 16-voxel sub-tile each; the 8-wave variant measured 9.6 vs 8.5 ms)
       }
 #undef DPF_GIP
       dx_done = true;
     }
   }
-  RegGeo rg{};
-  // the fused offset + weight gradient kernel picks its chunk width / halo like the forward; the stand-alone weight-gradient
-  // fallback works on 16-channel chunks with a halo of 3
-  const bool want_fuse = dx_done && !getenv("DPF_DCN_NOFUSE");
-  const int CHb = want_fuse ? region_chunk(C) : 16;
-  // aligned x-origin + float4 staging when the rows are 16-byte aligned; widest halo whose LDS image fits
-  const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2 && !getenv("DPF_DCN_NOVEC");
-  int vec_off = 0;
-  bool geo_ok = false;
-  if (want_fuse && can_vec) {
-    const int cand[4][2] = {{4, 6}, {4, 5}, {4, 4}, {3, 3}};
-    for (int i = 0; i < 4 && !geo_ok; ++i)
-      if (region_geo(rg, p, CHb, cand[i][0], true, cand[i][1]) == DPF_OK) { geo_ok = true; vec_off = 1; }
-  }
-  if (!geo_ok) geo_ok = (want_fuse ? region_pick(rg, p, CHb) : region_geo(rg, p, 16, 3)) == DPF_OK;
-  const bool region_ok = K <= 64 && !getenv("DPF_DCN_V1") && geo_ok &&
-                         (CHb == 16 || (C + 11) / 12 * 12 + 4 <= CT);   // 16 weight columns are fetched from each chunk origin
-  const bool fuse_wg = region_ok && want_fuse;
+  // grad_offset + grad_weight.  (1) the model's configuration: lean-sampler kernel of dcn_lean.hip; (2) any other geometry whose haloed
+  // LDS image fits next to three rotating [CH][256] tiles: role-split region kernel (sampler / gcol / wgrad waves); both write grad_weight
+  // partials into dwtmp[8][T][nchunk][64][16], folded below; (3) everything else: global-memory gather kernels
+  const int CHb = region_chunk(C);
+  const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2;
+  const bool region_ok = dx_done && K <= 64 && !getenv("DPF_DCN_V1") && (CHb == 16 || (C + 11) / 12 * 12 + 4 <= CT);   // 16 weight columns are fetched from each chunk origin
   float* dwtmp = ws + (long long)p.T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);
   const int nchunk = (C + CHb - 1) / CHb;
+  bool rs_done = false;
   if (region_ok) {
     if (hipMemsetAsync(dwtmp, 0, sizeof(float) * (size_t)WG_NREP * p.T * nchunk * 64 * 16, st) != hipSuccess) return DPF_ERR_LAUNCH;
+    if (kd == 3 && kh == 3 && kw == 3 && sd == 1 && sh == 1 && sw == 1 && pd == 1 && ph == 1 && pw == 1 && dd == 1 && dh == 1 && dw == 1 &&
+        CHb == dcn_lean_chunk(C)) {
+      rc = dcn_lean_bwd_offset(input, offset, weight, grad_output, grad_offset, dwtmp, ws, B, C, D, H, W, K, st);
+      if (rc == DPF_OK) rs_done = true;
+      else if (rc != DPF_ERR_UNSUPPORTED) return rc;
+    }
   }
-  // (A role-split variant of this kernel -- sampler waves + MFMA waves over three rotating tiles, like dcn_fwd_rs_kernel -- was built and
-  // measured slower, 17.9 vs 13.7 ms on the 64-channel layer: its MFMA waves carry both matrix products and the 256-register budget spills.)
-  // role-split variant (sampler / gcol / wgrad waves, three rotating tiles): its own region geometry, the widest halo that fits next to
-  // the three tiles; DPF_DCN_OFF_RS=0 selects the fused 4-wave kernel
-  static const int use_off_rs = getenv("DPF_DCN_OFF_RS") ? atoi(getenv("DPF_DCN_OFF_RS")) : 1;
-  bool rs_done = false;
-  // the model's configuration: lean-sampler kernel of dcn_lean.hip (same dwtmp layout and chunk width as the role-split kernel below)
-  if (region_ok && dx_done && fuse_wg && kd == 3 && kh == 3 && kw == 3 && sd == 1 && sh == 1 && sw == 1 && pd == 1 && ph == 1 && pw == 1 &&
-      dd == 1 && dh == 1 && dw == 1 && CHb == dcn_lean_chunk(C)) {
-    rc = dcn_lean_bwd_offset(input, offset, weight, grad_output, grad_offset, dwtmp, ws, B, C, D, H, W, K, st);
-    if (rc == DPF_OK) rs_done = true;
-    else if (rc != DPF_ERR_UNSUPPORTED) return rc;
-  }
-  if (!rs_done && region_ok && dx_done && fuse_wg && use_off_rs) {
+  if (!rs_done && region_ok) {
     RegGeo gr{};
     auto lds_of = [&](const RegGeo& qq) { return sizeof(float) * ((size_t)CHb * qq.RV + (size_t)3 * CHb * XS + 2 * 3 * 256); };
     bool ok = false;
     int vec_rs = 0;
     if (can_vec) {
-      // compact 4 x 4 x 16 tile (DPF_DCN_OFF_TX=16, default; 8 = 4 x 8 x 8, 32 = 4 x 2 x 32): the same 256 voxels need a smaller haloed
-      // region, so a wider halo fits next to the three rotating tiles -- less staging per tile and fewer samples on the global slow path.
-      // Per launch (tools/dcn_bench.py): 12-channel chunks 7.37 (32) / 6.88 (16) / 7.06 (8) ms, 16-channel chunks 9.20 / 9.20 / 9.50
-      static const int off_tx = getenv("DPF_DCN_OFF_TX") ? atoi(getenv("DPF_DCN_OFF_TX")) : 16;
-      const int TXo = (off_tx == 8 || off_tx == 16) ? off_tx : 32, TYo = 64 / TXo;
-      const int cand[8][2] = {{5, 6}, {4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}, {3, 3}};
+      // compact 4 x 4 x 16 tile: the 256 voxels need a smaller haloed region than 4 x 2 x 32, so a wider halo fits next to the three
+      // rotating tiles -- less staging per tile and fewer samples on the global slow path
+      const int cand[7][2] = {{5, 6}, {4, 6}, {4, 5}, {4, 4}, {3, 5}, {3, 4}, {3, 3}};
       for (int i = 0; i < 7 && !ok; ++i)
-        if (region_geo(gr, p, CHb, cand[i][0], true, cand[i][1], TXo, TYo) == DPF_OK && lds_of(gr) <= 160 * 1024) { ok = true; vec_rs = 1; }
+        if (region_geo(gr, p, CHb, cand[i][0], true, cand[i][1], 16, 4) == DPF_OK && lds_of(gr) <= 160 * 1024) { ok = true; vec_rs = 1; }
     }
     if (!ok) {
       for (int R = 4; R >= 3 && !ok; --R)
         if (region_geo(gr, p, CHb, R) == DPF_OK && lds_of(gr) <= 160 * 1024) ok = true;
     }
     if (ok) {
+      // (the lean kernel may have overwritten ws: wt2[T][64][CT] again)
+      hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * 64 * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1, 64);
       const size_t lds = lds_of(gr);
       const dim3 grid((unsigned)((long long)B * gr.tilesZ * gr.tilesY * gr.tilesX));
 #define DPF_OFFRS(Cw)                                                                                                          \
@@ -2440,25 +1846,12 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     }
   }
   if (rs_done) {
-  } else if (region_ok && dx_done) {
-    const size_t lds = region_lds(rg, CHb);
-    const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
-#define DPF_OFF(WGv, Cw)                                                                                                        \
-  {                                                                                                                             \
-    if (set_lds(dcn_bwd_offset_region_kernel<WGv, Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                   \
-    hipLaunchKernelGGL((dcn_bwd_offset_region_kernel<WGv, Cw>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, \
-                       p, rg, CT, nchunk, vec_off);                                                                             \
-  }
-    if (fuse_wg) {
-      if (CHb == 16) DPF_OFF(true, 16) else DPF_OFF(true, 12)
-    } else {
-      DPF_OFF(false, 16)
-    }
-#undef DPF_OFF
+    hipLaunchKernelGGL(dcn_wgrad_fold_kernel, dim3(dpf_ew_grid((long long)K * C * p.T)), dim3(256), 0, st, dwtmp, grad_weight, K, C, p.T, nchunk, CHb);
   } else {
     hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * K * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1);
-    const size_t lds = sizeof(float) * ((size_t)K * SP + (size_t)CT * SP + 3 * 4 * TP);
-    const dim3 grid((unsigned)(B * p.tiles_per_b));
+    {
+      const size_t lds = sizeof(float) * ((size_t)K * SP + (size_t)CT * SP + 3 * 4 * TP);
+      const dim3 grid((unsigned)(B * p.tiles_per_b));
 #define DPF_D(M)                                                                                                       \
   {                                                                                                                    \
     if (dx_done) {                                                                                                     \
@@ -2469,18 +1862,9 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
       hipLaunchKernelGGL((dcn_bwd_data_kernel<M, true>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_input, grad_offset, p); \
     }                                                                                                                  \
   }
-    switch (MTC) { case 1: DPF_D(1); break; case 2: DPF_D(2); break; case 3: DPF_D(3); break; default: DPF_D(4); break; }
+      switch (MTC) { case 1: DPF_D(1); break; case 2: DPF_D(2); break; case 3: DPF_D(3); break; default: DPF_D(4); break; }
 #undef DPF_D
-  }
-  if (region_ok) {
-    if (!fuse_wg) {
-      const size_t lds = region_lds(rg, 16);
-      const dim3 grid((unsigned)((long long)B * rg.tilesZ * rg.tilesY * rg.tilesX));
-      if (set_lds(dcn_wgrad_region_kernel, lds) != DPF_OK) return DPF_ERR_LAUNCH;
-      hipLaunchKernelGGL(dcn_wgrad_region_kernel, grid, dim3(256), lds, st, input, offset, grad_output, dwtmp, p, rg, nchunk);
     }
-    hipLaunchKernelGGL(dcn_wgrad_fold_kernel, dim3(dpf_ew_grid((long long)K * C * p.T)), dim3(256), 0, st, dwtmp, grad_weight, K, C, p.T, nchunk, CHb);
-  } else {
     const long long ntile = (long long)B * p.tiles_per_b;
     long long nchunkw = 2048 / p.T;
     if (nchunkw < 1) nchunkw = 1;

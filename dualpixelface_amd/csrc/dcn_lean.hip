@@ -2,17 +2,24 @@
 // stride 1, padding 1, dilation 1, depth 4): same arithmetic as dcn3d.hip (reference: src/module/dcn3d/src/cuda/deform_im2col_cuda.cuh:26-72
 // sampler, :192-265 im2col + validity rule :248; deform_conv_cuda.cu:93-123 GEMM + bias), different instruction budget.
 //
-// What round 3 measured: the role-split kernels are bound by the SAMPLER's instruction stream -- ~700 vector
-// instructions per (64 voxels x 16 channels x 1 tap), 128 of them the essential FMAs -- while the matrix waves need 2048 clocks for the
-// same step.  The diet here:
+// What the measurements said (tools/lean_probe.hip, tools/lean_probe2.hip):
+//   * round 3's role-split kernels were bound by the SAMPLER's instruction stream -- ~700 vector instructions per (64 voxels x 16 channels
+//     x 1 tap), 128 of them the essential FMAs -- while the matrix waves need 2048 clocks for the same step;
+//   * on this chip an fp32 MFMA and vector-ALU work never overlap on a SIMD -- not across waves (a wave issuing MFMAs back to back starves
+//     its SIMD partner of vector and LDS issue) and not inside a wave (4 v_pk_fma_f32 behind a 64-clock MFMA: +34 clocks) -- but LDS reads a
+//     wave issues between its OWN MFMAs are nearly free (2 ds_read_b128 per MFMA: +7 clocks).
+// The diet:
 //   * quad-planar LDS image  region[q][cell][4 channels]  (q = channel quad): the 16 lanes of a ds_read_b128 group read 16 consecutive
 //     cells = 256 contiguous bytes (conflict free without a swizzle), and because RY / RX are template constants every corner of every
 //     quad is  base + immediate offset : two address registers per tap instead of 32 computed addresses;
 //   * the region is staged WITH its out-of-volume cells as zeros, so corners outside the volume along y / x read zeros and need no masks
-//     (cuh:43-65 returns 0 for them); only z (whole depth staged, D <= 4) keeps its two masks;
+//     (cuh:43-65 returns 0 for them); only z (whole depth staged, D <= 4) keeps its two masks; the validity rule cuh:248 is kept explicitly
+//     (a sample exactly on -1 must not hand out a coordinate derivative);
 //   * the lane -> voxel map is permuted so that each lane group of a ds_read_b128 holds 16 x-consecutive voxels;
 //   * trilinear weights and the 8 x CH multiply-adds on v_pk_mul_f32 / v_pk_fma_f32 with op_sel broadcasting the weight (no splat moves);
-//   * samples are written as one ds_write_b128 per quad into a quad-planar tile  S[q][voxel][4]  that the matrix waves read as b128;
+//   * forward: every wave samples AND contracts its own 64 voxels -- corner reads of tap t + 1 in the shadow of the MFMAs of tap t, B operands
+//     from the wave's own registers (v_permlane32_swap_b32), no sample tile, no barrier inside a chunk, two workgroups per CU;
+//   * grad_offset + grad_weight: 4 sampler waves (a voxel per lane, all CH channels) + 4 matrix waves that run both products;
 //   * a sample whose corner block leaves the staged box is redone by the whole wave (lane = channel x corner pair: two global loads per
 //     lane, one round trip) instead of 16 serial channel round trips in the one slow lane.
 #include "dcn_internal.h"
@@ -101,22 +108,11 @@ __device__ __forceinline__ void lean_stage(const LeanP& p, const float* __restri
   }
 }
 
-// channel (within the chunk) that lane half hh contracts in k-step s of the matrix waves: the B operand of step s is component s & 3 of
-// the b128 read of quad 2 * (s >> 2) + hh (CH = 16; first 4 steps of CH = 12), or component s & 1 of the b64 read at quad 2 + 8 * hh bytes
-template <int CH>
-__device__ __forceinline__ int lean_kstep_channel(int s, int hh) {
-  if (CH == 16 || s < 4) return 4 * (2 * (s >> 2) + hh) + (s & 3);
-  return 8 + 2 * hh + (s & 1);
-}
-
 #ifdef DPF_STAMPS
 __device__ unsigned long long g_lean_stamps[16 * 128 * 4];
-#define LEAN_STAMP(step, slot)                                                                                          \
-  if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_lean_stamps[(wave_u * 128 + (step)) * 4 + (slot)] = __builtin_readcyclecounter();
 #define LEAN_STAMP4(step, slot) \
   if (blockIdx.x == 3000 && lane == 0 && (step) < 128) g_lean_stamps[((wave_u + 8) * 128 + (step)) * 4 + (slot)] = __builtin_readcyclecounter();
 #else
-#define LEAN_STAMP(step, slot)
 #define LEAN_STAMP4(step, slot)
 #endif
 
@@ -174,219 +170,6 @@ __device__ __forceinline__ LeanTab lean_tab(const LeanP& p, bool pvalid, int ry0
   dst[5] = *reinterpret_cast<const f32x4*>(r1 + (q) * G::PLANE + 16);                             \
   dst[6] = *reinterpret_cast<const f32x4*>(r1 + (q) * G::PLANE + G::RX * 16);                     \
   dst[7] = *reinterpret_cast<const f32x4*>(r1 + (q) * G::PLANE + G::RX * 16 + 16);
-
-// Trilinear samples of the CH staged channels for one (voxel, tap), written to this lane's cell of the sample tile; samples whose corner
-// block leaves the staged box are redone by the whole wave from global memory (see the file header).  The corner reads of two quads are
-// in flight while a third is accumulated; `between` runs right after the first reads were issued (the caller builds the next tap's table
-// there, under the LDS latency).
-template <class G, class F>
-__device__ __forceinline__ void lean_gather(const LeanP& p, const char* region, char* s_tile, int vox, int lane, bool pvalid, const LeanTab& tb,
-                                            const float* __restrict__ xb, int c0, F between) {
-  constexpr int CH = G::CH, NQ = G::NQ;
-  const char* r0 = region + tb.a0;
-  const char* r1 = region + tb.a1;
-  char* sdst = s_tile + vox * 16;
-  f32x4 cr[3][8];
-  LEAN_LOAD8(cr[0], 0)
-  if (NQ > 1) { LEAN_LOAD8(cr[1], 1) }
-  between();
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    if (q + 2 < NQ) { LEAN_LOAD8(cr[(q + 2) % 3], q + 2) }
-    const f32x4* c = cr[q % 3];
-    f32x2 lo = pk_mul_lo(tb.w00, c[0].xy), hi = pk_mul_lo(tb.w00, c[0].zw);
-    pk_fma_hi(lo, tb.w00, c[1].xy); pk_fma_hi(hi, tb.w00, c[1].zw);
-    pk_fma_lo(lo, tb.w01, c[2].xy); pk_fma_lo(hi, tb.w01, c[2].zw);
-    pk_fma_hi(lo, tb.w01, c[3].xy); pk_fma_hi(hi, tb.w01, c[3].zw);
-    pk_fma_lo(lo, tb.w10, c[4].xy); pk_fma_lo(hi, tb.w10, c[4].zw);
-    pk_fma_hi(lo, tb.w10, c[5].xy); pk_fma_hi(hi, tb.w10, c[5].zw);
-    pk_fma_lo(lo, tb.w11, c[6].xy); pk_fma_lo(hi, tb.w11, c[6].zw);
-    pk_fma_hi(lo, tb.w11, c[7].xy); pk_fma_hi(hi, tb.w11, c[7].zw);
-    *reinterpret_cast<f32x4*>(sdst + q * G::SQ) = f32x4{lo.x, lo.y, hi.x, hi.y};
-  }
-  // ---- samples whose corner block leaves the staged box (rare): the wave redoes them together from global memory.  Lane l takes
-  // channel l & 15 and the corner pair (jd, jh) = (l >> 5, (l >> 4) & 1): two loads (jw = 0, 1), then the four pairs are summed
-  // across lanes.  (cuh:248: a sample outside (-1, D) x (-1, H) x (-1, W) is zero -- it stays with the zero the fast path wrote.)
-  unsigned long long slow = __ballot(tb.slow);
-  while (slow) {
-    const int L = __builtin_ctzll(slow);
-    slow &= slow - 1;
-    const int sd0 = __builtin_amdgcn_readlane(tb.d0, L), sh0 = __builtin_amdgcn_readlane(tb.h0, L), sw0 = __builtin_amdgcn_readlane(tb.w0, L);
-    const float sld = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.ld), L));
-    const float slh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.lh), L));
-    const float slw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.lw), L));
-    const int svox = __builtin_amdgcn_readlane(vox, L);
-    const int ch = lane & 15, jd = lane >> 5, jh = (lane >> 4) & 1;
-    const int dz = sd0 + jd, hy = sh0 + jh;
-    const int cgl = c0 + ch;
-    const bool rowin = ch < CH && cgl < p.C && (unsigned)dz < (unsigned)p.D && (unsigned)hy < (unsigned)p.H;
-    const bool in0 = rowin && (unsigned)sw0 < (unsigned)p.W, in1 = rowin && (unsigned)(sw0 + 1) < (unsigned)p.W;
-    const float* xr = xb + (long long)(cgl < p.C ? cgl : 0) * p.P + ((long long)(rowin ? dz : 0) * p.H + (rowin ? hy : 0)) * p.W;
-    const float v0 = in0 ? xr[sw0] : 0.f, v1 = in1 ? xr[sw0 + 1] : 0.f;
-    const float wzy = (jd ? sld : 1.f - sld) * (jh ? slh : 1.f - slh);
-    float part = fmaf(wzy * slw, v1, (wzy * (1.f - slw)) * v0);
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
-    if (lane < CH) *reinterpret_cast<float*>(s_tile + (lane >> 2) * G::SQ + svox * 16 + (lane & 3) * 4) = part;
-  }
-}
-
-// Role-split forward: waves [0, NS) sample (a voxel per lane, all CH channels of the staged chunk), waves [NS, 2 NS) contract 64 voxels
-// each against the [K x CH] weight slice of the tap on v_mfma_f32_32x32x2_f32 (exact fp32).  The sample tile is double buffered: one
-// barrier per tap.  Latencies are taken out of the step: the samplers fetch a tap's offsets three taps ahead (a first-touch HBM read
-// each: the offset tensor is 0.5 GB), the matrix waves copy tile t into registers right after barrier t and meanwhile contract tile
-// t - 1, whose weight fragments were fetched (L2) during the step before.
-template <class G, int MT>
-__global__ __launch_bounds__(128 * G::NS) void dcn_lean_fwd_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                                  const float* __restrict__ wt, const float* __restrict__ bias,
-                                                                  float* __restrict__ out, LeanP p) {
-  extern __shared__ __align__(16) char smem[];
-  constexpr int CH = G::CH, NQ = G::NQ, NS = G::NS, KSTEPS = CH / 2, T = 27;
-  char* region = smem;
-  char* s_S = smem + NQ * G::PLANE;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int blk = lean_xcd_tile(blockIdx.x, gridDim.x);
-  const int tx = blk % p.tilesX; blk /= p.tilesX;
-  const int ty = blk % p.tilesY;
-  const int b = blk / p.tilesY;
-  const int y0 = ty * G::TY, x0 = tx * G::TX;
-  const int ry0 = y0 - 1 - G::RYH, rx0 = x0 - 1 - G::RXL;
-  const float* xb = x + (long long)b * p.C * p.P;
-  if (wave_u < NS) {
-    // ------------------------------------------------------------------------------------------------------------ samplers
-    const int vox = wave_u * 64 + (lane & 32) + lane_pos32(lane & 31);
-    const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
-    const int zo = pz, yo = y0 + py, xo = x0 + px;
-    const bool pvalid = zo < p.D && yo < p.H && xo < p.W;
-    const long long ppos = pvalid ? ((long long)zo * p.H + yo) * p.W + xo : 0;
-    const float* offp0 = offset + (long long)b * 3 * T * p.P + ppos;
-    const float zbf = (float)(zo - 1), ybf = (float)(yo - 1), xbf = (float)(xo - 1);
-    const long long P3 = 3 * p.P;
-    // Offsets are fetched four taps ahead of their use (first-touch HBM reads): slot (u % 3) of the ring holds tap u's three components.
-    // The table of tap t + 1 is built while tap t's first corner reads are in flight.
-    float od[3], oh[3], ow[3];
-    LeanTab tab = lean_tab<G>(p, pvalid, ry0, rx0, zbf + offp0[0], ybf + offp0[p.P], xbf + offp0[2 * p.P]);
-#pragma unroll
-    for (int u = 1; u <= 3; ++u) { od[u % 3] = offp0[u * P3]; oh[u % 3] = offp0[u * P3 + p.P]; ow[u % 3] = offp0[u * P3 + 2 * p.P]; }
-#pragma unroll 1
-    for (int c0 = 0; c0 < p.C; c0 += CH) {
-      __syncthreads();                                 // everybody is done with the previous chunk's region
-      lean_stage<G>(p, xb, c0, region, ry0, rx0, tid, 128 * NS);
-      __syncthreads();
-#pragma unroll 1
-      for (int g = 0; g < 9; ++g) {                    // tap row (ti, tj) = (g / 3, g % 3); the three tk are unrolled
-        const int gn = g < 8 ? g + 1 : 0;              // row of the tap after this row's last one (the next chunk starts over)
-        const int ti = g / 3, tj = g - 3 * ti, tin = gn / 3, tjn = gn - 3 * tin;
-        const float fz_same = zbf + (float)ti, fy_same = ybf + (float)tj, fz_next = zbf + (float)tin, fy_next = ybf + (float)tjn;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int t = 3 * g + r;
-          LEAN_STAMP(t, 0)
-          const int sl = (r + 1) % 3;                  // ring slot of tap t + 1
-          const float fdn = (r < 2 ? fz_same : fz_next) + od[sl], fhn = (r < 2 ? fy_same : fy_next) + oh[sl];
-          const float fwn = (xbf + (float)((r + 1) % 3)) + ow[sl];
-          {
-            int u = t + 4;                             // refill the slot with the tap three further on
-            if (u >= T) u -= T;
-            const float* np = offp0 + (long long)u * P3;
-            od[sl] = np[0]; oh[sl] = np[p.P]; ow[sl] = np[2 * p.P];
-          }
-          LeanTab tabn;
-#ifdef LEAN_NO_SAMPLE
-          tabn = lean_tab<G>(p, pvalid, ry0, rx0, fdn, fhn, fwn);
-#else
-          lean_gather<G>(p, region, s_S + ((g + r) & 1) * G::SBUF, vox, lane, pvalid, tab, xb, c0,
-                         [&]() { tabn = lean_tab<G>(p, pvalid, ry0, rx0, fdn, fhn, fwn); });
-#endif
-          tab = tabn;
-          LEAN_STAMP(t, 1)
-          __syncthreads();                             // barrier t: S[t & 1] is complete; the matrix waves hold S[(t - 1) & 1] in registers
-          LEAN_STAMP(t, 2)
-        }
-      }
-    }
-  } else {
-    // ------------------------------------------------------------------------------------------------------------ matrix waves
-    const int mw = wave_u - NS, l31 = lane & 31, hh = lane >> 5;
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[m][nt][j] = 0.f;
-    const unsigned sb = (unsigned)(NQ * G::PLANE + (mw * 64 + l31) * 16 + hh * G::SQ);              // quad hh of voxel mw*64 + l31 (LDS byte address)
-    const unsigned sb2 = (unsigned)(NQ * G::PLANE + (mw * 64 + l31) * 16 + 2 * G::SQ + hh * 8);     // CH = 12: this lane half's half of quad 2
-    const unsigned wlane = (unsigned)lane * 32u;       // this lane's 8 fragments of a (tap, chunk, m) block of the repacked weights
-    // one step: fetch the weight fragments of tile t (used in the NEXT step), pass barrier t, copy tile t from LDS into registers and meanwhile
-    // contract tile t - 1.  Two register sets alternate (the tap loop is unrolled by two), so nothing is copied.
-    auto step = [&](int t, int chunk, f32x4 (&aU)[MT][2], f32x4 (&bU)[2][2], f32x4 (&aL)[MT][2], f32x4 (&bL)[2][2]) {
-      // aU / bU: in use (tile t - 1);  aL / bL: being loaded (tile t)
-      if (t < T) {
-        const char* wb = reinterpret_cast<const char*>(wt) + ((long long)(t * p.nchunk + chunk) * MT) * 2048;   // uniform
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          aL[m][0] = *reinterpret_cast<const f32x4*>(wb + wlane + m * 2048);
-          aL[m][1] = *reinterpret_cast<const f32x4*>(wb + wlane + m * 2048 + 16);
-        }
-        __syncthreads();                               // barrier t
-        LEAN_STAMP(t, 0)
-        const unsigned so = (t & 1) * G::SBUF;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          bL[nt][0] = *reinterpret_cast<const f32x4*>(smem + sb + so + nt * 512);
-          if constexpr (CH == 16) {
-            bL[nt][1] = *reinterpret_cast<const f32x4*>(smem + sb + so + nt * 512 + 2 * G::SQ);
-          } else {
-            const f32x2 f1 = *reinterpret_cast<const f32x2*>(smem + sb2 + so + nt * 512);
-            bL[nt][1] = f32x4{f1.x, f1.y, 0.f, 0.f};
-          }
-        }
-      }
-#ifndef LEAN_NO_MFMA
-      if (t > 0) {
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[m][s >> 2][s & 3], bU[nt][s >> 2][s & 3], acc[m][nt], 0, 0, 0);
-      }
-#endif
-      LEAN_STAMP(t, 1)
-    };
-    f32x4 aA[MT][2], aB[MT][2], bA[2][2], bB[2][2];
-    int chunk = 0;
-#pragma unroll 1
-    for (int c0 = 0; c0 < p.C; c0 += CH, ++chunk) {
-      __syncthreads();
-      lean_stage<G>(p, xb, c0, region, ry0, rx0, tid, 128 * NS);
-      __syncthreads();
-#pragma unroll 1
-      for (int t = 0; t <= T; t += 2) {                // T + 1 = 28 steps: tile t is loaded in step t and contracted in step t + 1
-        step(t, chunk, aB, bB, aA, bA);
-        step(t + 1, chunk, aA, bA, aB, bB);
-      }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int vox = mw * 64 + nt * 32 + l31;
-      const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
-      const int gz = pz, gy = y0 + py, gx = x0 + px;
-      if (gz < p.D && gy < p.H && gx < p.W) {
-        const long long pos = ((long long)gz * p.H + gy) * p.W + gx;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-            if (k < p.K) out[((long long)b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
-          }
-      }
-    }
-  }
-}
 
 // ---- forward, second form: every wave samples AND contracts its own 64 voxels.  Measured on this chip (tools/lean_probe.hip,
 // tools/lean_probe2.hip): an fp32 MFMA and vector-ALU work never overlap on a SIMD -- not across waves (a wave issuing MFMAs back to back
@@ -914,51 +697,10 @@ __global__ void lean_repack_gcol_kernel(const float* __restrict__ w, float* __re
   }
 }
 
-// Weight fragments in the order the matrix waves consume them: wl[tap][chunk][m][lane][8] with fragment s of lane (l31, hh) =
-// W[k = 32 m + l31][c = chunk * CH + lean_kstep_channel(s, hh)][tap] (zero beyond K / C; CH = 12 uses s < 6), so that a lane fetches its 8
-// fragments of a (tap, chunk, m) block as two 16-byte loads from one uniform base + 32 * lane.
-template <int CH>
-__global__ void lean_repack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wl, int K, int C, int MT, int nchunk) {
-  const int total = 27 * nchunk * MT * 512;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int s = i & 7, lane = (i >> 3) & 63;
-    int r = i >> 9;
-    const int m = r % MT; r /= MT;
-    const int chunk = r % nchunk;
-    const int t = r / nchunk;
-    const int k = 32 * m + (lane & 31);
-    float v = 0.f;
-    if (s < CH / 2) {
-      const int c = chunk * CH + lean_kstep_channel<CH>(s, lane >> 5);
-      if (k < K && c < C) v = w[((long long)k * C + c) * 27 + t];
-    }
-    wl[i] = v;
-  }
-}
-
 template <typename F>
 int lean_set_lds(F f, size_t lds) {
   if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DPF_ERR_LAUNCH;
   return DPF_OK;
-}
-
-template <class G>
-int lean_launch_fwd(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, LeanP p, hipStream_t st) {
-  p.tilesY = dpf_div_up(p.H, G::TY);
-  p.tilesX = dpf_div_up(p.W, G::TX);
-  const long long blocks = (long long)p.B * p.tilesY * p.tilesX;
-  if (blocks >= 0x7fffffffLL) return DPF_ERR_UNSUPPORTED;
-  const int MT = p.KT / 32;
-  hipLaunchKernelGGL((lean_repack_fwd_kernel<G::CH>), dim3(dpf_ew_grid(27LL * p.nchunk * MT * 512)), dim3(256), 0, st, weight, ws, p.K, p.C, MT, p.nchunk);
-  const dim3 grid((unsigned)blocks), block(128 * G::NS);
-  if (MT == 1) {
-    if (lean_set_lds(dcn_lean_fwd_kernel<G, 1>, G::LDS) != DPF_OK) return DPF_ERR_LAUNCH;
-    hipLaunchKernelGGL((dcn_lean_fwd_kernel<G, 1>), grid, block, G::LDS, st, x, offset, ws, bias, out, p);
-  } else {
-    if (lean_set_lds(dcn_lean_fwd_kernel<G, 2>, G::LDS) != DPF_OK) return DPF_ERR_LAUNCH;
-    hipLaunchKernelGGL((dcn_lean_fwd_kernel<G, 2>), grid, block, G::LDS, st, x, offset, ws, bias, out, p);
-  }
-  return dpf_check_launch();
 }
 
 template <class G>
@@ -982,13 +724,9 @@ int lean_launch_fwd1(const float* x, const float* offset, const float* weight, c
 }
 
 //                  CH TY  TX RYH RXL RXR      voxels  region cells    LDS
-typedef Geo<16, 2, 32, 3, 3, 3> G16a;   //   256     4 x 10 x 40    135 168   one workgroup per CU
-typedef Geo<16, 2, 16, 3, 3, 3> G16b;   //   128     4 x 10 x 24     77 824   two per CU
-typedef Geo<16, 4, 16, 3, 3, 3> G16c;   //   256     4 x 12 x 24    106 496
-typedef Geo<12, 2, 32, 5, 7, 4> G12a;   //   256     4 x 14 x 48    153 600   the first layer's offsets are wider (p99 3.7 voxels): halo 4-7 / 5
-typedef Geo<12, 2, 16, 4, 3, 3> G12b;   //   128     4 x 12 x 24     67 584   two per CU
-typedef Geo<12, 4, 16, 5, 7, 4> G12c;   //   256     4 x 16 x 32    122 880
-typedef Geo<12, 4, 16, 5, 3, 3> G12d;   //   256     4 x 16 x 24     73 728 (region only: two all-in-one workgroups per CU)
+typedef Geo<16, 4, 16, 3, 3, 3> G16c;   //   256     4 x 12 x 24     73 728   forward: region only, two workgroups per CU
+typedef Geo<12, 4, 16, 5, 7, 4> G12c;   //   256     4 x 16 x 32     98 304   forward, wider x halo: one workgroup per CU (DPF_DCN_LEAN_WIDE12=1)
+typedef Geo<12, 4, 16, 5, 3, 3> G12d;   //   256     4 x 16 x 24     73 728   forward: region only, two workgroups per CU
 
 typedef Geo<16, 4, 16, 4, 3, 3> B16;    //   256     4 x 14 x 24    152 064   backward tiles: region + 2 gcol tiles + 2 sample tiles
 typedef Geo<12, 4, 16, 5, 7, 4> B12;    //   256     4 x 16 x 32    147 840
@@ -1034,22 +772,10 @@ int dcn_lean_forward(const float* x, const float* offset, const float* weight, c
   p.nchunk = p.Cpad / CH;
   p.KT = 32 * ((K + 31) / 32);
   p.P = (long long)D * H * W;
-  // DPF_DCN_LEAN_FWD = 1: every wave samples and contracts its own voxels; a | b | c: role-split kernel on tile variant a / b / c
-  static const char tile = getenv("DPF_DCN_LEAN_FWD") ? getenv("DPF_DCN_LEAN_FWD")[0] : '1';
-  if (tile == '1') {
-    if (CH == 16) return lean_launch_fwd1<G16c>(x, offset, weight, bias, out, ws, p, st);
-    static const int wide12 = getenv("DPF_DCN_LEAN_WIDE12") ? atoi(getenv("DPF_DCN_LEAN_WIDE12")) : 0;   // 1: wider x halo, one workgroup per CU
-    if (wide12) return lean_launch_fwd1<G12c>(x, offset, weight, bias, out, ws, p, st);
-    return lean_launch_fwd1<G12d>(x, offset, weight, bias, out, ws, p, st);
-  }
-  if (CH == 16) {
-    if (tile == 'b') return lean_launch_fwd<G16b>(x, offset, weight, bias, out, ws, p, st);
-    if (tile == 'a') return lean_launch_fwd<G16a>(x, offset, weight, bias, out, ws, p, st);
-    return lean_launch_fwd<G16c>(x, offset, weight, bias, out, ws, p, st);
-  }
-  if (tile == 'b') return lean_launch_fwd<G12b>(x, offset, weight, bias, out, ws, p, st);
-  if (tile == 'a') return lean_launch_fwd<G12a>(x, offset, weight, bias, out, ws, p, st);
-  return lean_launch_fwd<G12c>(x, offset, weight, bias, out, ws, p, st);
+  if (CH == 16) return lean_launch_fwd1<G16c>(x, offset, weight, bias, out, ws, p, st);
+  static const int wide12 = getenv("DPF_DCN_LEAN_WIDE12") ? atoi(getenv("DPF_DCN_LEAN_WIDE12")) : 0;   // 1: wider x halo, one workgroup per CU (3.7 vs 2.6 ms)
+  if (wide12) return lean_launch_fwd1<G12c>(x, offset, weight, bias, out, ws, p, st);
+  return lean_launch_fwd1<G12d>(x, offset, weight, bias, out, ws, p, st);
 }
 
 // grad_offset (fully written) + grad_weight partials into dwtmp[LEAN_NREP = 8][27][nchunk][64][16] (zero-initialised by the caller, folded by

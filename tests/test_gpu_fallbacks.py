@@ -10,16 +10,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SETS = [
-    # 8-wave packed grad_input kernel, fused (not role-split) grad_offset kernel, 8 waves per CU in the forward
-    ({'DPF_DCN_PK16': '0', 'DPF_DCN_OFF_RS': '0', 'DPF_DCN_FWD_RS': '8'}, 'test_deform_conv and not full_size'),
-    # 4 x 2 x 32 tile in the role-split grad_offset kernel, 4-row forward tile planes
-    ({'DPF_DCN_OFF_TX': '32', 'DPF_DCN_FWD_TY': '4'}, 'test_deform_conv and not full_size'),
-    # role-split forward off (region kernels), half-width tile off
-    ({'DPF_DCN_FWD_RS': '0'}, 'test_deform_conv and not full_size'),
+    # lean-sampler deformable kernels off: the role-split region kernels take the model's shapes too
+    ({'DPF_DCN_LEAN': '0'}, 'test_deform_conv and not full_size'),
+    # first-generation deformable kernels (global-memory gathers: what geometries without a fitting LDS image fall back to)
+    ({'DPF_DCN_V1': '1'}, 'test_deform_conv and not full_size'),
+    # the 35-channel forward on the wider x halo (one workgroup per CU)
+    ({'DPF_DCN_LEAN_WIDE12': '1'}, 'test_deform_conv and not full_size'),
     # consecutive-row weight-gradient tiles for dilated layers, one output plane per forward tile
     ({'DPF_W2_RSTEP': '0', 'DPF_G2_PZ': '1'}, 'test_conv_forward_backward'),
-    # four output planes per tile wherever the geometry allows it
-    ({'DPF_G2_PZ': '4'}, 'test_conv_forward_backward'),
+    # four output planes per tile wherever the geometry allows it; run-time column stride in the weight gradient
+    ({'DPF_G2_PZ': '4', 'DPF_W2_SW1': '0'}, 'test_conv_forward_backward'),
     # first-generation dense conv kernels (what unaligned shapes fall back to)
     ({'DPF_IGEMM2': '0', 'DPF_WGRAD2': '0', 'DPF_IGEMM2_TR2': '0'}, 'test_conv_forward_backward'),
 ]

@@ -412,7 +412,11 @@ def test_softargmin():
 
 @pytest.mark.parametrize('cfg', [(2, 35, 64, 4, 6, 9), (1, 64, 64, 4, 8, 12), (2, 5, 7, 3, 5, 6),
                                  # several tiles per axis and offsets reaching past the staged halo (slow paths), 12- and 16-wide chunks
-                                 (1, 20, 40, 5, 9, 70, 3.0), (1, 16, 24, 4, 7, 45, 4.0)])
+                                 (1, 20, 40, 5, 9, 70, 3.0), (1, 16, 24, 4, 7, 45, 4.0),
+                                 # the lean-sampler kernels' domain (depth <= 4, W % 4 == 0): the model's channel counts, several tiles, wide
+                                 # offsets (cooperative slow path), shallow volumes, a partial tile row
+                                 (2, 35, 64, 4, 6, 12), (1, 20, 40, 4, 9, 72, 3.0), (1, 16, 24, 3, 7, 44, 4.0), (1, 36, 33, 2, 37, 20, 6.0),
+                                 (1, 12, 8, 1, 5, 8, 1.0)])
 def test_deform_conv(cfg):
     from oracle import dcn3d
     ops = _ops()
@@ -433,6 +437,29 @@ def test_deform_conv(cfg):
     # known answer: zero offsets == plain conv3d
     y0 = ops.deform_conv3d(xg, torch.zeros_like(og), wg, bg)
     close(y0, F.conv3d(x, wt, bs, padding=1), 1e-4, 'dcn zero offset')
+
+
+@pytest.mark.parametrize('shape', [(1, 8, 16, 4, 6, 16), (1, 5, 7, 3, 5, 6)])
+def test_deform_conv_integer_offsets_and_the_validity_rule(shape):
+    """Integer offsets put samples exactly on voxel centres, on the borders and on coordinate -1: deform_im2col_cuda.cuh:248 declares a
+    sample outside the OPEN interval (-1, size) invalid -- no value and no coordinate derivative -- although its high corner would still
+    sit inside the volume.  (The lean kernels read a zero-padded image, which alone would hand such a sample a derivative.)"""
+    from oracle import dcn3d
+    ops = _ops()
+    B, C, K, D, H, W = shape
+    x = rnd(B, C, D, H, W, seed=170)
+    off = torch.randint(-2, 3, (B, 81, D, H, W), generator=torch.Generator().manual_seed(171)).float()
+    wt = rnd(K, C, 3, 3, 3, seed=172, scale=0.1)
+    bs = rnd(K, seed=173)
+    y_ref = dcn3d.deform_conv3d_forward(x, off, wt, bs)
+    go = rnd(*y_ref.shape, seed=174)
+    gr = dcn3d.deform_conv3d_backward(x, off, wt, bs, go)
+    xg, og, wg, bg = [t.to(DEV).requires_grad_() for t in (x, off, wt, bs)]
+    y = ops.deform_conv3d(xg, og, wg, bg)
+    close(y, y_ref, 1e-4, 'dcn fwd (integer offsets)')
+    gg = torch.autograd.grad(y, (xg, og, wg, bg), go.to(DEV))
+    for a, r, nm in zip(gg, gr, ('grad_input', 'grad_offset', 'grad_weight', 'grad_bias')):
+        close(a, r, 2e-4, 'dcn %s (integer offsets)' % nm)
 
 
 @pytest.mark.parametrize('gi', [None, 5, 17])

@@ -11,15 +11,31 @@ import sys
 
 
 def family(name):
-    for key in ('igemm2', 'wgrad2', 'pointwise', 'conv_igemm_kernel', 'conv_wgrad_kernel', 'dcn_bwd_input', 'dcn_fwd', 'dcn_bwd_offset',
-                'dcn_wgrad_region', 'smallk', 'bn_', 'head_'):
+    for key, fam in (('igemm2', 'igemm2'), ('wgrad2', 'wgrad2'), ('pointwise', 'pointwise'), ('conv_igemm_kernel', 'conv_igemm_kernel'),
+                     ('conv_wgrad_kernel', 'conv_wgrad_kernel'), ('dcn_bwd_input', 'dcn_bwd_input'), ('dcn_lean_fwd', 'dcn_fwd'), ('dcn_fwd', 'dcn_fwd'),
+                     ('dcn_lean_bwd_offset', 'dcn_bwd_offset'), ('dcn_bwd_offset', 'dcn_bwd_offset'), ('dcn_wgrad_fold', 'dcn_bwd_offset'),
+                     ('smallk', 'smallk'), ('bn_', 'bn_'), ('head_', 'head_')):
         if key in name:
-            return key
+            return fam
     return None
 
 
+def kernel_sources_sha16():
+    """sha-256 (first 16 hex digits) over the kernel sources the numbers belong to: bench.py recomputes it and says whether the committed
+    traffic file still matches the kernels it runs."""
+    import glob
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'dualpixelface_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 # helper launches of a family (weight packs, slab folds): their bytes belong to the operation, but "per launch" means per main kernel
-HELPERS = ('igemm2_pack', 'wgrad2_reduce', 'wgrad2_fold', 'pointwise_wgrad_fold', 'pointwise_wgrad_reduce', 'bn_finalize', 'bn_fold')
+HELPERS = ('igemm2_pack', 'wgrad2_reduce', 'wgrad2_fold', 'pointwise_wgrad_fold', 'pointwise_wgrad_reduce', 'bn_finalize', 'bn_fold', 'dcn_wgrad_fold')
 
 
 def agg(path, counter):
@@ -52,6 +68,11 @@ def main():
         if steps:      # all dispatches of the family (helpers included) per train step
             out[fam]['hbm_bytes_per_step'] = (2 * fetch.get(fam, 0.0) + write.get(fam, 0.0)) * 1024.0 / steps
             out[fam]['launches_per_step'] = launches / steps
+    import time
+    out['_meta'] = {'kernel_sources_sha16': kernel_sources_sha16(), 'collected_utc': time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime()),
+                    'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 '
+                               '--no-cpu-baseline --no-detail --wgrad-inline', 'train_steps_in_each_pass': steps,
+                    'units': 'FETCH_SIZE / WRITE_SIZE in KiB; FETCH doubled (gfx950 counts 64 B per 128-B request), MI355X_MICROARCH.md'}
     json.dump(out, open(sys.argv[3], 'w') if len(sys.argv) > 3 else sys.stdout, indent=1)
 
 
