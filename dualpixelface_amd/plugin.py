@@ -144,8 +144,7 @@ class _PluginHooks(object):
                     if main is not None and cur != main:
                         main.wait_stream(cur)
                     with (torch.cuda.stream(main) if main is not None else contextlib.nullcontext()):
-                        for p, g in ops.wgrad_async_take(lambda q: reducer.bucket_of(q) == bi):
-                            p.grad = g if p.grad is None else p.grad + g
+                        _attach_deferred(ops.wgrad_async_take(lambda q: reducer.bucket_of(q) == bi))
                         gather([(p, v) for p, v in pairs if reducer.bucket_of(p) == bi])
                         reducer.stage_launch(bi)
                 self._grad_stage = on_stage
@@ -157,8 +156,7 @@ class _PluginHooks(object):
             finally:
                 self._grad_stage = None
                 self._two_streams_ok = False
-            for p, g in ops.wgrad_async_finish():
-                p.grad = g if p.grad is None else p.grad + g
+            _attach_deferred(ops.wgrad_async_finish())
             gather(pairs)
             if reducer is not None:
                 if staged:
@@ -182,6 +180,25 @@ class _PluginHooks(object):
         ops.adam_step(self.flat_parameters(), flat_g, st['m'], st['v'], st['step'], float(lr if lr is not None else self.option.init_lr),
                       0.9, 0.999, 1e-5, gscale)
         return results
+
+
+def _attach_deferred(pairs):
+    """Hand the side-stream weight gradients to their parameters.  A weight used twice per step (the shared feature extractor: left and
+    right pass) gets two gradients: the second is added in place by ONE multi-tensor launch for all such weights instead of an add kernel
+    (and a fresh tensor) per weight."""
+    dst, src, busy = [], [], set()
+    for p, g in pairs:
+        if p.grad is None:
+            p.grad = g
+            continue
+        if id(p) in busy:                                  # a third gradient for the same weight: finish the pending adds first
+            torch._foreach_add_(dst, src)
+            dst, src, busy = [], [], set()
+        dst.append(p.grad)
+        src.append(g)
+        busy.add(id(p))
+    if dst:
+        torch._foreach_add_(dst, src)
 
 
 class STEREODPNET(_PluginHooks, StereoDPNetCore):
