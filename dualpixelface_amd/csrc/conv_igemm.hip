@@ -588,6 +588,11 @@ int dpf_conv_wgrad_slice(const float* g, const float* x, float* dw, int N, int C
 
 namespace { int g_operand_bf16 = 0; }
 int dpf_conv_operand_bf16() { return g_operand_bf16; }
+namespace { int g_f32_x9 = -1; }
+int dpf_conv_f32_x9() {
+  if (g_f32_x9 < 0) g_f32_x9 = getenv("DPF_F32_X9") ? (atoi(getenv("DPF_F32_X9")) != 0) : 1;
+  return g_f32_x9;
+}
 
 extern "C" {
 
@@ -598,6 +603,11 @@ int dpf_set_conv_operand_precision(int bf16) {
   return DPF_OK;
 }
 int dpf_get_conv_operand_precision(void) { return g_operand_bf16; }
+int dpf_set_f32_matrix_path(int split_bf16) {
+  g_f32_x9 = split_bf16 ? 1 : 0;
+  return DPF_OK;
+}
+int dpf_get_f32_matrix_path(void) { return dpf_conv_f32_x9(); }
 
 // workspace (floats) needed for the repacked weights of a conv with `T` taps, `reduce` reduction channels
 // and `outc` output channels

@@ -17,6 +17,8 @@ struct DpfConvDesc {
 // operand precision of the dense convolution kernels (dpf_set_conv_operand_precision): 0 = exact fp32, 1 = operands rounded to bf16
 // (RNE) in the staging path, fp32 accumulation and storage
 int dpf_conv_operand_bf16();
+// operand precision "f32": 1 = fp32 products as nine exact bf16 partial products on the bf16 matrix pipe (default), 0 = v_mfma_f32_* (DPF_F32_X9=0)
+int dpf_conv_f32_x9();
 
 // LDS-DMA double-buffered implicit GEMM (conv_igemm2.hip).  Returns DPF_OK when it launched, DPF_ERR_UNSUPPORTED when the
 // shape is not eligible (the caller then uses the generic kernel), another error code on failure.

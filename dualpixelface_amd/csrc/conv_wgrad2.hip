@@ -64,6 +64,25 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
 
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// exact three-way split of 8 floats into packed bf16 (truncations): v[i] = hi[i] + mid[i] + lo[i] exactly (24 significand bits = 3 x 8)
+__device__ __forceinline__ void split8_bf16(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  u32x4 h, m, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned a = __builtin_bit_cast(unsigned, v[2 * q]), b = __builtin_bit_cast(unsigned, v[2 * q + 1]);
+    h[q] = __builtin_amdgcn_perm(b, a, 0x07060302u);                                        // (a >> 16) | (b & 0xffff0000)
+    const float ra = v[2 * q] - __builtin_bit_cast(float, a & 0xffff0000u), rb = v[2 * q + 1] - __builtin_bit_cast(float, b & 0xffff0000u);
+    const unsigned ua = __builtin_bit_cast(unsigned, ra), ub = __builtin_bit_cast(unsigned, rb);
+    m[q] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const float sa = ra - __builtin_bit_cast(float, ua & 0xffff0000u), sb = rb - __builtin_bit_cast(float, ub & 0xffff0000u);
+    l[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
+  }
+  hi = __builtin_bit_cast(bf16x8, h); mid = __builtin_bit_cast(bf16x8, m); lo = __builtin_bit_cast(bf16x8, l);
+}
+
 constexpr int w2_occ_of(int nct) {
   const int est = nct * 17 + 2 * NLX + 64;
   return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
@@ -77,8 +96,14 @@ constexpr int w2_occ() { return w2_occ_of(NCT); }
 // SW1 = true: column stride 1 known at compile time -- the B-fragment reads s_x[colbase[t] + (8 j + i) * sw] become base + immediate (the
 // 109 v_add_u32 per tile pair that computed those addresses sat between the MFMAs of the loop, and on this chip vector-ALU work and fp32
 // MFMAs never overlap: tools/lean_probe2.hip)
-template <int NCT, bool BF = false, bool SW1 = false>
-__global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
+// X9 = true (the default for operand precision "f32", DPF_F32_X9=0 turns it off): fp32 products on the bf16 matrix pipe.  Both operands
+// are split EXACTLY into three bf16 terms (x = hi + mid + lo: three 8-bit truncations of the 24-bit significand), and a (16 positions x
+// column tile) unit is the 9 partial products hi/mid/lo x hi/mid/lo as v_mfma_f32_32x32x16_bf16 -- every partial product is exact, the sum
+// runs in the MFMA's fp32 accumulator, smallest terms first.  9 x 34 = 306 matrix-pipe clocks per 16 reduction indices instead of 8 x 64 =
+// 512 on v_mfma_f32_32x32x2_f32, and, unlike the fp32 MFMA, the bf16 MFMA leaves the vector ALU free: the ~11 split instructions per value
+// pair run in its shadow (tools/lean_probe2.hip: 4 v_fma_f32 per bf16 MFMA cost nothing, behind an fp32 MFMA they cost their full time).
+template <int NCT, bool BF = false, bool SW1 = false, bool X9 = false>
+__global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                      float* __restrict__ slab, W2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -211,6 +236,62 @@ __global__ __launch_bounds__(256, (w2_occ<NCT>())) void wgrad2_kernel(const floa
     // group j = positions 8j .. 8j+7 of this wave's row: lane half h takes 8j+4h .. 8j+4h+3; element i of both halves is one
     // MFMA k-step.  Units of (group, column-tile pair) are software pipelined over two B register sets; the A fragment of a
     // group is fetched one group ahead.
+    if constexpr (X9) {
+      // super-group J = positions 16 J .. 16 J + 15 of this wave's row: lane half h takes 16 J + 8 h .. + 7 (8 reduction indices of one
+      // v_mfma_f32_32x32x16_bf16); the g fragment (two 16-byte slots) is split once per super-group, an x fragment per column tile
+      const int colx = (8 - 4) * hh * sw;          // colbase[] points at position 4 hh; this path wants 8 hh
+      auto load_x = [&](int J, int t, float (&xv)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = s_x[colbase[t] + colx + (16 * J + i) * sw];
+      };
+      auto load_g = [&](int J, float (&gv)[8]) {
+        const int sl0 = wave * 8 + 4 * J + 2 * hh;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(s_g + (arow + (sl0 ^ axor)) * 4);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(s_g + (arow + ((sl0 + 1) ^ axor)) * 4);
+        gv[0] = g0[0]; gv[1] = g0[1]; gv[2] = g0[2]; gv[3] = g0[3]; gv[4] = g1[0]; gv[5] = g1[1]; gv[6] = g1[2]; gv[7] = g1[3];
+      };
+      // software pipeline over the 2 x NCT units: the x fragment of unit u + 2 is read and the one of unit u + 1 split (vector ALU)
+      // while unit u is contracted -- one MFMA, five vector instructions, alternating (sched_group_barrier)
+      float xr[8], gv[8];
+      bf16x8 aH, aM, aL, bH, bM, bL, nH, nM, nL;
+      load_g(0, gv);
+      load_x(0, 0, xr);
+      split8_bf16(gv, aH, aM, aL);
+      split8_bf16(xr, bH, bM, bL);
+      if (NCT > 1) load_x(0, 1, xr); else load_x(1, 0, xr);
+      bf16x8 a2H = aH, a2M = aM, a2L = aL;
+#pragma unroll
+      for (int J = 0; J < 2; ++J) {
+        if (J == 0) load_g(1, gv);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+          const int u = J * NCT + t;                      // this unit; u + 1 is split now, u + 2 is read now
+          if (u + 1 < 2 * NCT) split8_bf16(xr, nH, nM, nL);
+          if (u + 2 < 2 * NCT) load_x((u + 2) / NCT, (u + 2) % NCT, xr);
+          if (J == 0 && t == NCT - 1) split8_bf16(gv, a2H, a2M, a2L);      // g fragment of the second super-group
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bL, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bM, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM, bL, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bH, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bL, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM, bM, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM, bH, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bM, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bH, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // five vector-ALU instructions in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          bH = nH; bM = nM; bL = nL;
+        }
+        aH = a2H; aM = a2M; aL = a2L;
+      }
+      __syncthreads();     // vmcnt(0): next tile landed; barrier: this buffer is free
+      continue;
+    }
     constexpr int NP = (NCT + 1) / 2;            // column-tile pairs per group
     f32x4 aC, aN;
     float bA[2][4], bB[2][4];
@@ -364,25 +445,26 @@ int gather_conflicts(const DpfWgradDesc& d, int T, int ncolmax, int RS, int PS, 
   return total;
 }
 
-template <int NCT, bool BF, bool SW1>
+template <int NCT, bool BF, bool SW1, bool X9>
 int launch_w2c(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
   static bool done = false;
   if (lds > 48 * 1024 && !done) {
-    if (hipFuncSetAttribute((const void*)wgrad2_kernel<NCT, BF, SW1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)wgrad2_kernel<NCT, BF, SW1, X9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return DPF_ERR_LAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((wgrad2_kernel<NCT, BF, SW1>), dim3(blocks), dim3(256), lds, st, g, x, slab, p);
+  hipLaunchKernelGGL((wgrad2_kernel<NCT, BF, SW1, X9>), dim3(blocks), dim3(256), lds, st, g, x, slab, p);
   return dpf_check_launch();
 }
-template <int NCT, bool BF>
+template <int NCT, bool BF, bool X9>
 int launch_w2b(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
   static const int sw1 = env_int("DPF_W2_SW1", 1);
-  return (p.sw == 1 && sw1) ? launch_w2c<NCT, BF, true>(g, x, slab, p, lds, blocks, st) : launch_w2c<NCT, BF, false>(g, x, slab, p, lds, blocks, st);
+  return (p.sw == 1 && sw1) ? launch_w2c<NCT, BF, true, X9>(g, x, slab, p, lds, blocks, st) : launch_w2c<NCT, BF, false, X9>(g, x, slab, p, lds, blocks, st);
 }
 template <int NCT>
 int launch_w2(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
-  return dpf_conv_operand_bf16() ? launch_w2b<NCT, true>(g, x, slab, p, lds, blocks, st) : launch_w2b<NCT, false>(g, x, slab, p, lds, blocks, st);
+  if (dpf_conv_operand_bf16()) return launch_w2b<NCT, true, false>(g, x, slab, p, lds, blocks, st);
+  return dpf_conv_f32_x9() ? launch_w2b<NCT, false, true>(g, x, slab, p, lds, blocks, st) : launch_w2b<NCT, false, false>(g, x, slab, p, lds, blocks, st);
 }
 
 int w2_maxblocks() { return 1024; }     // upper bound of resident workgroups (4 per CU): sizes the slab workspace

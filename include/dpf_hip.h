@@ -56,6 +56,12 @@ int dpf_conv_transpose_acc(const float* x, const float* w, const float* bias, fl
  * shapes the bf16 kernels do not cover run exact fp32. */
 int dpf_set_conv_operand_precision(int bf16);
 int dpf_get_conv_operand_precision(void);
+/* How operand precision 0 (fp32) multiplies in the weight-gradient kernel: 1 (default; environment DPF_F32_X9=0 changes the default) = each
+ * fp32 product as the nine exact partial products of the three-way bf16 splits of its operands (x = hi + mid + lo, exact) on the bf16 matrix
+ * pipe, summed in the MFMA's fp32 accumulator; 0 = v_mfma_f32_32x32x2_f32.  Same results up to summation order (tests/test_gpu_ops.py:
+ * test_weight_gradient_f32_matrix_paths_agree); process-wide state. */
+int dpf_set_f32_matrix_path(int split_bf16);
+int dpf_get_f32_matrix_path(void);
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
 /* same, with caller scratch `ws` of dpf_conv_wgrad_workspace_floats(T, C, K) floats: eligible shapes (16-byte aligned rows, 3x3 /

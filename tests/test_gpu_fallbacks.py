@@ -18,8 +18,8 @@ SETS = [
     ({'DPF_DCN_LEAN_WIDE12': '1'}, 'test_deform_conv and not full_size'),
     # consecutive-row weight-gradient tiles for dilated layers, one output plane per forward tile
     ({'DPF_W2_RSTEP': '0', 'DPF_G2_PZ': '1'}, 'test_conv_forward_backward'),
-    # four output planes per tile wherever the geometry allows it; run-time column stride in the weight gradient
-    ({'DPF_G2_PZ': '4', 'DPF_W2_SW1': '0'}, 'test_conv_forward_backward'),
+    # four output planes per tile wherever the geometry allows it; run-time column stride and the fp32 matrix instruction in the weight gradient
+    ({'DPF_G2_PZ': '4', 'DPF_W2_SW1': '0', 'DPF_F32_X9': '0'}, 'test_conv_forward_backward'),
     # first-generation dense conv kernels (what unaligned shapes fall back to)
     ({'DPF_IGEMM2': '0', 'DPF_WGRAD2': '0', 'DPF_IGEMM2_TR2': '0'}, 'test_conv_forward_backward'),
 ]

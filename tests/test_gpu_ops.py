@@ -439,6 +439,34 @@ def test_deform_conv(cfg):
     close(y0, F.conv3d(x, wt, bs, padding=1), 1e-4, 'dcn zero offset')
 
 
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 4, 16, 64, (3, 3, 3), 1, 1), (2, 24, 40, 1, 24, 96, (1, 3, 3), 1, 3), (1, 32, 64, 4, 16, 32, (3, 3, 3), 2, 1)])
+def test_weight_gradient_f32_matrix_paths_agree(cfg):
+    """The weight gradient multiplies fp32 operands either on v_mfma_f32_32x32x2_f32 or as nine exact bf16 partial products on the bf16
+    matrix pipe (dpf_set_f32_matrix_path).  Both are fp32 arithmetic: against an fp64 reference neither may be worse than 2 x the other,
+    and each is within 1e-5 of the tensor scale."""
+    from dualpixelface_amd._lib import lib
+    ops = _ops()
+    N, C, K, D, H, W, ks, stride, dil = cfg
+    pad = tuple(((k - 1) * dil) // 2 if k > 1 else 0 for k in ks)
+    dl = tuple(dil if k > 1 else 1 for k in ks)
+    st = (stride if ks[0] > 1 else 1, stride, stride)
+    x = rnd(N, C, D, H, W, seed=180)
+    od = [(i + 2 * p - (d * (k - 1) + 1)) // s + 1 for i, k, s, p, d in zip((D, H, W), ks, st, pad, dl)]
+    g = rnd(N, K, *od, seed=181)
+    ref = torch.nn.grad.conv3d_weight(x.double(), (K, C) + ks, g.double(), st, pad, dl)
+    prev = lib().call('dpf_get_f32_matrix_path')
+    errs = []
+    try:
+        for path in (1, 0):
+            lib().call('dpf_set_f32_matrix_path', path)
+            got = ops._conv_wgrad_raw(g.to(DEV), x.to(DEV), (K, C) + ks, st, pad, dl).double().cpu()
+            errs.append(((got - ref).abs().max() / ref.abs().max()).item())
+    finally:
+        lib().call('dpf_set_f32_matrix_path', prev)
+    assert max(errs) <= 1e-5, errs
+    assert errs[0] <= 2 * errs[1] + 1e-7 and errs[1] <= 2 * errs[0] + 1e-7, errs
+
+
 @pytest.mark.parametrize('shape', [(1, 8, 16, 4, 6, 16), (1, 5, 7, 3, 5, 6)])
 def test_deform_conv_integer_offsets_and_the_validity_rule(shape):
     """Integer offsets put samples exactly on voxel centres, on the borders and on coordinate -1: deform_im2col_cuda.cuh:248 declares a

@@ -1,9 +1,3 @@
 cd /root/repo
-timeout 900 python tools/debug/dcn_bwd_check.py parity time 2>&1 | grep -v amdgpu.ids
-timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -x -q -k "side_stream or reference_fixture or flat_grad" 2>&1 | tail -3
-python bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/bench_b.json 2>/dev/null; python - <<'PY'
-import json
-d=json.loads([l for l in open('gpurun_out/bench_b.json') if l.startswith('{')][-1])
-print('value', d['value'], 'ms', d['ms_per_step'])
-for k,v in sorted(d['roofline']['families'].items(), key=lambda kv:-kv[1]['ms_per_step']): print('%-16s %7.2f ms' % (k, v['ms_per_step']))
-PY
+echo "== x9"; timeout 900 python tools/conv_shape_bench.py --check hg32 hg64 cv64_32 fe32 fe32q fe64 fe96_32 anm96d2 off81 fe32d5 2>&1 | grep -v amdgpu
+echo "== exact"; DPF_F32_X9=0 timeout 900 python tools/conv_shape_bench.py hg32 hg64 cv64_32 fe32 fe32q fe64 fe96_32 anm96d2 off81 fe32d5 2>&1 | grep -v amdgpu

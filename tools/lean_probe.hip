@@ -30,6 +30,17 @@ __global__ __launch_bounds__(512) void k(float* out, long long* clk, int iters, 
         }
       }
       s = a0[0] + a1[3];
+    } else if (with_mfma == 5) {
+      f32x16 a0 = {0}, a1 = {0};
+      f32x4 fa = {1.f, 2.f, 3.f, 4.f}, fb = {0.5f, 0.25f, 0.125f, 1.f};
+      for (int it = 0; it < iters * 4; ++it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(a0) : "v"(fa), "v"(fb));
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(a1) : "v"(fb), "v"(fa));
+        }
+      }
+      s = a0[0] + a1[3];
     } else if (with_mfma == 2 || with_mfma == 4) {
       f32x4 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
       float fa = 1.0001f * lane, fb = 0.5f;
@@ -50,7 +61,7 @@ __global__ __launch_bounds__(512) void k(float* out, long long* clk, int iters, 
     f32x2 w = {1.0001f, 0.9999f}, v = {0.5f, 0.25f};
     float x[8];
     for (int i = 0; i < 8; ++i) x[i] = i;
-    if (with_mfma >= 3) __builtin_amdgcn_s_setprio(3);
+    if (with_mfma == 3 || with_mfma == 4) __builtin_amdgcn_s_setprio(3);
     const int cell = cells[(blockIdx.x * 4 + wave) * 64 + lane];
     const unsigned base = (unsigned)((MODE == 2 ? lane : cell) * 16);   // dynamic LDS starts at address 0
     t0 = __builtin_readcyclecounter();
@@ -114,7 +125,7 @@ void run(const char* what, int per_iter, int with_mfma, float* out, long long* c
     hipEventElapsedTime(&ms, e0, e1);
   }
   long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
-  static const char* names[] = {"alone", "beside 32x32x2", "beside 16x16x4", "beside 32x32x2, VALU wave prio 3", "beside 16x16x4, VALU wave prio 3"};
+  static const char* names[] = {"alone", "beside 32x32x2", "beside 16x16x4", "beside 32x32x2, VALU wave prio 3", "beside 16x16x4, VALU wave prio 3", "beside 32x32x16 bf16"};
   printf("%-58s %-34s %7.2f clk/instr  (%.3f ms)\n", what, names[with_mfma], (double)c / iters / per_iter, ms);
 }
 
@@ -129,7 +140,7 @@ int main() {
   }
   hipMemcpy(c_rand, h_rand, sizeof(h_rand), hipMemcpyHostToDevice);
   hipMemcpy(c_jit, h_jit, sizeof(h_jit), hipMemcpyHostToDevice);
-  for (int mf = 0; mf < 5; ++mf) {
+  for (int mf = 0; mf < 6; mf += 5) {
     run<0>("v_fma_f32 x64 (8 chains)", 64, mf, out, clk, c_rand);
     run<1>("v_pk_fma_f32 x64 (8 chains)", 64, mf, out, clk, c_rand);
     run<2>("ds_read_b128 x64 contiguous cells, 8 in flight", 64, mf, out, clk, c_rand);

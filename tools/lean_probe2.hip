@@ -29,12 +29,20 @@ __global__ __launch_bounds__(256) void k(float* out, long long* clk, int iters) 
       if (KIND == 0) {
         if (m & 1) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(fa), "v"(fb));
         else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(fa), "v"(fb));
+      } else if (KIND == 4) {
+        if (m & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(a1) : "v"(r[6]), "v"(r[7]));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(a0) : "v"(r[6]), "v"(r[7]));
+      } else if (KIND == 3) {
+        if (m & 1) asm volatile("v_mfma_f32_32x32x8_bf16 %0, %1, %2, %0" : "+v"(a1) : "v"(w), "v"(v));
+        else asm volatile("v_mfma_f32_32x32x8_bf16 %0, %1, %2, %0" : "+v"(a0) : "v"(w), "v"(v));
       } else if (KIND == 1) {
         if (m & 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(b1) : "v"(fa), "v"(fb));
         else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(b0) : "v"(fa), "v"(fb));
       }
 #pragma unroll
-      for (int j = 0; j < NV; ++j) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j & 7]) : "v"(w), "v"(v));
+      for (int j = 0; j < (NV >= 100 ? 0 : NV); ++j) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j & 7]) : "v"(w), "v"(v));
+#pragma unroll
+      for (int j = 0; j < (NV >= 100 ? NV - 100 : 0); ++j) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[j & 7].x) : "v"(fa), "v"(fb));
 #pragma unroll
       for (int j = 0; j < NL; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[j & 7]) : "v"(base), "n"((j & 7) * 1024));
     }
@@ -54,7 +62,7 @@ void run(float* out, long long* clk) {
   hipFuncSetAttribute((const void*)k<KIND, NV, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
   for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((k<KIND, NV, NL>), dim3(256), dim3(256), 100 * 1024, 0, out, clk, iters); hipDeviceSynchronize(); }
   long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
-  printf("%-10s + %2d v_pk_fma + %2d ds_read_b128 per MFMA: %7.1f clk per MFMA\n", KIND == 0 ? "32x32x2" : (KIND == 1 ? "16x16x4" : "no MFMA"), NV, NL, (double)c / iters / 4);
+  printf("%-13s + %3d v_pk_fma (>=100: v_fma_f32 count + 100) + %2d ds_read_b128 per MFMA: %7.1f clk per MFMA\n", KIND == 0 ? "32x32x2" : (KIND == 1 ? "16x16x4" : (KIND == 3 ? "32x32x8 bf16" : (KIND == 4 ? "32x32x16 bf16" : "no MFMA"))), NV, NL, (double)c / iters / 4);
 }
 
 int main() {
@@ -62,6 +70,9 @@ int main() {
   run<0, 0, 0>(out, clk); run<0, 4, 0>(out, clk); run<0, 8, 0>(out, clk); run<0, 12, 0>(out, clk); run<0, 16, 0>(out, clk);
   run<0, 0, 2>(out, clk); run<0, 0, 4>(out, clk); run<0, 0, 8>(out, clk); run<0, 8, 4>(out, clk);
   run<2, 8, 0>(out, clk); run<2, 16, 0>(out, clk); run<2, 0, 4>(out, clk); run<2, 0, 8>(out, clk); run<2, 8, 4>(out, clk);
+  run<4, 0, 0>(out, clk); run<4, 102, 0>(out, clk); run<4, 104, 0>(out, clk); run<4, 108, 0>(out, clk); run<4, 2, 0>(out, clk); run<4, 4, 0>(out, clk); run<4, 104, 2>(out, clk);
+  run<0, 104, 0>(out, clk); run<0, 108, 0>(out, clk); run<3, 104, 0>(out, clk);
+  run<3, 0, 0>(out, clk); run<3, 2, 0>(out, clk); run<3, 4, 0>(out, clk); run<3, 8, 0>(out, clk); run<3, 0, 2>(out, clk); run<3, 2, 1>(out, clk); run<3, 3, 1>(out, clk);
   run<1, 0, 0>(out, clk); run<1, 4, 0>(out, clk); run<1, 8, 0>(out, clk); run<1, 0, 2>(out, clk); run<1, 0, 4>(out, clk); run<1, 4, 2>(out, clk);
   return 0;
 }
