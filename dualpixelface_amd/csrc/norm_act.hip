@@ -22,22 +22,24 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const int c = row % C;
   const float K = x[(long long)c * S];
   const float* xr = x + (long long)row * S;
-  const long long s0 = (long long)blockIdx.x * chunk;
-  const long long s1 = min(S, s0 + chunk);
   float a = 0.f, b = 0.f;
-  if ((S & 3) == 0) {
+  {
+    const long long s0 = (long long)blockIdx.x * chunk;
+    const long long s1 = min(S, s0 + chunk);
+    if ((S & 3) == 0) {
 #pragma unroll 4
-    for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
-      const float4 v = *reinterpret_cast<const float4*>(xr + s);
-      const float d0 = v.x - K, d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
-      a += (d0 + d1) + (d2 + d3);
-      b += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-  } else {
-    for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
-      const float d = xr[s] - K;
-      a += d;
-      b += d * d;
+      for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + s);
+        const float d0 = v.x - K, d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
+        a += (d0 + d1) + (d2 + d3);
+        b += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    } else {
+      for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
+        const float d = xr[s] - K;
+        a += d;
+        b += d * d;
+      }
     }
   }
   a = dpf_block_sum_256(a, sm);
@@ -173,12 +175,45 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* 
   invstd[c] = 1.0f / sqrtf(rv[c] + eps);
 }
 
+
+// The streaming kernels below are specialised at compile time on the activation and on which optional operands exist: with `act` as a
+// run-time argument every element went through a switch (and every iteration through `res ? load : 0` selects), and the kernels ran at
+// 3.1 - 3.7 TB/s where the same access shape without them reaches 5.8 - 6.6 (tools/stream_probe.hip).  Tensors that are read or written
+// once go through nontemporal accesses (+5 - 10 % in that probe).
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f ld4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); }
+__device__ __forceinline__ void st4(float* p, v4f v) { __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p)); }
+template <int ACT>
+__device__ __forceinline__ float act_t(float z, float slope) {
+  if (ACT == DPF_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (ACT == DPF_ACT_PRELU || ACT == DPF_ACT_LEAKY) return z > 0.f ? z : z * slope;
+  if (ACT == DPF_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+  return z;
+}
+template <int ACT>
+__device__ __forceinline__ float dact_t(float z, float slope) {
+  if (ACT == DPF_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (ACT == DPF_ACT_PRELU || ACT == DPF_ACT_LEAKY) return z > 0.f ? 1.f : slope;
+  if (ACT == DPF_ACT_SIGMOID) { const float sg = 1.f / (1.f + expf(-z)); return sg * (1.f - sg); }
+  return 1.f;
+}
+// run F<ACT, FLAG>() for the run-time (act, flag)
+#define DPF_ACT_DISPATCH(act, flag, CALL)                                                                    \
+  switch (act) {                                                                                             \
+    case DPF_ACT_RELU: if (flag) { CALL(DPF_ACT_RELU, true); } else { CALL(DPF_ACT_RELU, false); } break;    \
+    case DPF_ACT_PRELU: if (flag) { CALL(DPF_ACT_PRELU, true); } else { CALL(DPF_ACT_PRELU, false); } break; \
+    case DPF_ACT_LEAKY: if (flag) { CALL(DPF_ACT_LEAKY, true); } else { CALL(DPF_ACT_LEAKY, false); } break; \
+    case DPF_ACT_SIGMOID: if (flag) { CALL(DPF_ACT_SIGMOID, true); } else { CALL(DPF_ACT_SIGMOID, false); } break; \
+    default: if (flag) { CALL(DPF_ACT_NONE, true); } else { CALL(DPF_ACT_NONE, false); } break;              \
+  }
+
 // ---------------------------------------------------------------- apply
+template <int ACT, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ w,
                                                        const float* __restrict__ bsh, int wmod, const float* __restrict__ res,
                                                        const float* __restrict__ res2, int act, const float* __restrict__ slope_p,
-                                                       float slope_c, float* __restrict__ y, int C, long long S, int yC = 0, int yc0 = 0) {
+                                                       float slope_c, float* __restrict__ y, int C, long long S, int yC, int yc0) {
   const int row = blockIdx.y;
   const int c = row % C;
   // y may be a channel slice [yc0, yc0 + C) of a tensor with yC channels (the consumer's concatenation buffer)
@@ -194,28 +229,34 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const long long base = (long long)row * S;
   const long long s0 = (long long)blockIdx.x * ROW_CHUNK;
   const long long s1 = min(S, s0 + ROW_CHUNK);
+  (void)act;
   if ((S & 3) == 0) {
+#pragma unroll 2
     for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
-      float4 v = *reinterpret_cast<const float4*>(x + base + s);
-      float4 r = res ? *reinterpret_cast<const float4*>(res + base + s) : make_float4(0, 0, 0, 0);
-      float4 r2 = res2 ? *reinterpret_cast<const float4*>(res2 + base + s) : make_float4(0, 0, 0, 0);
-      float4 o;
-      o.x = dpf_act(fmaf(v.x, scale, shift) + r.x, act, slope) + r2.x;
-      o.y = dpf_act(fmaf(v.y, scale, shift) + r.y, act, slope) + r2.y;
-      o.z = dpf_act(fmaf(v.z, scale, shift) + r.z, act, slope) + r2.z;
-      o.w = dpf_act(fmaf(v.w, scale, shift) + r.w, act, slope) + r2.w;
-      *reinterpret_cast<float4*>(y + base + s) = o;
+      const v4f v = ld4(x + base + s);
+      v4f r = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
+      if (RES) {                                        // (either or both residuals)
+        if (res) r = ld4(res + base + s);
+        if (res2) r2 = ld4(res2 + base + s);
+      }
+      v4f o;
+      o.x = act_t<ACT>(fmaf(v.x, scale, shift) + r.x, slope) + r2.x;
+      o.y = act_t<ACT>(fmaf(v.y, scale, shift) + r.y, slope) + r2.y;
+      o.z = act_t<ACT>(fmaf(v.z, scale, shift) + r.z, slope) + r2.z;
+      o.w = act_t<ACT>(fmaf(v.w, scale, shift) + r.w, slope) + r2.w;
+      *reinterpret_cast<v4f*>(y + base + s) = o;        // (plain store: the consumer conv reads it next)
     }
   } else {
     for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
-      const float z = fmaf(x[base + s], scale, shift) + (res ? res[base + s] : 0.f);
-      y[base + s] = dpf_act(z, act, slope) + (res2 ? res2[base + s] : 0.f);
+      const float z = fmaf(x[base + s], scale, shift) + ((RES && res) ? res[base + s] : 0.f);
+      y[base + s] = act_t<ACT>(z, slope) + ((RES && res2) ? res2[base + s] : 0.f);
     }
   }
 }
 
 // ---------------------------------------------------------------- backward
 // sums[c] = { sum dz, sum dz*xhat, sum_{z<0} z*dy (PReLU slope gradient) }
+template <int ACT, bool RES>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ w, const float* __restrict__ bsh, int wmod,
@@ -235,27 +276,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
   const float slope = slope_p ? slope_p[0] : slope_c;
   const long long base = (long long)row * S;
-  const long long s0 = (long long)blockIdx.x * chunk;
-  const long long s1 = min(S, s0 + chunk);
   float a = 0.f, b = 0.f, sl = 0.f;
   auto one = [&](float xv, float rv, float d) {
     const float xh = (xv - mu) * is;
     const float z = fmaf(xh, g, be) + rv;
-    const float dz = d * dpf_dact(z, act, slope);
+    const float dz = d * dact_t<ACT>(z, slope);
     a += dz;
     b += dz * xh;
-    if (act == DPF_ACT_PRELU && z <= 0.f) sl += z * d;
+    if (ACT == DPF_ACT_PRELU && z <= 0.f) sl += z * d;
   };
-  if ((S & 3) == 0) {
-#pragma unroll 2
-    for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
-      const float4 xv = *reinterpret_cast<const float4*>(x + base + s);
-      const float4 dv = *reinterpret_cast<const float4*>(dy + base + s);
-      const float4 rv = res ? *reinterpret_cast<const float4*>(res + base + s) : make_float4(0, 0, 0, 0);
-      one(xv.x, rv.x, dv.x); one(xv.y, rv.y, dv.y); one(xv.z, rv.z, dv.z); one(xv.w, rv.w, dv.w);
+  (void)act;
+  {
+    const long long s0 = (long long)blockIdx.x * chunk;
+    const long long s1 = min(S, s0 + chunk);
+    if ((S & 3) == 0) {
+#pragma unroll 4
+      for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
+        const v4f xv = *reinterpret_cast<const v4f*>(x + base + s);      // (x and dy are read again by the apply kernel: plain loads)
+        const v4f dv = *reinterpret_cast<const v4f*>(dy + base + s);
+        v4f rv = {0.f, 0.f, 0.f, 0.f};
+        if (RES) rv = *reinterpret_cast<const v4f*>(res + base + s);
+        one(xv.x, rv.x, dv.x); one(xv.y, rv.y, dv.y); one(xv.z, rv.z, dv.z); one(xv.w, rv.w, dv.w);
+      }
+    } else {
+      for (long long s = s0 + threadIdx.x; s < s1; s += 256) one(x[base + s], RES ? res[base + s] : 0.f, dy[base + s]);
     }
-  } else {
-    for (long long s = s0 + threadIdx.x; s < s1; s += 256) one(x[base + s], res ? res[base + s] : 0.f, dy[base + s]);
   }
   a = dpf_block_sum_256(a, sm);
   b = dpf_block_sum_256(b, sm);
@@ -263,12 +308,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     atomicAdd(&sums[3 * c], a);
     atomicAdd(&sums[3 * c + 1], b);
   }
-  if (act == DPF_ACT_PRELU) {
+  if (ACT == DPF_ACT_PRELU) {
     sl = dpf_block_sum_256(sl, sm);
     if (threadIdx.x == 0) atomicAdd(&sums[3 * c + 2], sl);
   }
 }
 
+template <int ACT, bool RES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ w, const float* __restrict__ bsh, int wmod,
@@ -319,24 +365,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   auto one = [&](float xv, float rv, float d, float& o_dz, float& o_dx) {
     const float xh = (xv - mu) * is;
     const float z = fmaf(xh, g, be) + rv;
-    o_dz = d * dpf_dact(z, act, slope);
+    o_dz = d * dact_t<ACT>(z, slope);
     o_dx = mean ? gi * (o_dz - m_dz - xh * m_dzx) : o_dz;
   };
+  (void)act;
   if ((S & 3) == 0) {
+#pragma unroll 2
     for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
-      const float4 xv = *reinterpret_cast<const float4*>(x + base + s);
-      const float4 dv = *reinterpret_cast<const float4*>(dy + base + s);
-      const float4 rv = res ? *reinterpret_cast<const float4*>(res + base + s) : make_float4(0, 0, 0, 0);
-      float4 oz, ox;
-      one(xv.x, rv.x, dv.x, oz.x, ox.x); one(xv.y, rv.y, dv.y, oz.y, ox.y);
-      one(xv.z, rv.z, dv.z, oz.z, ox.z); one(xv.w, rv.w, dv.w, oz.w, ox.w);
-      if (dres) *reinterpret_cast<float4*>(dres + base + s) = oz;
-      if (dx) *reinterpret_cast<float4*>(dx + base + s) = ox;
+      const v4f xv = ld4(x + base + s);                  // last use of x and dy in the backward pass: nontemporal
+      const v4f dv = ld4(dy + base + s);
+      v4f rv = {0.f, 0.f, 0.f, 0.f};
+      if (RES) rv = ld4(res + base + s);
+      float z0, z1, z2, z3, x0, x1, x2, x3;
+      one(xv.x, rv.x, dv.x, z0, x0); one(xv.y, rv.y, dv.y, z1, x1);
+      one(xv.z, rv.z, dv.z, z2, x2); one(xv.w, rv.w, dv.w, z3, x3);
+      if (dres) *reinterpret_cast<v4f*>(dres + base + s) = v4f{z0, z1, z2, z3};
+      if (dx) *reinterpret_cast<v4f*>(dx + base + s) = v4f{x0, x1, x2, x3};
     }
   } else {
     for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
       float oz, ox;
-      one(x[base + s], res ? res[base + s] : 0.f, dy[base + s], oz, ox);
+      one(x[base + s], RES ? res[base + s] : 0.f, dy[base + s], oz, ox);
       if (dres) dres[base + s] = oz;
       if (dx) dx[base + s] = ox;
     }
@@ -369,17 +418,19 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   const int row = blockIdx.y;
   const int c = row % C;
   const long long base = (long long)row * S;
-  const long long s0 = (long long)blockIdx.x * chunk;
-  const long long s1 = min(S, s0 + chunk);
   float a = 0.f;
-  if ((S & 3) == 0) {
+  {
+    const long long s0 = (long long)blockIdx.x * chunk;
+    const long long s1 = min(S, s0 + chunk);
+    if ((S & 3) == 0) {
 #pragma unroll 4
-    for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
-      const float4 v = *reinterpret_cast<const float4*>(g + base + s);
-      a += (v.x + v.y) + (v.z + v.w);
+      for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
+        const float4 v = *reinterpret_cast<const float4*>(g + base + s);
+        a += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (long long s = s0 + threadIdx.x; s < s1; s += 256) a += g[base + s];
     }
-  } else {
-    for (long long s = s0 + threadIdx.x; s < s1; s += 256) a += g[base + s];
   }
   a = dpf_block_sum_256(a, sm);
   if (threadIdx.x == 0) atomicAdd(&out[c], a);
@@ -388,6 +439,8 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 inline dim3 row_grid(int rows, long long S) { return dim3((unsigned)dpf_div_up(S, ROW_CHUNK), (unsigned)rows); }
 
 // reduction kernels end in a block reduction + atomics, so they take larger row chunks while the grid still fills the chip
+// reduction kernels end in a block reduction + atomics, so they take larger row chunks while the grid still fills the chip (a strided
+// variant -- ~8192 blocks looping over 4096-element pieces -- measured the same: tools/debug/bn_sweep.py)
 inline int reduce_chunk(int rows, long long S) {
   long long chunk = ((S * rows / 4096 + 1023) / 1024) * 1024;
   if (chunk < ROW_CHUNK) chunk = ROW_CHUNK;
@@ -472,8 +525,9 @@ int dpf_norm_act_forward(const float* x, const float* mean, const float* invstd,
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!x || !y || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   if (wmod <= 0) wmod = C;
-  hipLaunchKernelGGL(bn_apply_kernel, row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, w, b, wmod, res, res2, act,
-                     slope, slope_const, y, C, S);
+#define DPF_CALL(A, R) hipLaunchKernelGGL((bn_apply_kernel<A, R>), row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, w, b, wmod, res, res2, act, slope, slope_const, y, C, S, 0, 0)
+  DPF_ACT_DISPATCH(act, (res != nullptr || res2 != nullptr), DPF_CALL)
+#undef DPF_CALL
   return dpf_check_launch();
 }
 
@@ -485,8 +539,9 @@ int dpf_norm_act_forward_slice(const float* x, const float* mean, const float* i
   dpf_clear_error();
   if (!x || !y || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535 || y_c0 < 0 || y_c0 + C > y_channels) return DPF_ERR_INVALID_ARG;
   if (wmod <= 0) wmod = C;
-  hipLaunchKernelGGL(bn_apply_kernel, row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, w, b, wmod, res, res2, act,
-                     slope, slope_const, y, C, S, y_channels, y_c0);
+#define DPF_CALL(A, R) hipLaunchKernelGGL((bn_apply_kernel<A, R>), row_grid(N * C, S), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, w, b, wmod, res, res2, act, slope, slope_const, y, C, S, y_channels, y_c0)
+  DPF_ACT_DISPATCH(act, (res != nullptr || res2 != nullptr), DPF_CALL)
+#undef DPF_CALL
   return dpf_check_launch();
 }
 
@@ -509,8 +564,9 @@ static int norm_act_backward_impl(const float* x, const float* dy, int gC, int g
     // phase 3: as phase 0 with a ws the caller guarantees to be zero (a slot of a pre-zeroed arena: one memset per arena, not per layer)
     if (phase != 3 && hipMemsetAsync(ws, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
     const int chunk = reduce_chunk(N * C, S);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act,
-                       slope, slope_const, ws, C, S, chunk, gC, gc0);
+#define DPF_CALL(A, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<A, R>), reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope, slope_const, ws, C, S, chunk, gC, gc0)
+    DPF_ACT_DISPATCH(act, (res != nullptr), DPF_CALL)
+#undef DPF_CALL
     fused_fin = (dx || dres) && phase != 1;       // the apply launch below writes the parameter gradients
     if (!fused_fin)
       hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpf_div_up(wmod, 64)), dim3(64), 0, st, ws, C, wmod, mean ? dweight : nullptr,
@@ -521,10 +577,13 @@ static int norm_act_backward_impl(const float* x, const float* dy, int gC, int g
     // phase 2 with count < 0: ws[3*C] holds the global element count (the caller all-reduced its local count with the sums)
     const float* count_dev = (phase == 2 && count < 0) ? ws + 3 * (long long)C : nullptr;
     if (count <= 0) count = (double)N * (double)S;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope,
-                       slope_const, ws, (float)(1.0 / count), training, dx, dres, C, S, count_dev, gC, gc0,
-                       (fused_fin && mean) ? dweight : nullptr, (fused_fin && mean) ? dbias : nullptr,
-                       (fused_fin && act == DPF_ACT_PRELU) ? dslope : nullptr);
+    const float inv_cnt = (float)(1.0 / count);
+    float* fdw = (fused_fin && mean) ? dweight : nullptr;
+    float* fdb = (fused_fin && mean) ? dbias : nullptr;
+    float* fds = (fused_fin && act == DPF_ACT_PRELU) ? dslope : nullptr;
+#define DPF_CALL(A, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, R>), row_grid(N * C, S), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope, slope_const, ws, inv_cnt, training, dx, dres, C, S, count_dev, gC, gc0, fdw, fdb, fds)
+    DPF_ACT_DISPATCH(act, (res != nullptr), DPF_CALL)
+#undef DPF_CALL
   }
   return dpf_check_launch();
 }

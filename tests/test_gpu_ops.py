@@ -454,7 +454,7 @@ def test_weight_gradient_f32_matrix_paths_agree(cfg):
     od = [(i + 2 * p - (d * (k - 1) + 1)) // s + 1 for i, k, s, p, d in zip((D, H, W), ks, st, pad, dl)]
     g = rnd(N, K, *od, seed=181)
     ref = torch.nn.grad.conv3d_weight(x.double(), (K, C) + ks, g.double(), st, pad, dl)
-    prev = lib().call('dpf_get_f32_matrix_path')
+    prev = lib().cdll.dpf_get_f32_matrix_path()          # (a getter: the value is not an error code)
     errs = []
     try:
         for path in (1, 0):
