@@ -46,6 +46,7 @@ struct G2P {
   int accum;                    // 1: out += result
   int single;                   // 1: one LDS buffer (more resident workgroups hide the DMA instead of a second buffer)
   double* stats;                // optional [ntiles][K][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
+  int tapoff[28];               // x9 kernel: patch offset (positions) of tap u; taps beyond T: 0 (their weights are zero)
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
 
@@ -62,6 +63,119 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+// Tile epilogue shared by the tile kernels of this file (accumulator layout of the 32x32 MFMAs, f32 or bf16 operands alike):
+// D row = (j&3) + 8*(j>>2) + 4*(lane>>5), col = lane&31.
+template <int MT, int NT>
+__device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[MT][NT], const G2P& p, const float* __restrict__ bias, float* __restrict__ out, float* smem,
+                                            int tile_id, int n, int qd, int q0h, int q0w, int wave, int l31, int hh, int tid) {
+  constexpr int KT = 32 * MT;
+  const int ow = q0w + l31;
+  const long long out_plane = (long long)p.OH * p.OW;
+  const long long kstride = (long long)p.OD * out_plane;
+  float* op = out + ((long long)n * p.Ktot + p.k0) * kstride + ow;
+  long long orow[NT];      // offset of position row t of this wave inside a channel
+  bool rok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r = wave * NT + t, oz = qd + (r >> p.thp_shift), oy = q0h + (r & (p.thp - 1));
+    rok[t] = oz < p.OD && oy < p.OH;
+    orow[t] = ((long long)oz * p.OH + oy) * p.OW;
+  }
+  if (ow < p.OW && !p.accum) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (k < p.K) {
+          const float bv = bias ? bias[p.k0 + k] : 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (rok[t]) op[(long long)k * kstride + orow[t]] = acc[m][t][j] + bv;
+        }
+      }
+    }
+  } else if (ow < p.OW) {                                         // out += result (kept apart: the plain path has no load in its store loop)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (k < p.K) {
+          const float bv = bias ? bias[p.k0 + k] : 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (rok[t]) {
+              float* o = op + (long long)k * kstride + orow[t];
+              *o += acc[m][t][j] + bv;
+            }
+        }
+      }
+    }
+  }
+  // ---- optional BatchNorm statistics of this tile (the consumer's bn_stats pass over the output tensor is then not needed):
+  // per output channel the sum and the sum of squares of the valid outputs, accumulated in fp64 from the first add, reduced over the 32 columns by shuffles and over the 4 waves through LDS in a fixed order, one
+  // [K][2] row per tile.  A finalize kernel folds the rows in a fixed order: deterministic, no atomics, no zero fill.
+  if (p.stats) {                                                 // uniform
+    double* red = reinterpret_cast<double*>(smem);               // [4 waves][2][MT * 16][2]; the operand buffers are dead by now
+    const bool colok = ow < p.OW;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      double v1[16], v2[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        const float bv = (bias && k < p.K) ? bias[p.k0 + k] : 0.f;
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const double v = (colok && rok[t]) ? (double)(acc[m][t][j] + bv) : 0.0;
+          d1 += v;
+          d2 += v * v;                                           // exact product, fp64 accumulation
+        }
+        v1[j] = d1;
+        v2[j] = d2;
+      }
+      // transpose-reduce over the 32 columns: at every step a lane hands half of its remaining rows to its partner and adds the
+      // partner's half of the rows it keeps -- 8 + 4 + 2 + 1 exchanges instead of 16 x 4, then one exchange between the two
+      // lanes that ended up with the same row.  Fixed order.
+#pragma unroll
+      for (int half = 8; half >= 1; half >>= 1) {
+        const bool upper = (l31 & (2 * half)) != 0;              // lane bit 4, 3, 2, 1 for half = 8, 4, 2, 1
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+          const double s1 = upper ? v1[i] : v1[i + half], s2 = upper ? v2[i] : v2[i + half];
+          const double k1 = upper ? v1[i + half] : v1[i], k2 = upper ? v2[i + half] : v2[i];
+          v1[i] = k1 + __shfl_xor(s1, 2 * half, 64);
+          v2[i] = k2 + __shfl_xor(s2, 2 * half, 64);
+        }
+      }
+      const double r1 = v1[0] + __shfl_xor(v1[0], 1, 64), r2 = v2[0] + __shfl_xor(v2[0], 1, 64);
+      if ((l31 & 1) == 0) {
+        const int j = (l31 >> 1) & 15;                           // bit 4 -> +8, bit 3 -> +4, bit 2 -> +2, bit 1 -> +1
+        double* dst = red + (((wave * 2 + hh) * MT + m) * 16 + j) * 2;
+        dst[0] = r1;
+        dst[1] = r2;
+      }
+    }
+    __syncthreads();
+    if (tid < KT && tid < p.K) {
+      const int m = tid >> 5, kk = tid & 31;
+      const int h2 = (kk >> 2) & 1, j = (kk & 3) + 4 * (kk >> 3);
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        const double* src = red + (((wv * 2 + h2) * MT + m) * 16 + j) * 2;
+        a1 += src[0];
+        a2 += src[1];
+      }
+      double* row = p.stats + ((long long)tile_id * p.K + tid) * 2;
+      row[0] = a1;
+      row[1] = a2;
+    }
+  }
 }
 
 // resident workgroups per CU the register budget is declared for: accumulators + two operand sets + ~40 of bookkeeping
@@ -298,114 +412,258 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
     }
   }
 
-  // ---- epilogue: D row = (j&3) + 8*(j>>2) + 4*(lane>>5), col = lane&31
-  const int ow = q0w + l31;
-  const long long out_plane = (long long)p.OH * p.OW;
-  const long long kstride = (long long)p.OD * out_plane;
-  float* op = out + ((long long)n * p.Ktot + p.k0) * kstride + ow;
-  long long orow[NT];      // offset of position row t of this wave inside a channel
-  bool rok[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int r = wave * NT + t, oz = qd + (r >> p.thp_shift), oy = q0h + (r & (p.thp - 1));
-    rok[t] = oz < p.OD && oy < p.OH;
-    orow[t] = ((long long)oz * p.OH + oy) * p.OW;
-  }
-  if (ow < p.OW && !p.accum) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        if (k < p.K) {
-          const float bv = bias ? bias[p.k0 + k] : 0.f;
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            if (rok[t]) op[(long long)k * kstride + orow[t]] = acc[m][t][j] + bv;
-        }
-      }
-    }
-  } else if (ow < p.OW) {                                         // out += result (kept apart: the plain path has no load in its store loop)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        if (k < p.K) {
-          const float bv = bias ? bias[p.k0 + k] : 0.f;
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            if (rok[t]) {
-              float* o = op + (long long)k * kstride + orow[t];
-              *o += acc[m][t][j] + bv;
-            }
-        }
-      }
-    }
-  }
-  // ---- optional BatchNorm statistics of this tile (the consumer's bn_stats pass over the output tensor is then not needed):
-  // per output channel the sum and the sum of squares of the valid outputs, accumulated in fp64 from the first add, reduced over the 32 columns by shuffles and over the 4 waves through LDS in a fixed order, one
-  // [K][2] row per tile.  A finalize kernel folds the rows in a fixed order: deterministic, no atomics, no zero fill.
-  if (p.stats) {                                                 // uniform
-    double* red = reinterpret_cast<double*>(smem);               // [4 waves][2][MT * 16][2]; the operand buffers are dead by now
-    const bool colok = ow < p.OW;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      double v1[16], v2[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        const float bv = (bias && k < p.K) ? bias[p.k0 + k] : 0.f;
-        double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const double v = (colok && rok[t]) ? (double)(acc[m][t][j] + bv) : 0.0;
-          d1 += v;
-          d2 += v * v;                                           // exact product, fp64 accumulation
-        }
-        v1[j] = d1;
-        v2[j] = d2;
-      }
-      // transpose-reduce over the 32 columns: at every step a lane hands half of its remaining rows to its partner and adds the
-      // partner's half of the rows it keeps -- 8 + 4 + 2 + 1 exchanges instead of 16 x 4, then one exchange between the two
-      // lanes that ended up with the same row.  Fixed order.
-#pragma unroll
-      for (int half = 8; half >= 1; half >>= 1) {
-        const bool upper = (l31 & (2 * half)) != 0;              // lane bit 4, 3, 2, 1 for half = 8, 4, 2, 1
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-          const double s1 = upper ? v1[i] : v1[i + half], s2 = upper ? v2[i] : v2[i + half];
-          const double k1 = upper ? v1[i + half] : v1[i], k2 = upper ? v2[i + half] : v2[i];
-          v1[i] = k1 + __shfl_xor(s1, 2 * half, 64);
-          v2[i] = k2 + __shfl_xor(s2, 2 * half, 64);
-        }
-      }
-      const double r1 = v1[0] + __shfl_xor(v1[0], 1, 64), r2 = v2[0] + __shfl_xor(v2[0], 1, 64);
-      if ((l31 & 1) == 0) {
-        const int j = (l31 >> 1) & 15;                           // bit 4 -> +8, bit 3 -> +4, bit 2 -> +2, bit 1 -> +1
-        double* dst = red + (((wave * 2 + hh) * MT + m) * 16 + j) * 2;
-        dst[0] = r1;
-        dst[1] = r2;
-      }
-    }
-    __syncthreads();
-    if (tid < KT && tid < p.K) {
-      const int m = tid >> 5, kk = tid & 31;
-      const int h2 = (kk >> 2) & 1, j = (kk & 3) + 4 * (kk >> 3);
-      double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-      for (int wv = 0; wv < 4; ++wv) {
-        const double* src = red + (((wv * 2 + h2) * MT + m) * 16 + j) * 2;
-        a1 += src[0];
-        a2 += src[1];
-      }
-      double* row = p.stats + ((long long)tile_id * p.K + tid) * 2;
-      row[0] = a1;
-      row[1] = a2;
-    }
-  }
+  g2_epilogue<MT, NT>(acc, p, bias, out, smem, tile_id, n, qd, q0h, q0w, wave, l31, hh, tid);
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Exact-f32 products on the bf16 matrix pipe ("x9"), stride-1 convolutions (forward and transposed).
+//
+// Every fp32 operand is split EXACTLY into three bf16 values by truncation (x = hi + mid + lo: 8 + 8 + 8 significant bits); the nine
+// partial products of a (weight, input) pair are exact in fp32 and are accumulated in fp32, smallest first, by nine
+// v_mfma_f32_32x32x16_bf16 (9 x 8 passes per 16 reduction elements against 8 x 16 passes of v_mfma_f32_32x32x2_f32: 0.56 of the
+// matrix-pipe time).  The split has to be paid once per staged ELEMENT, not once per use (27 uses per element: that variant is
+// VALU-bound), so the staging path differs from igemm2_kernel:
+//   * a chunk is 4 input channels; the patch is fetched into REGISTERS (16-byte row segments of the 4 channels, prefetched one chunk
+//     ahead, across the MFMA loop), split there (11 VALU per value pair) and written to LDS as [position][hi|mid|lo][4 channels]
+//     bf16 -- 24 bytes per position, so ONE address serves the three components of a tap;
+//   * the 16 reduction elements of an MFMA are 4 taps x 4 channels: a lane (column l31, K-half hh) reads the 8-byte channel
+//     quadruplets of taps 4g + 2hh and 4g + 2hh + 1 for each component (positions from a per-tap offset table in LDS);
+//   * the weights are split and laid out in fragment order by the pack kernel ([chunk][tap group][component][row tile][lane][8]) and
+//     arrive by LDS-DMA while the patch is being split;
+//   * one LDS buffer, two resident workgroups per CU: one stages while the other multiplies.
+constexpr int X9_NU = 2;         // patch units (4 channels x 4 positions) per thread and chunk
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// (x, y) -> packed bf16 pairs of the three components, x in the low half
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
+  h = __builtin_amdgcn_perm(b, a, 0x07060302u);
+  const float ra = x - __builtin_bit_cast(float, a & 0xffff0000u), rb = y - __builtin_bit_cast(float, b & 0xffff0000u);
+  const unsigned ua = __builtin_bit_cast(unsigned, ra), ub = __builtin_bit_cast(unsigned, rb);
+  m = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+  const float sa = ra - __builtin_bit_cast(float, ua & 0xffff0000u), sb = rb - __builtin_bit_cast(float, ub & 0xffff0000u);
+  l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
+                                                           const float* __restrict__ bias, float* __restrict__ out, G2P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KT = 32 * MT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int hh = lane >> 5;
+
+  int b = (blockIdx.x & 7) * p.cpx + (blockIdx.x >> 3);           // XCD-aware tile order, as igemm2_kernel
+  if (b >= p.ntiles) return;
+  const int tile_id = b;
+  const int qd = (b % p.odt) * p.pz; b /= p.odt;
+  const int tw = b % p.tilesW; b /= p.tilesW;
+  const int th = b % p.tilesH;
+  const int n = b / p.tilesH;
+  const int q0h = th * p.thp, q0w = tw * 32;
+  const int i0d = qd + p.e0d, i0h = q0h + p.e0h;
+  const int a0 = q0w + p.e0w - p.colshift;
+
+  const int TG = (p.T + 3) >> 2;
+  const int patchBytes = 24 * p.rpc * p.RS;
+  const int wBytes = TG * 3 * MT * 1024;
+  char* s_patch = reinterpret_cast<char*>(smem);
+  char* s_w = s_patch + patchBytes;
+  int* s_tab = reinterpret_cast<int*>(s_w + wBytes);
+  const long long x_chan = (long long)p.ID * p.IH * p.IW;
+  const float* xn = x + (long long)n * p.C * x_chan;
+  const int nunits = p.rpc * p.SR;
+
+  if (tid < 32) s_tab[tid] = tid < 28 ? 24 * p.tapoff[tid] : 0;
+
+  int goff[X9_NU], loff[X9_NU];
+#pragma unroll
+  for (int j = 0; j < X9_NU; ++j) {
+    const unsigned f = tid + 256 * j;
+    const unsigned row = (f * p.mSR) >> 20;
+    const int seg = f - row * p.SR;
+    const unsigned pl = (row * p.mEH) >> 20;
+    const int rr = row - pl * p.ext_h;
+    const int id = i0d + (int)pl, ih = i0h + rr, iw = a0 + 4 * seg;
+    const bool ok = (int)f < nunits && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+    goff[j] = ok ? (int)(((long long)id * p.IH + ih) * p.IW + iw) : -1;
+    loff[j] = (int)f < nunits ? 24 * ((int)row * p.RS + 4 * seg) : -1;
+  }
+
+  f32x4 pv[X9_NU][4];
+  auto prefetch = [&](int chunk) {
+    const float* xc = xn + (long long)chunk * 4 * x_chan;
+    const int crem = p.C - chunk * 4;
+#pragma unroll
+    for (int j = 0; j < X9_NU; ++j)
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (goff[j] >= 0 && ch < crem) v = *reinterpret_cast<const f32x4*>(xc + (long long)ch * x_chan + goff[j]);
+        pv[j][ch] = v;
+      }
+  };
+  auto issue_w = [&](int chunk) {
+    const char* wc = reinterpret_cast<const char*>(wpk) + (long long)chunk * wBytes;
+    const int nws = wBytes >> 4;
+    for (int f0 = wave * 64; f0 < nws; f0 += 256) {
+      const int f = f0 + lane;
+      if (f < nws) glds16(reinterpret_cast<const float*>(wc + f * 16), reinterpret_cast<float*>(s_w + f0 * 16));
+    }
+  };
+  auto split_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < X9_NU; ++j) {
+      if (loff[j] >= 0) {
+        unsigned q[4][6];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          split_pair(pv[j][0][ps], pv[j][1][ps], q[ps][0], q[ps][2], q[ps][4]);
+          split_pair(pv[j][2][ps], pv[j][3][ps], q[ps][1], q[ps][3], q[ps][5]);
+        }
+        u32x4* dst = reinterpret_cast<u32x4*>(s_patch + loff[j]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int e = 4 * i;
+          const u32x4 v = {q[e / 6][e % 6], q[(e + 1) / 6][(e + 1) % 6], q[(e + 2) / 6][(e + 2) % 6], q[(e + 3) / 6][(e + 3) % 6]};
+          dst[i] = v;
+        }
+      }
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
+
+  int lb[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r = wave * NT + t, rz = r >> p.thp_shift, ry = r & (p.thp - 1);
+    lb[t] = 24 * (rz * p.planeStride + ry * p.RS + l31 + p.colshift);
+  }
+
+  prefetch(0);
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    issue_w(chunk);
+    split_store();
+    __syncthreads();                                               // vmcnt(0): weights landed; barrier: patch + table written
+    if (chunk + 1 < p.nchunks) prefetch(chunk + 1);
+
+    u32x4 aC[3][MT], aN[3][MT], b0[3], b1[3];
+    int oC0, oC1, oN0 = 0, oN1 = 0;
+    auto load_a = [&](int g, u32x4 (&a)[3][MT]) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[c][m] = *reinterpret_cast<const u32x4*>(s_w + ((g * 3 + c) * MT + m) * 1024 + lane * 16);
+    };
+    auto load_t = [&](int g, int& o0, int& o1) {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(s_tab + 4 * g + 2 * hh);
+      o0 = (int)v[0]; o1 = (int)v[1];
+    };
+    auto load_b = [&](int t, int o0, int o1, u32x4 (&bb)[3]) {
+      const char* p0 = s_patch + lb[t] + o0;
+      const char* p1 = s_patch + lb[t] + o1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const u32x2 q0 = *reinterpret_cast<const u32x2*>(p0 + 8 * c), q1 = *reinterpret_cast<const u32x2*>(p1 + 8 * c);
+        const u32x4 v = {q0[0], q0[1], q1[0], q1[1]};
+        bb[c] = v;
+      }
+    };
+    auto touch_b = [&](const u32x4 (&bb)[3]) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) asm volatile("" ::"v"(bb[c]));
+      asm volatile("" ::: "memory");
+    };
+    auto touch_a = [&](const u32x4 (&a)[3][MT]) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a[c][m]));
+    };
+    auto mfma9 = [&](const u32x4 (&a)[3][MT], const u32x4 (&bb)[3], int t) {
+      // component index 0 = hi, 1 = mid, 2 = lo; smallest partial products first
+      constexpr int oa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+      constexpr int ob[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[oa[i]][m]), __builtin_bit_cast(bf16x8, bb[ob[i]]), acc[m][t], 0, 0, 0);
+    };
+    load_a(0, aC);
+    load_t(0, oC0, oC1);
+    load_b(0, oC0, oC1, b0);
+    for (int g = 0; g < TG; ++g) {
+      const int gn = g + 1 < TG ? g + 1 : 0;                      // the wrapped fetch of the last group is valid and unused
+      load_t(gn, oN0, oN1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t & 1) touch_b(b1); else touch_b(b0);
+        if (t == 0) touch_a(aC);
+        if (t + 1 < NT) {
+          if (t & 1) load_b(t + 1, oC0, oC1, b0); else load_b(t + 1, oC0, oC1, b1);
+        } else {
+          load_a(gn, aN);
+          load_b(0, oN0, oN1, b0);                                 // NT is even: the last position row of a group sits in b1
+        }
+        __builtin_amdgcn_sched_barrier(6);
+        if (t & 1) mfma9(aC, b1, t); else mfma9(aC, b0, t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) aC[c][m] = aN[c][m];
+      oC0 = oN0; oC1 = oN1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                               // the LDS buffer is free
+  }
+  g2_epilogue<MT, NT>(acc, p, bias, out, smem, tile_id, n, qd, q0h, q0w, wave, l31, hh, tid);
+}
+
+// x9 weights: shorts [chunk][tap group g][component][row tile m][lane][8]; value i of lane (l31, hh) = component of
+// w(out = k0 + 32 m + l31, reduce = 4 chunk + (i & 3), tap = 4 g + 2 hh + (i >> 2)), zero beyond T / C / K
+__global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int TG, int MT, int nchunks,
+                                      int mode, int k0, int K, int C) {
+  const long long total = (long long)nchunks * TG * MT * 512;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e & 7), ln = (int)((e >> 3) & 63);
+    const int m = (int)((e >> 9) % MT);
+    const int g = (int)((e / (512LL * MT)) % TG);
+    const int chunk = (int)(e / (512LL * MT * TG));
+    const int u = 4 * g + 2 * (ln >> 5) + (i >> 2), c = chunk * 4 + (i & 3), k = m * 32 + (ln & 31);
+    float v = 0.f;
+    if (u < T && c < C && k < K) {
+      const int a = mode == 0 ? k0 + k : c;
+      const int bb = mode == 0 ? c : k0 + k;
+      v = w[((long long)a * wB + bb) * T + u];
+    }
+    const unsigned a = __builtin_bit_cast(unsigned, v);
+    const float r1 = v - __builtin_bit_cast(float, a & 0xffff0000u);
+    const unsigned u1 = __builtin_bit_cast(unsigned, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned u2 = __builtin_bit_cast(unsigned, r2);
+    const long long base = (((long long)(chunk * TG + g) * 3) * MT + m) * 512 + ln * 8 + i;
+    wpk[base] = (unsigned short)(a >> 16);
+    wpk[base + 512LL * MT] = (unsigned short)(u1 >> 16);
+    wpk[base + 1024LL * MT] = (unsigned short)(u2 >> 16);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Stride-2 transposed 3x3x3 convolution (pad 1, dilation 1): data gradient of the hourglass' stride-2 convs and the forward of
@@ -732,6 +990,17 @@ int launch_g2(const float* x, const float* wpk, const float* bias, float* out, c
   return dpf_check_launch();
 }
 
+
+template <int MT, int NT>
+int launch_x9(const float* x, const unsigned short* wpk, const float* bias, float* out, const G2P& p, size_t lds, long long blocks, hipStream_t st) {
+  static bool done = false;   // per instantiation
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)igemm3_x9_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DPF_ERR_LAUNCH;
+    done = true;
+  }
+  hipLaunchKernelGGL((igemm3_x9_kernel<MT, NT>), dim3((unsigned)blocks), dim3(256), lds, st, x, wpk, bias, out, p);
+  return dpf_check_launch();
+}
 }  // namespace
 
 
@@ -802,7 +1071,9 @@ int igemm2_tr2(const float* x, const float* w, const float* bias, float* out, fl
 
 long long dpf_igemm2_workspace_floats(int T, int reduce, int outc) {
   const int KT = 32 * (((outc < 128 ? outc : 128) + 31) / 32);
-  return (long long)T * (reduce + 8) * KT + ZPAGE;
+  const long long plain = (long long)T * (reduce + 8) * KT + ZPAGE;
+  const long long x9 = (long long)((reduce + 3) / 4) * ((T + 3) / 4) * 3 * (KT / 32) * 256;   // split bf16 fragments, 1 KB per (chunk, tap group, component, row tile)
+  return plain > x9 ? plain : x9;
 }
 
 int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st,
@@ -919,6 +1190,67 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
       p.steps |= code << (2 * t);
     }
     p.tap0 = d.transposed ? ((d.kd - 1) * d.dd * p.ext_h + (d.kh - 1) * d.dh) * p.RS + (d.kw - 1) * d.dw : 0;
+  }
+  // ---- exact-f32 products on the bf16 pipe (igemm3_x9_kernel): stride-1 launches whose patch is at most 2 x 256 units
+  {
+    static const int x9_on = env_int("DPF_IGEMM3", 1), x9_min_c = env_int("DPF_IGEMM3_MINC", 8);
+    if (x9_on && dpf_conv_f32_x9() && !bf && T > 12 && MT <= 2 && p.sxd == 1 && p.sxh == 1 && p.sxw == 1 && d.C >= x9_min_c && NT * MT <= 4) {
+      G2P q = p;
+      // depth split: among the splits whose patch fits the per-thread unit budget, the one with the fewest staged rows
+      auto set_pz = [&](int pz) {
+        q.pz = pz; q.thp = TH / pz; q.thp_shift = 0;
+        while ((1 << q.thp_shift) < q.thp) ++q.thp_shift;
+        q.odt = dpf_div_up(d.OD, pz);
+        q.ext_d = (pz - 1) + (d.kd - 1) * d.dd + 1;
+        q.ext_h = (q.thp - 1) + (d.kh - 1) * d.dh + 1;
+        q.planeStride = q.ext_h * q.RS; q.SR = q.RS / 4; q.rpc = q.ext_d * q.ext_h;
+        return q.rpc * q.SR;
+      };
+      int best = 0, best_units = 1 << 30;
+      for (int pz : {1, 2, 4}) {
+        if (!(pz == 1 || (d.kd > 1 && pz <= TH / 2 && pz <= d.OD))) continue;
+        const int units = set_pz(pz);
+        if (units <= X9_NU * 256 && units < best_units) { best = pz; best_units = units; }
+      }
+      const int TG = (T + 3) / 4;
+      if (best) {
+        set_pz(best);
+        const size_t lds9 = (size_t)24 * q.rpc * q.RS + (size_t)TG * 3 * MT * 1024 + 128;
+        if (2 * lds9 <= 160 * 1024 && (long long)X9_NU * 256 * (q.SR > q.ext_h ? q.SR : q.ext_h) < (1LL << 20)) {
+          const int sgn = d.transposed ? -1 : 1;
+          const int t0 = d.transposed ? ((d.kd - 1) * d.dd * q.ext_h + (d.kh - 1) * d.dh) * q.RS + (d.kw - 1) * d.dw : 0;
+          for (int u = 0; u < 28; ++u) {
+            const int c = u % d.kw, b2 = (u / d.kw) % d.kh, a = u / (d.kw * d.kh);
+            q.tapoff[u] = u < T ? t0 + sgn * ((a * d.dd * q.ext_h + b2 * d.dh) * q.RS + c * d.dw) : 0;
+          }
+          q.nchunks = (d.C + 3) / 4;
+          q.tilesH = dpf_div_up(d.OH, q.thp);
+          q.tilesW = dpf_div_up(d.OW, 32);
+          q.mSR = magic20(q.SR); q.mEH = magic20(q.ext_h);
+          const long long nt9 = (long long)d.N * q.odt * q.tilesH * q.tilesW;
+          if (nt9 <= 0 || nt9 > 0x3fffffffLL) return DPF_ERR_INVALID_ARG;
+          q.ntiles = (int)nt9;
+          q.cpx = (int)((nt9 + 7) / 8);
+          q.stats = nullptr;
+          bool ok = true;
+          if (stats) {
+            if (nt9 * d.K * 2 > stats->capacity_doubles) ok = false;
+            else { q.stats = stats->slab; }
+          }
+          if (ok) {
+            unsigned short* wp = reinterpret_cast<unsigned short*>(ws);
+            const long long total = (long long)q.nchunks * TG * MT * 512;
+            hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, q.nchunks, d.mode, d.k0, d.K,
+                               d.C);
+            if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
+            if (stats) stats->parts = (int)nt9;
+            const long long blocks9 = 8LL * q.cpx;
+            if (MT == 1) return NT == 4 ? launch_x9<1, 4>(x, wp, bias, out, q, lds9, blocks9, st) : launch_x9<1, 2>(x, wp, bias, out, q, lds9, blocks9, st);
+            return launch_x9<2, 2>(x, wp, bias, out, q, lds9, blocks9, st);
+          }
+        }
+      }
+    }
   }
   // channels per chunk: the largest of {8, 4, 2} whose two buffers leave room for >= 3 resident workgroups
   auto buf_bytes = [&](int cc) { return (size_t)(cc * p.chanStride + T * cc * KT) * sizeof(float); };
