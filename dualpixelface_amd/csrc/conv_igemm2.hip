@@ -17,6 +17,7 @@
 // convs (data gradients); everything else stays on conv_igemm.hip.
 #include "conv_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -45,7 +46,8 @@ struct G2P {
   unsigned long long steps;     // 2-bit step code per tap (see the kernel's tap walk)
   int accum;                    // 1: out += result
   int single;                   // 1: one LDS buffer (more resident workgroups hide the DMA instead of a second buffer)
-  double* stats;                // optional [ntiles][K][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
+  double* stats;                // optional [ntiles][statsK][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
+  int statsK, statsk0;          // row length of the slab and first channel of this launch in it (K, 0 unless the launch is one slice of the channels)
   int tapoff[28];               // x9 kernel: patch offset (positions) of tap u; taps beyond T: 0 (their weights are zero)
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
@@ -171,7 +173,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[MT][NT], const G2P& p,
         a1 += src[0];
         a2 += src[1];
       }
-      double* row = p.stats + ((long long)tile_id * p.K + tid) * 2;
+      double* row = p.stats + ((long long)tile_id * p.statsK + p.statsk0 + tid) * 2;
       row[0] = a1;
       row[1] = a2;
     }
@@ -432,9 +434,10 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
 //     quadruplets of taps 4g + 2hh and 4g + 2hh + 1 for each component (positions from a per-tap offset table in LDS);
 //   * the weights are split and laid out in fragment order by the pack kernel ([chunk][tap group][component][row tile][lane][8]) and
 //     arrive by LDS-DMA while the patch is being split;
-//   * one LDS buffer, two resident workgroups per CU: one stages while the other multiplies.
-constexpr int X9_NU = 2;         // patch units (4 channels x 4 positions) per thread and chunk
-
+//   * the split of chunk i+1 is computed in the shadow of the last two tap groups' MFMAs of chunk i and kept in registers; between the
+//     chunks only the 16-byte LDS stores remain (one patch buffer, two weight buffers, two resident workgroups per CU);
+//   * 2-D kernels (9 taps) use 8-channel chunks and tap PAIRS (48 bytes per position, one ds_read_b128 per component): 10 instead
+//     of 12 tap slots.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -449,11 +452,31 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& h, unsign
   l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
 }
 
-template <int MT, int NT>
+// CC = 4: a group = 4 taps x 4 channels (3-D kernels: 27 taps -> 7 groups), two 256-unit rounds per chunk;
+// CC = 8: a group = 2 taps x 8 channels (2-D kernels:  9 taps -> 5 groups), one round.
+// first partial product of the nine (smallest first): 1 skips lo x lo, which is below 2^-32 of the product (-DDPF_X9_FIRST=0 keeps it)
+#ifndef DPF_X9_FIRST
+#define DPF_X9_FIRST 1
+#endif
+constexpr int X9_FIRST = DPF_X9_FIRST;
+constexpr int X9_NP = 9 - X9_FIRST;
+
+template <int CC> struct X9 {
+  static constexpr int NU = CC == 4 ? 2 : 1;     // patch units (CC channels x 4 positions) per thread and chunk
+  static constexpr int PB = 6 * CC;              // bytes per position: [hi | mid | lo][CC] bf16
+  static constexpr int TPG = 16 / CC;            // taps per group
+  static constexpr int PD = PB / 4;              // dwords per position
+};
+
+template <int MT, int NT, int CC, bool SH>
 __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ out, G2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(NT == 2 || NT == 4, "position rows are processed in pairs");
   constexpr int KT = 32 * MT;
+  constexpr int NU = X9<CC>::NU, PB = X9<CC>::PB, TPG = X9<CC>::TPG, PD = X9<CC>::PD;
+  constexpr int NPS = NT / 2;                    // pair steps (two position rows, interleaved accumulators) per group
+  constexpr int NSL = NU * 4;                    // split slices (one position of one unit) per chunk; half of them per tail group
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -471,21 +494,21 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   const int i0d = qd + p.e0d, i0h = q0h + p.e0h;
   const int a0 = q0w + p.e0w - p.colshift;
 
-  const int TG = (p.T + 3) >> 2;
-  const int patchBytes = 24 * p.rpc * p.RS;
+  const int TG = (p.T + TPG - 1) / TPG;
+  const int patchBytes = PB * p.rpc * p.RS;
   const int wBytes = TG * 3 * MT * 1024;
   char* s_patch = reinterpret_cast<char*>(smem);
-  char* s_w = s_patch + patchBytes;
-  int* s_tab = reinterpret_cast<int*>(s_w + wBytes);
+  char* s_w = s_patch + patchBytes;                                // SH: two weight buffers
+  int* s_tab = reinterpret_cast<int*>(s_w + (SH ? 2 : 1) * wBytes);
   const long long x_chan = (long long)p.ID * p.IH * p.IW;
   const float* xn = x + (long long)n * p.C * x_chan;
   const int nunits = p.rpc * p.SR;
 
-  if (tid < 32) s_tab[tid] = tid < 28 ? 24 * p.tapoff[tid] : 0;
+  if (tid < 32) s_tab[tid] = tid < 28 ? PB * p.tapoff[tid] : 0;
 
-  int goff[X9_NU], loff[X9_NU];
+  int goff[NU], loff[NU];
 #pragma unroll
-  for (int j = 0; j < X9_NU; ++j) {
+  for (int j = 0; j < NU; ++j) {
     const unsigned f = tid + 256 * j;
     const unsigned row = (f * p.mSR) >> 20;
     const int seg = f - row * p.SR;
@@ -494,49 +517,50 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     const int id = i0d + (int)pl, ih = i0h + rr, iw = a0 + 4 * seg;
     const bool ok = (int)f < nunits && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
     goff[j] = ok ? (int)(((long long)id * p.IH + ih) * p.IW + iw) : -1;
-    loff[j] = (int)f < nunits ? 24 * ((int)row * p.RS + 4 * seg) : -1;
+    loff[j] = (int)f < nunits ? PB * ((int)row * p.RS + 4 * seg) : -1;
   }
 
-  f32x4 pv[X9_NU][4];
+  f32x4 pv[NU][CC];                  // raw patch values of the NEXT chunk (in flight across the MFMA loop)
+  unsigned sp[NU][4][PD];            // their split form: [unit][position][hi: CC/2 dwords | mid | lo]
   auto prefetch = [&](int chunk) {
-    const float* xc = xn + (long long)chunk * 4 * x_chan;
-    const int crem = p.C - chunk * 4;
+    const float* xc = xn + (long long)chunk * CC * x_chan;
+    const int crem = p.C - chunk * CC;
 #pragma unroll
-    for (int j = 0; j < X9_NU; ++j)
+    for (int j = 0; j < NU; ++j)
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
+      for (int ch = 0; ch < CC; ++ch) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (goff[j] >= 0 && ch < crem) v = *reinterpret_cast<const f32x4*>(xc + (long long)ch * x_chan + goff[j]);
         pv[j][ch] = v;
       }
   };
-  auto issue_w = [&](int chunk) {
+  auto issue_w = [&](int chunk, int buf) {
     const char* wc = reinterpret_cast<const char*>(wpk) + (long long)chunk * wBytes;
+    char* dst = s_w + buf * wBytes;
     const int nws = wBytes >> 4;
     for (int f0 = wave * 64; f0 < nws; f0 += 256) {
       const int f = f0 + lane;
-      if (f < nws) glds16(reinterpret_cast<const float*>(wc + f * 16), reinterpret_cast<float*>(s_w + f0 * 16));
+      if (f < nws) glds16(reinterpret_cast<const float*>(wc + f * 16), reinterpret_cast<float*>(dst + f0 * 16));
     }
   };
-  auto split_store = [&]() {
+  auto split_slice = [&](int sl) {   // slice = (unit, position)
+    const int j = sl >> 2, ps = sl & 3;
 #pragma unroll
-    for (int j = 0; j < X9_NU; ++j) {
+    for (int k = 0; k < CC / 2; ++k)
+      split_pair(pv[j][2 * k][ps], pv[j][2 * k + 1][ps], sp[j][ps][k], sp[j][ps][CC / 2 + k], sp[j][ps][CC + k]);
+  };
+  auto store_split = [&]() {
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
       if (loff[j] >= 0) {
-        unsigned q[4][6];
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          split_pair(pv[j][0][ps], pv[j][1][ps], q[ps][0], q[ps][2], q[ps][4]);
-          split_pair(pv[j][2][ps], pv[j][3][ps], q[ps][1], q[ps][3], q[ps][5]);
-        }
         u32x4* dst = reinterpret_cast<u32x4*>(s_patch + loff[j]);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < PD; ++i) {
           const int e = 4 * i;
-          const u32x4 v = {q[e / 6][e % 6], q[(e + 1) / 6][(e + 1) % 6], q[(e + 2) / 6][(e + 2) % 6], q[(e + 3) / 6][(e + 3) % 6]};
+          const u32x4 v = {sp[j][e / PD][e % PD], sp[j][(e + 1) / PD][(e + 1) % PD], sp[j][(e + 2) / PD][(e + 2) % PD], sp[j][(e + 3) / PD][(e + 3) % PD]};
           dst[i] = v;
         }
       }
-    }
   };
 
   f32x16 acc[MT][NT];
@@ -551,41 +575,70 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int r = wave * NT + t, rz = r >> p.thp_shift, ry = r & (p.thp - 1);
-    lb[t] = 24 * (rz * p.planeStride + ry * p.RS + l31 + p.colshift);
+    lb[t] = PB * (rz * p.planeStride + ry * p.RS + l31 + p.colshift);
   }
 
+  // SH (split in the shadow): the split of chunk i+1 is computed behind the last two tap groups' MFMAs of chunk i, its weights arrive in
+  // the other weight buffer meanwhile, and only the LDS stores stand between two chunks.  !SH: one weight buffer; weights, split and
+  // stores form a phase of their own, hidden by the co-resident workgroup's MFMAs.
+  if constexpr (SH) issue_w(0, 0);
   prefetch(0);
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    issue_w(chunk);
-    split_store();
-    __syncthreads();                                               // vmcnt(0): weights landed; barrier: patch + table written
-    if (chunk + 1 < p.nchunks) prefetch(chunk + 1);
+  if constexpr (SH) {
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
+  }
 
-    u32x4 aC[3][MT], aN[3][MT], b0[3], b1[3];
-    int oC0, oC1, oN0 = 0, oN1 = 0;
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    if constexpr (!SH) {
+      issue_w(chunk, 0);
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
+    }
+    store_split();
+    __syncthreads();                                               // vmcnt(0): this chunk's weights landed; barrier: patch written
+    const char* s_wc = s_w + (SH ? (chunk & 1) * wBytes : 0);
+    if (chunk + 1 < p.nchunks) {
+      if constexpr (SH) issue_w(chunk + 1, (chunk + 1) & 1);
+      prefetch(chunk + 1);
+    }
+
+    u32x4 aC[3][MT], aN[3][MT], bP[2][2][3];                       // bP[set][row of the pair][component]
+    int oC0, oC1 = 0, oN0 = 0, oN1 = 0;
     auto load_a = [&](int g, u32x4 (&a)[3][MT]) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[c][m] = *reinterpret_cast<const u32x4*>(s_w + ((g * 3 + c) * MT + m) * 1024 + lane * 16);
+        for (int m = 0; m < MT; ++m) a[c][m] = *reinterpret_cast<const u32x4*>(s_wc + ((g * 3 + c) * MT + m) * 1024 + lane * 16);
     };
     auto load_t = [&](int g, int& o0, int& o1) {
-      const u32x2 v = *reinterpret_cast<const u32x2*>(s_tab + 4 * g + 2 * hh);
-      o0 = (int)v[0]; o1 = (int)v[1];
-    };
-    auto load_b = [&](int t, int o0, int o1, u32x4 (&bb)[3]) {
-      const char* p0 = s_patch + lb[t] + o0;
-      const char* p1 = s_patch + lb[t] + o1;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const u32x2 q0 = *reinterpret_cast<const u32x2*>(p0 + 8 * c), q1 = *reinterpret_cast<const u32x2*>(p1 + 8 * c);
-        const u32x4 v = {q0[0], q0[1], q1[0], q1[1]};
-        bb[c] = v;
+      if constexpr (CC == 4) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(s_tab + 4 * g + 2 * hh);
+        o0 = (int)v[0]; o1 = (int)v[1];
+      } else {
+        o0 = s_tab[2 * g + hh];
       }
     };
-    auto touch_b = [&](const u32x4 (&bb)[3]) {
+    auto load_b = [&](int t, int o0, int o1, u32x4 (&bb)[3]) {
+      if constexpr (CC == 4) {
+        const char* p0 = s_patch + lb[t] + o0;
+        const char* p1 = s_patch + lb[t] + o1;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) asm volatile("" ::"v"(bb[c]));
+        for (int c = 0; c < 3; ++c) {
+          const u32x2 q0 = *reinterpret_cast<const u32x2*>(p0 + 8 * c), q1 = *reinterpret_cast<const u32x2*>(p1 + 8 * c);
+          const u32x4 v = {q0[0], q0[1], q1[0], q1[1]};
+          bb[c] = v;
+        }
+      } else {
+        const char* p0 = s_patch + lb[t] + o0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bb[c] = *reinterpret_cast<const u32x4*>(p0 + 16 * c);
+      }
+    };
+    auto touch_pair = [&](const u32x4 (&bb)[2][3]) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) asm volatile("" ::"v"(bb[r][c]));
       asm volatile("" ::: "memory");
     };
     auto touch_a = [&](const u32x4 (&a)[3][MT]) {
@@ -594,34 +647,52 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
         for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a[c][m]));
     };
-    auto mfma9 = [&](const u32x4 (&a)[3][MT], const u32x4 (&bb)[3], int t) {
-      // component index 0 = hi, 1 = mid, 2 = lo; smallest partial products first
+    auto mfma_pair = [&](const u32x4 (&a)[3][MT], const u32x4 (&bb)[2][3], int t0) {
+      // component index 0 = hi, 1 = mid, 2 = lo; smallest partial products first; the two position rows (and the row tiles) alternate,
+      // so consecutive MFMAs never accumulate into the same registers
       constexpr int oa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
       constexpr int ob[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int i = 0; i < 9; ++i)
+      for (int i = X9_FIRST; i < 9; ++i)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[oa[i]][m]), __builtin_bit_cast(bf16x8, bb[ob[i]]), acc[m][t], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            acc[m][t0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[oa[i]][m]), __builtin_bit_cast(bf16x8, bb[r][ob[i]]),
+                                                                      acc[m][t0 + r], 0, 0, 0);
     };
-    load_a(0, aC);
-    load_t(0, oC0, oC1);
-    load_b(0, oC0, oC1, b0);
-    for (int g = 0; g < TG; ++g) {
+    // one tap group; HALF = 0 / 1: the first / second half of the next chunk's split slices is computed in the MFMAs' shadow
+    auto group = [&](int g, auto half_c) {
+      constexpr int HALF = decltype(half_c)::value;
       const int gn = g + 1 < TG ? g + 1 : 0;                      // the wrapped fetch of the last group is valid and unused
       load_t(gn, oN0, oN1);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (t & 1) touch_b(b1); else touch_b(b0);
-        if (t == 0) touch_a(aC);
-        if (t + 1 < NT) {
-          if (t & 1) load_b(t + 1, oC0, oC1, b0); else load_b(t + 1, oC0, oC1, b1);
+      for (int s = 0; s < NPS; ++s) {
+        touch_pair(bP[s & 1]);
+        if (s == 0) touch_a(aC);
+        if (s + 1 < NPS) {
+          load_b(2 * s + 2, oC0, oC1, bP[(s + 1) & 1][0]);
+          load_b(2 * s + 3, oC0, oC1, bP[(s + 1) & 1][1]);
         } else {
           load_a(gn, aN);
-          load_b(0, oN0, oN1, b0);                                 // NT is even: the last position row of a group sits in b1
+          load_b(0, oN0, oN1, bP[(s + 1) & 1][0]);
+          load_b(1, oN0, oN1, bP[(s + 1) & 1][1]);
         }
-        __builtin_amdgcn_sched_barrier(6);
-        if (t & 1) mfma9(aC, b1, t); else mfma9(aC, b0, t);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HALF >= 0) {
+          constexpr int per = NSL / 2 / NPS;                       // slices per pair step
+#pragma unroll
+          for (int q = 0; q < per; ++q) split_slice(HALF * (NSL / 2) + s * per + q);
+        }
+        mfma_pair(aC, bP[s & 1], 2 * s);
+        if constexpr (HALF >= 0) {
+          constexpr int NM = 2 * X9_NP * MT;
+#pragma unroll
+          for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (NSL / 2 / NPS * CC / 2 * 11 + NM - 1) / NM + 1, 0);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -629,24 +700,44 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
         for (int m = 0; m < MT; ++m) aC[c][m] = aN[c][m];
       oC0 = oN0; oC1 = oN1;
+      if constexpr (NPS & 1) {                                     // an odd number of pair steps leaves the next group's rows in set 1
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) bP[0][r][c] = bP[1][r][c];
+      }
+    };
+    load_a(0, aC);
+    load_t(0, oC0, oC1);
+    load_b(0, oC0, oC1, bP[0][0]);
+    load_b(1, oC0, oC1, bP[0][1]);
+    if constexpr (SH) {
+      for (int g = 0; g + 2 < TG; ++g) group(g, std::integral_constant<int, -1>{});
+      group(TG - 2, std::integral_constant<int, 0>{});
+      group(TG - 1, std::integral_constant<int, 1>{});
+    } else {
+      for (int g = 0; g < TG; ++g) group(g, std::integral_constant<int, -1>{});
     }
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                                               // the LDS buffer is free
+    __syncthreads();                                               // the patch buffer is free
   }
   g2_epilogue<MT, NT>(acc, p, bias, out, smem, tile_id, n, qd, q0h, q0w, wave, l31, hh, tid);
 }
 
 // x9 weights: shorts [chunk][tap group g][component][row tile m][lane][8]; value i of lane (l31, hh) = component of
-// w(out = k0 + 32 m + l31, reduce = 4 chunk + (i & 3), tap = 4 g + 2 hh + (i >> 2)), zero beyond T / C / K
-__global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int TG, int MT, int nchunks,
-                                      int mode, int k0, int K, int C) {
+// w(out = k0 + 32 m + l31, reduce, tap), zero beyond T / C / K, with
+//   CC = 4: reduce = 4 chunk + (i & 3), tap = 4 g + 2 hh + (i >> 2);      CC = 8: reduce = 8 chunk + i, tap = 2 g + hh
+__global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int TG, int MT, int CC,
+                                      int nchunks, int mode, int k0, int K, int C) {
   const long long total = (long long)nchunks * TG * MT * 512;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(e & 7), ln = (int)((e >> 3) & 63);
     const int m = (int)((e >> 9) % MT);
     const int g = (int)((e / (512LL * MT)) % TG);
     const int chunk = (int)(e / (512LL * MT * TG));
-    const int u = 4 * g + 2 * (ln >> 5) + (i >> 2), c = chunk * 4 + (i & 3), k = m * 32 + (ln & 31);
+    const int u = CC == 4 ? 4 * g + 2 * (ln >> 5) + (i >> 2) : 2 * g + (ln >> 5);
+    const int c = CC == 4 ? chunk * 4 + (i & 3) : chunk * 8 + i;
+    const int k = m * 32 + (ln & 31);
     float v = 0.f;
     if (u < T && c < C && k < K) {
       const int a = mode == 0 ? k0 + k : c;
@@ -991,15 +1082,89 @@ int launch_g2(const float* x, const float* wpk, const float* bias, float* out, c
 }
 
 
-template <int MT, int NT>
+template <int MT, int NT, int CC, bool SH>
 int launch_x9(const float* x, const unsigned short* wpk, const float* bias, float* out, const G2P& p, size_t lds, long long blocks, hipStream_t st) {
   static bool done = false;   // per instantiation
   if (!done) {
-    if (hipFuncSetAttribute((const void*)igemm3_x9_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DPF_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)igemm3_x9_kernel<MT, NT, CC, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DPF_ERR_LAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((igemm3_x9_kernel<MT, NT>), dim3((unsigned)blocks), dim3(256), lds, st, x, wpk, bias, out, p);
+  hipLaunchKernelGGL((igemm3_x9_kernel<MT, NT, CC, SH>), dim3((unsigned)blocks), dim3(256), lds, st, x, wpk, bias, out, p);
   return dpf_check_launch();
+}
+
+// One launch of igemm3_x9_kernel for the output channels [k_off, k_off + kn) of the launch `d` (kn <= 64); `p` carries the
+// tile-independent geometry (strides, e0*, RS, colshift).  DPF_ERR_UNSUPPORTED: not eligible, nothing was launched.
+int x9_try(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, const G2P& p, int k_off, int kn, int NT,
+           DpfConvStats* stats, hipStream_t st) {
+  static const int x9_on = env_int("DPF_IGEMM3", 1), x9_min_c = env_int("DPF_IGEMM3_MINC", 8), x9_cc = env_int("DPF_IGEMM3_CC", 0),
+                   x9_sh = env_int("DPF_IGEMM3_SH", -1);
+  const int T = d.kd * d.kh * d.kw, MT = (kn + 31) / 32, TH = 4 * NT;
+  if (!x9_on || !dpf_conv_f32_x9() || MT > 2 || NT * MT > 4 || d.C < x9_min_c) return DPF_ERR_UNSUPPORTED;
+  G2P q = p;
+  q.K = kn; q.k0 = d.k0 + k_off;
+  // chunk layout with the fewest tap slots (4 channels x tap quadruples or 8 channels x tap pairs); ties: the smaller patch
+  int CC9 = ((T + 1) / 2) * 2 < ((T + 3) / 4) * 4 ? 8 : 4;
+  if (x9_cc == 4 || x9_cc == 8) CC9 = x9_cc;
+  const int NU9 = CC9 == 4 ? 2 : 1, PB9 = 6 * CC9;
+  // depth split: among the splits whose patch fits the per-thread unit budget, the one with the fewest staged rows
+  auto set_pz = [&](int pz) {
+    q.pz = pz; q.thp = TH / pz; q.thp_shift = 0;
+    while ((1 << q.thp_shift) < q.thp) ++q.thp_shift;
+    q.odt = dpf_div_up(d.OD, pz);
+    q.ext_d = (pz - 1) + (d.kd - 1) * d.dd + 1;
+    q.ext_h = (q.thp - 1) + (d.kh - 1) * d.dh + 1;
+    q.planeStride = q.ext_h * q.RS; q.SR = q.RS / 4; q.rpc = q.ext_d * q.ext_h;
+    return q.rpc * q.SR;
+  };
+  const int TG = (T + 16 / CC9 - 1) / (16 / CC9);
+  int best = 0, best_units = 1 << 30, sh = 0;
+  for (int shc : {1, 0}) {                                     // split in the MFMAs' shadow (two weight buffers) when the LDS has room
+    if (best || (x9_sh >= 0 && shc != x9_sh)) continue;
+    for (int pz : {1, 2, 4}) {
+      if (!(pz == 1 || (d.kd > 1 && pz <= TH / 2 && pz <= d.OD))) continue;
+      const int units = set_pz(pz);
+      const size_t l9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(shc ? 2 : 1) * TG * 3 * MT * 1024 + 128;
+      if (units <= NU9 * 256 && 2 * l9 <= 160 * 1024 && units < best_units) { best = pz; best_units = units; sh = shc; }
+    }
+  }
+  if (!best || TG < 2) return DPF_ERR_UNSUPPORTED;
+  set_pz(best);
+  const size_t lds9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(sh ? 2 : 1) * TG * 3 * MT * 1024 + 128;
+  if ((long long)NU9 * 256 * (q.SR > q.ext_h ? q.SR : q.ext_h) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
+  const int sgn = d.transposed ? -1 : 1;
+  const int t0 = d.transposed ? ((d.kd - 1) * d.dd * q.ext_h + (d.kh - 1) * d.dh) * q.RS + (d.kw - 1) * d.dw : 0;
+  for (int u = 0; u < 28; ++u) {
+    const int c = u % d.kw, b2 = (u / d.kw) % d.kh, a = u / (d.kw * d.kh);
+    q.tapoff[u] = u < T ? t0 + sgn * ((a * d.dd * q.ext_h + b2 * d.dh) * q.RS + c * d.dw) : 0;
+  }
+  q.nchunks = (d.C + CC9 - 1) / CC9;
+  q.tilesH = dpf_div_up(d.OH, q.thp);
+  q.tilesW = dpf_div_up(d.OW, 32);
+  q.mSR = magic20(q.SR); q.mEH = magic20(q.ext_h);
+  const long long nt9 = (long long)d.N * q.odt * q.tilesH * q.tilesW;
+  if (nt9 <= 0 || nt9 > 0x3fffffffLL) return DPF_ERR_INVALID_ARG;
+  q.ntiles = (int)nt9;
+  q.cpx = (int)((nt9 + 7) / 8);
+  q.stats = nullptr;
+  if (stats) {
+    if (nt9 * d.K * 2 > stats->capacity_doubles) return DPF_ERR_UNSUPPORTED;
+    q.stats = stats->slab; q.statsK = d.K; q.statsk0 = k_off;
+  }
+  unsigned short* wp = reinterpret_cast<unsigned short*>(ws);
+  const long long total = (long long)q.nchunks * TG * MT * 512;
+  hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, q.nchunks, d.mode, q.k0, kn, d.C);
+  if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
+  if (stats) stats->parts = (int)nt9;
+  const long long blocks9 = 8LL * q.cpx;
+#define X9L(M, N_, C_) return sh ? launch_x9<M, N_, C_, true>(x, wp, bias, out, q, lds9, blocks9, st) : launch_x9<M, N_, C_, false>(x, wp, bias, out, q, lds9, blocks9, st)
+  if (CC9 == 4) {
+    if (MT == 1) { if (NT == 4) X9L(1, 4, 4); X9L(1, 2, 4); }
+    X9L(2, 2, 4);
+  }
+  if (MT == 1) { if (NT == 4) X9L(1, 4, 8); X9L(1, 2, 8); }
+  X9L(2, 2, 8);
+#undef X9L
 }
 }  // namespace
 
@@ -1072,7 +1237,9 @@ int igemm2_tr2(const float* x, const float* w, const float* bias, float* out, fl
 long long dpf_igemm2_workspace_floats(int T, int reduce, int outc) {
   const int KT = 32 * (((outc < 128 ? outc : 128) + 31) / 32);
   const long long plain = (long long)T * (reduce + 8) * KT + ZPAGE;
-  const long long x9 = (long long)((reduce + 3) / 4) * ((T + 3) / 4) * 3 * (KT / 32) * 256;   // split bf16 fragments, 1 KB per (chunk, tap group, component, row tile)
+  // split bf16 fragments of the x9 kernel: 1 KB per (chunk, tap group, component, row tile) in either chunk layout
+  const long long g4 = (long long)((reduce + 3) / 4) * ((T + 3) / 4), g8 = (long long)((reduce + 7) / 8) * ((T + 1) / 2);
+  const long long x9 = (g4 > g8 ? g4 : g8) * 3 * (KT / 32) * 256;
   return plain > x9 ? plain : x9;
 }
 
@@ -1191,64 +1358,17 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
     }
     p.tap0 = d.transposed ? ((d.kd - 1) * d.dd * p.ext_h + (d.kh - 1) * d.dh) * p.RS + (d.kw - 1) * d.dw : 0;
   }
-  // ---- exact-f32 products on the bf16 pipe (igemm3_x9_kernel): stride-1 launches whose patch is at most 2 x 256 units
-  {
-    static const int x9_on = env_int("DPF_IGEMM3", 1), x9_min_c = env_int("DPF_IGEMM3_MINC", 8);
-    if (x9_on && dpf_conv_f32_x9() && !bf && T > 12 && MT <= 2 && p.sxd == 1 && p.sxh == 1 && p.sxw == 1 && d.C >= x9_min_c && NT * MT <= 4) {
-      G2P q = p;
-      // depth split: among the splits whose patch fits the per-thread unit budget, the one with the fewest staged rows
-      auto set_pz = [&](int pz) {
-        q.pz = pz; q.thp = TH / pz; q.thp_shift = 0;
-        while ((1 << q.thp_shift) < q.thp) ++q.thp_shift;
-        q.odt = dpf_div_up(d.OD, pz);
-        q.ext_d = (pz - 1) + (d.kd - 1) * d.dd + 1;
-        q.ext_h = (q.thp - 1) + (d.kh - 1) * d.dh + 1;
-        q.planeStride = q.ext_h * q.RS; q.SR = q.RS / 4; q.rpc = q.ext_d * q.ext_h;
-        return q.rpc * q.SR;
-      };
-      int best = 0, best_units = 1 << 30;
-      for (int pz : {1, 2, 4}) {
-        if (!(pz == 1 || (d.kd > 1 && pz <= TH / 2 && pz <= d.OD))) continue;
-        const int units = set_pz(pz);
-        if (units <= X9_NU * 256 && units < best_units) { best = pz; best_units = units; }
-      }
-      const int TG = (T + 3) / 4;
-      if (best) {
-        set_pz(best);
-        const size_t lds9 = (size_t)24 * q.rpc * q.RS + (size_t)TG * 3 * MT * 1024 + 128;
-        if (2 * lds9 <= 160 * 1024 && (long long)X9_NU * 256 * (q.SR > q.ext_h ? q.SR : q.ext_h) < (1LL << 20)) {
-          const int sgn = d.transposed ? -1 : 1;
-          const int t0 = d.transposed ? ((d.kd - 1) * d.dd * q.ext_h + (d.kh - 1) * d.dh) * q.RS + (d.kw - 1) * d.dw : 0;
-          for (int u = 0; u < 28; ++u) {
-            const int c = u % d.kw, b2 = (u / d.kw) % d.kh, a = u / (d.kw * d.kh);
-            q.tapoff[u] = u < T ? t0 + sgn * ((a * d.dd * q.ext_h + b2 * d.dh) * q.RS + c * d.dw) : 0;
-          }
-          q.nchunks = (d.C + 3) / 4;
-          q.tilesH = dpf_div_up(d.OH, q.thp);
-          q.tilesW = dpf_div_up(d.OW, 32);
-          q.mSR = magic20(q.SR); q.mEH = magic20(q.ext_h);
-          const long long nt9 = (long long)d.N * q.odt * q.tilesH * q.tilesW;
-          if (nt9 <= 0 || nt9 > 0x3fffffffLL) return DPF_ERR_INVALID_ARG;
-          q.ntiles = (int)nt9;
-          q.cpx = (int)((nt9 + 7) / 8);
-          q.stats = nullptr;
-          bool ok = true;
-          if (stats) {
-            if (nt9 * d.K * 2 > stats->capacity_doubles) ok = false;
-            else { q.stats = stats->slab; }
-          }
-          if (ok) {
-            unsigned short* wp = reinterpret_cast<unsigned short*>(ws);
-            const long long total = (long long)q.nchunks * TG * MT * 512;
-            hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, q.nchunks, d.mode, d.k0, d.K,
-                               d.C);
-            if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
-            if (stats) stats->parts = (int)nt9;
-            const long long blocks9 = 8LL * q.cpx;
-            if (MT == 1) return NT == 4 ? launch_x9<1, 4>(x, wp, bias, out, q, lds9, blocks9, st) : launch_x9<1, 2>(x, wp, bias, out, q, lds9, blocks9, st);
-            return launch_x9<2, 2>(x, wp, bias, out, q, lds9, blocks9, st);
-          }
-        }
+  // ---- exact-f32 products on the bf16 pipe (igemm3_x9_kernel): stride-1 launches, output channels in slices of at most 64
+  if (!bf && T > 4 && p.sxd == 1 && p.sxh == 1 && p.sxw == 1) {
+    if (d.K <= 64) {
+      const int rc = x9_try(x, w, bias, out, ws, d, p, 0, d.K, MT == 1 ? NT : 2, stats, st);
+      if (rc != DPF_ERR_UNSUPPORTED) return rc;
+    } else {
+      for (int k_off = 0; k_off < d.K; k_off += 64) {
+        const int rc = x9_try(x, w, bias, out, ws, d, p, k_off, d.K - k_off < 64 ? d.K - k_off : 64, 2, stats, st);
+        if (rc == DPF_ERR_UNSUPPORTED && k_off == 0) break;      // nothing launched yet: the exact-f32 kernel below takes the launch
+        if (rc != DPF_OK) return rc == DPF_ERR_UNSUPPORTED ? DPF_ERR_LAUNCH : rc;
+        if (k_off + 64 >= d.K) return DPF_OK;
       }
     }
   }
@@ -1297,6 +1417,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   if (stats) {
     if (ntiles * d.K * 2 > stats->capacity_doubles || lds < (size_t)4 * 2 * MT * 16 * 2 * sizeof(double)) return DPF_ERR_UNSUPPORTED;
     p.stats = stats->slab;
+    p.statsK = d.K; p.statsk0 = 0;
     stats->parts = (int)ntiles;
   }
 #define G2B(M, N_) return launch_g2<M, N_, 8, true>(x, ws, bias, out, p, lds, blocks, st)
