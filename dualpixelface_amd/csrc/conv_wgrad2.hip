@@ -102,6 +102,11 @@ constexpr int w2_occ() { return w2_occ_of(NCT); }
 // runs in the MFMA's fp32 accumulator, smallest terms first.  9 x 34 = 306 matrix-pipe clocks per 16 reduction indices instead of 8 x 64 =
 // 512 on v_mfma_f32_32x32x2_f32, and, unlike the fp32 MFMA, the bf16 MFMA leaves the vector ALU free: the ~11 split instructions per value
 // pair run in its shadow (tools/lean_probe2.hip: 4 v_fma_f32 per bf16 MFMA cost nothing, behind an fp32 MFMA they cost their full time).
+// first of the nine partial products (smallest first): 1 skips lo x lo, which is below 2^-32 of the product (-DDPF_X9_FIRST=0 keeps it)
+#ifndef DPF_X9_FIRST
+#define DPF_X9_FIRST 1
+#endif
+constexpr int W2_X9_FIRST = DPF_X9_FIRST;
 template <int NCT, bool BF = false, bool SW1 = false, bool X9 = false>
 __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                      float* __restrict__ slab, W2P p) {
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
           if (u + 1 < 2 * NCT) split8_bf16(xr, nH, nM, nL);
           if (u + 2 < 2 * NCT) load_x((u + 2) / NCT, (u + 2) % NCT, xr);
           if (J == 0 && t == NCT - 1) split8_bf16(gv, a2H, a2M, a2L);      // g fragment of the second super-group
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bL, acc[t], 0, 0, 0);
+          if constexpr (W2_X9_FIRST == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bL, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bM, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM, bL, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bH, acc[t], 0, 0, 0);
@@ -279,9 +284,9 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bM, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bH, acc[t], 0, 0, 0);
 #pragma unroll
-          for (int i = 0; i < 9; ++i) {
+          for (int i = W2_X9_FIRST; i < 9; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // five vector-ALU instructions in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x002, W2_X9_FIRST ? 6 : 5, 0);      // the split's vector-ALU instructions in its shadow
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
           }
           __builtin_amdgcn_sched_barrier(0);

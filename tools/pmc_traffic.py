@@ -11,7 +11,7 @@ import sys
 
 
 def family(name):
-    for key, fam in (('igemm2', 'igemm2'), ('wgrad2', 'wgrad2'), ('pointwise', 'pointwise'), ('conv_igemm_kernel', 'conv_igemm_kernel'),
+    for key, fam in (('igemm2', 'igemm2'), ('igemm3', 'igemm2'), ('wgrad2', 'wgrad2'), ('pointwise', 'pointwise'), ('conv_igemm_kernel', 'conv_igemm_kernel'),
                      ('conv_wgrad_kernel', 'conv_wgrad_kernel'), ('dcn_bwd_input', 'dcn_bwd_input'), ('dcn_lean_fwd', 'dcn_fwd'), ('dcn_fwd', 'dcn_fwd'),
                      ('dcn_lean_bwd_offset', 'dcn_bwd_offset'), ('dcn_bwd_offset', 'dcn_bwd_offset'), ('dcn_wgrad_fold', 'dcn_bwd_offset'),
                      ('smallk', 'smallk'), ('bn_', 'bn_'), ('head_', 'head_')):
@@ -35,7 +35,7 @@ def kernel_sources_sha16():
 
 
 # helper launches of a family (weight packs, slab folds): their bytes belong to the operation, but "per launch" means per main kernel
-HELPERS = ('igemm2_pack', 'wgrad2_reduce', 'wgrad2_fold', 'pointwise_wgrad_fold', 'pointwise_wgrad_reduce', 'bn_finalize', 'bn_fold', 'dcn_wgrad_fold')
+HELPERS = ('igemm2_pack', 'igemm3_pack', 'wgrad2_reduce', 'wgrad2_fold', 'pointwise_wgrad_fold', 'pointwise_wgrad_reduce', 'bn_finalize', 'bn_fold', 'dcn_wgrad_fold')
 
 
 def agg(path, counter):
