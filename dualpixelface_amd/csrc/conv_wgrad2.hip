@@ -46,6 +46,7 @@ struct W2P {
   long long ntiles, per;       // tiles per position chunk (contiguous range)
   unsigned mCS, mPS, mSR;
   long long slab_stride;       // floats between position-chunk slabs  (K * C * T)
+  int dbg;                     // timing experiments (DPF_W2_DBG; results wrong): 1 = no DMA after the first two tiles
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -196,14 +197,17 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
     float* dbase = smem + buf * bufFloats;
     const int i0d = qd * p.sd - p.pd, i0h = q0h * p.sh - p.ph, a0 = q0w * p.sw - p.pw - p.colshift;
     const float* xt = x + ((long long)n * p.C + c0) * x_chan + ((long long)i0d * p.IH + i0h) * p.IW + a0;
+    const long long xzero = zero - xt;                           // offset of the zero page from this tile's origin (both 4-byte aligned)
 #pragma unroll
     for (int j = 0; j < NLX; ++j) {
       if (j * 256 < p.nxseg) {                                   // wave-uniform
         const int m = xmeta[j];
         if (m >= 0) {
-          const int id = i0d + (m >> 16), ih = i0h + ((m >> 8) & 0xff) * p.rstep, iw = a0 + 4 * (m & 0xff);
-          const bool ok = id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
-          glds16(ok ? xt + xoff[j] : zero, dbase + (j * 256 + wave * 64) * 4);
+          // branch-free bounds test (unsigned compares, bitwise and): the short-circuit form compiles to nested exec-mask regions
+          const unsigned id = (unsigned)(i0d + (m >> 16)), ih = (unsigned)(i0h + ((m >> 8) & 0xff) * p.rstep), iw = (unsigned)(a0 + 4 * (m & 0xff));
+          const bool ok = (id < (unsigned)p.ID) & (ih < (unsigned)p.IH) & (iw < (unsigned)p.IW);
+          const long long so = ok ? (long long)xoff[j] : xzero;
+          glds16(xt + so, dbase + (j * 256 + wave * 64) * 4);
         }
       }
     }
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
     for (int v = 0; v < 2; ++v) gok[v] = q0h + (glg[v] >> 3) * p.rstep < p.QH && q0w + 4 * (glg[v] & 7) < p.QW;
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-      const bool ok = gk0 + j * KSTEP < krows && gok[j & 1];
+      const bool ok = (gk0 + j * KSTEP < krows) & gok[j & 1];
       glds16(ok ? gt + (long long)j * KSTEP * g_chan + goff[j & 1] : zero, gbase + (j * 256 + wave * 64) * 4);
     }
   };
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
   __syncthreads();
   int buf = 0;
   for (long long tile = tbeg; tile < tend; ++tile, buf ^= 1) {
-    if (tile + 1 < tend) issue(buf ^ 1);
+    if (tile + 1 < tend && !(p.dbg == 1 && tile > tbeg)) issue(buf ^ 1);
     const float* s_x = smem + buf * bufFloats;
     const float* s_g = s_x + xFloats;
     // group j = positions 8j .. 8j+7 of this wave's row: lane half h takes 8j+4h .. 8j+4h+3; element i of both halves is one
@@ -573,6 +577,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   nchunk = (p.ntiles + p.per - 1) / p.per;
   p.nchunk = (int)nchunk;
   p.slab_stride = (long long)d.K * d.C * T;
+  p.dbg = env_int("DPF_W2_DBG", 0);
   if (getenv("DPF_W2_DEBUG"))
     fprintf(stderr, "wgrad2 C%d K%d T%d s%d: NCT %d CCW %d lds %zu occ %d groups %d capacity %d nchunk %lld per %lld ntiles %lld\n", d.C, d.K, T, d.sh, NCT, CCW,
             lds0, occ, p.groups, capacity, nchunk, (long long)p.per, (long long)p.ntiles);
