@@ -20,6 +20,12 @@ SETS = [
     ({'DPF_W2_RSTEP': '0', 'DPF_G2_PZ': '1'}, 'test_conv_forward_backward'),
     # four output planes per tile wherever the geometry allows it; run-time column stride and the fp32 matrix instruction in the weight gradient
     ({'DPF_G2_PZ': '4', 'DPF_W2_SW1': '0', 'DPF_F32_X9': '0'}, 'test_conv_forward_backward'),
+    # stride-1 convolutions on the exact-f32 matrix instruction instead of the bf16 partial products
+    ({'DPF_IGEMM3': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics'),
+    # x9 convolutions: split as a phase of its own (one weight buffer) instead of in the MFMAs' shadow; forced chunk layouts
+    ({'DPF_IGEMM3_SH': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics or test_conv_f32_matrix_paths_agree'),
+    ({'DPF_IGEMM3_CC': '4'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree'),
+    ({'DPF_IGEMM3_CC': '8'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree'),
     # first-generation dense conv kernels (what unaligned shapes fall back to)
     ({'DPF_IGEMM2': '0', 'DPF_WGRAD2': '0', 'DPF_IGEMM2_TR2': '0'}, 'test_conv_forward_backward'),
 ]

@@ -467,6 +467,53 @@ def test_weight_gradient_f32_matrix_paths_agree(cfg):
     assert errs[0] <= 2 * errs[1] + 1e-7 and errs[1] <= 2 * errs[0] + 1e-7, errs
 
 
+@pytest.mark.parametrize('cfg', [
+    # N, C, K, D, H, W, kernel, dilation, transposed (data gradient)
+    (1, 64, 32, 6, 20, 40, (3, 3, 3), 1, False),     # 4-channel chunks, tap quadruples, four output planes per tile
+    (2, 32, 64, 3, 18, 36, (3, 3, 3), 1, True),      # two row tiles, one weight buffer
+    (1, 35, 81, 4, 12, 36, (3, 3, 3), 1, False),     # channel tail (35 = 8 x 4 + 3), output channels in slices of 64 + 17
+    (2, 96, 32, 1, 24, 72, (1, 3, 3), 1, False),     # 8-channel chunks, tap pairs (9 taps -> 5 groups)
+    (1, 40, 96, 1, 21, 40, (1, 3, 3), 2, True),      # dilation 2, ragged rows, 64 + 32 output channels
+])
+def test_conv_f32_matrix_paths_agree(cfg):
+    """Stride-1 convolutions multiply fp32 operands either on v_mfma_f32_32x32x2_f32 (igemm2_kernel) or as exact bf16 partial products on
+    the bf16 matrix pipe (igemm3_x9_kernel: every operand split exactly into three bf16 terms, eight of the nine partial products -- the
+    dropped lo x lo term is below 2^-32 of a product).  Both are fp32 arithmetic: against an fp64 reference neither may be worse than
+    2 x the other, each is within 1e-5 of the tensor scale -- also on all-positive data, where a truncation bias would add up."""
+    from dualpixelface_amd._lib import lib
+    ops = _ops()
+    N, C, K, D, H, W, ks, dil, transposed = cfg
+    pad = tuple(((k - 1) * dil) // 2 if k > 1 else 0 for k in ks)
+    dl = tuple(dil if k > 1 else 1 for k in ks)
+    prev = lib().cdll.dpf_get_f32_matrix_path()
+    try:
+        for positive in (False, True):
+            x = rnd(N, C, D, H, W, seed=190)
+            w = rnd(K, C, *ks, seed=191, scale=0.1)
+            if positive:
+                x, w = x.abs(), w.abs()
+            if transposed:
+                g = rnd(N, K, D, H, W, seed=192)
+                g = g.abs() if positive else g
+                ref = torch.nn.grad.conv3d_input((N, C, D, H, W), w.double(), g.double(), 1, pad, dl)
+            else:
+                ref = F.conv3d(x.double(), w.double(), None, 1, pad, dl)
+            errs = []
+            for path in (1, 0):
+                lib().call('dpf_set_f32_matrix_path', path)
+                if transposed:
+                    xg = x.to(DEV).requires_grad_()
+                    y = ops.ConvFn.apply(xg, w.to(DEV), None, (1, 1, 1), pad, dl)
+                    (got,) = torch.autograd.grad(y, xg, g.to(DEV))
+                else:
+                    got = ops.ConvFn.apply(x.to(DEV), w.to(DEV), None, (1, 1, 1), pad, dl)
+                errs.append(((got.double().cpu() - ref).abs().max() / ref.abs().max()).item())
+            assert max(errs) <= 1e-5, (positive, errs)
+            assert errs[0] <= 2 * errs[1] + 1e-7 and errs[1] <= 2 * errs[0] + 1e-7, (positive, errs)
+    finally:
+        lib().call('dpf_set_f32_matrix_path', prev)
+
+
 @pytest.mark.parametrize('shape', [(1, 8, 16, 4, 6, 16), (1, 5, 7, 3, 5, 6)])
 def test_deform_conv_integer_offsets_and_the_validity_rule(shape):
     """Integer offsets put samples exactly on voxel centres, on the borders and on coordinate -1: deform_im2col_cuda.cuh:248 declares a
