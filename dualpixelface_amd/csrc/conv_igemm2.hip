@@ -461,20 +461,23 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& h, unsign
 constexpr int X9_FIRST = DPF_X9_FIRST;
 constexpr int X9_NP = 9 - X9_FIRST;
 
-template <int CC> struct X9 {
+// NC = 3: the exact split (x9 / x8); NC = 1 (operand precision "bf16"): one component, the operand rounded to bf16 (RNE) -- the same
+// staging and layouts with a third of the bytes and one MFMA per (row tile, position row, tap group).
+template <int CC, int NC> struct X9 {
   static constexpr int NU = CC == 4 ? 2 : 1;     // patch units (CC channels x 4 positions) per thread and chunk
-  static constexpr int PB = 6 * CC;              // bytes per position: [hi | mid | lo][CC] bf16
+  static constexpr int PB = 2 * NC * CC;         // bytes per position: [hi | mid | lo][CC] bf16
   static constexpr int TPG = 16 / CC;            // taps per group
   static constexpr int PD = PB / 4;              // dwords per position
 };
 
-template <int MT, int NT, int CC, bool SH>
+template <int MT, int NT, int CC, bool SH, int NC = 3>
 __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ out, G2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(NT == 2 || NT == 4, "position rows are processed in pairs");
   constexpr int KT = 32 * MT;
-  constexpr int NU = X9<CC>::NU, PB = X9<CC>::PB, TPG = X9<CC>::TPG, PD = X9<CC>::PD;
+  constexpr int NU = X9<CC, NC>::NU, PB = X9<CC, NC>::PB, TPG = X9<CC, NC>::TPG, PD = X9<CC, NC>::PD;
+  constexpr int NPROD = NC == 3 ? X9_NP : 1;     // MFMAs per (row tile, position row, tap group)
   constexpr int NPS = NT / 2;                    // pair steps (two position rows, interleaved accumulators) per group
   constexpr int NSL = NU * 4;                    // split slices (one position of one unit) per chunk; half of them per tail group
   const int tid = threadIdx.x;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 
   const int TG = (p.T + TPG - 1) / TPG;
   const int patchBytes = PB * p.rpc * p.RS;
-  const int wBytes = TG * 3 * MT * 1024;
+  const int wBytes = TG * NC * MT * 1024;
   char* s_patch = reinterpret_cast<char*>(smem);
   char* s_w = s_patch + patchBytes;                                // SH: two weight buffers
   int* s_tab = reinterpret_cast<int*>(s_w + (SH ? 2 : 1) * wBytes);
@@ -546,8 +549,10 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   auto split_slice = [&](int sl) {   // slice = (unit, position)
     const int j = sl >> 2, ps = sl & 3;
 #pragma unroll
-    for (int k = 0; k < CC / 2; ++k)
-      split_pair(pv[j][2 * k][ps], pv[j][2 * k + 1][ps], sp[j][ps][k], sp[j][ps][CC / 2 + k], sp[j][ps][CC + k]);
+    for (int k = 0; k < CC / 2; ++k) {
+      if constexpr (NC == 3) split_pair(pv[j][2 * k][ps], pv[j][2 * k + 1][ps], sp[j][ps][k], sp[j][ps][CC / 2 + k], sp[j][ps][CC + k]);
+      else sp[j][ps][k] = pk_bf16(pv[j][2 * k][ps], pv[j][2 * k + 1][ps]);
+    }
   };
   auto store_split = [&]() {
 #pragma unroll
@@ -602,13 +607,13 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       prefetch(chunk + 1);
     }
 
-    u32x4 aC[3][MT], aN[3][MT], bP[2][2][3];                       // bP[set][row of the pair][component]
+    u32x4 aC[NC][MT], aN[NC][MT], bP[2][2][NC];                       // bP[set][row of the pair][component]
     int oC0, oC1 = 0, oN0 = 0, oN1 = 0;
-    auto load_a = [&](int g, u32x4 (&a)[3][MT]) {
+    auto load_a = [&](int g, u32x4 (&a)[NC][MT]) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[c][m] = *reinterpret_cast<const u32x4*>(s_wc + ((g * 3 + c) * MT + m) * 1024 + lane * 16);
+        for (int m = 0; m < MT; ++m) a[c][m] = *reinterpret_cast<const u32x4*>(s_wc + ((g * NC + c) * MT + m) * 1024 + lane * 16);
     };
     auto load_t = [&](int g, int& o0, int& o1) {
       if constexpr (CC == 4) {
@@ -618,12 +623,12 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
         o0 = s_tab[2 * g + hh];
       }
     };
-    auto load_b = [&](int t, int o0, int o1, u32x4 (&bb)[3]) {
+    auto load_b = [&](int t, int o0, int o1, u32x4 (&bb)[NC]) {
       if constexpr (CC == 4) {
         const char* p0 = s_patch + lb[t] + o0;
         const char* p1 = s_patch + lb[t] + o1;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < NC; ++c) {
           const u32x2 q0 = *reinterpret_cast<const u32x2*>(p0 + 8 * c), q1 = *reinterpret_cast<const u32x2*>(p1 + 8 * c);
           const u32x4 v = {q0[0], q0[1], q1[0], q1[1]};
           bb[c] = v;
@@ -631,35 +636,35 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       } else {
         const char* p0 = s_patch + lb[t] + o0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) bb[c] = *reinterpret_cast<const u32x4*>(p0 + 16 * c);
+        for (int c = 0; c < NC; ++c) bb[c] = *reinterpret_cast<const u32x4*>(p0 + 16 * c);
       }
     };
-    auto touch_pair = [&](const u32x4 (&bb)[2][3]) {
+    auto touch_pair = [&](const u32x4 (&bb)[2][NC]) {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) asm volatile("" ::"v"(bb[r][c]));
+        for (int c = 0; c < NC; ++c) asm volatile("" ::"v"(bb[r][c]));
       asm volatile("" ::: "memory");
     };
-    auto touch_a = [&](const u32x4 (&a)[3][MT]) {
+    auto touch_a = [&](const u32x4 (&a)[NC][MT]) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a[c][m]));
     };
-    auto mfma_pair = [&](const u32x4 (&a)[3][MT], const u32x4 (&bb)[2][3], int t0) {
+    auto mfma_pair = [&](const u32x4 (&a)[NC][MT], const u32x4 (&bb)[2][NC], int t0) {
       // component index 0 = hi, 1 = mid, 2 = lo; smallest partial products first; the two position rows (and the row tiles) alternate,
       // so consecutive MFMAs never accumulate into the same registers
       constexpr int oa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
       constexpr int ob[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int i = X9_FIRST; i < 9; ++i)
+      for (int i = (NC == 3 ? X9_FIRST : 8); i < 9; ++i)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int r = 0; r < 2; ++r)
-            acc[m][t0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[oa[i]][m]), __builtin_bit_cast(bf16x8, bb[r][ob[i]]),
-                                                                      acc[m][t0 + r], 0, 0, 0);
+            acc[m][t0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[NC == 3 ? oa[i] : 0][m]),
+                                                                      __builtin_bit_cast(bf16x8, bb[r][NC == 3 ? ob[i] : 0]), acc[m][t0 + r], 0, 0, 0);
     };
     // one tap group; HALF = 0 / 1: the first / second half of the next chunk's split slices is computed in the MFMAs' shadow
     auto group = [&](int g, auto half_c) {
@@ -686,17 +691,17 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
         }
         mfma_pair(aC, bP[s & 1], 2 * s);
         if constexpr (HALF >= 0) {
-          constexpr int NM = 2 * X9_NP * MT;
+          constexpr int NM = 2 * NPROD * MT;
 #pragma unroll
           for (int i = 0; i < NM; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, (NSL / 2 / NPS * CC / 2 * 11 + NM - 1) / NM + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (NSL / 2 / NPS * CC / 2 * (NC == 3 ? 11 : 1) + NM - 1) / NM + 1, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int m = 0; m < MT; ++m) aC[c][m] = aN[c][m];
       oC0 = oN0; oC1 = oN1;
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) bP[0][r][c] = bP[1][r][c];
+          for (int c = 0; c < NC; ++c) bP[0][r][c] = bP[1][r][c];
       }
     };
     load_a(0, aC);
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 // w(out = k0 + 32 m + l31, reduce, tap), zero beyond T / C / K, with
 //   CC = 4: reduce = 4 chunk + (i & 3), tap = 4 g + 2 hh + (i >> 2);      CC = 8: reduce = 8 chunk + i, tap = 2 g + hh
 __global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int TG, int MT, int CC,
-                                      int nchunks, int mode, int k0, int K, int C) {
+                                      int NC, int nchunks, int mode, int k0, int K, int C) {
   const long long total = (long long)nchunks * TG * MT * 512;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(e & 7), ln = (int)((e >> 3) & 63);
@@ -749,10 +754,14 @@ __global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned shor
     const unsigned u1 = __builtin_bit_cast(unsigned, r1);
     const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
     const unsigned u2 = __builtin_bit_cast(unsigned, r2);
-    const long long base = (((long long)(chunk * TG + g) * 3) * MT + m) * 512 + ln * 8 + i;
-    wpk[base] = (unsigned short)(a >> 16);
-    wpk[base + 512LL * MT] = (unsigned short)(u1 >> 16);
-    wpk[base + 1024LL * MT] = (unsigned short)(u2 >> 16);
+    const long long base = (((long long)(chunk * TG + g) * NC) * MT + m) * 512 + ln * 8 + i;
+    if (NC == 1) {                                                 // operand precision "bf16": round to nearest even
+      wpk[base] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
+    } else {
+      wpk[base] = (unsigned short)(a >> 16);
+      wpk[base + 512LL * MT] = (unsigned short)(u1 >> 16);
+      wpk[base + 1024LL * MT] = (unsigned short)(u2 >> 16);
+    }
   }
 }
 
@@ -1082,31 +1091,31 @@ int launch_g2(const float* x, const float* wpk, const float* bias, float* out, c
 }
 
 
-template <int MT, int NT, int CC, bool SH>
+template <int MT, int NT, int CC, bool SH, int NC>
 int launch_x9(const float* x, const unsigned short* wpk, const float* bias, float* out, const G2P& p, size_t lds, long long blocks, hipStream_t st) {
   static bool done = false;   // per instantiation
   if (!done) {
-    if (hipFuncSetAttribute((const void*)igemm3_x9_kernel<MT, NT, CC, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DPF_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)igemm3_x9_kernel<MT, NT, CC, SH, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DPF_ERR_LAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((igemm3_x9_kernel<MT, NT, CC, SH>), dim3((unsigned)blocks), dim3(256), lds, st, x, wpk, bias, out, p);
+  hipLaunchKernelGGL((igemm3_x9_kernel<MT, NT, CC, SH, NC>), dim3((unsigned)blocks), dim3(256), lds, st, x, wpk, bias, out, p);
   return dpf_check_launch();
 }
 
 // One launch of igemm3_x9_kernel for the output channels [k_off, k_off + kn) of the launch `d` (kn <= 64); `p` carries the
 // tile-independent geometry (strides, e0*, RS, colshift).  DPF_ERR_UNSUPPORTED: not eligible, nothing was launched.
 int x9_try(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, const G2P& p, int k_off, int kn, int NT,
-           DpfConvStats* stats, hipStream_t st) {
+           DpfConvStats* stats, hipStream_t st, int NC) {
   static const int x9_on = env_int("DPF_IGEMM3", 1), x9_min_c = env_int("DPF_IGEMM3_MINC", 8), x9_cc = env_int("DPF_IGEMM3_CC", 0),
                    x9_sh = env_int("DPF_IGEMM3_SH", -1);
   const int T = d.kd * d.kh * d.kw, MT = (kn + 31) / 32, TH = 4 * NT;
-  if (!x9_on || !dpf_conv_f32_x9() || MT > 2 || NT * MT > 4 || d.C < x9_min_c) return DPF_ERR_UNSUPPORTED;
+  if (!x9_on || (NC == 3 && !dpf_conv_f32_x9()) || MT > 2 || NT * MT > 4 || d.C < x9_min_c) return DPF_ERR_UNSUPPORTED;
   G2P q = p;
   q.K = kn; q.k0 = d.k0 + k_off;
   // chunk layout with the fewest tap slots (4 channels x tap quadruples or 8 channels x tap pairs); ties: the smaller patch
   int CC9 = ((T + 1) / 2) * 2 < ((T + 3) / 4) * 4 ? 8 : 4;
   if (x9_cc == 4 || x9_cc == 8) CC9 = x9_cc;
-  const int NU9 = CC9 == 4 ? 2 : 1, PB9 = 6 * CC9;
+  const int NU9 = CC9 == 4 ? 2 : 1, PB9 = 2 * NC * CC9;
   // depth split: among the splits whose patch fits the per-thread unit budget, the one with the fewest staged rows
   auto set_pz = [&](int pz) {
     q.pz = pz; q.thp = TH / pz; q.thp_shift = 0;
@@ -1124,13 +1133,13 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
     for (int pz : {1, 2, 4}) {
       if (!(pz == 1 || (d.kd > 1 && pz <= TH / 2 && pz <= d.OD))) continue;
       const int units = set_pz(pz);
-      const size_t l9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(shc ? 2 : 1) * TG * 3 * MT * 1024 + 128;
+      const size_t l9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(shc ? 2 : 1) * TG * NC * MT * 1024 + 128;
       if (units <= NU9 * 256 && 2 * l9 <= 160 * 1024 && units < best_units) { best = pz; best_units = units; sh = shc; }
     }
   }
   if (!best || TG < 2) return DPF_ERR_UNSUPPORTED;
   set_pz(best);
-  const size_t lds9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(sh ? 2 : 1) * TG * 3 * MT * 1024 + 128;
+  const size_t lds9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(sh ? 2 : 1) * TG * NC * MT * 1024 + 128;
   if ((long long)NU9 * 256 * (q.SR > q.ext_h ? q.SR : q.ext_h) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
   const int sgn = d.transposed ? -1 : 1;
   const int t0 = d.transposed ? ((d.kd - 1) * d.dd * q.ext_h + (d.kh - 1) * d.dh) * q.RS + (d.kw - 1) * d.dw : 0;
@@ -1153,11 +1162,17 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   }
   unsigned short* wp = reinterpret_cast<unsigned short*>(ws);
   const long long total = (long long)q.nchunks * TG * MT * 512;
-  hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, q.nchunks, d.mode, q.k0, kn, d.C);
+  hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks, d.mode, q.k0, kn, d.C);
   if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
   if (stats) stats->parts = (int)nt9;
   const long long blocks9 = 8LL * q.cpx;
-#define X9L(M, N_, C_) return sh ? launch_x9<M, N_, C_, true>(x, wp, bias, out, q, lds9, blocks9, st) : launch_x9<M, N_, C_, false>(x, wp, bias, out, q, lds9, blocks9, st)
+#define X9L(M, N_, C_)                                                                                                   \
+  do {                                                                                                                 \
+    if (NC == 3) return sh ? launch_x9<M, N_, C_, true, 3>(x, wp, bias, out, q, lds9, blocks9, st)                      \
+                           : launch_x9<M, N_, C_, false, 3>(x, wp, bias, out, q, lds9, blocks9, st);                     \
+    return sh ? launch_x9<M, N_, C_, true, 1>(x, wp, bias, out, q, lds9, blocks9, st)                                   \
+              : launch_x9<M, N_, C_, false, 1>(x, wp, bias, out, q, lds9, blocks9, st);                                  \
+  } while (0)
   if (CC9 == 4) {
     if (MT == 1) { if (NT == 4) X9L(1, 4, 4); X9L(1, 2, 4); }
     X9L(2, 2, 4);
@@ -1264,6 +1279,8 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   // operand precision "bf16" (dpf_set_conv_operand_precision): 8-channel chunks; 16 position rows per workgroup when two buffers
   // of that patch fit the LDS, else 8
   bool bf = dpf_conv_operand_bf16() != 0 && T > 1;
+  const bool bf_mode = bf;                                        // (bf is cleared below when the igemm2 bf16 kernel cannot take the shape)
+  static const int bf3_on = env_int("DPF_IGEMM3_BF", 1);
   int p_single = 0;
   if (bf) {
     auto patch_for = [&](int nt) {      // bytes of an 8-channel fp32 patch
@@ -1358,15 +1375,18 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
     }
     p.tap0 = d.transposed ? ((d.kd - 1) * d.dd * p.ext_h + (d.kh - 1) * d.dh) * p.RS + (d.kw - 1) * d.dw : 0;
   }
-  // ---- exact-f32 products on the bf16 pipe (igemm3_x9_kernel): stride-1 launches, output channels in slices of at most 64
-  if (!bf && T > 4 && p.sxd == 1 && p.sxh == 1 && p.sxw == 1) {
+  // ---- igemm3_x9_kernel: stride-1 launches, output channels in slices of at most 64 -- fp32 products from exact bf16 splits, or (operand
+  //      precision "bf16") the operands rounded to bf16
+  // (bf16 operands, 2-D kernels with more than 64 output channels: igemm2's bf16 kernel stages the patch once for all of them and is faster)
+  if (T > 4 && p.sxd == 1 && p.sxh == 1 && p.sxw == 1 && (!bf_mode || (bf3_on && !(d.K > 64 && d.kd == 1)))) {
+    const int nc = bf_mode ? 1 : 3;
     if (d.K <= 64) {
-      const int rc = x9_try(x, w, bias, out, ws, d, p, 0, d.K, MT == 1 ? NT : 2, stats, st);
+      const int rc = x9_try(x, w, bias, out, ws, d, p, 0, d.K, MT == 1 ? 4 : 2, stats, st, nc);
       if (rc != DPF_ERR_UNSUPPORTED) return rc;
     } else {
       for (int k_off = 0; k_off < d.K; k_off += 64) {
-        const int rc = x9_try(x, w, bias, out, ws, d, p, k_off, d.K - k_off < 64 ? d.K - k_off : 64, 2, stats, st);
-        if (rc == DPF_ERR_UNSUPPORTED && k_off == 0) break;      // nothing launched yet: the exact-f32 kernel below takes the launch
+        const int rc = x9_try(x, w, bias, out, ws, d, p, k_off, d.K - k_off < 64 ? d.K - k_off : 64, 2, stats, st, nc);
+        if (rc == DPF_ERR_UNSUPPORTED && k_off == 0) break;      // nothing launched yet: the kernels below take the launch
         if (rc != DPF_OK) return rc == DPF_ERR_UNSUPPORTED ? DPF_ERR_LAUNCH : rc;
         if (k_off + 64 >= d.K) return DPF_OK;
       }
