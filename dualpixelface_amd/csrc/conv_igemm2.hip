@@ -45,6 +45,7 @@ struct G2P {
   unsigned mSR, mRPC, mEH;      // ceil(2^20 / d) for d = SR, rpc, ext_h
   unsigned long long steps;     // 2-bit step code per tap (see the kernel's tap walk)
   int accum;                    // 1: out += result
+  int vec;                      // 1: OW % 4 == 0 and a 16-byte aligned output: 16-byte stores (the epilogue transposes 4 x 4 blocks across lanes)
   int single;                   // 1: one LDS buffer (more resident workgroups hide the DMA instead of a second buffer)
   double* stats;                // optional [ntiles][statsK][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
   int statsK, statsk0;          // row length of the slab and first channel of this launch in it (K, 0 unless the launch is one slice of the channels)
@@ -85,7 +86,44 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[MT][NT], const G2P& p,
     rok[t] = oz < p.OD && oy < p.OH;
     orow[t] = ((long long)oz * p.OH + oy) * p.OW;
   }
-  if (ow < p.OW && !p.accum) {
+  if (p.vec) {
+    // 16-byte stores.  A lane holds ONE column and 16 rows of a 32 x 32 tile, so plain stores are 4 bytes per lane and 64 instructions
+    // per thread -- the store tail then takes as long as the MFMA loop of a 32-channel 2-D layer (in-kernel stamps: 30 k of 72 k clocks).
+    // Each 4 x 4 block (rows 8 i + 4 hh + 0..3, columns 4 c .. 4 c + 3: registers 4 i .. 4 i + 3 of the four lanes 4 c .. 4 c + 3) is
+    // transposed across its quad with two DPP exchange stages; lane 4 c + q then owns row q of the block, four consecutive columns.
+    const int q = l31 & 3, owv = q0w + (l31 & ~3);
+    const bool o1 = (q & 1) != 0, o2 = (q & 2) != 0;
+    float* opv = out + ((long long)n * p.Ktot + p.k0) * kstride + owv;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = m * 32 + 8 * i + 4 * hh + q;
+        const float bv = (bias && k < p.K) ? bias[p.k0 + k] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float r0 = acc[m][t][4 * i], r1 = acc[m][t][4 * i + 1], r2 = acc[m][t][4 * i + 2], r3 = acc[m][t][4 * i + 3];
+          {  // lanes q ^ 1: quad_perm [1, 0, 3, 2]
+            const float x = o1 ? r0 : r1, y = o1 ? r2 : r3;
+            const float xs = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+            const float ys = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y), 0xB1, 0xf, 0xf, true));
+            if (o1) { r0 = xs; r2 = ys; } else { r1 = xs; r3 = ys; }
+          }
+          {  // lanes q ^ 2: quad_perm [2, 3, 0, 1]
+            const float x = o2 ? r0 : r2, y = o2 ? r1 : r3;
+            const float xs = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+            const float ys = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y), 0x4E, 0xf, 0xf, true));
+            if (o2) { r0 = xs; r1 = ys; } else { r2 = xs; r3 = ys; }
+          }
+          if (rok[t] && k < p.K && owv < p.OW) {
+            f32x4* o = reinterpret_cast<f32x4*>(opv + (long long)k * kstride + orow[t]);
+            f32x4 v = {r0 + bv, r1 + bv, r2 + bv, r3 + bv};
+            if (p.accum) v += *o;
+            *o = v;
+          }
+        }
+      }
+  } else if (ow < p.OW && !p.accum) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -470,6 +508,15 @@ template <int CC, int NC> struct X9 {
   static constexpr int PD = PB / 4;              // dwords per position
 };
 
+// In-kernel s_memtime stamps (-DDPF_STAMPS builds only; tools/debug/x9_stamps.py reads them back): per workgroup [start, first barrier,
+// after the chunk loop, end, s_memrealtime at start, at end, XCC / CU id, chunks]
+#ifdef DPF_STAMPS
+__device__ unsigned long long g_x9_stamps[8 * 16384];
+#define X9_STAMP(slot, val) if (tid == 0 && blockIdx.x < 16384) g_x9_stamps[blockIdx.x * 8 + (slot)] = (val);
+#else
+#define X9_STAMP(slot, val)
+#endif
+
 template <int MT, int NT, int CC, bool SH, int NC = 3>
 __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ out, G2P p) {
@@ -488,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 
   int b = (blockIdx.x & 7) * p.cpx + (blockIdx.x >> 3);           // XCD-aware tile order, as igemm2_kernel
   if (b >= p.ntiles) return;
+  X9_STAMP(0, __builtin_readcyclecounter()) X9_STAMP(4, __builtin_amdgcn_s_memrealtime())
   const int tile_id = b;
   const int qd = (b % p.odt) * p.pz; b /= p.odt;
   const int tw = b % p.tilesW; b /= p.tilesW;
@@ -601,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     }
     store_split();
     __syncthreads();                                               // vmcnt(0): this chunk's weights landed; barrier: patch written
+    if (chunk == 0) { X9_STAMP(1, __builtin_readcyclecounter()) }
     const char* s_wc = s_w + (SH ? (chunk & 1) * wBytes : 0);
     if (chunk + 1 < p.nchunks) {
       if constexpr (SH) issue_w(chunk + 1, (chunk + 1) & 1);
@@ -726,7 +775,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                               // the patch buffer is free
   }
+  X9_STAMP(2, __builtin_readcyclecounter())
   g2_epilogue<MT, NT>(acc, p, bias, out, smem, tile_id, n, qd, q0h, q0w, wave, l31, hh, tid);
+  X9_STAMP(3, __builtin_readcyclecounter()) X9_STAMP(5, __builtin_amdgcn_s_memrealtime()) X9_STAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, all 32 bits */)) X9_STAMP(7, (unsigned long long)p.nchunks)
 }
 
 // x9 weights: shorts [chunk][tap group g][component][row tile m][lane][8]; value i of lane (l31, hh) = component of
@@ -1324,6 +1375,8 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.OD = d.OD; p.OH = d.OH; p.OW = d.OW;
   p.T = T;
   p.accum = d.accumulate;
+  static const int vec_on = env_int("DPF_G2_VEC_STORE", 1);
+  p.vec = vec_on && (d.OW & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   int ext_w;
   if (!d.transposed) {
     p.sxd = d.sd; p.sxh = d.sh; p.sxw = d.sw;
@@ -1381,7 +1434,8 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   if (T > 4 && p.sxd == 1 && p.sxh == 1 && p.sxw == 1 && (!bf_mode || (bf3_on && !(d.K > 64 && d.kd == 1)))) {
     const int nc = bf_mode ? 1 : 3;
     if (d.K <= 64) {
-      const int rc = x9_try(x, w, bias, out, ws, d, p, 0, d.K, MT == 1 ? 4 : 2, stats, st, nc);
+      static const int nt3 = env_int("DPF_IGEMM3_NT", 0);       // 2: 8-row tiles for <= 32 output channels too (three resident workgroups)
+      const int rc = x9_try(x, w, bias, out, ws, d, p, 0, d.K, MT == 1 ? ((nt3 == 2 || (nt3 == 12 && d.kd == 1)) ? 2 : 4) : 2, stats, st, nc);
       if (rc != DPF_ERR_UNSUPPORTED) return rc;
     } else {
       for (int k_off = 0; k_off < d.K; k_off += 64) {
@@ -1468,3 +1522,9 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
 #undef G2CC
 #undef G2
 }
+
+#ifdef DPF_STAMPS
+extern "C" int dpf_debug_x9_stamps(unsigned long long* host_out, int nblocks) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x9_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
+}
+#endif
