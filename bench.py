@@ -328,6 +328,14 @@ def main():
                     'avg_launch_ms': secs / n * 1e3, 'ms_per_step': secs / prof_steps * 1e3,
                     'measured_in': ('%d steps after the timed region on ONE stream (weight gradients in line, feature passes one after the other: kernels do not overlap, event time = kernel time)' % prof_steps)
                                    if not args.no_detail else 'the timed region', 'families': fam_out}
+            if args.precision != 'bf16':
+                # most fp32 launches (stride-1 convs, weight gradients) form each fp32 product from 8 exact bf16 partial products on the bf16
+                # matrix pipe: `peak` stays the dense fp32 MFMA peak the metric's FLOPs are priced against; the issue ceiling of that
+                # construction is the bf16 peak / 8 (x 27/28 tap padding) at 2.4 GHz -- the chip holds 1.6-1.9 GHz under such a stream
+                x8 = PEAK_BF16_TFLOPS / 8.0 * 27.0 / 28.0
+                roof['peak_note'] = ('fp32 FLOPs against the dense fp32 MFMA peak; where the kernels multiply on the bf16 pipe (8 exact partial '
+                                     'products per fp32 product) the issue ceiling is %.1f TFLOP/s of fp32 FLOPs at 2.4 GHz' % x8)
+                roof['frac_of_bf16_pipe_issue_ceiling'] = ach / x8
             if dom in fam_t and timed_async and not args.no_detail:      # the same family as the timed region saw it (overlapped by the side stream)
                 f2 = fam_t[dom]
                 roof['timed_region_overlapped'] = {'achieved': f2[0] / f2[1] / 1e12, 'frac': f2[0] / f2[1] / 1e12 / peak, 'avg_launch_ms': f2[1] / f2[2] * 1e3,

@@ -26,6 +26,9 @@ SETS = [
     ({'DPF_IGEMM3_SH': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics or test_conv_f32_matrix_paths_agree'),
     ({'DPF_IGEMM3_CC': '4'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree'),
     ({'DPF_IGEMM3_CC': '8'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree'),
+    # 4-byte stores in the conv tile epilogue (what outputs with W % 4 != 0 or an unaligned base get), bf16 operands on igemm2's own kernel
+    ({'DPF_G2_VEC_STORE': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics'),
+    ({'DPF_IGEMM3_BF': '0'}, 'test_conv_operands_bf16 or test_conv2d_bf16_operands'),
     # first-generation dense conv kernels (what unaligned shapes fall back to)
     ({'DPF_IGEMM2': '0', 'DPF_WGRAD2': '0', 'DPF_IGEMM2_TR2': '0'}, 'test_conv_forward_backward'),
 ]

@@ -41,6 +41,18 @@ if [ -z "$QUICK" ]; then
   bash tools/gpu_prof.sh ${R}bf16 --precision bf16 > "$O/${R}_bench_c5_bf16_family_ms.txt" 2>&1
   cp "gpurun_out/prof_${R}bf16_kernel_stats.csv" "$O/${R}_bench_c5_bf16_kernel_stats.csv"
   bash tools/gpu_kstats.sh ${R}dcn tools/dcn_bench.py all > "$O/${R}_dcn_bench_kernel_stats.txt" 2>&1
+  # per-shape conv times: x9 kernels (default) against the exact-f32 matrix instruction, 16-byte against 4-byte tile stores
+  SH9="hg32 hg64 hg64q cv64_32 fe32 fe32q fe32d5 fe96_32 fe64 fe192_64 anm96d2 anm64d8 off81 off81a hg_s2"
+  { echo "== default (x9 convolutions + weight gradient, 16-byte tile stores)"; python tools/conv_shape_bench.py --check $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
+    echo "== DPF_F32_X9=0 (v_mfma_f32_32x32x2_f32 everywhere)"; DPF_F32_X9=0 python tools/conv_shape_bench.py $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
+    echo "== DPF_G2_VEC_STORE=0 (4-byte tile stores)"; DPF_G2_VEC_STORE=0 python tools/conv_shape_bench.py $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
+    echo "== DPF_W2_DBG=1 (weight gradient without the DMA of tiles 2...: timing only, results wrong)"; DPF_W2_DBG=1 python tools/conv_shape_bench.py hg32 hg64 cv64_32 fe32 2>&1 | grep -v -e MIOpen -e amdgpu.ids
+  } > "$O/${R}_conv_x9_vs_f32_per_shape.txt"
+  { echo "== operand precision bf16: igemm3 NC=1 (default)"; python tools/conv_bf16_bench.py 2>&1 | grep -v -e MIOpen -e amdgpu.ids
+    echo "== DPF_IGEMM3_BF=0 (igemm2 bf16 kernel)"; DPF_IGEMM3_BF=0 python tools/conv_bf16_bench.py 2>&1 | grep -v -e MIOpen -e amdgpu.ids; } > "$O/${R}_conv_bf16_per_shape.txt"
+  make -C dualpixelface_amd/csrc -j8 OBJDIR=build_stamps LIB=../libdpf_hip_stamps.so EXTRA=-DDPF_STAMPS > /dev/null 2>&1
+  { echo "== 16-byte tile stores"; DPF_LIB_PATH=$PWD/dualpixelface_amd/libdpf_hip_stamps.so python tools/debug/x9_stamps.py fe32 hg32 fe32q hg64 fe96_32 2>&1 | grep -v amdgpu.ids
+    echo "== DPF_G2_VEC_STORE=0"; DPF_G2_VEC_STORE=0 DPF_LIB_PATH=$PWD/dualpixelface_amd/libdpf_hip_stamps.so python tools/debug/x9_stamps.py fe32 hg32 fe32q hg64 fe96_32 2>&1 | grep -v amdgpu.ids; } > "$O/${R}_x9_stamps.txt"
 fi
 cat "$O/${R}_bench.json"; cat "$O/${R}_bench_family_ms.txt"; python3 - "$O/${R}_pmc_traffic.json" <<'PY'
 import json, sys
