@@ -830,6 +830,7 @@ struct T2P {
   int RS, SR, rpc, chanStride, nseg, nwseg, nchunks;
   int tilesH, tilesW, ntiles, cpx, QD;
   unsigned mSR, mRPC, mEH;
+  int vec;                      // 16-byte stores allowed (DPF_G2_VEC_STORE)
 };
 
 struct T2Combo { int cls, tap; };
@@ -1048,6 +1049,7 @@ __global__ __launch_bounds__(256, 2) void igemm2_tr2_kernel(const float* __restr
   const long long kstride = (long long)p.OD * out_plane;
   float* on = out + ((long long)n * p.Ktot + p.k0) * kstride;
   const bool pair_ok = ((p.OW & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+  const bool quad_ok = ((p.OW & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && p.vec;
 #pragma unroll
   for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
@@ -1055,6 +1057,26 @@ __global__ __launch_bounds__(256, 2) void igemm2_tr2_kernel(const float* __restr
       const int od = 2 * qd + rd, oh = 2 * qh + rh, ow = 2 * qw;
       if (od >= p.OD || oh >= p.OH || ow >= p.OW) continue;
       float* op = on + ((long long)od * p.OH + oh) * p.OW + ow;
+      if (quad_ok) {
+        // 16-byte stores: lanes 2c and 2c + 1 hold ow = 4c .. 4c + 3 of rows j and j + 1; one DPP exchange hands the even lane row j's
+        // four values and the odd lane row j + 1's (the store tail of narrow stores: g2_epilogue)
+        const bool odd = (l31 & 1) != 0;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          const float a0 = acc[rd * 4 + rh * 2][j], a1 = acc[rd * 4 + rh * 2 + 1][j];
+          const float b0 = acc[rd * 4 + rh * 2][j + 1], b1 = acc[rd * 4 + rh * 2 + 1][j + 1];
+          const float s0 = odd ? a0 : b0, s1 = odd ? a1 : b1;                 // what the partner needs
+          const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xf, 0xf, true));
+          const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xf, 0xf, true));
+          const int k = ((j + (odd ? 1 : 0)) & 3) + 8 * (j >> 2) + 4 * hh;
+          if (k < p.K) {
+            const float bv = bias ? bias[p.k0 + k] : 0.f;
+            const f32x4 v = odd ? f32x4{t0 + bv, t1 + bv, b0 + bv, b1 + bv} : f32x4{a0 + bv, a1 + bv, t0 + bv, t1 + bv};
+            *reinterpret_cast<f32x4*>(on + ((long long)od * p.OH + oh) * p.OW + (ow & ~3) + (long long)k * kstride) = v;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int k = (j & 3) + 8 * (j >> 2) + 4 * hh;
@@ -1275,6 +1297,7 @@ int igemm2_tr2(const float* x, const float* w, const float* bias, float* out, fl
   p.ntiles = (int)ntiles;
   p.cpx = (int)((ntiles + 7) / 8);
   p.mSR = magic20(p.SR); p.mRPC = magic20(p.rpc); p.mEH = magic20(5);
+  p.vec = env_int("DPF_G2_VEC_STORE", 1);
   const size_t lds = 2 * (size_t)(CC * p.chanStride + 4 * p.nwseg) * sizeof(float);
   for (int k0 = 0; k0 < d.K; k0 += 32) {
     const int Kc = d.K - k0 < 32 ? d.K - k0 : 32;

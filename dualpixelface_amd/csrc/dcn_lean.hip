@@ -398,16 +398,37 @@ __global__ __launch_bounds__(256, 2) void dcn_lean_fwd1_kernel(const float* __re
     const int vo = wave_u * 64 + nt * 32 + lane_pos32(l31);      // column n of tile nt is the voxel the sampler lane (l31, nt) owns
     const int qx = vo % G::TX, qy = (vo / G::TX) % G::TY, qz = vo / (G::TX * G::TY);
     const int gz = qz, gy = y0 + qy, gx = x0 + qx;
-    if (gz < p.D && gy < p.H && gx < p.W) {
-      const long long pos = ((long long)gz * p.H + gy) * p.W + gx;
+    // 16-byte stores: the four lanes of a quad own four x-consecutive voxels (lane_pos32), so each 4 x 4 block (rows 8 i + 4 hh + 0..3 of
+    // the quad's columns) is transposed across the quad with two DPP exchange stages and lane q stores row q's four voxels at once
+    // (W % 4 == 0 and x0 % 16 == 0 for every lean geometry; the store tail of 4-byte stores: conv_igemm2.hip, g2_epilogue)
+    const int q = l31 & 3;
+    const bool o1 = (q & 1) != 0, o2 = (q & 2) != 0;
+    const bool inb = gz < p.D && gy < p.H && gx < p.W;             // uniform over a quad (gx - q is a multiple of 4, W % 4 == 0)
+    const long long pos = ((long long)gz * p.H + gy) * p.W + (gx - q);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int k = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-          if (k < p.K) out[((long long)b * p.K + k) * p.P + pos] = acc[m][nt][j] + (bias ? bias[k] : 0.f);
+      for (int i = 0; i < 4; ++i) {
+        float r0 = acc[m][nt][4 * i], r1 = acc[m][nt][4 * i + 1], r2 = acc[m][nt][4 * i + 2], r3 = acc[m][nt][4 * i + 3];
+        {
+          const float xa = o1 ? r0 : r1, ya = o1 ? r2 : r3;
+          const float xs = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0xB1, 0xf, 0xf, true));
+          const float ys = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ya), 0xB1, 0xf, 0xf, true));
+          if (o1) { r0 = xs; r2 = ys; } else { r1 = xs; r3 = ys; }
         }
-    }
+        {
+          const float xa = o2 ? r0 : r2, ya = o2 ? r1 : r3;
+          const float xs = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0x4E, 0xf, 0xf, true));
+          const float ys = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ya), 0x4E, 0xf, 0xf, true));
+          if (o2) { r0 = xs; r1 = ys; } else { r2 = xs; r3 = ys; }
+        }
+        const int k = m * 32 + 8 * i + 4 * hh + q;
+        if (inb && k < p.K) {
+          const float bv = bias ? bias[k] : 0.f;
+          const f32x4 v = {r0 + bv, r1 + bv, r2 + bv, r3 + bv};
+          *reinterpret_cast<f32x4*>(out + ((long long)b * p.K + k) * p.P + pos) = v;
+        }
+      }
   }
 }
 
@@ -763,7 +784,8 @@ long long dcn_lean_workspace_floats(int C, int K) {
 int dcn_lean_forward(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, int B, int C, int D, int H,
                      int W, int K, hipStream_t st) {
   static const int lean_env = getenv("DPF_DCN_LEAN") ? atoi(getenv("DPF_DCN_LEAN")) : 1;
-  if (!lean_env || D > 4 || D < 1 || (W & 3) || K > 64 || (reinterpret_cast<uintptr_t>(x) & 15)) return DPF_ERR_UNSUPPORTED;
+  if (!lean_env || D > 4 || D < 1 || (W & 3) || K > 64 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    return DPF_ERR_UNSUPPORTED;
   if ((long long)D * H * W >= 0x7fffffffLL / 4) return DPF_ERR_UNSUPPORTED;
   const int CH = dcn_lean_chunk(C);
   LeanP p{};
