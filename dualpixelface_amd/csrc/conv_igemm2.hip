@@ -44,6 +44,7 @@ struct G2P {
   int nchunks;
   unsigned mSR, mRPC, mEH;      // ceil(2^20 / d) for d = SR, rpc, ext_h
   unsigned long long steps;     // 2-bit step code per tap (see the kernel's tap walk)
+  int rstep;                    // rows of a tile are rstep apart (1; the x9 kernel's 2-D dilated layers: the rows of ONE dilation phase)
   int accum;                    // 1: out += result
   int vec;                      // 1: OW % 4 == 0 and a 16-byte aligned output: 16-byte stores (the epilogue transposes 4 x 4 blocks across lanes)
   int single;                   // 1: one LDS buffer (more resident workgroups hide the DMA instead of a second buffer)
@@ -82,7 +83,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[MT][NT], const G2P& p,
   bool rok[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int r = wave * NT + t, oz = qd + (r >> p.thp_shift), oy = q0h + (r & (p.thp - 1));
+    const int r = wave * NT + t, oz = qd + (r >> p.thp_shift), oy = q0h + (r & (p.thp - 1)) * p.rstep;
     rok[t] = oz < p.OD && oy < p.OH;
     orow[t] = ((long long)oz * p.OH + oy) * p.OW;
   }
@@ -541,7 +542,8 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   const int tw = b % p.tilesW; b /= p.tilesW;
   const int th = b % p.tilesH;
   const int n = b / p.tilesH;
-  const int q0h = th * p.thp, q0w = tw * 32;
+  // row-dilated tiles: tile row th = (block of thp * rstep rows, phase th % rstep); its rows are rstep apart
+  const int q0h = (th / p.rstep) * (p.thp * p.rstep) + th % p.rstep, q0w = tw * 32;
   const int i0d = qd + p.e0d, i0h = q0h + p.e0h;
   const int a0 = q0w + p.e0w - p.colshift;
 
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     const int seg = f - row * p.SR;
     const unsigned pl = (row * p.mEH) >> 20;
     const int rr = row - pl * p.ext_h;
-    const int id = i0d + (int)pl, ih = i0h + rr, iw = a0 + 4 * seg;
+    const int id = i0d + (int)pl, ih = i0h + rr * p.rstep, iw = a0 + 4 * seg;
     const bool ok = (int)f < nunits && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
     goff[j] = ok ? (int)(((long long)id * p.IH + ih) * p.IW + iw) : -1;
     loff[j] = (int)f < nunits ? PB * ((int)row * p.RS + 4 * seg) : -1;
@@ -1185,6 +1187,11 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   if (!x9_on || (NC == 3 && !dpf_conv_f32_x9()) || MT > 2 || NT * MT > 4 || d.C < x9_min_c) return DPF_ERR_UNSUPPORTED;
   G2P q = p;
   q.K = kn; q.k0 = d.k0 + k_off;
+  // 2-D layers dilated along H: a tile takes the rows of ONE dilation phase (dh apart), so its patch is thp + kh - 1 image rows fetched dh
+  // apart instead of thp + (kh - 1) * dh consecutive ones (dilation 8: 18 rows instead of 32 -- within the staging budget)
+  static const int rstep_on = env_int("DPF_IGEMM3_RSTEP", 1);
+  q.rstep = (rstep_on && d.kd == 1 && d.kh > 1 && d.dh > 1) ? d.dh : 1;
+  const int dhl = d.dh / q.rstep;
   // chunk layout with the fewest tap slots (4 channels x tap quadruples or 8 channels x tap pairs); ties: the smaller patch
   int CC9 = ((T + 1) / 2) * 2 < ((T + 3) / 4) * 4 ? 8 : 4;
   if (x9_cc == 4 || x9_cc == 8) CC9 = x9_cc;
@@ -1195,7 +1202,7 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
     while ((1 << q.thp_shift) < q.thp) ++q.thp_shift;
     q.odt = dpf_div_up(d.OD, pz);
     q.ext_d = (pz - 1) + (d.kd - 1) * d.dd + 1;
-    q.ext_h = (q.thp - 1) + (d.kh - 1) * d.dh + 1;
+    q.ext_h = (q.thp - 1) + (d.kh - 1) * dhl + 1;
     q.planeStride = q.ext_h * q.RS; q.SR = q.RS / 4; q.rpc = q.ext_d * q.ext_h;
     return q.rpc * q.SR;
   };
@@ -1215,13 +1222,13 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   const size_t lds9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(sh ? 2 : 1) * TG * NC * MT * 1024 + 128;
   if ((long long)NU9 * 256 * (q.SR > q.ext_h ? q.SR : q.ext_h) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
   const int sgn = d.transposed ? -1 : 1;
-  const int t0 = d.transposed ? ((d.kd - 1) * d.dd * q.ext_h + (d.kh - 1) * d.dh) * q.RS + (d.kw - 1) * d.dw : 0;
+  const int t0 = d.transposed ? ((d.kd - 1) * d.dd * q.ext_h + (d.kh - 1) * dhl) * q.RS + (d.kw - 1) * d.dw : 0;
   for (int u = 0; u < 28; ++u) {
     const int c = u % d.kw, b2 = (u / d.kw) % d.kh, a = u / (d.kw * d.kh);
-    q.tapoff[u] = u < T ? t0 + sgn * ((a * d.dd * q.ext_h + b2 * d.dh) * q.RS + c * d.dw) : 0;
+    q.tapoff[u] = u < T ? t0 + sgn * ((a * d.dd * q.ext_h + b2 * dhl) * q.RS + c * d.dw) : 0;
   }
   q.nchunks = (d.C + CC9 - 1) / CC9;
-  q.tilesH = dpf_div_up(d.OH, q.thp);
+  q.tilesH = dpf_div_up(d.OH, q.thp * q.rstep) * q.rstep;
   q.tilesW = dpf_div_up(d.OW, 32);
   q.mSR = magic20(q.SR); q.mEH = magic20(q.ext_h);
   const long long nt9 = (long long)d.N * q.odt * q.tilesH * q.tilesW;
@@ -1398,6 +1405,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   p.ID = d.ID; p.IH = d.IH; p.IW = d.IW; p.OD = d.OD; p.OH = d.OH; p.OW = d.OW;
   p.T = T;
   p.accum = d.accumulate;
+  p.rstep = 1;
   static const int vec_on = env_int("DPF_G2_VEC_STORE", 1);
   p.vec = vec_on && (d.OW & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   int ext_w;
