@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /root/repo
 export PYTHONPATH=/root/repo
-S="fe32d5 anm64d8 anm96d2"
-echo "== rstep"; timeout 600 python tools/conv_shape_bench.py --check $S 2>&1 | grep -v -e MIOpen -e amdgpu.ids | tail -4
-echo "== rstep off"; DPF_IGEMM3_RSTEP=0 timeout 600 python tools/conv_shape_bench.py $S 2>&1 | grep -v -e MIOpen -e amdgpu.ids | tail -4
-echo "== tests"; timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "conv and not deform" 2>&1 | tail -3
+S="hg32 fe32 fe32q fe96_32 hg64"
+echo "== default"; timeout 600 python tools/conv_shape_bench.py $S 2>&1 | grep -v -e MIOpen -e amdgpu.ids | tail -5
+echo "== nt stores"; DPF_G2_VEC_STORE=2 timeout 600 python tools/conv_shape_bench.py $S 2>&1 | grep -v -e MIOpen -e amdgpu.ids | tail -5
+for v in 1 2; do DPF_G2_VEC_STORE=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c60-140; done
