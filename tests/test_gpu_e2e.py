@@ -537,25 +537,26 @@ def test_train_256x256_vs_reference_fixture(golden_dir):
     assert len(rels) > 200 and float(np.median(rels)) <= 2e-2, (len(rels), float(np.median(rels)))
 
 
-# relative L2 distance of the HIP gradients from the imported reference's (fp32, CPU), worst of three runs of tools/parity_probe.py on
-# MI355X (round 4); the test allows 2.5 x these.  The reference's own fp32 gradients sit ~1e-2 from the fp64 oracle through this random-weight
-# network (test_gradients_no_worse_than_the_reference_vs_fp64), so the budgets are conditioning, not kernel error: the head agrees to 2e-6.
+# relative L2 distance of the HIP gradients from the imported reference's (fp32, CPU) on MI355X (round 4), per tensor the LARGEST over the
+# equally valid fp32 kernel paths (profiles/r04_grad_rel_by_kernel_path.txt); the test allows 2.5 x these.  The reference's own fp32
+# gradients sit ~1e-2 from the fp64 oracle through this random-weight network (test_gradients_no_worse_than_the_reference_vs_fp64), so the
+# budgets are conditioning, not kernel error: the head agrees to 2e-6.
 GRAD_REL_MEASURED = {
-    'train_32x48_b2': {'aggregation.classif3.2.weight': 2.4e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0051,
-                       'cost_volume.attention_layer.normalize.weight': 0.0047, 'normal_estimator.deform_conv1.conv_offset.bias': 0.03,
-                       'normal_estimator.n_convs.5.0.weight': 0.00022, 'feature_extraction.firstconv.0.0.weight': 0.005,
-                       'feature_extraction.block1.prelu.weight': 0.0016, 'feature_extraction.fpn.inner_blocks.0.bias': 0.0053,
-                       'aggregation.dres2.conv6.0.weight': 0.0021},
-    'train_64x96_b1': {'aggregation.classif3.2.weight': 1.8e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0073,
-                       'cost_volume.attention_layer.normalize.weight': 0.0077, 'normal_estimator.deform_conv1.conv_offset.bias': 0.021,
-                       'normal_estimator.n_convs.5.0.weight': 0.0017, 'feature_extraction.firstconv.0.0.weight': 0.0091,
-                       'feature_extraction.block1.prelu.weight': 0.04, 'feature_extraction.fpn.inner_blocks.0.bias': 0.011,
-                       'aggregation.dres2.conv6.0.weight': 0.0034},
-    'train_128x128_b2': {'aggregation.classif3.2.weight': 1.4e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0073,
-                         'cost_volume.attention_layer.normalize.weight': 0.008, 'normal_estimator.deform_conv1.conv_offset.bias': 0.028,
-                         'normal_estimator.n_convs.5.0.weight': 0.0048, 'feature_extraction.firstconv.0.0.weight': 0.011,
-                         'feature_extraction.block1.prelu.weight': 0.0087, 'feature_extraction.fpn.inner_blocks.0.bias': 0.012,
-                         'aggregation.dres2.conv6.0.weight': 0.0018},
+    'train_32x48_b2': {'aggregation.classif3.2.weight': 2.5e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0053,
+                       'cost_volume.attention_layer.normalize.weight': 0.0063, 'normal_estimator.deform_conv1.conv_offset.bias': 0.03,
+                       'normal_estimator.n_convs.5.0.weight': 0.00022, 'feature_extraction.firstconv.0.0.weight': 0.0061,
+                       'feature_extraction.block1.prelu.weight': 0.0068, 'feature_extraction.fpn.inner_blocks.0.bias': 0.0073,
+                       'aggregation.dres2.conv6.0.weight': 0.0022},
+    'train_64x96_b1': {'aggregation.classif3.2.weight': 2e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0073,
+                       'cost_volume.attention_layer.normalize.weight': 0.0077,
+                       'normal_estimator.deform_conv1.conv_offset.bias': 0.021, 'normal_estimator.n_convs.5.0.weight': 0.0023,
+                       'feature_extraction.firstconv.0.0.weight': 0.0093, 'feature_extraction.block1.prelu.weight': 0.04,
+                       'feature_extraction.fpn.inner_blocks.0.bias': 0.011, 'aggregation.dres2.conv6.0.weight': 0.0034},
+    'train_128x128_b2': {'aggregation.classif3.2.weight': 1.4e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0077,
+                         'cost_volume.attention_layer.normalize.weight': 0.0095,
+                         'normal_estimator.deform_conv1.conv_offset.bias': 0.027, 'normal_estimator.n_convs.5.0.weight': 0.0054,
+                         'feature_extraction.firstconv.0.0.weight': 0.011, 'feature_extraction.block1.prelu.weight': 0.015,
+                         'feature_extraction.fpn.inner_blocks.0.bias': 0.013, 'aggregation.dres2.conv6.0.weight': 0.0019},
 }
 
 
@@ -565,7 +566,10 @@ def test_gradients_and_adam_step_vs_reference_fixture(golden_dir, tag):
     full gradients of 10 parameters, {sum, sum|.|, sum .^2} of every gradient, and of every state_dict entry after
     optimizer.step()).  Measured (tools/parity_probe.py): the last layers agree to 1e-6; through ~100 fp32 conv + BatchNorm layers of
     this random-weight network the reference's own fp32 gradients sit ~1e-2 from the fp64 oracle, and so do ours -- hence per-tensor
-    budgets of 2.5 x the measured distance (GRAD_REL_MEASURED: 4e-3 ... 7e-2; the head 1e-5), 5e-3 on the median checksum."""
+    budgets of 2.5 x the measured distance (the head 1e-5), 5e-3 on the median checksum.  The distance is rounding noise: it moves by up
+    to 10 x between equally valid fp32 kernel paths (exact-f32 MFMA / bf16-split products, tile orders, one or two streams:
+    profiles/r04_grad_rel_by_kernel_path.txt, tools/debug/grad_rel_measure.py), so GRAD_REL_MEASURED holds, per tensor, the LARGEST
+    distance over those paths -- a budget tied to one path's rounding pattern fails on the next legitimate change of summation order."""
     g = np.load(golden_dir + '/e2e_%s.npz' % tag)
     model = build_model(True)
     res = model.train_step(load_batch(g))
