@@ -605,8 +605,13 @@ def test_gradients_and_adam_step_vs_reference_fixture(golden_dir, tag):
 
 
 def test_gradients_no_worse_than_the_reference_vs_fp64(golden_dir):
-    """For the 10 parameters whose full reference gradient is in the fixture: our distance to the fp64 oracle's gradient is within
-    2x the reference's own fp32 distance (+1e-3): the HIP kernels are as accurate as the fp32 reference path itself."""
+    """For the 10 parameters whose full reference gradient is in the fixture: our distance to the fp64 oracle's gradient against the
+    reference's own fp32 distance.  Both are rounding noise amplified by ~100 layers, and the ratio of two noise draws scatters: over the
+    equally valid fp32 kernel paths (exact-f32 MFMA everywhere, bf16-split products, tile orders, one / two streams) the geometric mean
+    of the 9 ratios is 0.7-1.8 and single tensors reach 3.3 -- on the exact-f32 path as well (profiles/r04_grad_fp64_by_kernel_path.txt,
+    tools/debug/grad_fp64_measure.py).  Bounds: geometric mean <= 2.5, every tensor <= 4 x the reference's distance + 1e-3 -- a kernel
+    that loses precision (bf16-rounded operands: 30-100 x) fails both by a wide margin."""
+    import math
     from oracle import recipe_state
     from oracle.stereodpnet import StereoDPNetOracle
     g = np.load(golden_dir + '/e2e_train_32x48_b2.npz')
@@ -616,6 +621,7 @@ def test_gradients_no_worse_than_the_reference_vs_fp64(golden_dir):
     model = build_model(True)
     model.train_step(load_batch(g))
     pd = dict(model.named_parameters())
+    logs = []
     for k in g.files:
         if not k.startswith('grad::'):
             continue
@@ -626,7 +632,9 @@ def test_gradients_no_worse_than_the_reference_vs_fp64(golden_dir):
         mine = pd[k[6:]].grad.detach().cpu().double()
         e_ref = ((ref32 - exact).norm() / exact.norm()).item()
         e_mine = ((mine - exact).norm() / exact.norm()).item()
-        assert e_mine <= 2.0 * e_ref + 1e-3, (k, e_mine, e_ref)
+        assert e_mine <= 4.0 * e_ref + 1e-3, (k, e_mine, e_ref)
+        logs.append(math.log(max(e_mine, 1e-12) / max(e_ref, 1e-12)))
+    assert len(logs) >= 8 and math.exp(sum(logs) / len(logs)) <= 2.5, math.exp(sum(logs) / len(logs))
 
 
 @pytest.mark.parametrize('bn_cat', ['0', '1'])
