@@ -15,6 +15,15 @@
 //   * descriptors (per-lane source offsets) are computed once per workgroup with multiply-shift divisions.
 // Eligibility (host): IW % 4 == 0, 16-byte aligned x, forward convs of any stride / dilation and stride-1 transposed
 // convs (data gradients); everything else stays on conv_igemm.hip.
+//
+// Kernels of this file (one host entry, dpf_igemm2_conv, picks):
+//   igemm3_x9_kernel   stride-1 launches (forward and transposed): fp32 products from exact bf16 splits on the bf16 matrix pipe, or
+//                      bf16-rounded operands (operand precision "bf16"); patch staged through registers, split once per element
+//   igemm2_kernel      every other eligible launch on v_mfma_f32_32x32x2_f32 (stride 2, patches beyond the x9 staging budget, C < 8),
+//                      and its bf16-operand variant
+//   igemm2_tr2_kernel  stride-2 transposed 3x3x3 (class-fused)
+// They share the tile geometry (G2P), the XCD-aware tile order and the tile epilogue (g2_epilogue: bias, accumulate, 16-byte stores,
+// fused BatchNorm statistics).
 #include "conv_internal.h"
 #include <cstdlib>
 #include <type_traits>
