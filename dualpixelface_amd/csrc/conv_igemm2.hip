@@ -470,11 +470,12 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
 // ---------------------------------------------------------------------------------------------------------------------
 // Exact-f32 products on the bf16 matrix pipe ("x9"), stride-1 convolutions (forward and transposed).
 //
-// Every fp32 operand is split EXACTLY into three bf16 values by truncation (x = hi + mid + lo: 8 + 8 + 8 significant bits); the nine
-// partial products of a (weight, input) pair are exact in fp32 and are accumulated in fp32, smallest first, by nine
-// v_mfma_f32_32x32x16_bf16 (9 x 8 passes per 16 reduction elements against 8 x 16 passes of v_mfma_f32_32x32x2_f32: 0.56 of the
-// matrix-pipe time).  The split has to be paid once per staged ELEMENT, not once per use (27 uses per element: that variant is
-// VALU-bound), so the staging path differs from igemm2_kernel:
+// Every fp32 operand is split EXACTLY into three bf16 values by truncation (x = hi + mid + lo: 8 + 8 + 8 significant bits); the
+// partial products of a (weight, input) pair are exact in fp32 and are accumulated in fp32, smallest first, by one
+// v_mfma_f32_32x32x16_bf16 each -- eight of the nine: lo x lo is below 2^-32 of the product and is dropped (X9_FIRST; 8 x 8 passes per 16
+// reduction elements against 8 x 16 passes of v_mfma_f32_32x32x2_f32: half the matrix-pipe time).  The split has to be paid once per
+// staged ELEMENT, not once per use (27 uses per element: that variant is VALU-bound), so the staging path differs
+// from igemm2_kernel:
 //   * a chunk is 4 input channels; the patch is fetched into REGISTERS (16-byte row segments of the 4 channels, prefetched one chunk
 //     ahead, across the MFMA loop), split there (11 VALU per value pair) and written to LDS as [position][hi|mid|lo][4 channels]
 //     bf16 -- 24 bytes per position, so ONE address serves the three components of a tap;
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
 //   * the split of chunk i+1 is computed in the shadow of the last two tap groups' MFMAs of chunk i and kept in registers; between the
 //     chunks only the 16-byte LDS stores remain (one patch buffer, two weight buffers, two resident workgroups per CU);
 //   * 2-D kernels (9 taps) use 8-channel chunks and tap PAIRS (48 bytes per position, one ds_read_b128 per component): 10 instead
-//     of 12 tap slots.
+//     of 12 tap slots; layers dilated along H take the rows of one dilation phase per tile (G2P::rstep);
+//   * NC = 1 (operand precision "bf16"): one component -- the operands rounded to bf16 (RNE) once per staged element.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
