@@ -491,23 +491,12 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// (x, y) -> packed bf16 pairs of the three components, x in the low half
-__device__ __forceinline__ void split_pair(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
-  const unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
-  h = __builtin_amdgcn_perm(b, a, 0x07060302u);
-  const float ra = x - __builtin_bit_cast(float, a & 0xffff0000u), rb = y - __builtin_bit_cast(float, b & 0xffff0000u);
-  const unsigned ua = __builtin_bit_cast(unsigned, ra), ub = __builtin_bit_cast(unsigned, rb);
-  m = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-  const float sa = ra - __builtin_bit_cast(float, ua & 0xffff0000u), sb = rb - __builtin_bit_cast(float, ub & 0xffff0000u);
-  l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
-}
+// (x, y) -> packed bf16 pairs of the three components, x in the low half (conv_internal.h: round-to-nearest split)
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& h, unsigned& m, unsigned& l) { dpf_split_pair(x, y, h, m, l); }
 
 // CC = 4: a group = 4 taps x 4 channels (3-D kernels: 27 taps -> 7 groups), two 256-unit rounds per chunk;
 // CC = 8: a group = 2 taps x 8 channels (2-D kernels:  9 taps -> 5 groups), one round.
-// first partial product of the nine (smallest first): 1 skips lo x lo, which is below 2^-32 of the product (-DDPF_X9_FIRST=0 keeps it)
-#ifndef DPF_X9_FIRST
-#define DPF_X9_FIRST 1
-#endif
+// first partial product of the nine (smallest first) that is issued: 3 (default, conv_internal.h) skips lo x lo, lo x mid, mid x lo
 constexpr int X9_FIRST = DPF_X9_FIRST;
 constexpr int X9_NP = 9 - X9_FIRST;
 
@@ -813,18 +802,15 @@ __global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned shor
       const int bb = mode == 0 ? c : k0 + k;
       v = w[((long long)a * wB + bb) * T + u];
     }
-    const unsigned a = __builtin_bit_cast(unsigned, v);
-    const float r1 = v - __builtin_bit_cast(float, a & 0xffff0000u);
-    const unsigned u1 = __builtin_bit_cast(unsigned, r1);
-    const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned u2 = __builtin_bit_cast(unsigned, r2);
+    unsigned sh, sm, sl;
+    dpf_split_pair(v, 0.f, sh, sm, sl);
     const long long base = (((long long)(chunk * TG + g) * NC) * MT + m) * 512 + ln * 8 + i;
     if (NC == 1) {                                                 // operand precision "bf16": round to nearest even
       wpk[base] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
     } else {
-      wpk[base] = (unsigned short)(a >> 16);
-      wpk[base + 512LL * MT] = (unsigned short)(u1 >> 16);
-      wpk[base + 1024LL * MT] = (unsigned short)(u2 >> 16);
+      wpk[base] = (unsigned short)(sh & 0xffffu);
+      wpk[base + 512LL * MT] = (unsigned short)(sm & 0xffffu);
+      wpk[base + 1024LL * MT] = (unsigned short)(sl & 0xffffu);
     }
   }
 }

@@ -49,3 +49,31 @@ int dpf_pointwise_conv(const float* x, const float* w, const float* bias, float*
 int dpf_pointwise_wgrad(const float* g, const float* x, float* dw, float* ws, long long ws_floats, const DpfWgradDesc& d, int accumulate,
                         hipStream_t st);
 long long dpf_pointwise_wgrad_workspace_floats(int C, int K);
+
+// ---- fp32 products on the bf16 matrix pipe: the operand split shared by igemm3_x9_kernel, its weight pack kernel and wgrad2_kernel<.., X9>.
+// x = hi + mid + lo EXACTLY, by rounding to nearest: hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (the residuals are exact in fp32 and
+// the last one has at most 8 significant bits, so its conversion is exact too).  |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, residuals signed.
+// Of the nine partial products of a pair the SIX that can reach 2^-24 of the product are issued -- hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
+// lo*hi; mid*lo + lo*mid <= 2^-23 |xy| worst case (rms 2^-26, zero mean: the split rounds to nearest) and lo*lo <= 2^-32 |xy| are dropped:
+// below the rounding of the fp32 accumulation every product goes into (sum of 864 positive products: dropped terms 1e-9 of the sum, the
+// fp32 accumulation itself 7e-7).  DPF_X9_FIRST = 1 issues eight (drops lo*lo only), 0 all nine.
+#ifdef __HIPCC__
+#ifndef DPF_X9_FIRST
+#define DPF_X9_FIRST 3
+#endif
+typedef __bf16 dpf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dpf_f32x2 __attribute__((ext_vector_type(2)));
+// two floats -> two bf16 (round to nearest even) in one register, x in the low half: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned dpf_pk_bf16(float x, float y) {
+  const dpf_f32x2 f = {x, y};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, dpf_bf16x2));
+}
+// (x, y) -> packed bf16 pairs of the three components (11 vector instructions)
+__device__ __forceinline__ void dpf_split_pair(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
+  h = dpf_pk_bf16(x, y);
+  const float r1x = x - __builtin_bit_cast(float, h << 16), r1y = y - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = dpf_pk_bf16(r1x, r1y);
+  const float r2x = r1x - __builtin_bit_cast(float, m << 16), r2y = r1y - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = dpf_pk_bf16(r2x, r2y);
+}
+#endif

@@ -68,18 +68,14 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// exact three-way split of 8 floats into packed bf16 (truncations): v[i] = hi[i] + mid[i] + lo[i] exactly (24 significand bits = 3 x 8)
+// exact three-way split of 8 floats into packed bf16 (conv_internal.h: round-to-nearest split): v[i] = hi[i] + mid[i] + lo[i]
 __device__ __forceinline__ void split8_bf16(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
   u32x4 h, m, l;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const unsigned a = __builtin_bit_cast(unsigned, v[2 * q]), b = __builtin_bit_cast(unsigned, v[2 * q + 1]);
-    h[q] = __builtin_amdgcn_perm(b, a, 0x07060302u);                                        // (a >> 16) | (b & 0xffff0000)
-    const float ra = v[2 * q] - __builtin_bit_cast(float, a & 0xffff0000u), rb = v[2 * q + 1] - __builtin_bit_cast(float, b & 0xffff0000u);
-    const unsigned ua = __builtin_bit_cast(unsigned, ra), ub = __builtin_bit_cast(unsigned, rb);
-    m[q] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-    const float sa = ra - __builtin_bit_cast(float, ua & 0xffff0000u), sb = rb - __builtin_bit_cast(float, ub & 0xffff0000u);
-    l[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
+    unsigned a, b, c;
+    dpf_split_pair(v[2 * q], v[2 * q + 1], a, b, c);
+    h[q] = a; m[q] = b; l[q] = c;
   }
   hi = __builtin_bit_cast(bf16x8, h); mid = __builtin_bit_cast(bf16x8, m); lo = __builtin_bit_cast(bf16x8, l);
 }
@@ -103,10 +99,7 @@ constexpr int w2_occ() { return w2_occ_of(NCT); }
 // runs in the MFMA's fp32 accumulator, smallest terms first.  9 x 34 = 306 matrix-pipe clocks per 16 reduction indices instead of 8 x 64 =
 // 512 on v_mfma_f32_32x32x2_f32, and, unlike the fp32 MFMA, the bf16 MFMA leaves the vector ALU free: the ~11 split instructions per value
 // pair run in its shadow (tools/lean_probe2.hip: 4 v_fma_f32 per bf16 MFMA cost nothing, behind an fp32 MFMA they cost their full time).
-// first of the nine partial products (smallest first): 1 skips lo x lo, which is below 2^-32 of the product (-DDPF_X9_FIRST=0 keeps it)
-#ifndef DPF_X9_FIRST
-#define DPF_X9_FIRST 1
-#endif
+// first of the nine partial products (smallest first) that is issued: conv_internal.h (default 3: six products)
 constexpr int W2_X9_FIRST = DPF_X9_FIRST;
 template <int NCT, bool BF = false, bool SW1 = false, bool X9 = false>
 __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
@@ -278,20 +271,23 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
           if (u + 1 < 2 * NCT) split8_bf16(xr, nH, nM, nL);
           if (u + 2 < 2 * NCT) load_x((u + 2) / NCT, (u + 2) % NCT, xr);
           if (J == 0 && t == NCT - 1) split8_bf16(gv, a2H, a2M, a2L);      // g fragment of the second super-group
-          if constexpr (W2_X9_FIRST == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bL, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bM, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM, bL, acc[t], 0, 0, 0);
+          if constexpr (W2_X9_FIRST <= 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bL, acc[t], 0, 0, 0);
+          if constexpr (W2_X9_FIRST <= 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bM, acc[t], 0, 0, 0);
+          if constexpr (W2_X9_FIRST <= 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM, bL, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL, bH, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bL, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM, bM, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM, bH, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bM, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bH, acc[t], 0, 0, 0);
+          {
+            constexpr int NPR = 9 - W2_X9_FIRST;              // MFMAs of the unit; the split (44 vector instructions) and 8 LDS reads in their shadow
 #pragma unroll
-          for (int i = W2_X9_FIRST; i < 9; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, W2_X9_FIRST ? 6 : 5, 0);      // the split's vector-ALU instructions in its shadow
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+            for (int i = 0; i < NPR; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
+              __builtin_amdgcn_sched_group_barrier(0x002, (44 + NPR - 1) / NPR + (NPR >= 8 ? 0 : 1), 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, (8 + NPR - 1) / NPR, 0);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
           bH = nH; bM = nM; bL = nL;
