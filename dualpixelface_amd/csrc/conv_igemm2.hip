@@ -509,7 +509,7 @@ template <int CC, int NC> struct X9 {
   static constexpr int PD = PB / 4;              // dwords per position
 };
 
-// In-kernel s_memtime stamps (-DDPF_STAMPS builds only; tools/debug/x9_stamps.py reads them back): per workgroup [start, first barrier,
+// In-kernel s_memtime stamps (-DDPF_STAMPS builds only; tools/x9_stamps.py reads them back): per workgroup [start, first barrier,
 // after the chunk loop, end, s_memrealtime at start, at end, XCC / CU id, chunks]
 #ifdef DPF_STAMPS
 __device__ unsigned long long g_x9_stamps[8 * 16384];
@@ -1176,8 +1176,10 @@ int launch_x9(const float* x, const unsigned short* wpk, const float* bias, floa
 
 // One launch of igemm3_x9_kernel for the output channels [k_off, k_off + kn) of the launch `d` (kn <= 64); `p` carries the
 // tile-independent geometry (strides, e0*, RS, colshift).  DPF_ERR_UNSUPPORTED: not eligible, nothing was launched.
+// mt_fit: row tiles the tile geometry (depth split, weight buffers) is chosen for -- the slices of one K > 64 launch pass the LARGEST slice's
+// count, so that every slice picks the same depth split / tile order and the shared BatchNorm statistics slab has one row numbering.
 int x9_try(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, const G2P& p, int k_off, int kn, int NT,
-           DpfConvStats* stats, hipStream_t st, int NC) {
+           DpfConvStats* stats, hipStream_t st, int NC, int mt_fit = 0) {
   static const int x9_on = env_int("DPF_IGEMM3", 1), x9_min_c = env_int("DPF_IGEMM3_MINC", 8), x9_cc = env_int("DPF_IGEMM3_CC", 0),
                    x9_sh = env_int("DPF_IGEMM3_SH", -1);
   const int T = d.kd * d.kh * d.kw, MT = (kn + 31) / 32, TH = 4 * NT;
@@ -1210,7 +1212,7 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
     for (int pz : {1, 2, 4}) {
       if (!(pz == 1 || (d.kd > 1 && pz <= TH / 2 && pz <= d.OD))) continue;
       const int units = set_pz(pz);
-      const size_t l9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(shc ? 2 : 1) * TG * NC * MT * 1024 + 128;
+      const size_t l9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(shc ? 2 : 1) * TG * NC * (mt_fit > MT ? mt_fit : MT) * 1024 + 128;
       if (units <= NU9 * 256 && 2 * l9 <= 160 * 1024 && units < best_units) { best = pz; best_units = units; sh = shc; }
     }
   }
@@ -1235,6 +1237,7 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   q.stats = nullptr;
   if (stats) {
     if (nt9 * d.K * 2 > stats->capacity_doubles) return DPF_ERR_UNSUPPORTED;
+    if (k_off > 0 && stats->parts != (int)nt9) return DPF_ERR_LAUNCH;   // a later slice must number the slab rows as the first one did
     q.stats = stats->slab; q.statsK = d.K; q.statsk0 = k_off;
   }
   unsigned short* wp = reinterpret_cast<unsigned short*>(ws);
@@ -1467,7 +1470,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
       if (rc != DPF_ERR_UNSUPPORTED) return rc;
     } else {
       for (int k_off = 0; k_off < d.K; k_off += 64) {
-        const int rc = x9_try(x, w, bias, out, ws, d, p, k_off, d.K - k_off < 64 ? d.K - k_off : 64, 2, stats, st, nc);
+        const int rc = x9_try(x, w, bias, out, ws, d, p, k_off, d.K - k_off < 64 ? d.K - k_off : 64, 2, stats, st, nc, 2);
         if (rc == DPF_ERR_UNSUPPORTED && k_off == 0) break;      // nothing launched yet: the kernels below take the launch
         if (rc != DPF_OK) return rc == DPF_ERR_UNSUPPORTED ? DPF_ERR_LAUNCH : rc;
         if (k_off + 64 >= d.K) return DPF_OK;

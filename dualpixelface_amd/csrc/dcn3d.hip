@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_fwd_rs_kernel(const float* __rest
   }
 }
 
-constexpr int WG_NREP = 8;   // replicas of the grad_weight scratch tensor (spreads same-address atomic contention)
+constexpr int WG_NREP = DCN_WG_NREP;   // replicas of the grad_weight scratch tensor (dcn_internal.h: shared with the lean kernels)
 
 // ---- role-split grad_offset + grad_weight: 16 waves = 8 SAMPLER waves (a thread PAIR per voxel, each thread half of the chunk's
 // channels: corner reads, coordinate derivatives, samples), 4 GCOL waves (gcol = W^T go for 64 voxels each) and 4 WGRAD waves (dW partial
@@ -1641,10 +1641,17 @@ extern "C" {
 int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void* stream);   // norm_act.hip
 
 // workspace floats for dpf_deform_conv3d_forward / _backward (repacked weights)
-long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
-  long long repack = (long long)T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);   // either repack, reduce index padded
+// floats of the repacked-weights region at the head of the workspace: the largest of every kernel family's repack (region / gather kernels:
+// reduce index padded; lean forward and lean backward fragment orders, which can exceed it -- C = 49..60 or 81..84 with 12-wide chunks).
+// The grad_weight replicas start right behind it, so the SAME number sizes the workspace and places them (they overlapped).
+static long long dcn_repack_floats(int C, int K, int T) {
+  long long repack = (long long)T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);
   if (T == 27 && dcn_lean_workspace_floats(C, K) > repack) repack = dcn_lean_workspace_floats(C, K);
-  return repack + (long long)WG_NREP * T * ((C + 11) / 12) * 64 * 16 + 64;   // + grad_weight scratch replicas (chunks of >= 12 channels) + max|W| per channel chunk
+  return repack;
+}
+
+long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
+  return dcn_repack_floats(C, K, T) + (long long)WG_NREP * T * ((C + 11) / 12) * 64 * 16 + 64;   // + grad_weight scratch replicas (chunks of >= 12 channels) + max|W| per channel chunk
 }
 
 // Mirrors DCN.deform_conv_forward(input, weight, bias, offset, kd,kh,kw, sd,sh,sw, pd,ph,pw, dd,dh,dw, group, deformable_group,
@@ -1801,7 +1808,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   const int CHb = region_chunk(C);
   const bool can_vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(input) % 16 == 0) && sw <= 2;
   const bool region_ok = dx_done && K <= 64 && !getenv("DPF_DCN_V1") && (CHb == 16 || (C + 11) / 12 * 12 + 4 <= CT);   // 16 weight columns are fetched from each chunk origin
-  float* dwtmp = ws + (long long)p.T * (((C + 31) / 32) * 32) * (((K + 63) / 64) * 64);
+  float* dwtmp = ws + dcn_repack_floats(C, K, p.T);
   const int nchunk = (C + CHb - 1) / CHb;
   bool rs_done = false;
   if (region_ok) {

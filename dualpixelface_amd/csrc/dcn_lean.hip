@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void dcn_lean_fwd1_kernel(const float* __re
 // reads its voxel's CH values as NQ ds_read_b128) and S[2][CH][260] (channel major: the weight-gradient B operands of 4 consecutive voxels
 // are one ds_read_b128).  Step i: matrix waves write G(i + 1) and contract S(i - 1); samplers read G(i), write S(i); one barrier.
 constexpr int LEAN_SS = 260;          // padded row of the S tile (floats)
-constexpr int LEAN_NREP = 8;          // replicas of the grad_weight scratch tensor (same layout as dcn3d.hip: [rep][T][nchunk][64][16])
+constexpr int LEAN_NREP = DCN_WG_NREP; // replicas of the grad_weight scratch tensor (dcn_internal.h; layout [rep][T][nchunk][64][16], folded by dcn3d.hip)
 
 template <class G>
 struct BwdLds {
@@ -778,7 +778,10 @@ int dcn_lean_chunk(int C) { return ((C + 11) / 12 * 12 < (C + 15) / 16 * 16) ? 1
 
 long long dcn_lean_workspace_floats(int C, int K) {
   const int CH = dcn_lean_chunk(C);
-  return 27LL * ((C + CH - 1) / CH) * ((K + 31) / 32) * 512;
+  const long long nchunk = (C + CH - 1) / CH;
+  const long long fwd = 27LL * nchunk * ((K + 31) / 32) * 512;     // lean_repack_fwd1_kernel
+  const long long bwd = 27LL * nchunk * 1024;                      // lean_repack_gcol_kernel (independent of K)
+  return fwd > bwd ? fwd : bwd;
 }
 
 int dcn_lean_forward(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, int B, int C, int D, int H,

@@ -86,12 +86,14 @@ class Trainer(object):
         """``resume``: restore optimizer moments and counters too (PL's resume_from_checkpoint); else weights only."""
         ckpt = torch.load(path, map_location='cpu', weights_only=False)
         weights = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt['model']
-        model.load_state_dict(weights, strict=bool(getattr(self.option, 'load_strict', True)))
+        epoch, global_step = self.epoch, self.global_step
         if resume:
-            self.epoch = int(ckpt.get('epoch', 0))                            # PL restores current_epoch = ckpt['epoch']
-            self.global_step = int(ckpt.get('global_step', 0))
+            # Resolve the counters BEFORE anything is restored: a checkpoint whose convention cannot be determined must leave the model
+            # and the trainer untouched (ADVICE r4: the error used to fire after load_state_dict and the counter update).
+            epoch = int(ckpt.get('epoch', 0))                                 # PL restores current_epoch = ckpt['epoch']
+            global_step = int(ckpt.get('global_step', 0))
             if int(ckpt.get('dpf_ckpt_version', 0)) >= 2:
-                self.global_step = max(self.global_step - 1, 0)               # our own files: undo dump_checkpoint's + 1 exactly
+                global_step = max(global_step - 1, 0)                         # our own files: undo dump_checkpoint's + 1 exactly
             elif 'pytorch-lightning_version' not in ckpt and 'epoch' in ckpt:
                 # Unversioned files of this trainer exist in two generations that no key tells apart: round 1 stored the FINISHED epoch,
                 # later revisions the NEXT epoch to run (and the plain global_step).  save_checkpoint names the file after the finished
@@ -100,15 +102,19 @@ class Trainer(object):
                 m = re.search(r'checkpoint_epoch=(\d+)\.ckpt$', os.path.basename(path))
                 conv = getattr(self.option, 'legacy_ckpt_epoch', None)
                 if conv is None and m is not None:
-                    if self.epoch == int(m.group(1)):
+                    if epoch == int(m.group(1)):
                         conv = 'finished'
-                    elif self.epoch == int(m.group(1)) + 1:
+                    elif epoch == int(m.group(1)) + 1:
                         conv = 'next'
                 if conv not in ('finished', 'next'):
                     raise ValueError("unversioned checkpoint %r: cannot tell whether its 'epoch' = %d is the finished epoch or the next one to "
-                                     "run; set option.legacy_ckpt_epoch to 'finished' or 'next'" % (path, self.epoch))
+                                     "run; set option.legacy_ckpt_epoch to 'finished' or 'next', or load the weights only "
+                                     "(load_checkpoint(..., resume=False) / --load_model without resume).  Nothing was restored." % (path, epoch))
                 if conv == 'finished':
-                    self.epoch += 1
+                    epoch += 1
+        model.load_state_dict(weights, strict=bool(getattr(self.option, 'load_strict', True)))
+        if resume:
+            self.epoch, self.global_step = epoch, global_step
             states = ckpt.get('optimizer_states') or []
             if states and states[0].get('kind') == 'flat_adam' and states[0].get('m') is not None:
                 dev = model.flat_parameters().device

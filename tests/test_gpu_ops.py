@@ -416,7 +416,10 @@ def test_softargmin():
                                  # the lean-sampler kernels' domain (depth <= 4, W % 4 == 0): the model's channel counts, several tiles, wide
                                  # offsets (cooperative slow path), shallow volumes, a partial tile row
                                  (2, 35, 64, 4, 6, 12), (1, 20, 40, 4, 9, 72, 3.0), (1, 16, 24, 3, 7, 44, 4.0), (1, 36, 33, 2, 37, 20, 6.0),
-                                 (1, 12, 8, 1, 5, 8, 1.0)])
+                                 (1, 12, 8, 1, 5, 8, 1.0),
+                                 # channel counts whose lean BACKWARD weight repack (27 x ceil(C / 12) x 1024 floats) is larger than the region
+                                 # kernels' repack (27 x pad32(C) x pad64(K)): the grad_weight replicas must start behind it
+                                 (1, 60, 24, 2, 6, 12), (1, 84, 16, 3, 5, 8, 2.0)])
 def test_deform_conv(cfg):
     from oracle import dcn3d
     ops = _ops()

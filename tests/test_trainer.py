@@ -85,8 +85,14 @@ def test_checkpoint_every_epoch_and_resume(tmp_path):
     assert tr5.epoch == 2 and tr5.global_step == 8
     torch.save(legacy, str(tmp_path / 'legacy.ckpt'))                                 # renamed file: refuse to guess ...
     tr6 = Trainer(opt, str(tmp_path / 'legacy3'), rank=0, world_size=1)
+    fresh = _Stub()
+    w_before = fresh.w.data.clone()
     with pytest.raises(ValueError):
-        tr6.load_checkpoint(_Stub(), str(tmp_path / 'legacy.ckpt'))
+        tr6.load_checkpoint(fresh, str(tmp_path / 'legacy.ckpt'))
+    # ... and the refusal restores NOTHING: weights, optimizer state and the trainer's counters are as they were
+    assert torch.equal(fresh.w.data, w_before) and tr6.epoch == 0 and tr6.global_step == 0 and not getattr(fresh, '_adam', None)
+    tr6.load_checkpoint(fresh, str(tmp_path / 'legacy.ckpt'), resume=False)           # weights only always works
+    assert torch.equal(fresh.w.data, legacy['state_dict']['w']) and tr6.epoch == 0
     opt.legacy_ckpt_epoch = 'finished'                                                # ... unless the caller says which
     tr6.load_checkpoint(_Stub(), str(tmp_path / 'legacy.ckpt'))
     assert tr6.epoch == 2

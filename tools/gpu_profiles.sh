@@ -51,8 +51,8 @@ if [ -z "$QUICK" ]; then
   { echo "== operand precision bf16: igemm3 NC=1 (default)"; python tools/conv_bf16_bench.py 2>&1 | grep -v -e MIOpen -e amdgpu.ids
     echo "== DPF_IGEMM3_BF=0 (igemm2 bf16 kernel)"; DPF_IGEMM3_BF=0 python tools/conv_bf16_bench.py 2>&1 | grep -v -e MIOpen -e amdgpu.ids; } > "$O/${R}_conv_bf16_per_shape.txt"
   make -C dualpixelface_amd/csrc -j8 OBJDIR=build_stamps LIB=../libdpf_hip_stamps.so EXTRA=-DDPF_STAMPS > /dev/null 2>&1
-  { echo "== 16-byte tile stores"; DPF_LIB_PATH=$PWD/dualpixelface_amd/libdpf_hip_stamps.so python tools/debug/x9_stamps.py fe32 hg32 fe32q hg64 fe96_32 2>&1 | grep -v amdgpu.ids
-    echo "== DPF_G2_VEC_STORE=0"; DPF_G2_VEC_STORE=0 DPF_LIB_PATH=$PWD/dualpixelface_amd/libdpf_hip_stamps.so python tools/debug/x9_stamps.py fe32 hg32 fe32q hg64 fe96_32 2>&1 | grep -v amdgpu.ids; } > "$O/${R}_x9_stamps.txt"
+  { echo "== 16-byte tile stores"; DPF_LIB_PATH=$PWD/dualpixelface_amd/libdpf_hip_stamps.so python tools/x9_stamps.py fe32 hg32 fe32q hg64 fe96_32 2>&1 | grep -v amdgpu.ids
+    echo "== DPF_G2_VEC_STORE=0"; DPF_G2_VEC_STORE=0 DPF_LIB_PATH=$PWD/dualpixelface_amd/libdpf_hip_stamps.so python tools/x9_stamps.py fe32 hg32 fe32q hg64 fe96_32 2>&1 | grep -v amdgpu.ids; } > "$O/${R}_x9_stamps.txt"
 fi
 cat "$O/${R}_bench.json"; cat "$O/${R}_bench_family_ms.txt"; python3 - "$O/${R}_pmc_traffic.json" <<'PY'
 import json, sys

@@ -1,5 +1,5 @@
 """Phase stamps of igemm3_x9_kernel (library built with -DDPF_STAMPS: DPF_LIB_PATH=dualpixelface_amd/libdpf_hip_stamps.so).
-usage: python tools/debug/x9_stamps.py <shape name of tools/conv_shape_bench.py>"""
+usage: python tools/x9_stamps.py <shape name of tools/conv_shape_bench.py>"""
 import sys, ctypes, torch
 sys.path.insert(0, '.')
 import numpy as np
