@@ -39,19 +39,21 @@ __global__ __launch_bounds__(256) void dw_conv3_kernel(const float* __restrict__
 }
 
 // dw[c][t] += sum_{n,y,x} g[n,c,y,x] * x[n,c,y+ty-1,x+tx-1];  grid = (row blocks, N*C): a block walks whole rows, lanes along x
+// nrows > 1 (deterministic mode, dpf_common.h): grid = (1, C) and rows_per_block = H -- one workgroup per channel walks every sample, so
+// each dw address receives a single atomic add
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw,
-                                                       int C, int H, int W, int rows_per_block) {
+                                                       int C, int H, int W, int rows_per_block, int nrows) {
   __shared__ float sm[4];
-  const int row = blockIdx.y;
-  const int c = row % C;
+  const int c = blockIdx.y % C;
   const long long S = (long long)H * W;
-  const float* gp = g + (long long)row * S;
-  const float* xp = x + (long long)row * S;
   const int y0 = blockIdx.x * rows_per_block, y1 = min(H, y0 + rows_per_block);
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (int row = blockIdx.y; row < (nrows > 1 ? nrows : blockIdx.y + 1); row += C)
   for (int yy = y0; yy < y1; ++yy) {
+    const float* gp = g + (long long)row * S;
+    const float* xp = x + (long long)row * S;
     for (int xx = threadIdx.x; xx < W; xx += 256) {
       const float gv = gp[(long long)yy * W + xx];
 #pragma unroll
@@ -110,8 +112,11 @@ int dpf_depthwise_conv2d_backward_weight(const float* g, const float* x, float* 
   {
     int rpb = dpf_div_up(4096, W);                 // ~4096 elements per block
     if (rpb < 1) rpb = 1;
-    hipLaunchKernelGGL(dw_wgrad_kernel, dim3((unsigned)dpf_div_up(H, rpb), (unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, g, x, dw, C, H, W,
-                       rpb);
+    if (dpf_deterministic())
+      hipLaunchKernelGGL(dw_wgrad_kernel, dim3(1, (unsigned)C), dim3(256), 0, (hipStream_t)stream, g, x, dw, C, H, W, H, N * C);
+    else
+      hipLaunchKernelGGL(dw_wgrad_kernel, dim3((unsigned)dpf_div_up(H, rpb), (unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, g, x, dw, C, H, W,
+                         rpb, 1);
   }
   return dpf_check_launch();
 }

@@ -795,6 +795,7 @@ int dpf_conv_wgrad_slice(const float* g, const float* x, float* dw, int N, int C
   long long nchunk = 2048 / cchunks;
   if (nchunk < 1) nchunk = 1;
   if (nchunk > p.ntiles) nchunk = p.ntiles;
+  if (dpf_deterministic()) nchunk = 1;     // every dW address then receives ONE atomic add per launch: order-independent (dpf_common.h)
   p.nchunk = (int)nchunk;
   const size_t lds = lds_bytes(CCW);
   const dim3 grid((unsigned)(cchunks * p.nchunk));

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(const float* __restrict__ 
 template <int MTC, bool DO_DX>
 __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                            const float* __restrict__ wt2 /*[T][K][CT]*/, const float* __restrict__ go,
-                                                           float* __restrict__ dx, float* __restrict__ doff, DcnP p) {
+                                                           float* __restrict__ dx, float* __restrict__ doff, DcnP p, long long* gi_shadow) {
   extern __shared__ __align__(16) float smem[];
   constexpr int CT = 32 * MTC;
   float* s_go = smem;                    // [K][SP]
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(const float* __restri
         for (int j = 0; j < 8; ++j) {
           if (idx[j] < 0) continue;
           const int jd = (j >> 2) & 1, jh = (j >> 1) & 1, jw = j & 1;
-          if (DO_DX) atomicAdd(&dxc[idx[j]], wg[j] * gcv);                       // cuh:313-331 (fallback path)
+          if (DO_DX) dcn_acc_add(dx, gi_shadow, &dxc[idx[j]], wg[j] * gcv);       // cuh:313-331 (fallback path)
           const float v = xc[idx[j]] * gcv;
           const float fd = jd ? cn.ld : 1.f - cn.ld, fh = jh ? cn.lh : 1.f - cn.lh, fw = jw ? cn.lw : 1.f - cn.lw;
           gd += (jd ? 1.f : -1.f) * fh * fw * v;                                  // cuh:131-187
@@ -428,7 +428,8 @@ constexpr float PK_MASS0 = 128.f, PK_MASS_Q = 131072.f;   // first-pass mass bou
 template <int NST, int NW>
 __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
                                                                    const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT,
-                                                                   const float* __restrict__ wmaxv /*[chunks of GI_CH] max |W|*/) {
+                                                                   const float* __restrict__ wmaxv /*[chunks of GI_CH] max |W|*/,
+                                                                   long long* gi_shadow /* deterministic mode: dcn_internal.h */) {
   extern __shared__ __align__(16) long long smem_q[];
   constexpr int NT = 64 * NW;
   constexpr int npos = 16 * NST * NW;
@@ -686,8 +687,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
               const int jd = ((jb + j) >> 2) & 1, jh = ((jb + j) >> 1) & 1, jw = (jb + j) & 1;
               const int lz = cn.d0 + jd - rz0, ly = cn.h0 + jh - ry0, lx = cn.w0 + jw - rx0;
               if (lz >= 0 && lz < RZ && ly >= 0 && ly < q.RY && lx >= 0 && lx < q.RX) continue;   // went into the region
-              if (ce < q.CG) atomicAdd(&dxb[(long long)ce * chan + v], wg * ge[r]);
-              if (ce + 1 < q.CG) atomicAdd(&dxb[(long long)(ce + 1) * chan + v], wg * gd[r]);
+              if (ce < q.CG) dcn_acc_add(dx, gi_shadow, &dxb[(long long)ce * chan + v], wg * ge[r]);
+              if (ce + 1 < q.CG) dcn_acc_add(dx, gi_shadow, &dxb[(long long)(ce + 1) * chan + v], wg * gd[r]);
             }
           }
         }
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
       float* dst = dxb + (long long)(c0 + 4 * qt) * chan + ((long long)gz * p.H + gy) * p.W + gx;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (c0 + 4 * qt + k < q.CG && v[k] != 0.f) atomicAdd(dst + (long long)k * chan, v[k]);
+        if (c0 + 4 * qt + k < q.CG && v[k] != 0.f) dcn_acc_add(dx, gi_shadow, dst + (long long)k * chan, v[k]);
     }
     attempt = 0;
     c0 += PK_CH;
@@ -1367,7 +1368,7 @@ template <int CH>
 __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                  const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
                                                                  const float* __restrict__ go, float* __restrict__ doff, float* __restrict__ dwtmp,
-                                                                 DcnP p, RegGeo g, int CT, int nchunk, int vec) {
+                                                                 DcnP p, RegGeo g, int CT, int nchunk, int vec, int det) {
   extern __shared__ __align__(16) float smem[];
   float* s_reg = smem;                                 // [RV][VS]
   float* s_x = s_reg + RegCfg<CH>::VS * g.RV;          // [3][CH][XS]
@@ -1526,7 +1527,8 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
       const bool ok = kk < p.K && az < g.TZ && gz < p.Do && gy < p.Ho && gx < p.Wo;
       wfrag[ks] = ok ? go[((long long)c.b * p.K + kk) * p.P + ((long long)gz * p.Ho + gy) * p.Wo + gx] : 0.f;
     }
-    float* rep = dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
+    float* rep = det ? dwtmp : dwtmp + (long long)(blockIdx.x % WG_NREP) * p.T * nchunk * 64 * 16;
+    long long* rep_shadow = det ? reinterpret_cast<long long*>(dwtmp) : nullptr;       // deterministic mode: dcn_internal.h
     const int brow = (l15 < CH ? l15 : CH - 1) * XS + 4 * lg;  // B operand: S[channel l15][voxels 16 q + 4 lg ..+3]; rows beyond CH are masked below
     stage_region_any<CH>(p, g, c, xb, 0, s_reg, tid - 256, 768, vec != 0);
     __syncthreads();                                   // prologue barrier
@@ -1551,7 +1553,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
           float* dst = rep + ((long long)(ts * nchunk + cs) * 64 + 16 * rw + 4 * lg) * 16 + l15;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (16 * rw + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], (wacc[0][r] + wacc[1][r]) + (wacc[2][r] + wacc[3][r]));
+            if (16 * rw + 4 * lg + r < p.K) dcn_acc_add(rep, rep_shadow, &dst[r * 16], (wacc[0][r] + wacc[1][r]) + (wacc[2][r] + wacc[3][r]));
         }
         if (++ts == p.T) { ts = 0; ++cs; }
       }
@@ -1568,14 +1570,22 @@ __global__ __launch_bounds__(1024) void dcn_bwd_offset_rs_kernel(const float* __
 }
 
 // dW[k][c][t] = sum_rep tmp[rep][t][c/ch][k][c%ch]   (ch = channels per chunk of the producing kernel)
-__global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __restrict__ dw, int K, int C, int T, int nchunk, int ch) {
+// det: the scratch holds ONE replica of order-independent integer pairs (dcn_internal.h)
+__global__ void dcn_wgrad_fold_kernel(const float* __restrict__ dwtmp, float* __restrict__ dw, int K, int C, int T, int nchunk, int ch, int det) {
   const int total = K * C * T;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int t = i % T, cc = (i / T) % C, k = i / (T * C);
     float s = 0.f;
-    for (int r = 0; r < WG_NREP; ++r) s += dwtmp[(((long long)r * T + t) * nchunk + cc / ch) * 64 * 16 + k * 16 + (cc % ch)];
+    if (det) s = dpf_det_value(reinterpret_cast<const long long*>(dwtmp) + 2 * ((((long long)t) * nchunk + cc / ch) * 64 * 16 + k * 16 + (cc % ch)));
+    else
+      for (int r = 0; r < WG_NREP; ++r) s += dwtmp[(((long long)r * T + t) * nchunk + cc / ch) * 64 * 16 + k * 16 + (cc % ch)];
     dw[i] = s;
   }
+}
+
+// deterministic mode: grad_input = value of its integer shadow (every contribution went there; the tensor itself was only zero-filled)
+__global__ void dcn_gi_finalize_kernel(const long long* __restrict__ shadow, float* __restrict__ gi, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) gi[i] = dpf_det_value(shadow + 2 * i);
 }
 
 size_t region_lds(const RegGeo& g, int CH) { return sizeof(float) * ((size_t)CH * g.RV + (size_t)16 * ST); }
@@ -1650,8 +1660,14 @@ static long long dcn_repack_floats(int C, int K, int T) {
   return repack;
 }
 
-long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) {
-  return dcn_repack_floats(C, K, T) + (long long)WG_NREP * T * ((C + 11) / 12) * 64 * 16 + 64;   // + grad_weight scratch replicas (chunks of >= 12 channels) + max|W| per channel chunk
+static long long dcn_workspace_floats(int C, int K, int T) {
+  return (dcn_repack_floats(C, K, T) + (long long)WG_NREP * T * ((C + 11) / 12) * 64 * 16 + 64 + 3) / 4 * 4;   // + grad_weight scratch replicas (chunks of >= 12 channels) + max|W| per channel chunk
+}
+long long dpf_deform_conv3d_workspace_floats(int C, int K, int T) { return dcn_workspace_floats(C, K, T); }
+// workspace of dpf_deform_conv3d_backward*: in deterministic mode (dpf_set_deterministic) grad_input is accumulated as order-independent
+// integer pairs in a shadow behind the ordinary workspace -- 4 more floats per element of the input tensor
+long long dpf_deform_conv3d_backward_workspace_floats(int B, int C, int D, int H, int W, int K, int T) {
+  return dcn_workspace_floats(C, K, T) + (dpf_deterministic() ? 4LL * B * C * D * H * W : 0);
 }
 
 // Mirrors DCN.deform_conv_forward(input, weight, bias, offset, kd,kh,kw, sd,sh,sw, pd,ph,pw, dd,dh,dw, group, deformable_group,
@@ -1758,6 +1774,15 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   const int MT = (K + 31) / 32, MTC = (p.CP + 31) / 32, CT = 32 * MTC;
   const long long in_elems = (long long)B * C * D * H * W;
   if (hipMemsetAsync(grad_input, 0, sizeof(float) * in_elems, st) != hipSuccess) return DPF_ERR_LAUNCH;
+  // deterministic mode: every merge of partial results is order-independent (dcn_internal.h) -- grad_input through an integer shadow behind
+  // the workspace (the caller sized it with dpf_deform_conv3d_backward_workspace_floats), the grad_weight scratch as one integer replica
+  const int det = dpf_deterministic();
+  long long* gi_shadow = nullptr;
+  if (det) {
+    gi_shadow = reinterpret_cast<long long*>(ws + dcn_workspace_floats(C, K, p.T));
+    if (reinterpret_cast<uintptr_t>(gi_shadow) & 7) return DPF_ERR_INVALID_ARG;
+    if (hipMemsetAsync(gi_shadow, 0, sizeof(long long) * 2 * (size_t)in_elems, st) != hipSuccess) return DPF_ERR_LAUNCH;
+  }
   if (hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)K * C * p.T, st) != hipSuccess) return DPF_ERR_LAUNCH;
   // wt2[T][K][CT]: reduce = K (A), out = C (B); the region kernels read it with K zero-padded to 64 rows
   // grad_input: LDS-privatised scatter when the haloed region fits, else the reference-style global atomics
@@ -1785,12 +1810,12 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
                          64);
       // packed fixed-point region (two channels per ds_add_u64): per-chunk max |W| for the quantisation bound, kept behind the
       // grad_weight scratch in ws
-      float* wmaxv = ws + dpf_deform_conv3d_workspace_floats(C, K, p.T) - 64;
+      float* wmaxv = ws + dcn_repack_floats(C, K, p.T) + (long long)WG_NREP * p.T * ((C + 11) / 12) * 64 * 16;
       hipLaunchKernelGGL(dcn_wmax_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, ws, wmaxv, p.T, CT, C);
 #define DPF_GIP(NS, NWv)                                                                                                       \
   {                                                                                                                            \
     if (set_lds(dcn_bwd_input_pk_kernel<NS, NWv>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                       \
-    hipLaunchKernelGGL((dcn_bwd_input_pk_kernel<NS, NWv>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv); \
+    hipLaunchKernelGGL((dcn_bwd_input_pk_kernel<NS, NWv>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv, gi_shadow); \
   }
       switch (q.TZ) {
         case 1: DPF_GIP(1, 4); break;
@@ -1815,7 +1840,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     if (hipMemsetAsync(dwtmp, 0, sizeof(float) * (size_t)WG_NREP * p.T * nchunk * 64 * 16, st) != hipSuccess) return DPF_ERR_LAUNCH;
     if (kd == 3 && kh == 3 && kw == 3 && sd == 1 && sh == 1 && sw == 1 && pd == 1 && ph == 1 && pw == 1 && dd == 1 && dh == 1 && dw == 1 &&
         CHb == dcn_lean_chunk(C)) {
-      rc = dcn_lean_bwd_offset(input, offset, weight, grad_output, grad_offset, dwtmp, ws, B, C, D, H, W, K, st);
+      rc = dcn_lean_bwd_offset(input, offset, weight, grad_output, grad_offset, dwtmp, ws, B, C, D, H, W, K, st, det);
       if (rc == DPF_OK) rs_done = true;
       else if (rc != DPF_ERR_UNSUPPORTED) return rc;
     }
@@ -1845,7 +1870,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   {                                                                                                                            \
     if (set_lds(dcn_bwd_offset_rs_kernel<Cw>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                           \
     hipLaunchKernelGGL((dcn_bwd_offset_rs_kernel<Cw>), grid, dim3(1024), lds, st, input, offset, ws, grad_output, grad_offset, dwtmp, p, gr, \
-                       CT, nchunk, vec_rs);                                                                                    \
+                       CT, nchunk, vec_rs, det);                                                                               \
   }
       if (CHb == 16) DPF_OFFRS(16) else DPF_OFFRS(12)
 #undef DPF_OFFRS
@@ -1853,7 +1878,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     }
   }
   if (rs_done) {
-    hipLaunchKernelGGL(dcn_wgrad_fold_kernel, dim3(dpf_ew_grid((long long)K * C * p.T)), dim3(256), 0, st, dwtmp, grad_weight, K, C, p.T, nchunk, CHb);
+    hipLaunchKernelGGL(dcn_wgrad_fold_kernel, dim3(dpf_ew_grid((long long)K * C * p.T)), dim3(256), 0, st, dwtmp, grad_weight, K, C, p.T, nchunk, CHb, det);
   } else {
     hipLaunchKernelGGL(repack_weights_kernel, dim3(dpf_ew_grid((long long)p.T * K * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1);
     {
@@ -1863,10 +1888,10 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
   {                                                                                                                    \
     if (dx_done) {                                                                                                     \
       if (set_lds(dcn_bwd_data_kernel<M, false>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                \
-      hipLaunchKernelGGL((dcn_bwd_data_kernel<M, false>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_input, grad_offset, p); \
+      hipLaunchKernelGGL((dcn_bwd_data_kernel<M, false>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_input, grad_offset, p, gi_shadow); \
     } else {                                                                                                           \
       if (set_lds(dcn_bwd_data_kernel<M, true>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                 \
-      hipLaunchKernelGGL((dcn_bwd_data_kernel<M, true>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_input, grad_offset, p); \
+      hipLaunchKernelGGL((dcn_bwd_data_kernel<M, true>), grid, dim3(256), lds, st, input, offset, ws, grad_output, grad_input, grad_offset, p, gi_shadow); \
     }                                                                                                                  \
   }
       switch (MTC) { case 1: DPF_D(1); break; case 2: DPF_D(2); break; case 3: DPF_D(3); break; default: DPF_D(4); break; }
@@ -1876,6 +1901,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     long long nchunkw = 2048 / p.T;
     if (nchunkw < 1) nchunkw = 1;
     if (nchunkw > ntile) nchunkw = ntile;
+    if (det) nchunkw = 1;            // each dW address then receives ONE atomic add: order-independent
     p.nchunk = (int)nchunkw;
     const size_t lds = sizeof(float) * ((size_t)32 * MTC * SP + (size_t)32 * MT * SP);
     const dim3 grid((unsigned)(p.T * p.nchunk));
@@ -1891,6 +1917,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     }
 #undef DPF_W
   }
+  if (det) hipLaunchKernelGGL(dcn_gi_finalize_kernel, dim3(dpf_ew_grid(in_elems)), dim3(256), 0, st, gi_shadow, grad_input, in_elems);
   if (grad_bias) {
     // grad_bias[k] = sum_{b,p} go[b,k,p]  (cu:277) -- small row reduction
     if (hipMemsetAsync(grad_bias, 0, sizeof(float) * K, st) != hipSuccess) return DPF_ERR_LAUNCH;

@@ -461,7 +461,7 @@ template <class G>
 __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                   const float* __restrict__ wg /*[T][nchunk][64 lanes][16]*/,
                                                                   const float* __restrict__ go, float* __restrict__ doff, float* __restrict__ dwtmp,
-                                                                  LeanP p) {
+                                                                  LeanP p, int det) {
   extern __shared__ __align__(16) char smem[];
   constexpr int CH = G::CH, NQ = G::NQ, T = 27;
   typedef BwdLds<G> L;
@@ -647,7 +647,8 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
         wfrag[ks] = ok ? gob[(long long)kk * p.P + ((long long)pz * p.H + y0 + py) * p.W + x0 + px] : 0.f;
       }
     }
-    float* rep = dwtmp + (long long)(blockIdx.x % LEAN_NREP) * T * p.nchunk * 64 * 16;
+    float* rep = det ? dwtmp : dwtmp + (long long)(blockIdx.x % LEAN_NREP) * T * p.nchunk * 64 * 16;
+    long long* rep_shadow = det ? reinterpret_cast<long long*>(dwtmp) : nullptr;
     const int brow = (l15 < CH ? l15 : CH - 1) * LEAN_SS + 4 * lg;
     const unsigned wlane = (unsigned)lane * 64u;
     auto gcol = [&](int j) {                           // gcol(j) -> G[j & 1]
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
           float* dst = rep + ((long long)(ts * p.nchunk + cs) * 64 + 16 * mw + 4 * lg) * 16 + l15;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (16 * mw + 4 * lg + r < p.K) atomicAdd(&dst[r * 16], (wacc[0][r] + wacc[1][r]) + (wacc[2][r] + wacc[3][r]));
+            if (16 * mw + 4 * lg + r < p.K) dcn_acc_add(rep, rep_shadow, &dst[r * 16], (wacc[0][r] + wacc[1][r]) + (wacc[2][r] + wacc[3][r]));
         }
       }
       if (i < NS) {
@@ -754,14 +755,14 @@ typedef Geo<12, 4, 16, 5, 7, 4> B12;    //   256     4 x 16 x 32    147 840
 
 template <class G>
 int lean_launch_bwd_offset(const float* x, const float* offset, const float* weight, const float* go, float* doff, float* dwtmp, float* ws, LeanP p,
-                           hipStream_t st) {
+                           hipStream_t st, int det) {
   p.tilesY = dpf_div_up(p.H, G::TY);
   p.tilesX = dpf_div_up(p.W, G::TX);
   const long long blocks = (long long)p.B * p.tilesY * p.tilesX;
   if (blocks >= 0x7fffffffLL) return DPF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(lean_repack_gcol_kernel, dim3(dpf_ew_grid(27LL * p.nchunk * 1024)), dim3(256), 0, st, weight, ws, p.K, p.C, G::CH, p.nchunk);
   if (lean_set_lds(dcn_lean_bwd_offset_kernel<G>, BwdLds<G>::LDS) != DPF_OK) return DPF_ERR_LAUNCH;
-  hipLaunchKernelGGL((dcn_lean_bwd_offset_kernel<G>), dim3((unsigned)blocks), dim3(512), BwdLds<G>::LDS, st, x, offset, ws, go, doff, dwtmp, p);
+  hipLaunchKernelGGL((dcn_lean_bwd_offset_kernel<G>), dim3((unsigned)blocks), dim3(512), BwdLds<G>::LDS, st, x, offset, ws, go, doff, dwtmp, p, det);
   return dpf_check_launch();
 }
 
@@ -806,7 +807,7 @@ int dcn_lean_forward(const float* x, const float* offset, const float* weight, c
 // grad_offset (fully written) + grad_weight partials into dwtmp[LEAN_NREP = 8][27][nchunk][64][16] (zero-initialised by the caller, folded by
 // dcn3d.hip's dcn_wgrad_fold_kernel with chunk width dcn_lean_chunk(C)).  ws: >= 27 * nchunk * 1024 floats.
 int dcn_lean_bwd_offset(const float* x, const float* offset, const float* weight, const float* go, float* doff, float* dwtmp, float* ws, int B, int C,
-                        int D, int H, int W, int K, hipStream_t st) {
+                        int D, int H, int W, int K, hipStream_t st, int det) {
   static const int lean_env = getenv("DPF_DCN_LEAN") ? atoi(getenv("DPF_DCN_LEAN")) : 1;
   if (!lean_env || (lean_env & 4) || D > 4 || D < 1 || (W & 3) || K > 64 || (reinterpret_cast<uintptr_t>(x) & 15)) return DPF_ERR_UNSUPPORTED;
   if ((long long)D * H * W >= 0x7fffffffLL / 4) return DPF_ERR_UNSUPPORTED;
@@ -817,6 +818,6 @@ int dcn_lean_bwd_offset(const float* x, const float* offset, const float* weight
   p.nchunk = p.Cpad / CH;
   p.KT = 32 * ((K + 31) / 32);
   p.P = (long long)D * H * W;
-  if (CH == 16) return lean_launch_bwd_offset<B16>(x, offset, weight, go, doff, dwtmp, ws, p, st);
-  return lean_launch_bwd_offset<B12>(x, offset, weight, go, doff, dwtmp, ws, p, st);
+  if (CH == 16) return lean_launch_bwd_offset<B16>(x, offset, weight, go, doff, dwtmp, ws, p, st, det);
+  return lean_launch_bwd_offset<B12>(x, offset, weight, go, doff, dwtmp, ws, p, st, det);
 }

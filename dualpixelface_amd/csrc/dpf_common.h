@@ -20,6 +20,11 @@ static inline int dpf_check_launch() {
   return e == hipSuccess ? DPF_OK : DPF_ERR_LAUNCH;
 }
 
+// Deterministic mode (dpf_set_deterministic(1) / DPF_DETERMINISTIC=1, layout.hip): every reduction that merges partial results with float
+// atomics switches to a form whose result does not depend on the order in which workgroups retire -- one committing workgroup per output
+// address, phased launches of overlapping tiles, or integer accumulation (below).  Slower; bitwise reproducible run to run.
+int dpf_deterministic();
+
 static inline int dpf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // grid size for a grid-stride elementwise kernel (guide: cap at ~8 blocks/CU x 256 CUs)
@@ -44,6 +49,22 @@ __device__ __forceinline__ float dpf_wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// Order-independent accumulation of floats: a value is added as TWO 64-bit integers (units 2^-24 and 2^-56) with integer atomics.  The
+// conversion is a pure function of the value (exact for |v| >= 2^-33, rounded to 2^-56 below that; |sum| < 2^38), integer adds commute, so
+// the pair -- and dpf_det_value() of it -- is the same whatever order the contributions arrive in.  acc2: two zero-initialised long longs.
+__device__ __forceinline__ void dpf_det_add(long long* acc2, float v) {
+  const float s = v * 16777216.f;                       // exact (power of two)
+  const float t = truncf(s);
+  const float r = s - t;                                // exact; 0 once |s| >= 2^23
+  const long long qh = (long long)t;
+  const long long ql = (long long)rintf(r * 4294967296.f);
+  if (qh != 0) atomicAdd(reinterpret_cast<unsigned long long*>(acc2), (unsigned long long)qh);
+  if (ql != 0) atomicAdd(reinterpret_cast<unsigned long long*>(acc2) + 1, (unsigned long long)ql);
+}
+__device__ __forceinline__ float dpf_det_value(const long long* acc2) {
+  return (float)((double)acc2[0] * 5.9604644775390625e-08 + (double)acc2[1] * 1.3877787807814457e-17);   // 2^-24, 2^-56
 }
 
 // block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread

@@ -4,6 +4,19 @@
 // maximum returned as `ref_feature` (mainmodel.py:104) and the closed-form replay of the attention BatchNorm's running
 // statistics.  All HBM-bound, float4 where the row length allows.
 #include "dpf_common.h"
+#include <cstdlib>
+
+// ---- deterministic mode (process-wide; see dpf_common.h)
+namespace { int g_deterministic = -1; }
+int dpf_deterministic() {
+  if (g_deterministic < 0) g_deterministic = getenv("DPF_DETERMINISTIC") ? (atoi(getenv("DPF_DETERMINISTIC")) != 0) : 0;
+  return g_deterministic;
+}
+extern "C" int dpf_set_deterministic(int on) {
+  g_deterministic = on ? 1 : 0;
+  return DPF_OK;
+}
+extern "C" int dpf_get_deterministic(void) { return dpf_deterministic(); }
 
 namespace {
 

@@ -178,7 +178,9 @@ int dpf_loss_forward(const float* pred_depth, const float* pred_normal, const fl
   fill(p, B, n, H, W, head_weights_host, lambda_depth, lambda_normal);
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(acc_ws, 0, sizeof(float) * (n + 2), st) != hipSuccess) return DPF_ERR_LAUNCH;
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(dpf_ew_grid((long long)B * H * W)), dim3(256), 0, st, pred_depth, pred_normal, disp, normal, mask, acc_ws, p);
+  // deterministic mode: ONE workgroup, so the float atomics that merge the workgroups' partial sums have no partner (dpf_common.h)
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(dpf_deterministic() ? 1 : dpf_ew_grid((long long)B * H * W)), dim3(256), 0, st, pred_depth, pred_normal, disp,
+                     normal, mask, acc_ws, p);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, acc_ws, out, p, pred_normal ? 1 : 0);
   return dpf_check_launch();
 }

@@ -14,18 +14,37 @@ namespace {
 constexpr int ROW_CHUNK = 4096;   // elements of one row handled by one block
 
 // ---------------------------------------------------------------- statistics (training)
+// DET (deterministic mode, dpf_common.h): grid = (1, C) -- ONE workgroup per channel walks the rows c, c + C, ... of every sample over the
+// whole S, so each output address receives exactly one (partner-less) atomic add and the result does not depend on the retirement order
+// of workgroups.  Its long per-thread chains accumulate in fp64.
+template <bool DET> struct RedAcc { typedef float type; };
+template <> struct RedAcc<true> { typedef double type; };
+
+__device__ __forceinline__ float red_block_sum(float v, float* sm4) { return dpf_block_sum_256(v, sm4); }
+__device__ __forceinline__ float red_block_sum(double v, float* sm4) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  double* smd = reinterpret_cast<double*>(sm4);        // callers declare __shared__ float sm[8] (4 doubles)
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smd[w] = v;
+  __syncthreads();
+  return (float)((smd[0] + smd[1]) + (smd[2] + smd[3]));
+}
+
 // sums[c] = { sum(x - K_c), sum((x - K_c)^2) } with the shift K_c = x[0, c, 0] (single pass, cancellation-safe)
+template <bool DET>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ sums, int N, int C, long long S,
                                                        int chunk) {
-  __shared__ float sm[4];
-  const int row = blockIdx.y;   // n*C + c
-  const int c = row % C;
+  __shared__ float sm[8];
+  typedef typename RedAcc<DET>::type acc_t;
+  const int c = blockIdx.y % C;
   const float K = x[(long long)c * S];
-  const float* xr = x + (long long)row * S;
-  float a = 0.f, b = 0.f;
-  {
-    const long long s0 = (long long)blockIdx.x * chunk;
-    const long long s1 = min(S, s0 + chunk);
+  acc_t a = 0, b = 0;
+  for (int row = blockIdx.y; row < (DET ? N * C : blockIdx.y + 1); row += C) {   // row = n*C + c
+    const float* xr = x + (long long)row * S;
+    const long long s0 = DET ? 0 : (long long)blockIdx.x * chunk;
+    const long long s1 = DET ? S : min(S, s0 + chunk);
     if ((S & 3) == 0) {
 #pragma unroll 4
       for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
@@ -42,11 +61,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
       }
     }
   }
-  a = dpf_block_sum_256(a, sm);
-  b = dpf_block_sum_256(b, sm);
+  const float af = red_block_sum(a, sm);
+  const float bf = red_block_sum(b, sm);
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[2 * c], a);
-    atomicAdd(&sums[2 * c + 1], b);
+    atomicAdd(&sums[2 * c], af);
+    atomicAdd(&sums[2 * c + 1], bf);
   }
 }
 
@@ -256,17 +275,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------- backward
 // sums[c] = { sum dz, sum dz*xhat, sum_{z<0} z*dy (PReLU slope gradient) }
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool DET>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ w, const float* __restrict__ bsh, int wmod,
                                                             const float* __restrict__ res, int act, const float* __restrict__ slope_p,
-                                                            float slope_c, float* __restrict__ sums, int C, long long S, int chunk, int gC = 0,
-                                                            int gc0 = 0) {
-  __shared__ float sm[4];
-  const int row = blockIdx.y;
-  const int c = row % C;
-  if (gC > 0) dy += (((long long)(row / C) * gC + gc0 + c) - row) * S;      // dy is a channel slice of a [N, gC, S] tensor
+                                                            float slope_c, float* __restrict__ sums, int N, int C, long long S, int chunk,
+                                                            int gC = 0, int gc0 = 0) {
+  __shared__ float sm[8];
+  typedef typename RedAcc<DET>::type acc_t;
+  const int c = blockIdx.y % C;
   float mu = 0.f, is = 1.f, g = 1.f, be = 0.f;
   if (mean) {
     mu = mean[c];
@@ -275,8 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     be = bsh ? bsh[c % wmod] : 0.f;
   }
   const float slope = slope_p ? slope_p[0] : slope_c;
-  const long long base = (long long)row * S;
-  float a = 0.f, b = 0.f, sl = 0.f;
+  acc_t a = 0, b = 0, sl = 0;
   auto one = [&](float xv, float rv, float d) {
     const float xh = (xv - mu) * is;
     const float z = fmaf(xh, g, be) + rv;
@@ -286,31 +303,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (ACT == DPF_ACT_PRELU && z <= 0.f) sl += z * d;
   };
   (void)act;
-  {
-    const long long s0 = (long long)blockIdx.x * chunk;
-    const long long s1 = min(S, s0 + chunk);
+  // DET: one workgroup per channel walks every sample's row over the whole S (see bn_stats_kernel)
+  for (int row = blockIdx.y; row < (DET ? N * C : blockIdx.y + 1); row += C) {
+    const float* dyr = dy + (gC > 0 ? (((long long)(row / C) * gC + gc0 + c) - row) * S : 0);   // dy: a channel slice of a [N, gC, S] tensor
+    const long long base = (long long)row * S;
+    const long long s0 = DET ? 0 : (long long)blockIdx.x * chunk;
+    const long long s1 = DET ? S : min(S, s0 + chunk);
     if ((S & 3) == 0) {
 #pragma unroll 4
       for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
         const v4f xv = *reinterpret_cast<const v4f*>(x + base + s);      // (x and dy are read again by the apply kernel: plain loads)
-        const v4f dv = *reinterpret_cast<const v4f*>(dy + base + s);
+        const v4f dv = *reinterpret_cast<const v4f*>(dyr + base + s);
         v4f rv = {0.f, 0.f, 0.f, 0.f};
         if (RES) rv = *reinterpret_cast<const v4f*>(res + base + s);
         one(xv.x, rv.x, dv.x); one(xv.y, rv.y, dv.y); one(xv.z, rv.z, dv.z); one(xv.w, rv.w, dv.w);
       }
     } else {
-      for (long long s = s0 + threadIdx.x; s < s1; s += 256) one(x[base + s], RES ? res[base + s] : 0.f, dy[base + s]);
+      for (long long s = s0 + threadIdx.x; s < s1; s += 256) one(x[base + s], RES ? res[base + s] : 0.f, dyr[base + s]);
     }
   }
-  a = dpf_block_sum_256(a, sm);
-  b = dpf_block_sum_256(b, sm);
+  const float af = red_block_sum(a, sm);
+  const float bf = red_block_sum(b, sm);
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[3 * c], a);
-    atomicAdd(&sums[3 * c + 1], b);
+    atomicAdd(&sums[3 * c], af);
+    atomicAdd(&sums[3 * c + 1], bf);
   }
   if (ACT == DPF_ACT_PRELU) {
-    sl = dpf_block_sum_256(sl, sm);
-    if (threadIdx.x == 0) atomicAdd(&sums[3 * c + 2], sl);
+    const float slf = red_block_sum(sl, sm);
+    if (threadIdx.x == 0) atomicAdd(&sums[3 * c + 2], slf);
   }
 }
 
@@ -412,16 +432,17 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, in
   }
 }
 
-// per-channel sum of g[N,C,S] -> out[C] (+=): conv bias gradients
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int C, long long S, int chunk) {
-  __shared__ float sm[4];
-  const int row = blockIdx.y;
-  const int c = row % C;
-  const long long base = (long long)row * S;
-  float a = 0.f;
-  {
-    const long long s0 = (long long)blockIdx.x * chunk;
-    const long long s1 = min(S, s0 + chunk);
+// per-channel sum of g[N,C,S] -> out[C] (+=): conv bias gradients.  DET: one workgroup per channel (see bn_stats_kernel)
+template <bool DET>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int C, long long S, int chunk) {
+  __shared__ float sm[8];
+  typedef typename RedAcc<DET>::type acc_t;
+  const int c = blockIdx.y % C;
+  acc_t a = 0;
+  for (int row = blockIdx.y; row < (DET ? N * C : blockIdx.y + 1); row += C) {
+    const long long base = (long long)row * S;
+    const long long s0 = DET ? 0 : (long long)blockIdx.x * chunk;
+    const long long s1 = DET ? S : min(S, s0 + chunk);
     if ((S & 3) == 0) {
 #pragma unroll 4
       for (long long s = s0 + 4 * threadIdx.x; s < s1; s += 4 * 256) {
@@ -432,8 +453,8 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
       for (long long s = s0 + threadIdx.x; s < s1; s += 256) a += g[base + s];
     }
   }
-  a = dpf_block_sum_256(a, sm);
-  if (threadIdx.x == 0) atomicAdd(&out[c], a);
+  const float af = red_block_sum(a, sm);
+  if (threadIdx.x == 0) atomicAdd(&out[c], af);
 }
 
 inline dim3 row_grid(int rows, long long S) { return dim3((unsigned)dpf_div_up(S, ROW_CHUNK), (unsigned)rows); }
@@ -449,6 +470,12 @@ inline int reduce_chunk(int rows, long long S) {
 }
 inline dim3 reduce_grid(int rows, long long S, int chunk) { return dim3((unsigned)dpf_div_up(S, chunk), (unsigned)rows); }
 
+// deterministic mode: one workgroup per channel (grid (1, C)) instead of one per (row chunk, row)
+inline void launch_bn_stats(const float* x, float* ws, int N, int C, long long S, int chunk, hipStream_t st) {
+  if (dpf_deterministic()) hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(1, (unsigned)C), dim3(256), 0, st, x, ws, N, C, S, chunk);
+  else hipLaunchKernelGGL(bn_stats_kernel<false>, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, ws, N, C, S, chunk);
+}
+
 }  // namespace
 
 extern "C" {
@@ -462,7 +489,7 @@ int dpf_bn_stats(const float* x, int N, int C, long long S, float eps, float mom
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
   const int chunk = reduce_chunk(N * C, S);
-  hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, ws, N, C, S, chunk);
+  launch_bn_stats(x, ws, N, C, S, chunk, st);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, st, x, ws, C, S, (double)N * (double)S, eps, momentum,
                      running_mean, running_var, mean, invstd);
   return dpf_check_launch();
@@ -493,7 +520,7 @@ int dpf_bn_local_moments(const float* x, int N, int C, long long S, float* momen
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
   const int chunk = reduce_chunk(N * C, S);
-  hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, ws, N, C, S, chunk);
+  launch_bn_stats(x, ws, N, C, S, chunk, st);
   hipLaunchKernelGGL(bn_local_moments_kernel, dim3(dpf_div_up(C, 64)), dim3(64), 0, st, x, ws, C, S, (double)N * (double)S, moments);
   return dpf_check_launch();
 }
@@ -564,7 +591,14 @@ static int norm_act_backward_impl(const float* x, const float* dy, int gC, int g
     // phase 3: as phase 0 with a ws the caller guarantees to be zero (a slot of a pre-zeroed arena: one memset per arena, not per layer)
     if (phase != 3 && hipMemsetAsync(ws, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DPF_ERR_LAUNCH;
     const int chunk = reduce_chunk(N * C, S);
-#define DPF_CALL(A, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<A, R>), reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, act, slope, slope_const, ws, C, S, chunk, gC, gc0)
+    const bool det = dpf_deterministic() != 0;
+#define DPF_CALL(A, R)                                                                                                                              \
+  do {                                                                                                                                              \
+    if (det) hipLaunchKernelGGL((bn_bwd_reduce_kernel<A, R, true>), dim3(1, (unsigned)C), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod, res, \
+                                act, slope, slope_const, ws, N, C, S, chunk, gC, gc0);                                                             \
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<A, R, false>), reduce_grid(N * C, S, chunk), dim3(256), 0, st, x, dy, mean, invstd, w, b, wmod,   \
+                            res, act, slope, slope_const, ws, N, C, S, chunk, gC, gc0);                                                             \
+  } while (0)
     DPF_ACT_DISPATCH(act, (res != nullptr), DPF_CALL)
 #undef DPF_CALL
     fused_fin = (dx || dres) && phase != 1;       // the apply launch below writes the parameter gradients
@@ -629,7 +663,8 @@ int dpf_channel_sum(const float* g, float* out, int N, int C, long long S, void*
   dpf_clear_error();   // drop any stale error left by other runtime users (e.g. PyTorch) in this thread
   if (!g || !out || N <= 0 || C <= 0 || S <= 0 || (long long)N * C > 65535) return DPF_ERR_INVALID_ARG;
   const int chunk = reduce_chunk(N * C, S);
-  hipLaunchKernelGGL(channel_sum_kernel, reduce_grid(N * C, S, chunk), dim3(256), 0, (hipStream_t)stream, g, out, C, S, chunk);
+  if (dpf_deterministic()) hipLaunchKernelGGL(channel_sum_kernel<true>, dim3(1, (unsigned)C), dim3(256), 0, (hipStream_t)stream, g, out, N, C, S, chunk);
+  else hipLaunchKernelGGL(channel_sum_kernel<false>, reduce_grid(N * C, S, chunk), dim3(256), 0, (hipStream_t)stream, g, out, N, C, S, chunk);
   return dpf_check_launch();
 }
 

@@ -7,6 +7,7 @@
 // Backward scatters d(logit) into the low-resolution volume through an LDS-privatised tile (one LDS atomic per
 // contribution, one global atomic per touched low-res cell and tile).
 #include "dpf_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -163,30 +164,40 @@ __global__ __launch_bounds__(256) void head_fwd_8x32_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ k, const float* __restrict__ gpred, float* __restrict__ dk, HeadP p) {
+// DET (deterministic mode, dpf_common.h): (i) the LDS cells are 64-bit integers -- contributions are converted with a scale derived from the
+// workgroup's largest gradient (|cell sum| < 2^60, resolution 2^-50 of that maximum), integer adds commute; (ii) the launch is split into
+// Py x Px phases of tiles whose low-resolution footprints are disjoint (host: softargmin_bwd), and a workgroup outside the phase (py, px)
+// exits: within a launch every dk cell receives at most one atomic add, and the phases run in stream order.
+template <bool DET>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ k, const float* __restrict__ gpred, float* __restrict__ dk, HeadP p,
+                                                       int Py, int Px, int py, int px) {
   // fp64 cells: on MI355X ds_add_f32 sustains 0.33 lanes/clk/CU, ds_add_f64 3.1 (profiles/r01_lds_atomic_microbench.txt)
-  __shared__ double tile[MAXD][TY + 2][TX + 2];
+  typedef typename std::conditional<DET, long long, double>::type cell_t;
+  __shared__ cell_t tile[MAXD][TY + 2][TX + 2];
   __shared__ float s_bl[MAXD][256];   // per-thread bilinear values / gradients, thread index fastest (conflict-free)
   __shared__ float s_db[MAXD][256];
+  __shared__ float s_max[4];
   const float rd = head_ratio(p.D, p.L, p.off), ry = head_ratio(p.h, p.H, p.off), rx = head_ratio(p.w, p.W, p.off);
   const int tilesX = (p.W + TX - 1) / TX, tilesY = (p.H + TY - 1) / TY;
   int bb = blockIdx.x;
   const int tx = bb % tilesX; bb /= tilesX;
   const int ty = bb % tilesY;
   const int b = bb / tilesY;
+  if (DET && (ty % Py != py || tx % Px != px)) return;
   const int Y0 = ty * TY, X0 = tx * TX;
   int ybase, xbase, t1;
   float tl;
   ac_src(Y0, ry, p.h, ybase, t1, tl, p.off);
   ac_src(X0, rx, p.w, xbase, t1, tl, p.off);
-  double* flat = &tile[0][0][0];
-  for (int i = threadIdx.x; i < MAXD * (TY + 2) * (TX + 2); i += 256) flat[i] = 0.0;
+  cell_t* flat = &tile[0][0][0];
+  for (int i = threadIdx.x; i < MAXD * (TY + 2) * (TX + 2); i += 256) flat[i] = 0;
   __syncthreads();
   const int tid = threadIdx.x;
   const int Y = Y0 + (tid >> 5), X = X0 + (tid & 31);
-  if (Y < p.H && X < p.W) {
-    int y0, y1, x0, x1;
-    float ly, lx;
+  const bool active = Y < p.H && X < p.W;
+  int y0 = 0, y1 = 0, x0 = 0, x1 = 0;
+  float ly = 0.f, lx = 0.f, vmax = 0.f;
+  if (active) {
     ac_src(Y, ry, p.h, y0, y1, ly, p.off);
     ac_src(X, rx, p.w, x0, x1, lx, p.off);
     const float hy = 1.f - ly, hx = 1.f - lx;
@@ -223,13 +234,40 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       s_db[d0][tid] += (1.f - ld) * dl;
       s_db[d1][tid] += ld * dl;
     }
+    if (DET)
+      for (int d = 0; d < p.D; ++d) vmax = fmaxf(vmax, fabsf(s_db[d][tid]));
+  }
+  float qs = 0.f;
+  double qinv = 0.0;
+  if (DET) {                                   // workgroup-wide maximum -> a power-of-two scale with |q| <= 2^50 per contribution
+    vmax = dpf_wave_max(vmax);
+    if ((tid & 63) == 0) s_max[tid >> 6] = vmax;
+    __syncthreads();
+    vmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    if (vmax > 0.f && vmax < 3.0e38f) {
+      int e;
+      frexpf(vmax, &e);                        // vmax < 2^e
+      qs = ldexpf(1.f, 50 - e);
+      qinv = ldexp(1.0, e - 50);
+    }
+  }
+  if (active) {
+    const float hy = 1.f - ly, hx = 1.f - lx;
     const int ya = y0 - ybase, yb = y1 - ybase, xa = x0 - xbase, xb = x1 - xbase;
     for (int d = 0; d < p.D; ++d) {
       const float v = s_db[d][tid];
-      atomicAdd(&tile[d][ya][xa], (double)(hy * hx * v));
-      atomicAdd(&tile[d][ya][xb], (double)(hy * lx * v));
-      atomicAdd(&tile[d][yb][xa], (double)(ly * hx * v));
-      atomicAdd(&tile[d][yb][xb], (double)(ly * lx * v));
+      if (DET) {
+        const float vs = v * qs;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&tile[d][ya][xa]), (unsigned long long)(long long)rintf(hy * hx * vs));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&tile[d][ya][xb]), (unsigned long long)(long long)rintf(hy * lx * vs));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&tile[d][yb][xa]), (unsigned long long)(long long)rintf(ly * hx * vs));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&tile[d][yb][xb]), (unsigned long long)(long long)rintf(ly * lx * vs));
+      } else {
+        atomicAdd(reinterpret_cast<double*>(&tile[d][ya][xa]), (double)(hy * hx * v));
+        atomicAdd(reinterpret_cast<double*>(&tile[d][ya][xb]), (double)(hy * lx * v));
+        atomicAdd(reinterpret_cast<double*>(&tile[d][yb][xa]), (double)(ly * hx * v));
+        atomicAdd(reinterpret_cast<double*>(&tile[d][yb][xb]), (double)(ly * lx * v));
+      }
     }
   }
   __syncthreads();
@@ -237,7 +275,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int xx = i % (TX + 2);
     const int yy = (i / (TX + 2)) % (TY + 2);
     const int d = i / ((TX + 2) * (TY + 2));
-    const float v = (float)tile[d][yy][xx];
+    const float v = DET ? (float)((double)tile[d][yy][xx] * qinv) : (float)tile[d][yy][xx];
     const int y = ybase + yy, x = xbase + xx;
     if (v != 0.f && y < p.h && x < p.w) atomicAdd(&dk[(((long long)b * p.D + d) * p.h + y) * p.w + x], v);
   }
@@ -362,10 +400,21 @@ static int softargmin_bwd(const float* logits, const float* gpred, float* dlogit
   for (int i = 0; i < MAXL; ++i) p.disp[i] = i < L ? disp_host[i] : 0.f;
   if (hipMemsetAsync(dlogits, 0, sizeof(float) * (size_t)B * D * h * w, st) != hipSuccess) return DPF_ERR_LAUNCH;
   const long long blocks = (long long)B * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
-  if (D == 8 && L == 32 && off == 0.f)
+  if (dpf_deterministic()) {
+    // phases of tiles with disjoint low-resolution footprints: tiles P apart do not meet when (P * T - T + 1) * ratio >= 2
+    const float ry = off > 0.f ? (float)h / (float)H : (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f);
+    const float rx = off > 0.f ? (float)w / (float)W : (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f);
+    int Py = 1, Px = 1;
+    const int tilesY = (H + TY - 1) / TY, tilesX = (W + TX - 1) / TX;
+    while (Py < tilesY && (float)(Py * TY - TY + 1) * ry < 2.f) ++Py;
+    while (Px < tilesX && (float)(Px * TX - TX + 1) * rx < 2.f) ++Px;
+    for (int py = 0; py < Py; ++py)
+      for (int px = 0; px < Px; ++px)
+        hipLaunchKernelGGL(head_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p, Py, Px, py, px);
+  } else if (D == 8 && L == 32 && off == 0.f)
     hipLaunchKernelGGL(head_bwd_8x32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p);
   else
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p);
+    hipLaunchKernelGGL(head_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, logits, gpred, dlogits, p, 1, 1, 0, 0);
   return dpf_check_launch();
 }
 

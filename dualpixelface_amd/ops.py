@@ -125,6 +125,33 @@ def _t3(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
 
 
+# ----------------------------------------------------------------------------------------------- deterministic mode
+def set_deterministic(on):
+    """dpf_set_deterministic: every merge of partial results becomes order-independent (include/dpf_hip.h), so two runs of the same step
+    produce the same bits; slower.  DPF_DETERMINISTIC=1 in the environment makes it the default."""
+    lib().call('dpf_set_deterministic', int(bool(on)))
+
+
+def deterministic():
+    return bool(lib().cdll.dpf_get_deterministic())
+
+
+class deterministic_mode(object):
+    """``with deterministic_mode():`` -- the mode is on inside and restored afterwards."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = deterministic()
+        set_deterministic(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        set_deterministic(self.prev)
+        return False
+
+
 # ----------------------------------------------------------------------------------------------- convolution
 CONV_OPERANDS_BF16 = False      # current operand precision of the dense conv kernels; the autograd functions capture it at forward time
 
@@ -233,9 +260,11 @@ def _conv_wgrad_raw(g, x, wshape, stride, pad, dil):
     N, C, ID, IH, IW = x.shape
     K, QD, QH, QW = g.shape[1], g.shape[2], g.shape[3], g.shape[4]
     kd, kh, kw = wshape[2:]
-    smallk = K <= 4 and stride[2] == 1 and dil[2] == 1 and kw <= 3 and 16 * kd * kh <= 256
+    # (the register-window kernels for <= 4 output channels merge their workgroups with float atomics: deterministic mode takes the general
+    # kernels, whose slabs are folded in a fixed order)
+    smallk = K <= 4 and stride[2] == 1 and dil[2] == 1 and kw <= 3 and 16 * kd * kh <= 256 and not deterministic()
     dw = (torch.zeros if smallk else torch.empty)(wshape, dtype=torch.float32, device=x.device)
-    if K <= 4 and stride[2] == 1 and dil[2] == 1 and kw <= 3 and 16 * kd * kh <= 256:
+    if smallk:
         with _Timed('conv_smallk', 2.0 * N * K * C * kd * kh * kw * QD * QH * QW, 'skw N%d C%d K%d x%dx%dx%d' % (N, C, K, ID, IH, IW)):
             lib().call('dpf_conv_smallk_wgrad', _ptr(g), _ptr(x), _ptr(dw), N, C, ID, IH, IW, K, kd, kh, kw, *stride, *pad, *dil, _stream())
         return dw
@@ -1229,7 +1258,7 @@ def deform_conv_backward_raw(x, weight, bias, offset, go, stride, pad, dil, grou
     goff = torch.empty_like(offset)
     gw = torch.empty_like(weight)
     gb = torch.empty_like(bias)
-    ws = scratch(L.call('dpf_deform_conv3d_workspace_floats', C, K, kd * kh * kw), x.device, 'convw')
+    ws = scratch(L.call('dpf_deform_conv3d_backward_workspace_floats', B, C, D, H, W, K, kd * kh * kw), x.device, 'convw')
     cg = C if gi_channels is None else int(gi_channels)
     # algorithmic work: gcol GEMM for grad_offset (all C) + grad_weight GEMM + gcol GEMM for the cg channels of grad_input; bytes = x, offset,
     # grad_output read, grad_input (cg channels) and grad_offset written, once each

@@ -216,9 +216,20 @@ int dpf_softargmin_forward_strided(const float* logits, float* pred, float* prob
 int dpf_softargmin_backward_ex(const float* logits, const float* gpred, float* dlogits, const float* disp_host, int B, int D, int h, int w,
                                int L, int H, int W, int align_corners, void* stream);
 
+/* ---- deterministic mode (SURVEY section 5 "race detection"; the reference scatters with float atomics, deform_im2col_cuda.cuh:313-331, and
+ * is not reproducible either).  0 (default; environment DPF_DETERMINISTIC=1 changes the default): partial results of overlapping tiles /
+ * workgroups are merged with float atomics where that is fastest.  1: every such merge is order-independent -- one committing workgroup per
+ * output address (BatchNorm statistics and backward sums, bias gradients, depthwise / first-generation weight gradients, the loss sums),
+ * phased launches of tiles with disjoint footprints + integer LDS cells (soft-argmin head backward), integer accumulation (deformable conv
+ * grad_input through a shadow tensor, grad_weight scratch) -- so two runs of the same step produce the same bits.  Slower.  Process-wide. */
+int dpf_set_deterministic(int on);
+int dpf_get_deterministic(void);
+
 /* ---- deformable conv3d: the reference's pybind module `DCN` (src/module/dcn3d/src/vision.cpp:4-7,
  * src/module/dcn3d/src/deform_conv.h:10-29,49-69; deform_conv_cuda.cu:18-285) -- same argument order and meaning ----- */
 long long dpf_deform_conv3d_workspace_floats(int C, int K, int T);
+/* workspace of dpf_deform_conv3d_backward* for this problem: the above, plus (deterministic mode only) the integer shadow of grad_input */
+long long dpf_deform_conv3d_backward_workspace_floats(int B, int C, int D, int H, int W, int K, int T);
 int dpf_deform_conv3d_forward(const float* input, const float* weight, const float* bias, const float* offset, float* output, float* ws,
                               int B, int C, int D, int H, int W, int K, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
                               int pw, int dd, int dh, int dw, int group, int deformable_group, int im2col_step, void* stream);

@@ -1,0 +1,83 @@
+"""BASELINE configs[1] exactly as stated -- batch 4 of 512 x 768 pairs -- from the CPU oracle (fp32, recipe weights, synthetic_batch seed 21):
+tests/golden/c2_b4_oracle.npz.  The oracle (oracle/stereodpnet.py) is pinned to the imported reference at 32x48 ... 256x256 by
+make_golden.py / tests/test_oracle_golden.py; this file saves the ~3 x 3 minutes (and ~36 GB) its runs take at this size, which the GPU box's
+test run should not spend.  Three runs at 8 / 5 / 3 intra-op threads: the 8-thread run is the fixture, the largest pairwise distance per
+parameter gradient is the oracle's own fp32 noise at this size (the budget of tests/test_gpu_e2e.py::test_c2_batch4_... is K_SPREAD x it,
+the constant of the small fixtures).  An fp64 run does not fit this container at batch 4 (17.8 GB at batch 1).
+    python tests/golden/make_golden_c2_b4.py
+Stored: losses; every 4th pixel of pred_depth / pred_normal + {sum, sum|.|, sum .^2}; {sum, sum|.|, sum .^2} of the cost volume; the ANM level
+selection; per parameter gradient sum g^2 (8 threads) and the self-spread; 12 full gradients spread over the network (8 threads).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from dualpixelface_amd.recipe import synthetic_batch     # noqa: E402
+from oracle import recipe_state                          # noqa: E402
+from oracle.stereodpnet import StereoDPNetOracle         # noqa: E402
+
+FULL = ['aggregation.classif3.2.weight', 'cost_volume.attention_layer.mask_convs.0.weight', 'cost_volume.attention_layer.normalize.weight',
+        'normal_estimator.deform_conv1.conv_offset.bias', 'normal_estimator.deform_conv2.weight',
+        'normal_estimator.n_convs.5.0.weight', 'feature_extraction.firstconv.0.0.weight', 'feature_extraction.block1.prelu.weight',
+        'feature_extraction.fpn.inner_blocks.0.bias', 'aggregation.dres2.conv6.0.weight', 'aggregation.dres0.0.0.weight',
+        'feature_extraction.lastconv.2.0.weight']
+THREADS = (8, 5, 3)
+B, H, W, SEED = 4, 512, 768, 21
+
+
+def cs(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+def run(threads):
+    torch.set_num_threads(threads)
+    batch = synthetic_batch(B, H, W, seed=SEED, mask_mode='bern')
+    st = recipe_state()
+    orc = StereoDPNetOracle(st, training=True)
+    res = orc.forward(batch)
+    res['final_loss'].backward()
+    grads = {k: t.grad.detach().clone() for k, t in st.items() if getattr(t, 'grad', None) is not None}
+    return res, orc, grads
+
+
+def main():
+    out = {'batch_args': np.array([B, H, W, SEED]), 'mask_mode': np.array('bern'), 'threads': np.array(THREADS)}
+    runs = []
+    for i, t in enumerate(THREADS):
+        res, orc, grads = run(t)
+        print('threads', t, 'loss %.7f' % res['final_loss'].item(), flush=True)
+        if i == 0:
+            for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
+                out[k] = np.float64(res[k].item())
+            for k in ('pred_depth', 'pred_normal'):
+                out[k + '_s'] = res[k].detach()[..., ::4, ::4].numpy().astype(np.float32)
+                out[k + '_cs'] = cs(res[k])
+            out['volume_cs'] = cs(orc.taps['volume'])
+            out['anm_idx'] = orc.taps['anm_idx'].to(torch.uint8).numpy()
+        runs.append(grads)
+        del res, orc
+    names = sorted(runs[0].keys())
+    spread = []
+    for n in names:
+        ref = max(runs[0][n].double().norm().item(), 1e-30)
+        s = 0.0
+        for i in range(len(runs)):
+            for j in range(i + 1, len(runs)):
+                s = max(s, (runs[i][n].double() - runs[j][n].double()).norm().item() / ref)
+        spread.append(s)
+    out['grad_names'] = np.array(names)
+    out['grad_sumsq'] = np.array([float((runs[0][n].double() ** 2).sum()) for n in names], dtype=np.float64)
+    out['grad_spread'] = np.array(spread, dtype=np.float64)
+    for k in FULL:
+        out['grad::' + k] = runs[0][k].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'c2_b4_oracle.npz'), **out)
+    print('saved', len(names), 'gradient checksums; median self-spread %.2e' % float(np.median(spread)))
+
+
+if __name__ == '__main__':
+    main()

@@ -537,44 +537,38 @@ def test_train_256x256_vs_reference_fixture(golden_dir):
     assert len(rels) > 200 and float(np.median(rels)) <= 2e-2, (len(rels), float(np.median(rels)))
 
 
-# relative L2 distance of the HIP gradients from the imported reference's (fp32, CPU) on MI355X (round 4), per tensor the LARGEST over the
-# equally valid fp32 kernel paths (profiles/r04_grad_rel_by_kernel_path.txt); the test allows 2.5 x these.  The reference's own fp32
-# gradients sit ~1e-2 from the fp64 oracle through this random-weight network (test_gradients_no_worse_than_the_reference_vs_fp64), so the
-# budgets are conditioning, not kernel error: the head agrees to 2e-6.
-GRAD_REL_MEASURED = {
-    'train_32x48_b2': {'aggregation.classif3.2.weight': 2.5e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0053,
-                       'cost_volume.attention_layer.normalize.weight': 0.0063, 'normal_estimator.deform_conv1.conv_offset.bias': 0.03,
-                       'normal_estimator.n_convs.5.0.weight': 0.00022, 'feature_extraction.firstconv.0.0.weight': 0.0061,
-                       'feature_extraction.block1.prelu.weight': 0.0068, 'feature_extraction.fpn.inner_blocks.0.bias': 0.0073,
-                       'aggregation.dres2.conv6.0.weight': 0.0022},
-    'train_64x96_b1': {'aggregation.classif3.2.weight': 2e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0073,
-                       'cost_volume.attention_layer.normalize.weight': 0.0077,
-                       'normal_estimator.deform_conv1.conv_offset.bias': 0.021, 'normal_estimator.n_convs.5.0.weight': 0.0023,
-                       'feature_extraction.firstconv.0.0.weight': 0.0093, 'feature_extraction.block1.prelu.weight': 0.04,
-                       'feature_extraction.fpn.inner_blocks.0.bias': 0.011, 'aggregation.dres2.conv6.0.weight': 0.0034},
-    'train_128x128_b2': {'aggregation.classif3.2.weight': 1.4e-06, 'cost_volume.attention_layer.mask_convs.0.weight': 0.0077,
-                         'cost_volume.attention_layer.normalize.weight': 0.0095,
-                         'normal_estimator.deform_conv1.conv_offset.bias': 0.027, 'normal_estimator.n_convs.5.0.weight': 0.0054,
-                         'feature_extraction.firstconv.0.0.weight': 0.011, 'feature_extraction.block1.prelu.weight': 0.015,
-                         'feature_extraction.fpn.inner_blocks.0.bias': 0.013, 'aggregation.dres2.conv6.0.weight': 0.0019},
-}
+# ---- gradient budgets tied to the REFERENCE's own fp32 noise (tests/golden/make_golden_grad_spread.py -> tests/golden/grad_spread.npz).
+# For every parameter tensor of the three gradient fixtures the imported reference was run at 1 / 2 / 4 / 8 threads (four fp32 summation
+# orders of the same program) and once in fp64.  noise[t] = max(self-spread over the thread pairs, max over the thread counts of the fp32
+# run's distance to the fp64 run): how far the reference's own gradient of that tensor moves when nothing but the order of its fp32 sums
+# changes.  The HIP path is one more summation order; its distance from the committed (8-thread) fixture may be K_SPREAD x that noise, its
+# distance from the reference's fp64 gradient K_FP64 x the reference's own (worst thread count) -- constants stated once, for every tensor
+# of every fixture.  A path that loses precision (bf16-rounded operands) sits 30-100 x outside.
+K_SPREAD = 4.0
+K_FP64 = 3.0
+GRAD_FLOOR = 1e-5          # the head's last layer: noise 1e-6, nothing to amplify it
+
+
+def ref_noise(golden_dir, tag):
+    s = np.load(golden_dir + '/grad_spread.npz')
+    names = [str(n) for n in s[tag + '/names']]
+    noise = np.maximum(s[tag + '/spread'], s[tag + '/d64'].max(1))
+    return s, dict(zip(names, noise)), dict(zip(names, s[tag + '/d64'].max(1))), dict(zip(names, s[tag + '/norm64']))
 
 
 @pytest.mark.parametrize('tag', ['train_32x48_b2', 'train_64x96_b1', 'train_128x128_b2'])
 def test_gradients_and_adam_step_vs_reference_fixture(golden_dir, tag):
     """Gradients and the parameters after ONE Adam step against what the imported reference produced (tests/golden/make_golden.py:
-    full gradients of 10 parameters, {sum, sum|.|, sum .^2} of every gradient, and of every state_dict entry after
-    optimizer.step()).  Measured (tools/parity_probe.py): the last layers agree to 1e-6; through ~100 fp32 conv + BatchNorm layers of
-    this random-weight network the reference's own fp32 gradients sit ~1e-2 from the fp64 oracle, and so do ours -- hence per-tensor
-    budgets of 2.5 x the measured distance (the head 1e-5), 5e-3 on the median checksum.  The distance is rounding noise: it moves by up
-    to 10 x between equally valid fp32 kernel paths (exact-f32 MFMA / bf16-split products, tile orders, one or two streams:
-    profiles/r04_grad_rel_by_kernel_path.txt, tools/debug/grad_rel_measure.py), so GRAD_REL_MEASURED holds, per tensor, the LARGEST
-    distance over those paths -- a budget tied to one path's rounding pattern fails on the next legitimate change of summation order."""
+    full gradients of 10 parameters, {sum, sum|.|, sum .^2} of every gradient, and of every state_dict entry after optimizer.step()).
+    Through ~100 fp32 conv + BatchNorm layers of this random-weight network the reference's own gradients move by 1e-3 ... 2e-2 when only
+    its thread count changes; the budget of each tensor is K_SPREAD x ITS noise in the reference (grad_spread.npz), the head 1e-5."""
     g = np.load(golden_dir + '/e2e_%s.npz' % tag)
+    _, noise, _, _ = ref_noise(golden_dir, tag)
     model = build_model(True)
     res = model.train_step(load_batch(g))
     close(res['final_loss'], g['final_loss'], 1e-5, 'final_loss')
     pd = dict(model.named_parameters())
+    report = []
     for k in g.files:
         if not k.startswith('grad::'):
             continue
@@ -583,18 +577,26 @@ def test_gradients_and_adam_step_vs_reference_fixture(golden_dir, tag):
             continue                                                          # analytically zero (conv bias in front of BatchNorm): rounding noise
         mine = pd[k[6:]].grad.detach().cpu().double()
         rel = ((mine - ref).norm() / ref.norm()).item()
-        budget = 2.5 * GRAD_REL_MEASURED[tag].get(k[6:], 1.6e-2)
-        assert rel <= max(budget, 1e-5), (k, rel, budget)
-    rels = []
-    for n, c in zip((str(s) for s in g['grad_names']), g['grad_cs']):
-        if n in pd and pd[n].grad is not None and c[2] > 1e-12:
+        budget = max(K_SPREAD * noise[k[6:]], GRAD_FLOOR)
+        report.append((rel / noise[k[6:]], k[6:], rel, noise[k[6:]]))
+        assert rel <= budget, (k, rel, budget, noise[k[6:]])
+    print(tag, 'distance / reference noise per tensor:', ', '.join('%s %.2f' % (n.split('.')[-3] + '.' + n.split('.')[-1], r) for r, n, _, _ in sorted(report, reverse=True)))
+    # every other parameter through its sum of squares (|S_mine - S_ref| / S_ref <= 2 d + d^2 for a relative L2 distance d), same K_SPREAD
+    rels, over = [], []
+    for n, c in zip((str(s_) for s_ in g['grad_names']), g['grad_cs']):
+        if n in pd and pd[n].grad is not None and c[2] > 1e-12 and noise.get(n, 1.0) < 0.25:
             t = pd[n].grad.detach().double()
-            rels.append(abs((t * t).sum().item() - c[2]) / c[2])
-    assert len(rels) > 250 and float(np.median(rels)) <= 5e-3, (len(rels), float(np.median(rels)))
+            r = abs((t * t).sum().item() - c[2]) / c[2]
+            rels.append(r)
+            d = max(K_SPREAD * noise[n], GRAD_FLOOR)
+            if r > 2 * d + d * d:
+                over.append((n, r, d))
+    assert len(rels) > 250 and not over, over[:5]
+    assert float(np.median(rels)) <= 5e-3, float(np.median(rels))
     # parameters after one Adam step (lr 1e-4, eps 1e-5: SURVEY a10): per-element mean deviation of every tensor <= 0.2 lr
     sd = model.state_dict()
     checked = 0
-    for n, c in zip((str(s) for s in g['post_names']), g['post_cs']):
+    for n, c in zip((str(s_) for s_ in g['post_names']), g['post_cs']):
         if n not in sd or not torch.is_floating_point(sd[n]) or 'running_' in n or n.endswith('.grid'):
             continue
         t = sd[n].detach().double()
@@ -604,20 +606,14 @@ def test_gradients_and_adam_step_vs_reference_fixture(golden_dir, tag):
     assert checked > 280
 
 
-def test_gradients_no_worse_than_the_reference_vs_fp64(golden_dir):
-    """For the 10 parameters whose full reference gradient is in the fixture: our distance to the fp64 oracle's gradient against the
-    reference's own fp32 distance.  Both are rounding noise amplified by ~100 layers, and the ratio of two noise draws scatters: over the
-    equally valid fp32 kernel paths (exact-f32 MFMA everywhere, bf16-split products, tile orders, one / two streams) the geometric mean
-    of the 9 ratios is 0.7-1.8 and single tensors reach 3.3 -- on the exact-f32 path as well (profiles/r04_grad_fp64_by_kernel_path.txt,
-    tools/debug/grad_fp64_measure.py).  Bounds: geometric mean <= 2.5, every tensor <= 4 x the reference's distance + 1e-3 -- a kernel
-    that loses precision (bf16-rounded operands: 30-100 x) fails both by a wide margin."""
+@pytest.mark.parametrize('tag', ['train_32x48_b2', 'train_64x96_b1', 'train_128x128_b2'])
+def test_gradients_no_worse_than_the_reference_vs_fp64(golden_dir, tag):
+    """The yardstick is the REFERENCE run in fp64 (grad_spread.npz: full fp64 gradients of the 10 tensors the fixtures store): the HIP
+    gradient's distance to it against the reference's own fp32 distance (the worst of its four thread counts -- they differ by up to 27 x for
+    one tensor, so one draw is not a bound).  Per tensor <= K_FP64 x, geometric mean over the tensors <= 2."""
     import math
-    from oracle import recipe_state
-    from oracle.stereodpnet import StereoDPNetOracle
-    g = np.load(golden_dir + '/e2e_train_32x48_b2.npz')
-    st = recipe_state(dtype=torch.float64)
-    orc = StereoDPNetOracle(st, training=True)
-    orc.forward({k[3:]: torch.from_numpy(g[k]).double() for k in g.files if k.startswith('in_')})['final_loss'].backward()
+    g = np.load(golden_dir + '/e2e_%s.npz' % tag)
+    s, _, d64max, _ = ref_noise(golden_dir, tag)
     model = build_model(True)
     model.train_step(load_batch(g))
     pd = dict(model.named_parameters())
@@ -625,16 +621,137 @@ def test_gradients_no_worse_than_the_reference_vs_fp64(golden_dir):
     for k in g.files:
         if not k.startswith('grad::'):
             continue
-        exact = st[k[6:]].grad
-        if exact is None or exact.norm().item() < 1e-6:
+        exact = torch.from_numpy(s[tag + '/grad64::' + k[6:]]).double()
+        if exact.norm().item() < 1e-6:
             continue
-        ref32 = torch.from_numpy(g[k]).double()
         mine = pd[k[6:]].grad.detach().cpu().double()
-        e_ref = ((ref32 - exact).norm() / exact.norm()).item()
+        e_ref = max(d64max[k[6:]], 1e-7)
         e_mine = ((mine - exact).norm() / exact.norm()).item()
-        assert e_mine <= 4.0 * e_ref + 1e-3, (k, e_mine, e_ref)
-        logs.append(math.log(max(e_mine, 1e-12) / max(e_ref, 1e-12)))
-    assert len(logs) >= 8 and math.exp(sum(logs) / len(logs)) <= 2.5, math.exp(sum(logs) / len(logs))
+        assert e_mine <= max(K_FP64 * e_ref, GRAD_FLOOR), (k, e_mine, e_ref)
+        logs.append(math.log(max(e_mine, 1e-12) / e_ref))
+    gm = math.exp(sum(logs) / len(logs))
+    print(tag, 'distance to the reference fp64 gradient / the reference fp32 distance: geometric mean %.2f, max %.2f' % (gm, math.exp(max(logs))))
+    assert len(logs) >= 8 and gm <= 2.0, gm
+
+
+def test_c2_batch4_forward_loss_and_gradients_vs_oracle_fixture(golden_dir):
+    """BASELINE configs[1] AS STATED -- batch 4 of 512 x 768 pairs -- against the CPU oracle's fp32 run at that size
+    (tests/golden/make_golden_c2_b4.py: 3 x 3 minutes and 36 GB of host memory, cached as a fixture; the oracle is pinned to the imported
+    reference by the smaller fixtures).  Forward: every 4th pixel of the predictions + checksums, the cost volume's checksums, the ANM level
+    selection, the losses.  Backward: 12 full gradients and sum g^2 of every gradient, each within K_SPREAD x the oracle's own fp32 noise in
+    that tensor -- the largest distance between its 8 / 5 / 3-thread runs, floored by the network-wide median of that distance (three thread
+    counts under-sample the noise of tensors whose kernels do not re-chunk)."""
+    from dualpixelface_amd.recipe import synthetic_batch
+    g = np.load(golden_dir + '/c2_b4_oracle.npz')
+    B, H, W, seed = (int(v) for v in g['batch_args'])
+    batch = synthetic_batch(B, H, W, seed=seed, mask_mode=str(g['mask_mode']))
+    model = build_model(True)
+    res = model.train_step({k: v.to(DEV) for k, v in batch.items()})
+    vol = model.last_taps['volume'].detach().double()
+    assert abs(float(vol.abs().sum()) - g['volume_cs'][1]) <= 2e-5 * g['volume_cs'][1] and abs(float((vol * vol).sum()) - g['volume_cs'][2]) <= 4e-5 * g['volume_cs'][2]
+    close(res['pred_depth'][..., ::4, ::4], g['pred_depth_s'], None, 'pred_depth', atol=3e-3)
+    pdd = res['pred_depth'].detach().double()
+    assert abs(float(pdd.sum()) - g['pred_depth_cs'][0]) <= 3e-4 * pdd.numel()
+    # ANM level selection (discontinuous, see the batch-1 test): at most 8 flipped quarter-resolution pixels per sample
+    idx_gpu = model.last_anm_idx.cpu().long()
+    idx_ref = torch.from_numpy(g['anm_idx']).long()
+    flipped = (idx_gpu != idx_ref).any(1, keepdim=True).float()                        # [B, 1, h, w]
+    nflip = int(flipped.sum())
+    assert nflip <= 8 * B, nflip
+    near = torch.nn.functional.max_pool2d(flipped, 65, 1, 32).bool()                   # 32 quarter-resolution pixels around a flip = the ::4 grid
+    err = (res['pred_normal'][..., ::4, ::4].detach().cpu().double() - torch.from_numpy(g['pred_normal_s']).double()).abs()   # [B, 1, 3, h, w]
+    outside = err.masked_fill(near.unsqueeze(2), 0.0)
+    assert float(outside.max()) <= 1e-3 and float(err.max()) <= 0.2, (float(outside.max()), float(err.max()), nflip)
+    close(res['smoothL1_loss'], g['smoothL1_loss'], 2e-4, 'smoothL1_loss')
+    for k in ('cosine_loss', 'final_loss'):
+        close(res[k], g[k], 2e-4 if nflip == 0 else 5e-3, k)
+    # ---- gradients
+    names = [str(n) for n in g['grad_names']]
+    spread = g['grad_spread']
+    med = float(np.median(spread))
+    noise = {n: max(float(sp), med) for n, sp in zip(names, spread)}
+    noise['aggregation.classif3.2.weight'] = float(spread[names.index('aggregation.classif3.2.weight')])    # the head: nothing amplifies its noise
+    pd = dict(model.named_parameters())
+    report = []
+    for k in g.files:
+        if not k.startswith('grad::'):
+            continue
+        ref = torch.from_numpy(g[k]).double()
+        mine = pd[k[6:]].grad.detach().cpu().double()
+        rel = ((mine - ref).norm() / ref.norm()).item()
+        loose = nflip > 0 and 'normal_estimator' in k
+        budget = max(K_SPREAD * noise[k[6:]], GRAD_FLOOR) * (10.0 if loose else 1.0)
+        report.append((rel / noise[k[6:]], k[6:]))
+        assert rel <= budget, (k, rel, budget, nflip)
+    print('c2 batch 4: flipped ANM pixels %d; distance / oracle noise per tensor:' % nflip, ', '.join('%s %.2f' % (n, r) for r, n in sorted(report, reverse=True)))
+    over, rels = [], []
+    for n, c in zip(names, g['grad_sumsq']):
+        if n in pd and pd[n].grad is not None and c > 1e-12 and noise[n] < 0.25 and not (nflip > 0 and 'normal_estimator' in n):
+            t = pd[n].grad.detach().double()
+            r = abs((t * t).sum().item() - c) / c
+            rels.append(r)
+            d = max(K_SPREAD * noise[n], GRAD_FLOOR)
+            if r > 2 * d + d * d:
+                over.append((n, r, d))
+    assert len(rels) > 200 and not over, over[:5]
+
+
+def _train_once(g):
+    model = build_model(True)
+    res = model.train_step(load_batch(g))
+    torch.cuda.synchronize()
+    out = {'pred_depth': res['pred_depth'].detach().clone(), 'pred_normal': res['pred_normal'].detach().clone(),
+           'final_loss': res['final_loss'].detach().clone(), 'anm_idx': model.last_anm_idx.clone()}
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model, out, grads, state
+
+
+def test_deterministic_mode_two_runs_are_bitwise_equal(golden_dir):
+    """dpf_set_deterministic(1) (VERDICT r4 "missing #1"): two whole train steps from the same weights and batch produce the
+    SAME BITS -- predictions, loss, every parameter gradient, every parameter and buffer after the Adam step -- with the default stream
+    overlap on (weight gradients on a side stream, feature passes on two streams).  The same step in the default mode is allowed to differ
+    (float atomics merge overlapping tiles in arrival order); it must agree with the deterministic one to the run-to-run noise."""
+    from dualpixelface_amd import ops
+    g = np.load(golden_dir + '/e2e_train_128x128_b2.npz')
+    with ops.deterministic_mode():
+        assert ops.deterministic()
+        _, o1, g1, s1 = _train_once(g)
+        _, o2, g2, s2 = _train_once(g)
+    assert not ops.deterministic()
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    assert set(g1) == set(g2) and len(g1) > 280
+    diff = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+    assert not diff, diff[:10]
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    _, o3, g3, _ = _train_once(g)                      # default mode: same numbers up to the float-atomic noise
+    assert (o1['pred_depth'] - o3['pred_depth']).abs().max().item() <= 2e-3
+    assert abs(o1['final_loss'].item() - o3['final_loss'].item()) <= 1e-5 * abs(o3['final_loss'].item())
+    tot = torch.cat([g1[n].flatten() for n in sorted(g1)]); tot3 = torch.cat([g3[n].flatten() for n in sorted(g1)])
+    assert ((tot - tot3).norm() / tot3.norm()).item() <= 2e-3
+
+
+@pytest.mark.parametrize('tag', ['train_32x48_b2', 'train_128x128_b2'])
+def test_deterministic_mode_gradients_vs_reference_fixture(golden_dir, tag):
+    """The order-independent kernels compute the same gradients: the reference-derived budgets of
+    test_gradients_and_adam_step_vs_reference_fixture hold in deterministic mode too."""
+    from dualpixelface_amd import ops
+    g = np.load(golden_dir + '/e2e_%s.npz' % tag)
+    _, noise, _, _ = ref_noise(golden_dir, tag)
+    with ops.deterministic_mode():
+        model, out, grads, _ = _train_once(g)
+    close(out['final_loss'], g['final_loss'], 1e-5, 'final_loss')
+    close(out['pred_depth'], g['pred_depth'], None, 'pred_depth', atol=2e-3)
+    for k in g.files:
+        if not k.startswith('grad::'):
+            continue
+        ref = torch.from_numpy(g[k]).double()
+        if ref.norm().item() < 1e-6:
+            continue
+        rel = ((grads[k[6:]].cpu().double() - ref).norm() / ref.norm()).item()
+        assert rel <= max(K_SPREAD * noise[k[6:]], GRAD_FLOOR), (k, rel, noise[k[6:]])
 
 
 @pytest.mark.parametrize('bn_cat', ['0', '1'])

@@ -31,6 +31,9 @@ SETS = [
     # 4-byte stores in the conv tile epilogue (what outputs with W % 4 != 0 or an unaligned base get), bf16 operands on igemm2's own kernel
     ({'DPF_G2_VEC_STORE': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics'),
     ({'DPF_IGEMM3_BF': '0'}, 'test_conv_operands_bf16 or test_conv2d_bf16_operands'),
+    # deterministic mode (dpf_set_deterministic): one committing workgroup per address, phased tiles, integer accumulation -- same answers
+    ({'DPF_DETERMINISTIC': '1'}, 'test_deform_conv or test_softargmin or test_batchnorm or test_depthwise or test_losses_against or '
+                                 'test_conv_forward_backward or test_sync_batchnorm or test_norm_act_concat or test_conv_transpose3d'),
     # first-generation dense conv kernels (what unaligned shapes fall back to)
     ({'DPF_IGEMM2': '0', 'DPF_WGRAD2': '0', 'DPF_IGEMM2_TR2': '0'}, 'test_conv_forward_backward'),
 ]

@@ -289,3 +289,40 @@ def test_stereonet_oracle_against_reference(golden_dir):
     with torch.no_grad():
         out = ev.forward(batch)
     _close(out['pred_depth'], g['eval_pred_depth'], 1e-4, 'stereonet eval pred_depth')
+
+
+def test_grad_spread_fixture_belongs_to_the_gradient_fixtures_and_pins_the_oracle_in_fp64(golden_dir):
+    """tests/golden/grad_spread.npz (make_golden_grad_spread.py: the imported reference at 1 / 2 / 4 / 8 threads and in fp64) is what the GPU
+    gradient budgets are derived from.  (i) Its 8-thread run IS the committed e2e fixture (sum g^2 of every gradient equal); (ii) the spreads
+    are sane (the head's last layer ~1e-6, a median of a few 1e-3, analytically-zero gradients pure noise); (iii) the ORACLE run in fp64
+    reproduces the REFERENCE run in fp64 -- gradients of the well-conditioned 32x48 / batch 2 fixture to 1e-5 (fp32-typed constants inside
+    the reference's fp64 run leave ~1e-8 relative input differences, which this network amplifies ~50 x there)."""
+    s = np.load(golden_dir + '/grad_spread.npz')
+    assert [int(t) for t in s['threads']] == [1, 2, 4, 8]
+    for tag in ('train_32x48_b2', 'train_64x96_b1', 'train_128x128_b2'):
+        g = np.load(golden_dir + '/e2e_%s.npz' % tag)
+        names = [str(n) for n in s[tag + '/names']]
+        assert names == [str(n) for n in g['grad_names']]
+        np.testing.assert_allclose(s[tag + '/check8'], g['grad_cs'][:, 2], rtol=1e-12, atol=0)
+        sp = dict(zip(names, s[tag + '/spread']))
+        assert sp['aggregation.classif3.2.weight'] < 5e-6
+        assert 5e-4 < float(np.median(s[tag + '/spread'])) < 3e-2
+        assert s[tag + '/d64'].shape == (len(names), 4)
+    tag = 'train_32x48_b2'
+    g = np.load(golden_dir + '/e2e_%s.npz' % tag)
+    st = recipe_state(dtype=torch.float64)
+    orc = StereoDPNetOracle(st, training=True)
+    res = orc.forward({k: (v.double() if v.is_floating_point() else v) for k, v in _batch(g).items()})
+    res['final_loss'].backward()
+    assert abs(res['final_loss'].item() - float(s[tag + '/loss64'])) <= 1e-7 * abs(float(s[tag + '/loss64']))
+    n = 0
+    for k in s.files:
+        if not k.startswith(tag + '/grad64::'):
+            continue
+        exact = torch.from_numpy(s[k])
+        if exact.norm().item() < 1e-9:
+            continue                                                        # analytically zero (a conv bias in front of BatchNorm)
+        rel = ((st[k.split('::')[1]].grad - exact).norm() / exact.norm()).item()
+        assert rel <= 1e-5, (k, rel)
+        n += 1
+    assert n >= 9
