@@ -115,6 +115,50 @@ def self_launch(n):
     sys.exit(r.returncode)
 
 
+def dry_run(args, rank, world):
+    """Everything `bench.py --gpus N` does around the GPU work, on the host: the ranks exist and see each other, every rank builds the same
+    model (parameters broadcast from rank 0), the reducer cuts the flat gradient arena into its 3 named buckets, one staged exchange in the
+    order the backward pass fires it ('normal', 'aggregation', then the feature extractor at stage_finish) sums a per-rank arena over the
+    ranks, and rank 0 prints the bench line's launch-related fields."""
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.distributed import make_reducer, broadcast_flat
+    from dualpixelface_amd.plugin import STEREODPNET
+    import torch.distributed as dist
+    torch.manual_seed(1 + rank)                       # different initial weights per rank: the broadcast must make them equal
+    model = STEREODPNET(load_option())
+    broadcast_flat(model.flat_parameters(), 0)
+    reducer = make_reducer(model) if world > 1 else None
+    psum = model.flat_parameters().double().sum().reshape(1)
+    ranks_seen, same_weights, summed_ok, log, ncoll = 1, True, True, [], 0
+    if world > 1:
+        flat_g = model.flat_gradients(zero=True)
+        flat_g.fill_(float(rank + 1))
+        reducer.stage_begin()
+        reducer.stage_launch(reducer.stage_of.get('normal'))
+        reducer.stage_launch(reducer.stage_of.get('aggregation'))
+        reducer.stage_finish()
+        summed_ok = bool((flat_g == float(world * (world + 1) // 2)).all())
+        log, ncoll = list(reducer.log), reducer.collective_calls
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        lo, hi = psum.clone(), psum.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same_weights = bool(lo.item() == hi.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'train samples/sec, StereoDPNet 1024x1536 DP pair', 'dry_run': True, 'n_gpus': world, 'value': None,
+                          'scaling': 'weak', 'ranks_seen': ranks_seen, 'same_weights_on_every_rank': same_weights,
+                          'gradient_arena_summed_over_ranks': summed_ok, 'gradient_collectives_per_step': ncoll,
+                          'stage_log': [list(e) for e in log], 'buckets': len(reducer.buckets) if reducer else 0,
+                          'collective_backend': dist.get_backend() if dist.is_initialized() else None,
+                          'config': {'workload': 'StereoDPNet train step, %d x %dx%d synthetic DP pairs per GPU' % (args.batch, args.height, args.width),
+                                     'global_batch': args.batch * world, 'parallelism': 'dp%d' % world}}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -142,6 +186,10 @@ def main():
     ap.add_argument('--force-dist', action='store_true',
                     help="with --gpus 1: still create a (world-size-1) 'nccl' process group and send every gradient bucket through it -- the "
                          "staged reducer (tensor-hook launches, side-stream joins, stage_finish, fused Adam) runs through RCCL's stream handling")
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launch path only: parse, start / join the ranks, build the model and the 3-bucket reducer on the HOST, exchange one '
+                         'staged gradient arena over the process group (DPF_DIST_BACKEND=gloo on a box without GPUs), print the line with '
+                         '"dry_run": true -- no GPU call is made (tests/test_host_logic.py covers `--gpus 8` this way)')
     ap.add_argument('--workload', default='train', choices=['train', 'psm_volume', 'cost_volume', 'cost_volume_fix'],
                     help="'train' = the BASELINE metric; the other two time one HBM-bound stage in isolation (BASELINE configs[3], SURVEY a2-a4)")
     args = ap.parse_args()
@@ -173,6 +221,8 @@ def main():
         torch.cuda.set_device(0)
         dist.init_process_group(os.environ.get('DPF_DIST_BACKEND') or 'nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or without RANK set)' % (args.gpus, world, args.gpus)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if os.environ.get('DPF_ONE_DEVICE'):
         local = 0
     dev = torch.device('cuda', local)

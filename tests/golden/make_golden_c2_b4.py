@@ -1,9 +1,12 @@
 """BASELINE configs[1] exactly as stated -- batch 4 of 512 x 768 pairs -- from the CPU oracle (fp32, recipe weights, synthetic_batch seed 21):
 tests/golden/c2_b4_oracle.npz.  The oracle (oracle/stereodpnet.py) is pinned to the imported reference at 32x48 ... 256x256 by
 make_golden.py / tests/test_oracle_golden.py; this file saves the ~3 x 3 minutes (and ~36 GB) its runs take at this size, which the GPU box's
-test run should not spend.  Three runs at 8 / 5 / 3 intra-op threads: the 8-thread run is the fixture, the largest pairwise distance per
-parameter gradient is the oracle's own fp32 noise at this size (the budget of tests/test_gpu_e2e.py::test_c2_batch4_... is K_SPREAD x it,
-the constant of the small fixtures).  An fp64 run does not fit this container at batch 4 (17.8 GB at batch 1).
+test run should not spend.  Five fp32 runs of the same program in different summation orders: 8 / 5 / 3 intra-op threads, the batch in another sample order (BatchNorm
+and weight-gradient sums run over the samples in that order; results are permuted back), and oneDNN switched off (ATen's native convolution
+kernels).  The 8-thread run is the fixture; the largest pairwise distance per parameter gradient is the oracle's own fp32 noise at this size
+(the budget of tests/test_gpu_e2e.py::test_c2_batch4_... is K_SPREAD x it, the constant of the small fixtures).  An fp64 run does not fit
+this container at batch 4 (17.8 GB at batch 1); thread counts alone are correlated draws (most oneDNN kernels block the same way), hence
+the two other reorderings.
     python tests/golden/make_golden_c2_b4.py
 Stored: losses; every 4th pixel of pred_depth / pred_normal + {sum, sum|.|, sum .^2}; {sum, sum|.|, sum .^2} of the cost volume; the ANM level
 selection; per parameter gradient sum g^2 (8 threads) and the self-spread; 12 full gradients spread over the network (8 threads).
@@ -25,7 +28,8 @@ FULL = ['aggregation.classif3.2.weight', 'cost_volume.attention_layer.mask_convs
         'normal_estimator.n_convs.5.0.weight', 'feature_extraction.firstconv.0.0.weight', 'feature_extraction.block1.prelu.weight',
         'feature_extraction.fpn.inner_blocks.0.bias', 'aggregation.dres2.conv6.0.weight', 'aggregation.dres0.0.0.weight',
         'feature_extraction.lastconv.2.0.weight']
-THREADS = (8, 5, 3)
+RUNS = (('threads 8', 8, None, True), ('threads 5', 5, None, True), ('threads 3', 3, None, True), ('batch order 2,0,3,1', 8, (2, 0, 3, 1), True),
+        ('oneDNN off', 8, None, False))
 B, H, W, SEED = 4, 512, 768, 21
 
 
@@ -34,23 +38,30 @@ def cs(t):
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
 
 
-def run(threads):
+def run(threads, perm, onednn):
     torch.set_num_threads(threads)
+    torch.backends.mkldnn.enabled = bool(onednn)
     batch = synthetic_batch(B, H, W, seed=SEED, mask_mode='bern')
+    if perm is not None:
+        idx = torch.tensor(perm)
+        batch = {k: (v[idx].contiguous() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in batch.items()}
     st = recipe_state()
     orc = StereoDPNetOracle(st, training=True)
     res = orc.forward(batch)
     res['final_loss'].backward()
+    torch.backends.mkldnn.enabled = True
     grads = {k: t.grad.detach().clone() for k, t in st.items() if getattr(t, 'grad', None) is not None}
     return res, orc, grads
 
 
 def main():
-    out = {'batch_args': np.array([B, H, W, SEED]), 'mask_mode': np.array('bern'), 'threads': np.array(THREADS)}
+    out = {'batch_args': np.array([B, H, W, SEED]), 'mask_mode': np.array('bern'), 'runs': np.array([r[0] for r in RUNS])}
     runs = []
-    for i, t in enumerate(THREADS):
-        res, orc, grads = run(t)
-        print('threads', t, 'loss %.7f' % res['final_loss'].item(), flush=True)
+    import time
+    for i, (label, t, perm, onednn) in enumerate(RUNS):
+        t0 = time.time()
+        res, orc, grads = run(t, perm, onednn)
+        print(label, 'loss %.7f' % res['final_loss'].item(), '%.0f s' % (time.time() - t0), flush=True)
         if i == 0:
             for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
                 out[k] = np.float64(res[k].item())

@@ -114,3 +114,41 @@ def test_stat_exchange_world2():
     M2 = (M2_r + n[:, None] * (mean_r - mu) ** 2).sum(0)
     assert torch.allclose(mu.float(), x.mean((0, 2, 3)), atol=1e-5)
     assert torch.allclose((M2 / n.sum()).float(), x.var((0, 2, 3), unbiased=False), atol=1e-4)
+
+
+def _bench_line(cmd, env_extra):
+    import json
+    import subprocess
+    env = dict(os.environ, DPF_DIST_BACKEND='gloo', **env_extra)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-800:])
+    return json.loads(lines[0])
+
+
+def test_bench_gpus8_launch_path_dry_run():
+    """`bench.py --gpus 8` exactly as the driver launches it (torch.distributed.run, 8 ranks on 127.0.0.1) with --dry-run: everything around the
+    GPU work runs -- rank / world from the environment, the model built on every rank and broadcast from rank 0, the flat gradient arena cut
+    into the 3 named buckets, one staged exchange in backward order summed over the 8 ranks, ONE JSON line from rank 0 -- and no GPU call is
+    made (gloo; this container has no GPU).  No scaling number comes out of this: it shows the N = 8 path starts, pairs its collectives and
+    stops cleanly."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    line = _bench_line([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--dry-run'], {})
+    assert line['dry_run'] is True and line['n_gpus'] == 8 and line['ranks_seen'] == 8 and line['scaling'] == 'weak'
+    assert line['same_weights_on_every_rank'] and line['gradient_arena_summed_over_ranks']
+    assert line['buckets'] == 3 and line['gradient_collectives_per_step'] == 3
+    assert line['stage_log'] == [['launch', 2], ['launch', 1], ['backward_done'], ['launch', 0]]      # normal head, aggregation, then the features
+    assert line['config']['global_batch'] == 32 and line['config']['parallelism'] == 'dp8'            # BASELINE configs[2]: 32 over 8 GPUs
+
+
+def test_bench_self_launch_dry_run_two_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no RANK in the environment): bench.py starts its own ranks as child processes and
+    relays rank 0's line."""
+    line = _bench_line([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], {})
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['gradient_arena_summed_over_ranks'] and line['gradient_collectives_per_step'] == 3

@@ -138,6 +138,29 @@ def test_sample_sharding_equal_steps_on_every_rank():
     assert list(Trainer(opt, '.', rank=0, world_size=1)._shard([1, 2, 3], 0)) == [1, 2, 3]
 
 
+def test_sample_sharding_eight_ranks_uneven_last_batch():
+    """BASELINE configs[2]'s world size: 8 ranks over 13 samples, batch 2 -- the sampler pads to 16 samples, every rank runs ONE batch of the
+    same shape per epoch (so the per-step collectives pair up), every sample is seen."""
+    from torch.utils.data import DataLoader, Dataset
+
+    class DS(Dataset):
+        def __len__(self):
+            return 13
+
+        def __getitem__(self, i):
+            return {'x': torch.tensor([float(i)])}
+
+    opt = load_option()
+    loader = DataLoader(DS(), batch_size=2, shuffle=True)
+    seen = []
+    for r in range(8):
+        tr = Trainer(opt, '.', rank=r, world_size=8)
+        seen.append([b['x'].flatten().tolist() for b in tr._shard(loader, 3)])
+    assert all(len(s) == 1 and len(s[0]) == 2 for s in seen), seen
+    flat = sorted(int(v) for s in seen for b in s for v in b)
+    assert set(flat) == set(range(13)) and len(flat) == 16
+
+
 def test_two_rank_trainer_gloo(tmp_path):
     """Two gloo ranks through Trainer.fit on a batch count that is not divisible by the world size, with a short last batch and a
     rank-0-only validation pass: both ranks must finish every epoch with the same number of steps (no hang, no mixed epochs)."""
