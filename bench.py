@@ -115,6 +115,31 @@ def self_launch(n):
     sys.exit(r.returncode)
 
 
+def held_clock_mhz(dev):
+    """The shader clock the chip holds under the dominant kernel's load: 60 launches of the aggregation stack's 32 -> 32 3x3x3 layer
+    (igemm3_x9_kernel, ~1 ms each) on the current stream while ONE lane on a side stream samples the shader cycle counter against the
+    100 MHz counter for 30 ms (dpf_debug_clock_probe).  MI355X clocks down under a dense matrix stream (MI355X_MICROARCH.md, DVFS), so an
+    issue-bound kernel's ceiling is `FLOP per clock` x THIS clock, not x 2.4 GHz."""
+    import ctypes
+    from dualpixelface_amd import ops
+    from dualpixelface_amd._lib import lib
+    x = torch.randn(4, 32, 8, 256, 384, device=dev)
+    w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.1
+    out4 = torch.zeros(4, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    one = (1, 1, 1)
+    for _ in range(5):
+        ops.ConvFn.apply(x, w, None, one, one, one)
+    torch.cuda.synchronize()
+    for i in range(60):
+        ops.ConvFn.apply(x, w, None, one, one, one)
+        if i == 8:
+            lib().call('dpf_debug_clock_probe', ctypes.c_void_p(out4.data_ptr()), 30000, ctypes.c_void_p(side.cuda_stream))
+    torch.cuda.synchronize()
+    c0, r0, c1, r1 = (int(v) for v in out4.tolist())
+    return (c1 - c0) / max(r1 - r0, 1) * 100.0
+
+
 def dry_run(args, rank, world):
     """Everything `bench.py --gpus N` does around the GPU work, on the host: the ranks exist and see each other, every rank builds the same
     model (parameters broadcast from rank 0), the reducer cuts the flat gradient arena into its 3 named buckets, one staged exchange in the
@@ -287,6 +312,9 @@ def main():
         prof, prof_steps = [r for r in prof_detail if r[0] != 'norm_act'], detail_steps
     else:
         prof_steps = args.steps
+    clock_mhz = None
+    if not args.no_detail and args.precision == 'f32' and args.model == 'stereodpnet':
+        clock_mhz = held_clock_mhz(dev)
     ranks_seen = world
     if world > 1 or (args.force_dist and dist.is_initialized()):
         ones = torch.ones(1, device=dev)
@@ -316,7 +344,7 @@ def main():
         # HBM bytes per step and family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_profiles.sh).  The file
         # carries a hash of the kernel sources it was collected on; the numbers are only reported for the workload, precision, world size
         # and kernels they were measured with -- otherwise `traffic` is null and `traffic_source` says why.
-        tname = 'r04_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r04_pmc_traffic.json'
+        tname = 'r05_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r05_pmc_traffic.json'
         tpath = os.path.join(ROOT, 'profiles', tname)
         pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
         meta = pmc.pop('_meta', {})
@@ -379,13 +407,21 @@ def main():
                     'measured_in': ('%d steps after the timed region on ONE stream (weight gradients in line, feature passes one after the other: kernels do not overlap, event time = kernel time)' % prof_steps)
                                    if not args.no_detail else 'the timed region', 'families': fam_out}
             if args.precision != 'bf16':
-                # most fp32 launches (stride-1 convs, weight gradients) form each fp32 product from 8 exact bf16 partial products on the bf16
-                # matrix pipe: `peak` stays the dense fp32 MFMA peak the metric's FLOPs are priced against; the issue ceiling of that
-                # construction is the bf16 peak / 8 (x 27/28 tap padding) at 2.4 GHz -- the chip holds 1.6-1.9 GHz under such a stream
-                x8 = PEAK_BF16_TFLOPS / 8.0 * 27.0 / 28.0
-                roof['peak_note'] = ('fp32 FLOPs against the dense fp32 MFMA peak; where the kernels multiply on the bf16 pipe (8 exact partial '
-                                     'products per fp32 product) the issue ceiling is %.1f TFLOP/s of fp32 FLOPs at 2.4 GHz' % x8)
-                roof['frac_of_bf16_pipe_issue_ceiling'] = ach / x8
+                # most fp32 launches (stride-1 convs, weight gradients) form each fp32 product from SIX bf16 partial products on the bf16 matrix
+                # pipe (round-to-nearest three-way split; the dropped cross terms are <= 2^-23 of a product): `peak` stays the dense fp32 MFMA
+                # peak the metric's FLOPs are priced against (MI355X_MICROARCH.md), and the construction's own ceiling is printed beside it --
+                # 1024 SIMDs x 32x32x16x2 FLOP per 32 clocks / 6 MFMAs per fp32 product = 174 763 fp32 FLOP per shader clock (x 27/28 for the
+                # zero taps that pad 27 to 28), at the nominal 2.4 GHz and at the clock the chip HOLDS under that stream (held_clock_mhz)
+                flop_per_clk = 1024 * (32 * 32 * 16 * 2 / 32.0) / 6.0 * 27.0 / 28.0
+                x6 = flop_per_clk * 2.4e9 / 1e12
+                roof['peak_note'] = ('fp32 FLOPs against the dense fp32 MFMA peak (the dtype of the metric); the launches that multiply on the bf16 '
+                                     'pipe (6 bf16 partial products per fp32 product) have an issue ceiling of %.1f TFLOP/s of fp32 FLOPs at 2.4 GHz' % x6)
+                roof['frac_of_bf16_pipe_issue_ceiling'] = ach / x6
+                if clock_mhz:
+                    held = flop_per_clk * clock_mhz * 1e6 / 1e12
+                    roof['shader_clock_mhz_under_conv_load'] = clock_mhz
+                    roof['bf16_pipe_issue_ceiling_at_held_clock'] = held
+                    roof['frac_of_ceiling_at_held_clock'] = ach / held
             if dom in fam_t and timed_async and not args.no_detail:      # the same family as the timed region saw it (overlapped by the side stream)
                 f2 = fam_t[dom]
                 roof['timed_region_overlapped'] = {'achieved': f2[0] / f2[1] / 1e12, 'frac': f2[0] / f2[1] / 1e12 / peak, 'avg_launch_ms': f2[1] / f2[2] * 1e3,

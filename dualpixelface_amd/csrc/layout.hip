@@ -18,6 +18,27 @@ extern "C" int dpf_set_deterministic(int on) {
 }
 extern "C" int dpf_get_deterministic(void) { return dpf_deterministic(); }
 
+// ---- measurement aid (bench.py): the shader clock the chip holds while other streams keep it busy.  One lane records the shader cycle
+// counter and the constant 100 MHz counter, naps until `spin_us` microseconds have passed, records both again: out4 = {cycles0, ticks0,
+// cycles1, ticks1}; MHz = (cycles1 - cycles0) / (ticks1 - ticks0) * 100.
+__global__ void dpf_clock_probe_kernel(unsigned long long* __restrict__ out4, unsigned long long spin_ticks) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < spin_ticks) {
+    __builtin_amdgcn_s_sleep(64);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  out4[0] = c0; out4[1] = r0; out4[2] = c1; out4[3] = r1;
+}
+extern "C" int dpf_debug_clock_probe(unsigned long long* out4, int spin_us, void* stream) {
+  dpf_clear_error();
+  if (!out4 || spin_us <= 0 || spin_us > 2000000) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(dpf_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out4, (unsigned long long)spin_us * 100ULL);
+  return dpf_check_launch();
+}
+
 namespace {
 
 // dst[n, cd0 + c, s] = src[n, cs0 + c, s]   for c < ncopy;  src has Cs channels, dst has Cd.

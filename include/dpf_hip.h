@@ -224,6 +224,10 @@ int dpf_softargmin_backward_ex(const float* logits, const float* gpred, float* d
  * grad_input through a shadow tensor, grad_weight scratch) -- so two runs of the same step produce the same bits.  Slower.  Process-wide. */
 int dpf_set_deterministic(int on);
 int dpf_get_deterministic(void);
+/* measurement aid: one lane samples {shader cycle counter, 100 MHz counter} at the start and after `spin_us` microseconds into out4 (device,
+ * 4 x 64 bit).  Launched on a side stream while the kernels of interest run on another, it reports the shader clock the chip holds under
+ * that load: MHz = (out4[2] - out4[0]) / (out4[3] - out4[1]) * 100 (bench.py "shader_clock_mhz_under_conv_load"). */
+int dpf_debug_clock_probe(unsigned long long* out4, int spin_us, void* stream);
 
 /* ---- deformable conv3d: the reference's pybind module `DCN` (src/module/dcn3d/src/vision.cpp:4-7,
  * src/module/dcn3d/src/deform_conv.h:10-29,49-69; deform_conv_cuda.cu:18-285) -- same argument order and meaning ----- */

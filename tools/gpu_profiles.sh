@@ -22,7 +22,7 @@ mkdir -p profiles; cp "$O/${R}_pmc_traffic.json" profiles/
 run python bench.py --steps 10 --warmup 3 --shapes "$O/${R}_conv_shape_table.txt" > "$O/${R}_bench.json"
 bash tools/gpu_prof.sh "$R" > "$O/${R}_bench_family_ms.txt" 2>&1
 cp "gpurun_out/prof_${R}_kernel_stats.csv" "$O/${R}_bench_kernel_stats.csv"
-export PMC_FILTER="igemm2 wgrad2 dcn_ pointwise bn_"
+export PMC_FILTER="igemm3 igemm2 wgrad2 dcn_ pointwise bn_"
 bash tools/gpu_pmc.sh ${R}sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline > "$O/${R}_sq_counters.txt" 2>&1
 if [ -z "$QUICK" ]; then
   pmc_pass pmc_f3 FETCH_SIZE --precision bf16; pmc_pass pmc_w3 WRITE_SIZE --precision bf16

@@ -21,16 +21,21 @@ def family(name):
 
 
 def kernel_sources_sha16():
-    """sha-256 (first 16 hex digits) over the kernel sources the numbers belong to: bench.py recomputes it and says whether the committed
-    traffic file still matches the kernels it runs."""
+    """sha-256 (first 16 hex digits) over the CODE of the kernel sources the numbers belong to -- comments and white space are stripped first,
+    so that a comment edit does not orphan a committed traffic file: bench.py recomputes it and says whether the committed
+    file still matches the kernels it runs."""
     import glob
     import hashlib
     import os
+    import re
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'dualpixelface_amd', 'csrc')
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h'))):
+        src = open(f, encoding='utf-8', errors='replace').read()
+        src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+        src = re.sub(r'//[^\n]*', ' ', src)
         h.update(os.path.basename(f).encode())
-        h.update(open(f, 'rb').read())
+        h.update(''.join(src.split()).encode())
     return h.hexdigest()[:16]
 
 
