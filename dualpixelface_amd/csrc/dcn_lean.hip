@@ -23,6 +23,7 @@
 //   * a sample whose corner block leaves the staged box is redone by the whole wave (lane = channel x corner pair: two global loads per
 //     lane, one round trip) instead of 16 serial channel round trips in the one slow lane.
 #include "dcn_internal.h"
+#include "conv_internal.h"
 #include <cstdlib>
 
 namespace {
@@ -432,6 +433,275 @@ __global__ __launch_bounds__(256, 2) void dcn_lean_fwd1_kernel(const float* __re
   }
 }
 
+// ---- forward, third form: the contraction on the bf16 matrix pipe (the convolutions' "x6" construction, conv_internal.h).  The fp32 MFMAs
+// of dcn_lean_fwd1_kernel cost 2048 clocks per tap and wave and nothing else issues beside them; as bf16 MFMAs the same GEMM is 24 x 32 = 768
+// clocks and the vector ALU stays free, so the sampler (~1300 clocks per tap with the operand split) runs in their shadow.
+//   * a lane's 16 samples (fp32, one voxel) become the B operands of both 32-voxel column tiles with 8 v_permlane32_swap_b32 -- (s[i], s[8+i])
+//     -> (tile 0: channels 8 hh + i of the low half's voxels, tile 1: of the high half's) -- and are split ONCE into three bf16 terms;
+//   * the weights are split by the pack kernel: wl[tap][chunk][row tile][hi | mid | lo][lane][8 bf16], value i of lane (l31, hh) =
+//     W[32 m + l31][chunk * CH + 8 hh + i][tap] (zero beyond K / C / CH); three 16-byte loads per tap and row tile;
+//   * six MFMAs per (row tile, column tile): hi*lo, lo*hi, mid*mid, mid*hi, hi*mid, hi*hi (DPF_X9_FIRST = 3).
+typedef __bf16 lean_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned lean_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CH>
+__global__ void lean_repack_fwd6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wl, int K, int C, int MT, int nchunk) {
+  const int total = 27 * nchunk * MT * 512;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = i & 7, lane = (i >> 3) & 63;
+    int r = i >> 9;
+    const int m = r % MT; r /= MT;
+    const int chunk = r % nchunk;
+    const int t = r / nchunk;
+    const int k = 32 * m + (lane & 31), cl = 8 * (lane >> 5) + e, c = chunk * CH + cl;
+    const float v = (cl < CH && k < K && c < C) ? w[((long long)k * C + c) * 27 + t] : 0.f;
+    unsigned h, md, lo;
+    dpf_split_pair(v, 0.f, h, md, lo);
+    const long long base = ((long long)((t * nchunk + chunk) * MT + m) * 3) * 512 + lane * 8 + e;
+    wl[base] = (unsigned short)(h & 0xffffu);
+    wl[base + 512] = (unsigned short)(md & 0xffffu);
+    wl[base + 1024] = (unsigned short)(lo & 0xffffu);
+  }
+}
+
+template <class G, int MT>
+__global__ __launch_bounds__(256, 2) void dcn_lean_fwd6_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                            const unsigned short* __restrict__ wl, const float* __restrict__ bias,
+                                                            float* __restrict__ out, LeanP p) {
+  extern __shared__ __align__(16) char smem[];
+  constexpr int CH = G::CH, NQ = G::NQ, T = 27;
+  static_assert(G::NV == 256, "four waves of 64 voxels");
+  char* region = smem;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int blk = lean_xcd_tile(blockIdx.x, gridDim.x);
+  const int tx = blk % p.tilesX; blk /= p.tilesX;
+  const int ty = blk % p.tilesY;
+  const int b = blk / p.tilesY;
+  const int y0 = ty * G::TY, x0 = tx * G::TX;
+  const int ry0 = y0 - 1 - G::RYH, rx0 = x0 - 1 - G::RXL;
+  const float* xb = x + (long long)b * p.C * p.P;
+  const int vox = wave_u * 64 + (lane & 32) + lane_pos32(l31);
+  const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+  const int zo = pz, yo = y0 + py, xo = x0 + px;
+  const bool pvalid = zo < p.D && yo < p.H && xo < p.W;
+  const long long ppos = pvalid ? ((long long)zo * p.H + yo) * p.W + xo : 0;
+  const float* offp0 = offset + (long long)b * 3 * T * p.P + ppos;
+  const float zbf = (float)(zo - 1), ybf = (float)(yo - 1), xbf = (float)(xo - 1);
+  const long long P3 = 3 * p.P;
+  const unsigned wlane = (unsigned)lane * 16u;
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][nt][j] = 0.f;
+
+  // accumulate ONE quad of a tap from its 8 corner reads into 4 sample registers (two independent packed multiply-add chains)
+  auto accum1 = [&](const f32x2& w00, const f32x2& w01, const f32x2& w10, const f32x2& w11, const f32x4* c, float* sv) {
+    f32x2 lo = pk_mul_lo(w00, c[0].xy), hi = pk_mul_lo(w00, c[0].zw);
+    pk_fma_hi(lo, w00, c[1].xy); pk_fma_hi(hi, w00, c[1].zw);
+    pk_fma_lo(lo, w01, c[2].xy); pk_fma_lo(hi, w01, c[2].zw);
+    pk_fma_hi(lo, w01, c[3].xy); pk_fma_hi(hi, w01, c[3].zw);
+    pk_fma_lo(lo, w10, c[4].xy); pk_fma_lo(hi, w10, c[4].zw);
+    pk_fma_hi(lo, w10, c[5].xy); pk_fma_hi(hi, w10, c[5].zw);
+    pk_fma_lo(lo, w11, c[6].xy); pk_fma_lo(hi, w11, c[6].zw);
+    pk_fma_hi(lo, w11, c[7].xy); pk_fma_hi(hi, w11, c[7].zw);
+    sv[0] = lo.x; sv[1] = lo.y; sv[2] = hi.x; sv[3] = hi.y;
+  };
+  // samples that leave the staged box: redone by the wave from global memory (lane = channel x corner pair), then handed to the owning lane
+  auto slow_fix = [&](const LeanTab& tb, float* sv, int c0) {
+    unsigned long long slow = __ballot(tb.slow);
+    while (slow) {
+      const int L = __builtin_ctzll(slow);
+      slow &= slow - 1;
+      const int sd0 = __builtin_amdgcn_readlane(tb.d0, L), sh0 = __builtin_amdgcn_readlane(tb.h0, L), sw0 = __builtin_amdgcn_readlane(tb.w0, L);
+      const float sld = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.ld), L));
+      const float slh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.lh), L));
+      const float slw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb.lw), L));
+      const int ch = lane & 15, jd = lane >> 5, jh = (lane >> 4) & 1;
+      const int dz = sd0 + jd, hy = sh0 + jh;
+      const int cgl = c0 + ch;
+      const bool rowin = ch < CH && cgl < p.C && (unsigned)dz < (unsigned)p.D && (unsigned)hy < (unsigned)p.H;
+      const bool in0 = rowin && (unsigned)sw0 < (unsigned)p.W, in1 = rowin && (unsigned)(sw0 + 1) < (unsigned)p.W;
+      const float* xr = xb + (long long)(cgl < p.C ? cgl : 0) * p.P + ((long long)(rowin ? dz : 0) * p.H + (rowin ? hy : 0)) * p.W;
+      const float v0 = in0 ? xr[sw0] : 0.f, v1 = in1 ? xr[sw0 + 1] : 0.f;
+      const float wzy = (jd ? sld : 1.f - sld) * (jh ? slh : 1.f - slh);
+      float part = fmaf(wzy * slw, v1, (wzy * (1.f - slw)) * v0);
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);                // lanes 0 .. 15 (and their copies) hold channel `lane & 15` of voxel L
+#pragma unroll
+      for (int ch2 = 0; ch2 < CH; ++ch2) {
+        const float vch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), ch2));
+        if (lane == L) sv[ch2] = vch;
+      }
+    }
+  };
+  // one tap's samples (16 fp32 of the lane's voxel) -> the split bf16 B operands of both column tiles
+  auto make_b = [&](float (&sv)[16], lean_u32x4 (&bh)[2], lean_u32x4 (&bm)[2], lean_u32x4 (&bl)[2]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(sv[i]), "+v"(sv[8 + i]));
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned h, m, l;
+        dpf_split_pair(sv[8 * nt + 2 * j], sv[8 * nt + 2 * j + 1], h, m, l);
+        bh[nt][j] = h; bm[nt][j] = m; bl[nt][j] = l;
+      }
+  };
+
+  // offsets ring: slot (u % 3) holds tap u's three components, fetched four taps ahead
+  float od[3], oh[3], ow[3];
+  LeanTab tab = lean_tab<G>(p, pvalid, ry0, rx0, zbf + offp0[0], ybf + offp0[p.P], xbf + offp0[2 * p.P]);
+#pragma unroll
+  for (int u = 1; u <= 3; ++u) { od[u % 3] = offp0[u * P3]; oh[u % 3] = offp0[u * P3 + p.P]; ow[u % 3] = offp0[u * P3 + 2 * p.P]; }
+  LeanTab tab1;                                        // tap 1's table while tap 0 is gathered at a chunk's start
+
+  lean_u32x4 bH[2], bM[2], bL[2];                      // B operands of the tap being contracted
+  lean_u32x4 aC[MT][3], aN[MT][3];                     // its weight fragments [row tile][hi, mid, lo] and the next tap's
+  float nxt[16];
+  auto load_a = [&](int tn, int cn, lean_u32x4 (&a)[MT][3]) {
+    const char* wb = reinterpret_cast<const char*>(wl) + ((long long)(tn * p.nchunk + cn) * MT) * 3072;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[m][c] = *reinterpret_cast<const lean_u32x4*>(wb + (m * 3 + c) * 1024 + wlane);
+  };
+  // sample tap `tab` into nxt (corner reads quad by quad)
+  auto sample_core = [&]() {
+    const char* r0 = region + tab.a0;
+    const char* r1 = region + tab.a1;
+    const f32x2 zy0 = pk_mul_lo(tab.wz, tab.wy), zy1 = pk_mul_hi(tab.wz, tab.wy);
+    const f32x2 w00 = pk_mul_lo(zy0, tab.wx), w01 = pk_mul_hi(zy0, tab.wx), w10 = pk_mul_lo(zy1, tab.wx), w11 = pk_mul_hi(zy1, tab.wx);
+    f32x4 cr[2][8];
+    LEAN_LOAD8(cr[0], 0)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q + 1 < NQ) { LEAN_LOAD8(cr[(q + 1) & 1], q + 1) }
+      accum1(w00, w01, w10, w11, cr[q & 1], nxt + 4 * q);
+    }
+#pragma unroll
+    for (int i = 4 * NQ; i < 16; ++i) nxt[i] = 0.f;
+  };
+  // the table of tap u (ring slot u % 3) and the refill of that slot with tap u + 3
+  auto next_table = [&](int u) {
+    const int ti = u / 9, tj = (u - 9 * ti) / 3, tk = u - 9 * ti - 3 * tj;
+    const int sl = u % 3;
+    const float fdn = (zbf + (float)ti) + od[sl], fhn = (ybf + (float)tj) + oh[sl], fwn = (xbf + (float)tk) + ow[sl];
+    int v = u + 3;
+    if (v >= T) v -= T;
+    const float* np = offp0 + (long long)v * P3;
+    od[sl] = np[0]; oh[sl] = np[p.P]; ow[sl] = np[2 * p.P];
+    return lean_tab<G>(p, pvalid, ry0, rx0, fdn, fhn, fwn);
+  };
+  auto mfmas = [&]() {
+    // smallest partial products first; row tiles and column tiles alternate so that consecutive MFMAs never share an accumulator
+    constexpr int oa[6] = {2, 0, 1, 1, 0, 0};          // weight component   (0 = hi, 1 = mid, 2 = lo)
+    constexpr int ob[6] = {0, 2, 1, 0, 1, 0};          // sample component
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const lean_u32x4 bv = ob[i] == 0 ? bH[nt] : (ob[i] == 1 ? bM[nt] : bL[nt]);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(lean_bf16x8, aC[m][oa[i]]), __builtin_bit_cast(lean_bf16x8, bv), acc[m][nt], 0, 0, 0);
+        }
+  };
+
+  {
+    const float fd1 = zbf + od[1], fh1 = ybf + oh[1], fw1 = (xbf + 1.f) + ow[1];      // tap 1 = (ti, tj, tk) = (0, 0, 1)
+    const float* np = offp0 + 4 * P3;
+    od[1] = np[0]; oh[1] = np[p.P]; ow[1] = np[2 * p.P];
+    tab1 = lean_tab<G>(p, pvalid, ry0, rx0, fd1, fh1, fw1);
+  }
+  int chunk = 0;
+#pragma unroll 1
+  for (int c0 = 0; c0 < p.C; c0 += CH, ++chunk) {
+    __syncthreads();                                   // every wave is done with the previous chunk's region
+    lean_stage<G>(p, xb, c0, region, ry0, rx0, tid, 256);
+    load_a(0, chunk, aC);
+    __syncthreads();
+    sample_core();                                     // tap 0 of the chunk: nothing to contract yet
+    slow_fix(tab, nxt, c0);
+    make_b(nxt, bH, bM, bL);
+    tab = tab1;
+#pragma unroll 1
+    for (int t = 0; t < T - 1; ++t) {
+      // contract tap t (B operands / weight fragments in registers) while tap t + 1 is sampled by the vector ALU in the MFMAs' shadow: the
+      // MFMAs and the corner reads / multiply-adds of the sampler form ONE basic block, interleaved by the scheduling hints
+      load_a(t + 1, chunk, aN);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas();
+      sample_core();
+      int u = t + 2;
+      if (u >= T) u -= T;
+      const LeanTab tabn = next_table(u);                // (t = T - 2: tap 0's table of the next chunk)
+      // phase A: the corner reads of the first two quads go out between the first MFMAs; phase B: one MFMA, then the multiply-adds of a
+      // quad whose reads have landed, the reads of the next quad, the next table's arithmetic
+#pragma unroll
+      for (int i = 0; i < 4 * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT == 2 ? 2 : 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, MT == 2 ? 2 : 4, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8 * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, MT == 2 ? 9 : 18, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT == 2 ? 1 : 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      slow_fix(tab, nxt, c0);
+      tab = tabn;
+      make_b(nxt, bH, bM, bL);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) aC[m][c] = aN[m][c];
+    }
+    // tap 26: nothing left to sample in this chunk
+    mfmas();
+    tab1 = next_table(1);                              // tap 1's table of the next chunk (`tab` already is tap 0's)
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int vo = wave_u * 64 + nt * 32 + lane_pos32(l31);      // column n of tile nt is the voxel the sampler lane (l31, nt) owns
+    const int qx = vo % G::TX, qy = (vo / G::TX) % G::TY, qz = vo / (G::TX * G::TY);
+    const int gz = qz, gy = y0 + qy, gx = x0 + qx;
+    const int q = l31 & 3;
+    const bool o1 = (q & 1) != 0, o2 = (q & 2) != 0;
+    const bool inb = gz < p.D && gy < p.H && gx < p.W;             // uniform over a quad (gx - q is a multiple of 4, W % 4 == 0)
+    const long long pos = ((long long)gz * p.H + gy) * p.W + (gx - q);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float r0 = acc[m][nt][4 * i], r1 = acc[m][nt][4 * i + 1], r2 = acc[m][nt][4 * i + 2], r3 = acc[m][nt][4 * i + 3];
+        {
+          const float xa = o1 ? r0 : r1, ya = o1 ? r2 : r3;
+          const float xs = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0xB1, 0xf, 0xf, true));
+          const float ys = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ya), 0xB1, 0xf, 0xf, true));
+          if (o1) { r0 = xs; r2 = ys; } else { r1 = xs; r3 = ys; }
+        }
+        {
+          const float xa = o2 ? r0 : r2, ya = o2 ? r1 : r3;
+          const float xs = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0x4E, 0xf, 0xf, true));
+          const float ys = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ya), 0x4E, 0xf, 0xf, true));
+          if (o2) { r0 = xs; r1 = ys; } else { r2 = xs; r3 = ys; }
+        }
+        const int k = m * 32 + 8 * i + 4 * hh + q;
+        if (inb && k < p.K) {
+          const float bv = bias ? bias[k] : 0.f;
+          const f32x4 v = {r0 + bv, r1 + bv, r2 + bv, r3 + bv};
+          *reinterpret_cast<f32x4*>(out + ((long long)b * p.K + k) * p.P + pos) = v;
+        }
+      }
+  }
+}
+
 // ====================================================================================================================================
 // grad_offset + grad_weight (reference: deformable_col2im_coord, deform_im2col_cuda.cuh:111-190,336-405; the grad_weight GEMM,
 // deform_conv_cuda.cu:220-279).  Per (chunk, tap) step:
@@ -745,6 +1015,27 @@ int lean_launch_fwd1(const float* x, const float* offset, const float* weight, c
   return dpf_check_launch();
 }
 
+template <class G>
+int lean_launch_fwd6(const float* x, const float* offset, const float* weight, const float* bias, float* out, float* ws, LeanP p, hipStream_t st) {
+  p.tilesY = dpf_div_up(p.H, G::TY);
+  p.tilesX = dpf_div_up(p.W, G::TX);
+  const long long blocks = (long long)p.B * p.tilesY * p.tilesX;
+  if (blocks >= 0x7fffffffLL) return DPF_ERR_UNSUPPORTED;
+  const int MT = p.KT / 32;
+  constexpr int LDS = G::NQ * G::PLANE;
+  unsigned short* wl = reinterpret_cast<unsigned short*>(ws);
+  hipLaunchKernelGGL((lean_repack_fwd6_kernel<G::CH>), dim3(dpf_ew_grid(27LL * p.nchunk * MT * 512)), dim3(256), 0, st, weight, wl, p.K, p.C, MT, p.nchunk);
+  const dim3 grid((unsigned)blocks), block(256);
+  if (MT == 1) {
+    if (lean_set_lds(dcn_lean_fwd6_kernel<G, 1>, LDS) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL((dcn_lean_fwd6_kernel<G, 1>), grid, block, LDS, st, x, offset, wl, bias, out, p);
+  } else {
+    if (lean_set_lds(dcn_lean_fwd6_kernel<G, 2>, LDS) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL((dcn_lean_fwd6_kernel<G, 2>), grid, block, LDS, st, x, offset, wl, bias, out, p);
+  }
+  return dpf_check_launch();
+}
+
 //                  CH TY  TX RYH RXL RXR      voxels  region cells    LDS
 typedef Geo<16, 4, 16, 3, 3, 3> G16c;   //   256     4 x 12 x 24     73 728   forward: region only, two workgroups per CU
 typedef Geo<12, 4, 16, 5, 7, 4> G12c;   //   256     4 x 16 x 32     98 304   forward, wider x halo: one workgroup per CU (DPF_DCN_LEAN_WIDE12=1)
@@ -780,7 +1071,7 @@ int dcn_lean_chunk(int C) { return ((C + 11) / 12 * 12 < (C + 15) / 16 * 16) ? 1
 long long dcn_lean_workspace_floats(int C, int K) {
   const int CH = dcn_lean_chunk(C);
   const long long nchunk = (C + CH - 1) / CH;
-  const long long fwd = 27LL * nchunk * ((K + 31) / 32) * 512;     // lean_repack_fwd1_kernel
+  const long long fwd = 27LL * nchunk * ((K + 31) / 32) * 768;     // lean_repack_fwd6_kernel (3 x 512 bf16; lean_repack_fwd1_kernel: 512 floats)
   const long long bwd = 27LL * nchunk * 1024;                      // lean_repack_gcol_kernel (independent of K)
   return fwd > bwd ? fwd : bwd;
 }
@@ -798,6 +1089,12 @@ int dcn_lean_forward(const float* x, const float* offset, const float* weight, c
   p.nchunk = p.Cpad / CH;
   p.KT = 32 * ((K + 31) / 32);
   p.P = (long long)D * H * W;
+  // fp32 products: six bf16 partial products on the bf16 matrix pipe (default), or v_mfma_f32_32x32x2_f32 (dpf_set_f32_matrix_path(0), DPF_DCN_FWD6=0)
+  static const int fwd6_env = getenv("DPF_DCN_FWD6") ? atoi(getenv("DPF_DCN_FWD6")) : 1;
+  if (fwd6_env && dpf_conv_f32_x9()) {
+    if (CH == 16) return lean_launch_fwd6<G16c>(x, offset, weight, bias, out, ws, p, st);
+    return lean_launch_fwd6<G12d>(x, offset, weight, bias, out, ws, p, st);
+  }
   if (CH == 16) return lean_launch_fwd1<G16c>(x, offset, weight, bias, out, ws, p, st);
   static const int wide12 = getenv("DPF_DCN_LEAN_WIDE12") ? atoi(getenv("DPF_DCN_LEAN_WIDE12")) : 0;   // 1: wider x halo, one workgroup per CU (3.7 vs 2.6 ms)
   if (wide12) return lean_launch_fwd1<G12c>(x, offset, weight, bias, out, ws, p, st);
