@@ -652,8 +652,9 @@ def test_c2_batch4_forward_loss_and_gradients_vs_oracle_fixture(golden_dir):
     (tests/golden/make_golden_c2_b4.py: 3 x 3 minutes and 36 GB of host memory, cached as a fixture; the oracle is pinned to the imported
     reference by the smaller fixtures).  Forward: every 4th pixel of the predictions + checksums, the cost volume's checksums, the ANM level
     selection, the losses.  Backward: 12 full gradients and sum g^2 of every gradient, each within K_SPREAD x the oracle's own fp32 noise in
-    that tensor -- the largest distance between its 8 / 5 / 3-thread runs, floored by the network-wide median of that distance (three thread
-    counts under-sample the noise of tensors whose kernels do not re-chunk)."""
+    that tensor: the largest distance between five fp32 runs of the oracle in different summation orders (8 / 5 / 3 threads, another batch
+    order, oneDNN off -- thread counts alone are correlated draws: with them only, the median noise reads 4.9e-3 instead of 1.3e-2).
+    Measured on MI355X (round 5): distance / noise of the 12 tensors 0.2 ... 2.9, the head's last layer 1.0."""
     from dualpixelface_amd.recipe import synthetic_batch
     g = np.load(golden_dir + '/c2_b4_oracle.npz')
     B, H, W, seed = (int(v) for v in g['batch_args'])
@@ -681,9 +682,7 @@ def test_c2_batch4_forward_loss_and_gradients_vs_oracle_fixture(golden_dir):
     # ---- gradients
     names = [str(n) for n in g['grad_names']]
     spread = g['grad_spread']
-    med = float(np.median(spread))
-    noise = {n: max(float(sp), med) for n, sp in zip(names, spread)}
-    noise['aggregation.classif3.2.weight'] = float(spread[names.index('aggregation.classif3.2.weight')])    # the head: nothing amplifies its noise
+    noise = {n: float(sp) for n, sp in zip(names, spread)}
     pd = dict(model.named_parameters())
     report = []
     for k in g.files:
