@@ -211,6 +211,7 @@ def main():
     ap.add_argument('--force-dist', action='store_true',
                     help="with --gpus 1: still create a (world-size-1) 'nccl' process group and send every gradient bucket through it -- the "
                          "staged reducer (tensor-hook launches, side-stream joins, stage_finish, fused Adam) runs through RCCL's stream handling")
+    ap.add_argument('--no-graph', action='store_true', help='eager kernel launches in the timed region (default: the step replays as one HIP graph)')
     ap.add_argument('--dry-run', action='store_true',
                     help='launch path only: parse, start / join the ranks, build the model and the 3-bucket reducer on the HOST, exchange one '
                          'staged gradient arena over the process group (DPF_DIST_BACKEND=gloo on a box without GPUs), print the line with '
@@ -276,16 +277,22 @@ def main():
         ops.WGRAD_ASYNC = bool(on) and os.environ.get('DPF_WGRAD_ASYNC', '1') == '1'
         sdn.FEATURES_TWO_STREAMS = bool(on) and os.environ.get('DPF_FEATURES_TWO_STREAMS', '1') == '1'
     set_streams(not args.wgrad_inline)
-    for _ in range(args.warmup):
+    # the step as ONE HIP graph (plugin.train_step: captured on the third call of a shape, replayed afterwards; single-process steps only --
+    # with a reducer the collectives stay eager).  The capture must not fall into the timed region: at least four untimed steps.
+    use_graph = reducer is None and not args.no_graph and os.environ.get('DPF_STEP_GRAPH', '1') != '0'
+    if not use_graph:
+        os.environ['DPF_STEP_GRAPH'] = '0'
+    for _ in range(max(args.warmup, 4) if use_graph else args.warmup):
         model.train_step(batch, reducer)
     sync()
-    ops.PROFILE = []
+    graph_live = bool(use_graph and getattr(model, '_graph_state', None) and model._graph_state.get('graph') is not None)
+    ops.PROFILE = None if graph_live else []             # per-launch event pairs need eager launches: with the graph live they come from the detail steps only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = model.train_step(batch, reducer)
     sync()
     elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof, ops.PROFILE = (ops.PROFILE or []), None
     loss = float(res['final_loss'].detach())
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -448,7 +455,8 @@ def main():
                                    % ({'psmnet': 'PSMNet', 'nnet': 'NNet', 'stereonet': 'StereoNet'}.get(args.model, 'StereoDPNet'), args.batch, args.height, args.width),
                        'global_batch': global_batch, 'height': args.height, 'width': args.width, 'parallelism': 'dp%d' % world,
                        'batchnorm': 'global-batch statistics (SyncBatchNorm)' if (args.sync_bn and world > 1) else 'per-rank statistics',
-                       'streams': ('weight gradients on a side stream, left / right feature passes on two streams' if timed_async else 'one stream')},
+                       'streams': ('weight gradients on a side stream, left / right feature passes on two streams' if timed_async else 'one stream'),
+                       'launch': ('one HIP graph per step (captured in the warm-up, replayed in the timed region)' if graph_live else 'eager kernel launches')},
             'final_loss': loss,
             'rccl_ranks_seen': ranks_seen,
             'collective_backend': (dist.get_backend() if dist.is_initialized() else None),

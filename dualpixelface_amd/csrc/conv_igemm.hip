@@ -566,7 +566,7 @@ int conv_launch(const float* x, const float* wt_ws, const float* bias, float* ou
   p.ntmax = ntmax;
   auto lds_bytes = [&](int CC) { return (size_t)(CC * p.chanStrideMax + 2 * MAXT + 4 + 2 * CC * ext_d * ext_h) * sizeof(float); };
   int CC = 8;
-  static const int lds_cap = getenv("DPF_CONV_LDS_CAP") ? atoi(getenv("DPF_CONV_LDS_CAP")) : 20000;   // tuning knob
+  constexpr int lds_cap = 20000;
   if (lds_bytes(8) > (size_t)lds_cap || p.C <= 4) CC = 4;
   const size_t lds = lds_bytes(CC);
   if (lds > 160 * 1024) return DPF_ERR_UNSUPPORTED;
@@ -763,7 +763,7 @@ int dpf_conv_wgrad_slice(const float* g, const float* x, float* dw, int N, int C
   // d*d interleaved dilation-1 problems.  Tiles then carry a (kh-1)-wide halo instead of (kh-1)*d, at the price of strided
   // (every d-th element) staging loads, which L2 absorbs.
   p.es = 1;
-  if (sh == 1 && sw == 1 && dh == dw_ && dh > 1 && !getenv("DPF_WGRAD_NO_POLYPHASE")) {
+  if (sh == 1 && sw == 1 && dh == dw_ && dh > 1) {
     p.es = dh;
     p.dh = p.dw = 1;
     dh = dw_ = 1;

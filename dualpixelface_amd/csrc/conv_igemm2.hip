@@ -1180,7 +1180,7 @@ int launch_x9(const float* x, const unsigned short* wpk, const float* bias, floa
 // count, so that every slice picks the same depth split / tile order and the shared BatchNorm statistics slab has one row numbering.
 int x9_try(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, const G2P& p, int k_off, int kn, int NT,
            DpfConvStats* stats, hipStream_t st, int NC, int mt_fit = 0) {
-  static const int x9_on = env_int("DPF_IGEMM3", 1), x9_min_c = env_int("DPF_IGEMM3_MINC", 8), x9_cc = env_int("DPF_IGEMM3_CC", 0),
+  static const int x9_on = env_int("DPF_IGEMM3", 1), x9_min_c = 8, x9_cc = env_int("DPF_IGEMM3_CC", 0),
                    x9_sh = env_int("DPF_IGEMM3_SH", -1);
   const int T = d.kd * d.kh * d.kw, MT = (kn + 31) / 32, TH = 4 * NT;
   if (!x9_on || (NC == 3 && !dpf_conv_f32_x9()) || MT > 2 || NT * MT > 4 || d.C < x9_min_c) return DPF_ERR_UNSUPPORTED;
@@ -1278,7 +1278,7 @@ int launch_t2(const float* x, const float* wpk, const float* bias, float* out, c
 
 // stride-2 transposed 3x3x3 (pad 1): loops over 32-channel output slices
 int igemm2_tr2(const float* x, const float* w, const float* bias, float* out, float* ws, const DpfConvDesc& d, hipStream_t st) {
-  static const int enabled = env_int("DPF_IGEMM2_TR2", 1), cc_over = env_int("DPF_T2_CC", 0);
+  static const int enabled = env_int("DPF_IGEMM2_TR2", 1), cc_over = 0;
   if (!enabled) return DPF_ERR_UNSUPPORTED;
   if (d.kd != 3 || d.kh != 3 || d.kw != 3 || d.sd != 2 || d.sh != 2 || d.sw != 2 || d.pd != 1 || d.ph != 1 || d.pw != 1 || d.dd != 1 ||
       d.dh != 1 || d.dw != 1)
@@ -1354,7 +1354,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   if (d.transposed && (d.sd != 1 || d.sh != 1 || d.sw != 1)) return igemm2_tr2(x, w, bias, out, ws, d, st);
 
   const int MT = (d.K + 31) / 32, KT = 32 * MT;
-  static const int nt_over = env_int("DPF_G2_NT", 0), cc_over = env_int("DPF_G2_CC", 0), lds_target = env_int("DPF_G2_LDS", 53 * 1024);
+  static const int nt_over = 0, cc_over = 0, lds_target = 53 * 1024;
   int NT = MT == 1 ? 4 : 2;
   if (nt_over == 2 || (nt_over == 4 && MT <= 2)) NT = nt_over;
   // operand precision "bf16" (dpf_set_conv_operand_precision): 8-channel chunks; 16 position rows per workgroup when two buffers
@@ -1375,7 +1375,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
     // (rows per workgroup, one or two LDS buffers): the candidate with the most resident workgroups per CU wins (LDS and the
     // register budget of the instantiation; more than 3 buys nothing) -- at equal residency two buffers beat one and 16 rows beat 8
     // (less halo).  tools/conv_bf16_bench.py: the 3-D K = 32 convs run 2x faster on 8 rows x 1 buffer (3 resident) than on 2 buffers.
-    static const int single_over = env_int("DPF_G2_BF_SINGLE", -1);
+    static const int single_over = -1;
     auto occ_regs = [&](int nt) {
       const int est = MT * nt * 16 + 2 * (2 * MT + 4 * nt) + 2 * NLD + 44;
       return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
@@ -1465,7 +1465,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   if (T > 4 && p.sxd == 1 && p.sxh == 1 && p.sxw == 1 && (!bf_mode || (bf3_on && !(d.K > 64 && d.kd == 1)))) {
     const int nc = bf_mode ? 1 : 3;
     if (d.K <= 64) {
-      static const int nt3 = env_int("DPF_IGEMM3_NT", 0);       // 2: 8-row tiles for <= 32 output channels too (three resident workgroups)
+      constexpr int nt3 = 0;       // (2 = 8-row tiles for <= 32 output channels too, three resident workgroups: measured slower)
       const int rc = x9_try(x, w, bias, out, ws, d, p, 0, d.K, MT == 1 ? ((nt3 == 2 || (nt3 == 12 && d.kd == 1)) ? 2 : 4) : 2, stats, st, nc);
       if (rc != DPF_ERR_UNSUPPORTED) return rc;
     } else {

@@ -331,7 +331,7 @@ int dpf_pointwise_wgrad(const float* g, const float* x, float* dw, float* ws, lo
   // chunk: enough workgroups to fill the chip, rows of the slab bounded by the workspace
   long long chunk = 1024;
   const long long total = (long long)d.N * p.Pg;
-  static const long long fill = env_flag("DPF_PW_WGRAD_BLOCKS", 512);    // workgroups to aim for (2048 measured slower: more slab rows to fold)
+  static const long long fill = 512;    // workgroups to aim for (2048 measured slower: more slab rows to fold)
   while (chunk > PT && total / chunk < fill) chunk /= 2;
   // workspace: slab rows (one per workgroup) + their group sums (rows / RGROUP + 1 more rows)
   auto need = [&](long long ch) {

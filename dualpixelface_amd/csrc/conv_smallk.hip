@@ -474,12 +474,12 @@ int dpf_conv_smallk_forward(const float* x, const float* w, const float* bias, f
   if (rc != DPF_OK) return rc;
   if (sw != 1 || dw != 1 || kw > 3) return DPF_ERR_UNSUPPORTED;
   const long long total = (long long)N * p.OD * p.OH * ((p.OW + XB - 1) / XB);
-  if (kh == 3 && kw == 3 && (kd == 1 || kd == 3) && sd == 1 && sh == 1 && dh == 1 && !getenv("DPF_SMALLK_FWD_GENERIC")) {
+  if (kh == 3 && kw == 3 && (kd == 1 || kd == 3) && sd == 1 && sh == 1 && dh == 1) {
     const dim3 grid(dpf_ew_grid((long long)N * p.OD * ((p.OH + SKR - 1) / SKR) * ((p.OW + XB - 1) / XB)));
     hipStream_t st = (hipStream_t)stream;
     const bool vec = pw == 1 && (IW & 3) == 0 && (p.OW & 3) == 0 && XB == 4;
     // rows per thread: 4 (default; 0.30 ms per 32 -> 1 cost head at 8 x 256 x 384 once the loads are unconditional) or 2 (0.37 ms)
-    static const int rows_over = getenv("DPF_SKF_ROWS") ? atoi(getenv("DPF_SKF_ROWS")) : 4;
+    constexpr int rows_over = 4;
     if (K == 1 && kd == 3 && vec && rows_over == 2) {
       const dim3 grid2(dpf_ew_grid((long long)N * p.OD * ((p.OH + 1) / 2) * ((p.OW + XB - 1) / XB)));
       hipLaunchKernelGGL((smallk_fwd3_kernel<1, 3, true, 2>), grid2, dim3(256), 0, st, x, w, bias, out, p);
@@ -512,7 +512,7 @@ int dpf_conv_smallk_dgrad(const float* g, const float* w, float* dx, int N, int 
   int rc = fill(p, N, C, ID, IH, IW, K, kd, kh, kw, 1, 1, 1, pd, ph, pw, 1, 1, 1);
   if (rc != DPF_OK) return rc;
   if (kh != 3 || kw != 3 || (kd != 1 && kd != 3) || (IW & 3) || (reinterpret_cast<uintptr_t>(dx) & 15) || (reinterpret_cast<uintptr_t>(g) & 15) ||
-      K * kd > 6 || getenv("DPF_SMALLK_DGRAD_OFF"))
+      K * kd > 6)
     return DPF_ERR_UNSUPPORTED;
   const long long total = (long long)N * ID * IH * (IW / 4);
   const dim3 grid(dpf_ew_grid(total));
@@ -535,7 +535,7 @@ int dpf_conv_smallk_wgrad(const float* g, const float* x, float* dw, int N, int 
   SkP p{};
   int rc = fill(p, N, C, ID, IH, IW, K, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw_);
   if (rc != DPF_OK) return rc;
-  if (kh == 3 && kw == 3 && (kd == 1 || kd == 3) && sd == 1 && sh == 1 && sw == 1 && dh == 1 && dw_ == 1 && !getenv("DPF_SMALLK_WGRAD_TILED")) {
+  if (kh == 3 && kw == 3 && (kd == 1 || kd == 3) && sd == 1 && sh == 1 && sw == 1 && dh == 1 && dw_ == 1) {
     // register-window kernel; split the rows of short strips so that the grid still fills the chip
     const int segs = dpf_div_up(p.OW, 64);
     const long long strips = (long long)N * p.OD * segs * C;

@@ -46,7 +46,6 @@ struct W2P {
   long long ntiles, per;       // tiles per position chunk (contiguous range)
   unsigned mCS, mPS, mSR;
   long long slab_stride;       // floats between position-chunk slabs  (K * C * T)
-  int dbg;                     // timing experiments (DPF_W2_DBG; results wrong): 1 = no DMA after the first two tiles
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
   __syncthreads();
   int buf = 0;
   for (long long tile = tbeg; tile < tend; ++tile, buf ^= 1) {
-    if (tile + 1 < tend && !(p.dbg == 1 && tile > tbeg)) issue(buf ^ 1);
+    if (tile + 1 < tend) issue(buf ^ 1);
     const float* s_x = smem + buf * bufFloats;
     const float* s_g = s_x + xFloats;
     // group j = positions 8j .. 8j+7 of this wave's row: lane half h takes 8j+4h .. 8j+4h+3; element i of both halves is one
@@ -489,14 +488,14 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   static const int enabled = env_int("DPF_WGRAD2", 1);
   if (!enabled || !ws) return DPF_ERR_UNSUPPORTED;
   const int T = d.kd * d.kh * d.kw;
-  static const int min_t = env_int("DPF_W2_MINT", 9);
+  constexpr int min_t = 9;
   if (T > 27 || T < min_t || d.K > 128) return DPF_ERR_UNSUPPORTED;
   if ((d.IW & 3) || (d.QW & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(g) & 15)) return DPF_ERR_UNSUPPORTED;
-  static const int maxdil = env_int("DPF_W2_MAXDIL", 8);
+  constexpr int maxdil = 8;
   if (d.dh > maxdil || d.dw > maxdil || d.dd > maxdil) return DPF_ERR_UNSUPPORTED;   // widely dilated: polyphase kernel (conv_igemm.hip)
   if (d.sw > 2 || d.sh > 2) return DPF_ERR_UNSUPPORTED;
   const long long x_chan = (long long)d.ID * d.IH * d.IW;
-  static const int nct_max = env_int("DPF_W2_NCT", 7), lds_max = env_int("DPF_W2_LDS", 80 * 1024);
+  constexpr int nct_max = 7, lds_max = 80 * 1024;
 
   W2P p{};
   p.N = d.N; p.C = d.C; p.K = d.K; p.Ktot = d.Ktot; p.k0 = d.k0;
@@ -517,7 +516,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   int NCT = 0, CCW = 0;
   // stride 2: the x patch of a tile is 2.8x larger per channel; two column tiles (fewer channels per buffer, more resident
   // workgroups) measured 69 vs 56 TFLOP/s against the stride-1 optimum of seven
-  const int nct_cap = (d.sh == 2 || d.sw == 2) && !getenv("DPF_W2_NCT") ? 2 : nct_max;
+  const int nct_cap = (d.sh == 2 || d.sw == 2) ? 2 : nct_max;
   for (int nmax = nct_cap; nmax >= 1; --nmax) {
     int ccw_cap = (nmax * 32) / T;
     if (ccw_cap < 1) continue;
@@ -556,7 +555,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   int occ = w2_occ_of(NCT);
   if ((size_t)occ * lds0 > 160 * 1024) occ = (int)((160 * 1024) / lds0);
   if (occ < 1) occ = 1;
-  static const int cap_over = env_int("DPF_W2_CAPACITY", 0);
+  constexpr int cap_over = 0;
   // one resident round of workgroups; with many (column chunk, k slice) groups the position chunks get coarse, and two rounds
   // balance the CUs better (measured: K = 81 / 96 layers 58 -> 71-86 TFLOP/s, the 32-channel layers unchanged)
   const int capacity = cap_over ? cap_over : occ * 256 * (p.groups >= 12 ? 2 : 1);
@@ -565,7 +564,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   if (nchunk > p.ntiles) nchunk = p.ntiles;
   // position chunks in multiples of 16 (8 XCD labels x 2): the workgroups of a chunk share their x / g tiles through one XCD's L2, and
   // an uneven deal of chunks to XCDs costs 15-25 % (K = 81 layers: 42 chunks 73 TFLOP/s, 32 chunks 89; 68 chunks 73, 64 chunks 86)
-  if (!cap_over || getenv("DPF_W2_ROUND")) {
+  if (!cap_over) {
     if (nchunk >= 16 && (nchunk & 7)) nchunk &= ~15LL;          // already a multiple of 8: keep (56 chunks beat 48 on the 96-channel layer)
     else if (nchunk > 8 && nchunk < 16) nchunk = 8;
   }
@@ -573,10 +572,6 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   nchunk = (p.ntiles + p.per - 1) / p.per;
   p.nchunk = (int)nchunk;
   p.slab_stride = (long long)d.K * d.C * T;
-  p.dbg = env_int("DPF_W2_DBG", 0);
-  if (getenv("DPF_W2_DEBUG"))
-    fprintf(stderr, "wgrad2 C%d K%d T%d s%d: NCT %d CCW %d lds %zu occ %d groups %d capacity %d nchunk %lld per %lld ntiles %lld\n", d.C, d.K, T, d.sh, NCT, CCW,
-            lds0, occ, p.groups, capacity, nchunk, (long long)p.per, (long long)p.ntiles);
   if (nchunk * p.slab_stride > ws_floats) return DPF_ERR_UNSUPPORTED;
 
   const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);

@@ -157,6 +157,21 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// the same step with its two step-dependent scalars read from device memory: hyper = { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) }.  A captured
+// HIP graph of the train step replays this launch with fixed arguments; the host refreshes the two floats before each replay.
+__global__ void adam_hyper_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                                  float gscale, const float* __restrict__ hyper, float b1, float b2, float omb1, float omb2, float eps) {
+  const float lr_over_bc1 = hyper[0], inv_sqrt_bc2 = hyper[1];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
 void fill(LossP& p, int B, int n, int H, int W, const float* w, float l0, float l1) {
   p.B = B; p.n = n; p.H = H; p.W = W;
   for (int i = 0; i < MAXHEADS; ++i) p.wts[i] = i < n ? w[i] : 0.f;
@@ -206,6 +221,16 @@ int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, gscale,
                      (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
+  return dpf_check_launch();
+}
+
+// dpf_adam_step with { (float)(lr / (1 - beta1^step)), (float)(1 / sqrt(1 - beta2^step)) } supplied in device memory (hyper[2])
+int dpf_adam_step_hyper(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, const float* hyper, double beta1,
+                        double beta2, double eps, float gscale, void* stream) {
+  dpf_clear_error();
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return DPF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(dpf_ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, gscale, hyper,
+                     (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
   return dpf_check_launch();
 }
 

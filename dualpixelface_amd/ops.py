@@ -1488,3 +1488,25 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
     _need(param, grad, exp_avg, exp_avg_sq)
     lib().call('dpf_adam_step', _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step), float(lr), float(beta1),
                float(beta2), float(eps), float(gscale), _stream())
+
+
+def adam_hyper(step, lr, beta1=0.9, beta2=0.999):
+    """The two step-dependent scalars of dpf_adam_step as float32, computed as the C side computes them."""
+    import numpy as np
+    bc1 = 1.0 - beta1 ** int(step)
+    bc2 = 1.0 - beta2 ** int(step)
+    return np.float32(float(lr) / bc1), np.float32(1.0 / (bc2 ** 0.5))
+
+
+def adam_step_hyper(param, grad, exp_avg, exp_avg_sq, hyper, beta1=0.9, beta2=0.999, eps=1e-5, gscale=1.0):
+    """adam_step with the step-dependent scalars in device memory (hyper: 2 floats) -- the launch a captured train-step graph replays."""
+    _need(param, grad, exp_avg, exp_avg_sq, hyper)
+    lib().call('dpf_adam_step_hyper', _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), _ptr(hyper), float(beta1),
+               float(beta2), float(eps), float(gscale), _stream())
+
+
+def reset_zero_arenas():
+    """Forget what is left of the pre-zeroed arenas: the next zero_slot() clears its arena again.  A graph capture of the train step starts
+    with this, so that the clearing fill is PART of the captured work (a replay finds the slots zero, as the eager step does)."""
+    for st in _zero_arena.values():
+        st[1] = st[0].numel()

@@ -92,9 +92,91 @@ class _PluginHooks(object):
         return cache[1]
 
     def train_step(self, batch, reducer=None, lr=None):
-        """forward + loss + backward + (gradient all-reduce) + fused Adam; returns the results dict."""
+        """forward + loss + backward + (gradient all-reduce) + fused Adam; returns the results dict.
+
+        Single-process steps on a fixed batch shape are captured into ONE HIP graph after two eager warm-up steps and replayed from then on
+        (option.step_graph / DPF_STEP_GRAPH, default on): the ~2 400 kernel launches of a step leave the host once, so the launch gaps between
+        the many short kernels disappear.  The C ABI never allocates or synchronises, which is what makes the step capturable."""
         if self.option.optim != 'adam':
             raise NotImplementedError('the fused step implements the shipped Adam configuration')
+        # (eager when a per-launch profile is being recorded -- ops.PROFILE -- or gradients are exchanged between ranks)
+        if reducer is None and ops.PROFILE is None and _graph_enabled(self) and all(v.is_cuda for v in batch.values() if torch.is_tensor(v)):
+            return self._graph_step(batch, lr)
+        return self._eager_step(batch, reducer, lr)
+
+    # ---- the step as one HIP graph ---------------------------------------------------------------------
+    def _graph_step(self, batch, lr):
+        tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        from . import stereodpnet as _sdn
+        # everything a captured graph has baked in: shapes, the kernel-path switches, the arenas' addresses (a device move re-creates them)
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())) + (
+            bool(ops.deterministic()), ops.CONV_OPERANDS_BF16, ops.WGRAD_ASYNC, _sdn.FEATURES_TWO_STREAMS, self.flat_parameters().data_ptr(),
+            self.flat_gradients(zero=False).data_ptr(), self._adam['m'].data_ptr() if self._adam else 0, self.stat_exchange is None)
+        st = getattr(self, '_graph_state', None)
+        if st is not None and st.get('failed') and st['key'] == key:
+            return self._eager_step(batch, None, lr)
+        if st is None or st['key'] != key:
+            st = self._graph_state = {'key': key, 'calls': 0, 'graph': None}
+        st['calls'] += 1
+        lr = float(lr if lr is not None else self.option.init_lr)
+        flat_g = self.flat_gradients(zero=False)
+        # The step lives on its OWN stream, warm-up included: autograd's gradient-accumulation nodes remember the stream they were created
+        # on, and a capture cannot make the default stream wait for the capturing one.
+        ss = getattr(self, '_step_stream', None)
+        if ss is None or ss.device != flat_g.device:
+            ss = self._step_stream = torch.cuda.Stream(device=flat_g.device)
+        cur = torch.cuda.current_stream(flat_g.device)
+        if st['calls'] <= 2 or self._adam is None:         # warm-up: lazily created streams, scratch buffers, sampler tables, kernel attributes
+            ss.wait_stream(cur)
+            with torch.cuda.stream(ss):
+                res = self._eager_step(batch, None, lr)
+            cur.wait_stream(ss)
+            for v in res.values():
+                if torch.is_tensor(v):
+                    v.record_stream(cur)
+            return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in res.items()}
+        ad = self._adam
+        if st['graph'] is None:
+            # static inputs (the caller's tensors are copied in before every replay), the hyper-parameter slot, then the capture itself
+            st['inputs'] = {k: v.clone() for k, v in tensors.items()}
+            st['extra'] = {k: v for k, v in batch.items() if not torch.is_tensor(v)}
+            st['hyper'] = torch.zeros(2, dtype=torch.float32, device=flat_g.device)
+            counts_before = dict(self._pending_counts)
+            self._flush_counts()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                torch.cuda.synchronize()
+                ops.reset_zero_arenas()
+                with torch.cuda.graph(graph, stream=ss):
+                    cap_batch = dict(st['extra'])
+                    cap_batch.update(st['inputs'])
+                    res = self._eager_step(cap_batch, None, lr, hyper=st['hyper'])
+                    st['results'] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in res.items()}
+                    del res
+                st['counts'] = dict(self._pending_counts)            # BatchNorm call counters one step adds (host-side bookkeeping)
+                self._pending_counts = {}
+                ad['step'] -= 1                                      # the capture only RECORDED the step: nothing ran
+                st['graph'] = graph
+            except Exception as e:                                   # capture refused (unsupported call inside): stay eager, say so once
+                import warnings
+                warnings.warn('train_step: HIP graph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
+                st['failed'] = True
+                self._pending_counts = counts_before
+                torch.cuda.synchronize()
+                return self._eager_step(batch, None, lr)
+        for k, v in tensors.items():
+            if v.data_ptr() != st['inputs'][k].data_ptr():
+                st['inputs'][k].copy_(v, non_blocking=True)
+        ad['step'] += 1
+        h0, h1 = ops.adam_hyper(ad['step'], lr)
+        st['hyper'][0:1].fill_(float(h0))                  # (scalars travel as kernel arguments: no host buffer the next step could overwrite)
+        st['hyper'][1:2].fill_(float(h1))
+        st['graph'].replay()
+        for name, n in st['counts'].items():
+            self._pending_counts[name] = self._pending_counts.get(name, 0) + n
+        return st['results']
+
+    def _eager_step(self, batch, reducer=None, lr=None, hyper=None):
         self.train()
         gscale = 1.0
         if getattr(self, 'gather_grads', True):
@@ -177,9 +259,20 @@ class _PluginHooks(object):
             self._adam = {'m': torch.zeros_like(flat_g), 'v': torch.zeros_like(flat_g), 'step': 0}
         st = self._adam
         st['step'] += 1
-        ops.adam_step(self.flat_parameters(), flat_g, st['m'], st['v'], st['step'], float(lr if lr is not None else self.option.init_lr),
-                      0.9, 0.999, 1e-5, gscale)
+        if hyper is not None:                              # (graph capture: the step-dependent scalars come from device memory)
+            ops.adam_step_hyper(self.flat_parameters(), flat_g, st['m'], st['v'], hyper, 0.9, 0.999, 1e-5, gscale)
+        else:
+            ops.adam_step(self.flat_parameters(), flat_g, st['m'], st['v'], st['step'], float(lr if lr is not None else self.option.init_lr),
+                          0.9, 0.999, 1e-5, gscale)
         return results
+
+
+def _graph_enabled(model):
+    import os
+    env = os.environ.get('DPF_STEP_GRAPH')
+    if env is not None:
+        return env != '0'
+    return bool(getattr(model.option, 'step_graph', True))
 
 
 def _attach_deferred(pairs):

@@ -283,6 +283,10 @@ int dpf_loss_backward(const float* pred_depth, const float* pred_normal, const f
                       const float* head_weights_host, float lambda_depth, float lambda_normal, void* stream);
 int dpf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, double lr, double beta1,
                   double beta2, double eps, float gscale, void* stream);
+/* the same update with the two step-dependent scalars { (float)(lr / (1 - beta1^step)), (float)(1 / sqrt(1 - beta2^step)) } read from device
+ * memory (hyper[2]): a captured HIP graph of the whole train step replays this launch unchanged while the host refreshes the two floats */
+int dpf_adam_step_hyper(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, const float* hyper, double beta1,
+                        double beta2, double eps, float gscale, void* stream);
 
 /* ---- FaceDP sample preprocessing: the per-sample host work of the reference's DataLoader workers,
  * dataloader/FaceDP/path_reader.py:150-168 (read_depth), :196-232 (read_disparity), dataloader/preprocess/preprocess.py:46-88

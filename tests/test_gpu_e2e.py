@@ -772,6 +772,38 @@ def test_deterministic_mode_gradients_vs_reference_fixture(golden_dir, tag):
         assert rel <= max(K_SPREAD * noise[k[6:]], GRAD_FLOOR), (k, rel, noise[k[6:]])
 
 
+def test_train_step_as_one_hip_graph_equals_eager_launches(golden_dir):
+    """plugin.train_step captures the whole step (forward, loss, backward on three streams, gradient gather, fused Adam) into ONE HIP graph
+    on the third call of a batch shape and replays it afterwards.  In deterministic mode eager steps are reproducible, so five graph-mode
+    steps (2 eager + capture + 2 replays... the capture itself executes nothing) must leave EXACTLY the parameters, Adam moments, BatchNorm
+    buffers and call counters that five eager steps leave; the learning rate changes on the way (it travels through device memory)."""
+    from dualpixelface_amd import ops
+    g = np.load(golden_dir + '/e2e_train_128x128_b2.npz')
+    batch = load_batch(g)
+    lrs = [1e-4, 1e-4, 1e-4, 5e-5, 2e-5]
+    outs = []
+    with ops.deterministic_mode():
+        for graph in (False, True):
+            model = build_model(True)
+            model.option.step_graph = graph
+            losses = []
+            for lr in lrs:
+                res = model.train_step({k: v.clone() for k, v in batch.items()}, lr=lr)
+                losses.append(float(res['final_loss']))
+            torch.cuda.synchronize()
+            live = getattr(model, '_graph_state', None) is not None and model._graph_state.get('graph') is not None
+            assert live == graph, (graph, getattr(model, '_graph_state', None) and model._graph_state.get('failed'))
+            outs.append((losses, model.flat_parameters().clone(), model._adam['m'].clone(), model._adam['v'].clone(), model._adam['step'],
+                         {k: v.clone() for k, v in model.state_dict().items()}))
+    (l0, p0, m0, v0, s0, sd0), (l1, p1, m1, v1, s1, sd1) = outs
+    assert s0 == s1 == len(lrs)
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    assert int(sd1['feature_extraction.firstconv.0.1.num_batches_tracked']) == 2 * len(lrs)      # two feature passes per step
+
+
 @pytest.mark.parametrize('bn_cat', ['0', '1'])
 def test_side_stream_weight_gradients_match_in_line(golden_dir, monkeypatch, bn_cat):
     """DPF_WGRAD_ASYNC: the weight-gradient launches move to a side stream; the gradients that reach Adam must be the same ones.

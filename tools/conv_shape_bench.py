@@ -1,5 +1,5 @@
 """Time (and check against torch's own GPU convolution) one convolution shape through the C-ABI: forward, data gradient,
-weight gradient.  usage: python tools/conv_shape_bench.py [--check] [names...]   (env knobs: DPF_IGEMM2, DPF_G2_CC, DPF_G2_NT, ...)"""
+weight gradient.  usage: python tools/conv_shape_bench.py [--check] [names...]   (env knobs: DPF_IGEMM2, DPF_IGEMM3, DPF_F32_X9, ...)"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from dualpixelface_amd import ops

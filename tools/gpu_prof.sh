@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/prof_$tag
 rm -rf "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline "$@" > gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline --no-graph "$@" > gpurun_out/prof_$tag.log 2>&1
 f=$(find "$out" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] || { echo "no kernel_stats.csv under $out (rocprofv3 failed, see the .log beside it)" >&2; exit 1; }
 cp "$f" gpurun_out/prof_${tag}_kernel_stats.csv

@@ -13,7 +13,7 @@ run() { "$@" 2>> "$O/bench.err"; }
 pmc_pass() {   # <dir> <counter> <bench args...>
   local d=$1 c=$2; shift 2
   rm -rf "gpurun_out/$d"
-  rocprofv3 --kernel-trace --pmc "$c" --output-format csv -d "gpurun_out/$d" -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline "$@" > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc "$c" --output-format csv -d "gpurun_out/$d" -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline --no-graph "$@" > /dev/null 2>&1
 }
 pmc_pass pmc_f FETCH_SIZE; pmc_pass pmc_w WRITE_SIZE
 python3 tools/pmc_traffic.py gpurun_out/pmc_f/p_counter_collection.csv gpurun_out/pmc_w/p_counter_collection.csv "$O/${R}_pmc_traffic.json" 3
@@ -23,7 +23,7 @@ run python bench.py --steps 10 --warmup 3 --shapes "$O/${R}_conv_shape_table.txt
 bash tools/gpu_prof.sh "$R" > "$O/${R}_bench_family_ms.txt" 2>&1
 cp "gpurun_out/prof_${R}_kernel_stats.csv" "$O/${R}_bench_kernel_stats.csv"
 export PMC_FILTER="igemm3 igemm2 wgrad2 dcn_ pointwise bn_"
-bash tools/gpu_pmc.sh ${R}sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline > "$O/${R}_sq_counters.txt" 2>&1
+bash tools/gpu_pmc.sh ${R}sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-detail --wgrad-inline --no-graph > "$O/${R}_sq_counters.txt" 2>&1
 if [ -z "$QUICK" ]; then
   pmc_pass pmc_f3 FETCH_SIZE --precision bf16; pmc_pass pmc_w3 WRITE_SIZE --precision bf16
   python3 tools/pmc_traffic.py gpurun_out/pmc_f3/p_counter_collection.csv gpurun_out/pmc_w3/p_counter_collection.csv "$O/${R}_pmc_traffic_bf16.json" 3
@@ -46,7 +46,6 @@ if [ -z "$QUICK" ]; then
   { echo "== default (x9 convolutions + weight gradient, 16-byte tile stores)"; python tools/conv_shape_bench.py --check $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
     echo "== DPF_F32_X9=0 (v_mfma_f32_32x32x2_f32 everywhere)"; DPF_F32_X9=0 python tools/conv_shape_bench.py $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
     echo "== DPF_G2_VEC_STORE=0 (4-byte tile stores)"; DPF_G2_VEC_STORE=0 python tools/conv_shape_bench.py $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
-    echo "== DPF_W2_DBG=1 (weight gradient without the DMA of tiles 2...: timing only, results wrong)"; DPF_W2_DBG=1 python tools/conv_shape_bench.py hg32 hg64 cv64_32 fe32 2>&1 | grep -v -e MIOpen -e amdgpu.ids
   } > "$O/${R}_conv_x9_vs_f32_per_shape.txt"
   { echo "== operand precision bf16: igemm3 NC=1 (default)"; python tools/conv_bf16_bench.py 2>&1 | grep -v -e MIOpen -e amdgpu.ids
     echo "== DPF_IGEMM3_BF=0 (igemm2 bf16 kernel)"; DPF_IGEMM3_BF=0 python tools/conv_bf16_bench.py 2>&1 | grep -v -e MIOpen -e amdgpu.ids; } > "$O/${R}_conv_bf16_per_shape.txt"
