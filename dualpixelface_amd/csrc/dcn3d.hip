@@ -1903,7 +1903,10 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     if (nchunkw > ntile) nchunkw = ntile;
     if (det) nchunkw = 1;            // each dW address then receives ONE atomic add: order-independent
     p.nchunk = (int)nchunkw;
-    const size_t lds = sizeof(float) * ((size_t)32 * MTC * SP + (size_t)32 * MT * SP);
+    // LDS of the INSTANTIATION that runs (<4, 4> for more than two row tiles on either side lays its tiles out for 4 + 4: sizing it for
+    // the actual counts put the grad_output tile outside the allocation -- C = 84 on this path returned a zero grad_weight)
+    const bool small = MT <= 2 && MTC <= 2;
+    const size_t lds = sizeof(float) * ((size_t)32 * (small ? MTC : 4) * SP + (size_t)32 * (small ? MT : 4) * SP);
     const dim3 grid((unsigned)(p.T * p.nchunk));
 #define DPF_W(M, N)                                                                                           \
   {                                                                                                           \
