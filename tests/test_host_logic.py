@@ -176,3 +176,22 @@ def test_reducer_stage_names_follow_the_bucket_cut():
     rc = FlatGradReducer(model.flat_gradients(zero=True), layout, [mid])
     assert stage_names(model, rc) == {}
     rc.remove()
+
+
+def test_every_environment_switch_is_documented():
+    """Sprawl guard: every DPF_* environment variable the product reads -- getenv / env_int / env_flag in the kernels' host
+    code, os.environ in the Python package and bench.py -- is listed in README.md's "Environment switches" paragraph."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for f in glob.glob(os.path.join(root, 'dualpixelface_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(root, 'dualpixelface_amd', 'csrc', '*.h')):
+        found |= set(re.findall(r'(?:getenv|env_int|env_flag)\(\s*"(DPF_[A-Z0-9_]+)"', open(f).read()))
+    for f in glob.glob(os.path.join(root, 'dualpixelface_amd', '*.py')) + [os.path.join(root, 'bench.py')]:
+        found |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*'(DPF_[A-Z0-9_]+)'", open(f).read()))
+    readme = open(os.path.join(root, 'README.md')).read()
+    switches = readme[readme.index('Environment switches'):]
+    # (DPF_ONE_DEVICE is a test hook of tests/test_gpu_distributed.py, documented there and in bench.py)
+    missing = sorted(v for v in found if v not in switches and v != 'DPF_ONE_DEVICE')
+    assert not missing, missing
+    assert len(found) <= 40, (len(found), 'collapse switches that have a measured winner')
