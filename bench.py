@@ -407,6 +407,20 @@ def main():
             # the dense conv kernels contract on the bf16 matrix cores in --precision bf16: price them against THAT peak (they are then
             # staging-bound -- LDS-DMA / LDS reads of the fp32 patch -- far below it)
             peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+            x6_flop_per_clk = 1024 * (32 * 32 * 16 * 2 / 32.0) / 6.0 * 27.0 / 28.0       # fp32 FLOP per shader clock of the six-product construction
+            x6_peak = x6_flop_per_clk * 2.4e9 / 1e12
+            f32_frac_pipe = None
+            if args.precision == 'f32' and dom == 'conv_igemm':
+                # The family mixes two pipes: stride-1 launches with >= 8 input channels multiply on the bf16 pipe (six partial products per fp32
+                # product: ceiling 2.5 PFLOP/s / 6 x 27/28), the rest (stride 2, the 3-channel first layer) on v_mfma_f32_32x32x2_f32 (157.3).
+                # `peak` is the FLOP-weighted (harmonic) blend of the two -- the rate at which the family would run with every launch at ITS
+                # pipe's dense peak -- so that `frac` cannot exceed 1 (157.3 is not the peak of a bf16-pipe kernel).
+                on_bf16 = lambda tag: (' s1 ' in tag) and not any((' C%d ' % c) in tag for c in range(1, 8)) and ' k111 ' not in tag
+                fl_b = sum(r[1] for r in prof if r[0] == dom and on_bf16(r[4]))
+                fl_f = sum(r[1] for r in prof if r[0] == dom and not on_bf16(r[4]))
+                if fl_b + fl_f > 0:
+                    peak = (fl_b + fl_f) / (fl_b / x6_peak + fl_f / PEAK_F32_TFLOPS)
+                    f32_frac_pipe = fl_b / (fl_b + fl_f)
             inline_ms = sum(v[1] for v in fam.values()) / prof_steps * 1e3
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                     'traffic': (hb / (n / prof_steps)) if hb is not None else None, 'traffic_source': traffic_source, 'algorithmic_bytes_per_launch': alg_bytes / n, 'launches': n,
@@ -414,21 +428,20 @@ def main():
                     'measured_in': ('%d steps after the timed region on ONE stream (weight gradients in line, feature passes one after the other: kernels do not overlap, event time = kernel time)' % prof_steps)
                                    if not args.no_detail else 'the timed region', 'families': fam_out}
             if args.precision != 'bf16':
-                # most fp32 launches (stride-1 convs, weight gradients) form each fp32 product from SIX bf16 partial products on the bf16 matrix
-                # pipe (round-to-nearest three-way split; the dropped cross terms are <= 2^-23 of a product): `peak` stays the dense fp32 MFMA
-                # peak the metric's FLOPs are priced against (MI355X_MICROARCH.md), and the construction's own ceiling is printed beside it --
-                # 1024 SIMDs x 32x32x16x2 FLOP per 32 clocks / 6 MFMAs per fp32 product = 174 763 fp32 FLOP per shader clock (x 27/28 for the
-                # zero taps that pad 27 to 28), at the nominal 2.4 GHz and at the clock the chip HOLDS under that stream (held_clock_mhz)
-                flop_per_clk = 1024 * (32 * 32 * 16 * 2 / 32.0) / 6.0 * 27.0 / 28.0
-                x6 = flop_per_clk * 2.4e9 / 1e12
-                roof['peak_note'] = ('fp32 FLOPs against the dense fp32 MFMA peak (the dtype of the metric); the launches that multiply on the bf16 '
-                                     'pipe (6 bf16 partial products per fp32 product) have an issue ceiling of %.1f TFLOP/s of fp32 FLOPs at 2.4 GHz' % x6)
-                roof['frac_of_bf16_pipe_issue_ceiling'] = ach / x6
+                # (see the blend above: `peak` prices every launch at the dense peak of the pipe it runs on)
+                roof['peak_note'] = ('FLOP-weighted blend of the pipes the launches run on: %.0f %% of the family\'s fp32 FLOPs multiply on the bf16 matrix pipe '
+                                     '(six bf16 partial products per fp32 product: 2.5 PFLOP/s / 6 x 27/28 = %.1f TFLOP/s of fp32 FLOPs at 2.4 GHz), the rest on '
+                                     'v_mfma_f32_32x32x2_f32 (157.3)' % (100.0 * (f32_frac_pipe or 0.0), x6_peak))
+                roof['frac_of_f32_mfma_peak'] = ach / PEAK_F32_TFLOPS        # the dtype's own dense peak (individual bf16-pipe launches exceed it)
                 if clock_mhz:
-                    held = flop_per_clk * clock_mhz * 1e6 / 1e12
+                    # the bf16-pipe share priced at the clock the chip HOLDS under that stream (power-bound: MI355X_MICROARCH.md, DVFS)
+                    held_b = x6_flop_per_clk * clock_mhz * 1e6 / 1e12
+                    fb = f32_frac_pipe if f32_frac_pipe is not None else 1.0
+                    held = 1.0 / (fb / held_b + (1.0 - fb) / PEAK_F32_TFLOPS)
                     roof['shader_clock_mhz_under_conv_load'] = clock_mhz
-                    roof['bf16_pipe_issue_ceiling_at_held_clock'] = held
-                    roof['frac_of_ceiling_at_held_clock'] = ach / held
+                    roof['bf16_pipe_issue_ceiling_at_held_clock'] = held_b
+                    roof['peak_at_held_clock'] = held
+                    roof['frac_of_peak_at_held_clock'] = ach / held
             if dom in fam_t and timed_async and not args.no_detail:      # the same family as the timed region saw it (overlapped by the side stream)
                 f2 = fam_t[dom]
                 roof['timed_region_overlapped'] = {'achieved': f2[0] / f2[1] / 1e12, 'frac': f2[0] / f2[1] / 1e12 / peak, 'avg_launch_ms': f2[1] / f2[2] * 1e3,
