@@ -1296,16 +1296,23 @@ def deform_conv3d(x, offset, weight, bias, stride=1, pad=1, dil=1, gi_channels=N
 # ----------------------------------------------------------------------------------------------- normal module glue
 class AnmVolumeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cost, disp_full, Kmat, abvalue, costrange, ksel):
+    def forward(ctx, cost, disp_full, Kmat, abvalue, costrange, ksel, idx_override=None):
         cost, disp_full, Kmat, abvalue = _c(cost), _c(disp_full), _c(Kmat), _c(abvalue)
         _need(cost, disp_full, Kmat, abvalue)
         B, C, L, h, w = cost.shape
         H, W = disp_full.shape[1], disp_full.shape[2]
         dev = cost.device
-        idx = torch.empty((B, ksel, h, w), dtype=torch.int32, device=dev)
-        sdisp = torch.empty((B, ksel, h, w), dtype=torch.float32, device=dev)
         lb = lib()
-        lb.call('dpf_anm_select', _ptr(disp_full), _ptr(idx), _ptr(sdisp), _host_floats(costrange), B, H, W, h, w, L, ksel, _stream())
+        if idx_override is not None:
+            # diagnostic hook (tests): the level selection is a discontinuous function of the predicted disparity -- a comparison against
+            # another implementation imposes ITS selection [B, ksel, h, w] so that everything downstream is comparable pixel by pixel
+            idx = idx_override.to(device=dev, dtype=torch.int32).contiguous()
+            assert tuple(idx.shape) == (B, ksel, h, w)
+            sdisp = torch.tensor(list(costrange), dtype=torch.float32, device=dev)[idx.long()].contiguous()
+        else:
+            idx = torch.empty((B, ksel, h, w), dtype=torch.int32, device=dev)
+            sdisp = torch.empty((B, ksel, h, w), dtype=torch.float32, device=dev)
+            lb.call('dpf_anm_select', _ptr(disp_full), _ptr(idx), _ptr(sdisp), _host_floats(costrange), B, H, W, h, w, L, ksel, _stream())
         vol = torch.empty((B, C + 3, ksel, h, w), dtype=torch.float32, device=dev)
         mm = torch.empty(2 * B, dtype=torch.int32, device=dev)
         lb.call('dpf_anm_volume_forward', _ptr(cost), _ptr(idx), _ptr(sdisp), _ptr(Kmat), _ptr(abvalue), _ptr(vol), _ptr(mm), B, C, L, ksel,
@@ -1322,11 +1329,11 @@ class AnmVolumeFn(torch.autograd.Function):
         dvol = _c(dvol)
         dcost = torch.empty((B, C, L, h, w), dtype=torch.float32, device=dvol.device)
         lib().call('dpf_anm_volume_backward', _ptr(dvol), _ptr(idx), _ptr(dcost), B, C, L, ksel, h, w, _stream())
-        return dcost, None, None, None, None, None
+        return dcost, None, None, None, None, None, None
 
 
-def anm_volume(cost, disp_full, Kmat, abvalue, costrange, ksel):
-    return AnmVolumeFn.apply(cost, disp_full, Kmat, abvalue, tuple(costrange), ksel)
+def anm_volume(cost, disp_full, Kmat, abvalue, costrange, ksel, idx_override=None):
+    return AnmVolumeFn.apply(cost, disp_full, Kmat, abvalue, tuple(costrange), ksel, idx_override)
 
 
 class SigmoidMeanFn(torch.autograd.Function):

@@ -562,7 +562,8 @@ class StereoDPNetCore(_Base):
             self._index()
         if not m.use_sampling:
             raise NotImplementedError('use_sampling=false is not on the StereoDPNet hot path')
-        vol, idx = ops.anm_volume(cost, disp_full, batch['K'].float(), batch['abvalue'].float(), self.costrange, int(m.dsample_num))
+        vol, idx = ops.anm_volume(cost, disp_full, batch['K'].float(), batch['abvalue'].float(), self.costrange, int(m.dsample_num),
+                                  getattr(self, 'anm_idx_override', None))      # (diagnostic hook of the parity tests, see ops.AnmVolumeFn)
         self.last_anm_idx = idx                  # selected cost levels [B, k, h, w] (diagnostics / tests)
         if m.use_deform:
             # the 3 XYZ channels of `vol` are constants of the batch (no gradient consumer): skip their grad_input

@@ -442,31 +442,26 @@ def test_c2_shape_forward_loss_and_gradients_vs_cpu_oracle(golden_dir):
     res = model.train_step({k: v.to(DEV) for k, v in batch.items()})          # forward + loss + backward + Adam at this size
     close(model.last_taps['volume'], orc.taps['volume'], 2e-4, 'volume')
     close(res['pred_depth'], ref['pred_depth'], None, 'pred_depth', atol=3e-3)
-    # The normal head samples the 4 cost levels nearest to the predicted disparity (normal_module.py:80-138): a discontinuous
-    # selection.  Over 98 304 quarter-resolution pixels a prediction that sits within fp32 rounding of a level boundary can pick
-    # the neighbouring level on one side only (observed: one run in eight, a single pixel), and that pixel's different cost
-    # slices then reach every normal inside the head's receptive field (two 3x3x3 deformable convs + 2-D dilations 1,2,4,8,1,1:
-    # measured with tools/c2_flip_probe.py over 30 runs: 2 runs with one flipped pixel, error 8e-2 at the pixel, 7e-4 beyond 24
-    # quarter-resolution pixels, 2.7e-4 beyond 32; 1.0e-4 .. 1.3e-4 everywhere when nothing flips).  So: the selected levels are
-    # compared first (at most 8 pixels may differ), the normals are compared outside a 32-pixel neighbourhood of those pixels to
-    # 1e-3, and inside it to a loose 0.2.
+    # The normal head samples the 4 cost levels nearest to the predicted disparity (normal_module.py:80-138): a DISCONTINUOUS selection.
+    # Over 98 304 quarter-resolution pixels a prediction that sits within fp32 rounding of a level boundary can pick the neighbouring level
+    # on one side only (tools/c2_flip_probe.py: 2 runs in 30, one pixel each), and that pixel's different cost slices then reach every normal
+    # in the head's receptive field and, through the head's gradient, every parameter.  So the comparison is split: (i) the selection itself
+    # -- at most 8 pixels may differ; (ii) everything downstream of it with the ORACLE's selection imposed (model.anm_idx_override, a
+    # diagnostic hook): then normals, losses and gradients are compared pixel by pixel with no allowance for flips.
     idx_gpu = model.last_anm_idx.cpu().long()
     idx_cpu = orc.taps['anm_idx'].long()
-    flipped = (idx_gpu != idx_cpu).any(1, keepdim=True).float()                       # [B, 1, h, w]
-    assert int(flipped.sum()) <= 8, int(flipped.sum())
-    R = 32
-    near = torch.nn.functional.max_pool2d(flipped, 2 * R + 1, 1, R)
-    near = torch.nn.functional.interpolate(near, scale_factor=4, mode='nearest').bool()  # [B, 1, H, W]
+    nflip = int((idx_gpu != idx_cpu).any(1).sum())
+    assert nflip <= 8, nflip
+    if nflip:
+        model = build_model(True)
+        model.anm_idx_override = idx_cpu.to(DEV)
+        res = model.train_step({k: v.to(DEV) for k, v in batch.items()})
+        assert torch.equal(model.last_anm_idx.cpu().long(), idx_cpu)
     err = (res['pred_normal'].detach().cpu().double() - ref['pred_normal'].double()).abs()   # [B, 1, 3, H, W]
-    outside = err.masked_fill(near.unsqueeze(2), 0.0)
-    assert float(outside.max()) <= 1e-3 and float(err.max()) <= 0.2, (float(outside.max()), float(err.max()), int(flipped.sum()))
-    # mean error: 1.0e-5 when nothing flips; a flipped pixel also moves the head's BatchNorm batch statistics a little, which every
-    # normal sees (measured 2.06e-5 in 2 of 10 runs)
-    assert float(outside.mean()) <= (2e-5 if int(flipped.sum()) == 0 else 6e-5), (float(outside.mean()), int(flipped.sum()))
+    assert float(err.max()) <= 1e-3 and float(err.mean()) <= 2e-5, (float(err.max()), float(err.mean()), nflip)
     close(res['smoothL1_loss'], ref['smoothL1_loss'], 2e-4, 'smoothL1_loss')
-    loose = 2e-4 if int(flipped.sum()) == 0 else 5e-3                                 # a flipped pixel moves the normals around it
     for k in ('cosine_loss', 'final_loss'):
-        close(res[k], ref[k], loose, k)
+        close(res[k], ref[k], 2e-4, k)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     # ---- gradients at production tiling.  With ONE sample per BatchNorm batch this configuration is ill-conditioned in fp32: measured
     # (tools/debug/c2_grad_probe.py) the fp32 CPU oracle sits 1e-1 (median over the 287 parameter gradients) from the fp64 oracle, the HIP
@@ -658,7 +653,8 @@ def test_c2_batch4_forward_loss_and_gradients_vs_oracle_fixture(golden_dir):
     selection, the losses.  Backward: 12 full gradients and sum g^2 of every gradient, each within K_SPREAD x the oracle's own fp32 noise in
     that tensor: the largest distance between five fp32 runs of the oracle in different summation orders (8 / 5 / 3 threads, another batch
     order, oneDNN off -- thread counts alone are correlated draws: with them only, the median noise reads 4.9e-3 instead of 1.3e-2).
-    Measured on MI355X (round 5): distance / noise of the 12 tensors 0.2 ... 2.9, the head's last layer 1.0."""
+    The ANM level selection is compared first; if a pixel differs, the step is repeated with the oracle's selection imposed and everything
+    is compared without allowance for flips.  Measured on MI355X (round 5): distance / noise of the 12 tensors 0.2 ... 2.9, the head 1.0."""
     from dualpixelface_amd.recipe import synthetic_batch
     g = np.load(golden_dir + '/c2_b4_oracle.npz')
     B, H, W, seed = (int(v) for v in g['batch_args'])
@@ -670,19 +666,21 @@ def test_c2_batch4_forward_loss_and_gradients_vs_oracle_fixture(golden_dir):
     close(res['pred_depth'][..., ::4, ::4], g['pred_depth_s'], None, 'pred_depth', atol=3e-3)
     pdd = res['pred_depth'].detach().double()
     assert abs(float(pdd.sum()) - g['pred_depth_cs'][0]) <= 3e-4 * pdd.numel()
-    # ANM level selection (discontinuous, see the batch-1 test): at most 8 flipped quarter-resolution pixels per sample
-    idx_gpu = model.last_anm_idx.cpu().long()
+    # ANM level selection (discontinuous, see the batch-1 test): (i) at most 8 flipped quarter-resolution pixels per sample; (ii) with the
+    # oracle's selection imposed, everything downstream is compared without any allowance for flips
     idx_ref = torch.from_numpy(g['anm_idx']).long()
-    flipped = (idx_gpu != idx_ref).any(1, keepdim=True).float()                        # [B, 1, h, w]
-    nflip = int(flipped.sum())
+    nflip = int((model.last_anm_idx.cpu().long() != idx_ref).any(1).sum())
     assert nflip <= 8 * B, nflip
-    near = torch.nn.functional.max_pool2d(flipped, 65, 1, 32).bool()                   # 32 quarter-resolution pixels around a flip = the ::4 grid
+    if nflip:
+        model = build_model(True)
+        model.anm_idx_override = idx_ref.to(DEV)
+        res = model.train_step({k: v.to(DEV) for k, v in batch.items()})
+        assert torch.equal(model.last_anm_idx.cpu().long(), idx_ref)
     err = (res['pred_normal'][..., ::4, ::4].detach().cpu().double() - torch.from_numpy(g['pred_normal_s']).double()).abs()   # [B, 1, 3, h, w]
-    outside = err.masked_fill(near.unsqueeze(2), 0.0)
-    assert float(outside.max()) <= 1e-3 and float(err.max()) <= 0.2, (float(outside.max()), float(err.max()), nflip)
+    assert float(err.max()) <= 1e-3, (float(err.max()), nflip)
     close(res['smoothL1_loss'], g['smoothL1_loss'], 2e-4, 'smoothL1_loss')
     for k in ('cosine_loss', 'final_loss'):
-        close(res[k], g[k], 2e-4 if nflip == 0 else 5e-3, k)
+        close(res[k], g[k], 2e-4, k)
     # ---- gradients
     names = [str(n) for n in g['grad_names']]
     spread = g['grad_spread']
@@ -695,15 +693,14 @@ def test_c2_batch4_forward_loss_and_gradients_vs_oracle_fixture(golden_dir):
         ref = torch.from_numpy(g[k]).double()
         mine = pd[k[6:]].grad.detach().cpu().double()
         rel = ((mine - ref).norm() / ref.norm()).item()
-        loose = nflip > 0 and 'normal_estimator' in k
-        budget = max(K_SPREAD * noise[k[6:]], GRAD_FLOOR) * (10.0 if loose else 1.0)
+        budget = max(K_SPREAD * noise[k[6:]], GRAD_FLOOR)
         report.append((rel / noise[k[6:]], k[6:], rel, budget))
-    print('c2 batch 4: flipped ANM pixels %d; distance / oracle noise per tensor:' % nflip, ', '.join('%s %.2f (%.1e)' % (n, r, rel) for r, n, rel, _ in sorted(report, reverse=True)))
+    print('c2 batch 4: flipped ANM pixels %d (oracle selection imposed afterwards); distance / oracle noise per tensor:' % nflip, ', '.join('%s %.2f (%.1e)' % (n, r, rel) for r, n, rel, _ in sorted(report, reverse=True)))
     for r, n, rel, budget in report:
         assert rel <= budget, (n, rel, budget, nflip)
     over, rels = [], []
     for n, c in zip(names, g['grad_sumsq']):
-        if n in pd and pd[n].grad is not None and c > 1e-12 and noise[n] < 0.25 and not (nflip > 0 and 'normal_estimator' in n):
+        if n in pd and pd[n].grad is not None and c > 1e-12 and noise[n] < 0.25:
             t = pd[n].grad.detach().double()
             r = abs((t * t).sum().item() - c) / c
             rels.append(r)

@@ -687,6 +687,35 @@ def test_psm_volume_against_reference_fixture(golden_dir):
     close_elem(ops.psm_volume(ref, tar, shifts, 40), torch.from_numpy(g['vol_gwcnet']), 'gwcnet volume')
 
 
+def test_psm_volume_full_size_bit_exact():
+    """BASELINE configs[3] at its stated size (c4 was pinned at the 256 x 256 fixture only): the PSMNet cost-volume path on
+    2 x 1024 x 1536 pairs = 32-channel features at 256 x 384, 8 integer shifts.  The oracle's volume is pure indexing, so it runs on the
+    device tensors as well: the concat volume must be BIT-EXACT (403 MB), the group-wise correlation channels and the backward element-wise
+    close."""
+    from oracle.psmnet_volume import psm_volume
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    ref = torch.randn(2, 32, 256, 384, generator=g).to(DEV)
+    tar = torch.randn(2, 32, 256, 384, generator=g).to(DEV)
+    costrange = [i * 0.5 - 1.0 for i in range(8)]
+    shifts = [int(c) for c in costrange]
+    vol = ops.psm_volume(ref, tar, shifts, 0)
+    want = psm_volume(ref, tar, costrange, 0)
+    assert vol.shape == want.shape == (2, 64, 8, 256, 384) and torch.equal(vol, want)
+    del vol, want
+    rg, tg = ref.clone().requires_grad_(), tar.clone().requires_grad_()
+    v2 = ops.psm_volume(rg, tg, shifts, 8)
+    ro, to = ref.clone().requires_grad_(), tar.clone().requires_grad_()
+    w2 = psm_volume(ro, to, costrange, 8)
+    assert torch.equal(v2[:, :64], w2[:, :64])
+    close_elem(v2[:, 64:], w2[:, 64:].detach().cpu(), 'gwc channels at full size')
+    go = torch.randn(v2.shape, generator=torch.Generator().manual_seed(32)).to(DEV)
+    g1 = torch.autograd.grad(v2, (rg, tg), go)
+    g2 = torch.autograd.grad(w2, (ro, to), go)
+    for a, b, nm in zip(g1, g2, ('d ref', 'd tar')):
+        close_elem(a, b.cpu(), 'psm volume backward ' + nm)
+
+
 def test_layout_kernels():
     ops = _ops()
     a, b, c = rnd(2, 5, 3, 7, seed=100).requires_grad_(), rnd(2, 8, 3, 7, seed=101).requires_grad_(), rnd(2, 1, 3, 7, seed=102).requires_grad_()
