@@ -200,6 +200,17 @@ def gen_e2e(tag, B, H, W, train, mask_mode, stages, prepare=None, compact=False)
         lambda m, inp: cap.__setitem__('anm_volume', inp[0])))
     hooks.append(model.normal_estimator.deform_conv2.register_forward_hook(grab('dcn2')))
 
+    # the ANM level selection (normal_module.py:118-136): sample_with_sort returns the selected levels' disparities = costrange[sorted indices];
+    # the bound method is wrapped (out of the reference tree) and the indices recovered from those values
+    ne = model.normal_estimator
+    if hasattr(ne, 'sample_with_sort'):
+        orig_sws = ne.sample_with_sort
+
+        def sws(cost, value):
+            res_ = orig_sws(cost, value)
+            cap['anm_sdisp'] = res_[1].detach().clone()
+            return res_
+        ne.sample_with_sort = sws
     res = model(batch)
     for h in hooks:
         h.remove()
@@ -217,6 +228,9 @@ def gen_e2e(tag, B, H, W, train, mask_mode, stages, prepare=None, compact=False)
         out['pred_depth'] = f32(res['pred_depth'])
         out['pred_normal'] = f32(res['pred_normal'])
         out['ref_feature'] = f32(res['ref_feature'])
+    if 'anm_sdisp' in cap:
+        cr = model.normal_estimator.costrange.detach().reshape(1, -1, 1, 1, 1)                  # [1, L, 1, 1, 1]
+        out['anm_idx'] = (cap['anm_sdisp'].unsqueeze(1) - cr).abs().argmin(1).to(torch.uint8).numpy()      # [B, K, h, w]
     out['prob_depth_cs'] = checksum(res['prob_depth'])
     out['prob_depth_s'] = f32(res['prob_depth'][:, :, ::4, ::8, ::8])
     if stages:

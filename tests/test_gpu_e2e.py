@@ -509,14 +509,21 @@ def test_train_256x256_vs_reference_fixture(golden_dir):
     cs = res['pred_depth'].detach().double()
     assert abs(float(cs.sum()) - g['pred_depth_cs'][0]) <= 3e-4 * cs.numel()
     close(res['ref_feature'][..., ::2, ::2], g['ref_feature_s'], 2e-4, 'ref_feature')
-    # normals: the ANM level selection is discontinuous (see the c2 test): either nothing flipped (1e-3 everywhere) or a flipped
-    # quarter-resolution pixel disturbs its receptive field -- which is most of a 64 x 64 plane -- a little
+    # the ANM level selection is discontinuous (see the c2 tests): the REFERENCE's own selection is in the fixture -- at most 4 of the 4 096
+    # quarter-resolution pixels may differ, and if one does, the step is repeated with the reference's selection imposed, so that everything
+    # downstream is compared without any allowance for flips
+    idx_ref = torch.from_numpy(g['anm_idx']).long()
+    nflip = int((model.last_anm_idx.cpu().long() != idx_ref).any(1).sum())
+    assert nflip <= 4, nflip
+    if nflip:
+        model = build_model(True)
+        model.anm_idx_override = idx_ref.to(DEV)
+        res = model.train_step({k: v.to(DEV) for k, v in batch.items()})
     err = (res['pred_normal'][..., ::2, ::2].detach().cpu().double() - torch.from_numpy(g['pred_normal_s']).double()).abs()
-    assert float(err.max()) <= 1e-3 or (float(err.max()) <= 0.2 and float(err.mean()) <= 2e-4), (float(err.max()), float(err.mean()))
-    flipped = float(err.max()) > 1e-3
+    assert float(err.max()) <= 1e-3, (float(err.max()), float(err.mean()), nflip)
     close(res['smoothL1_loss'], g['smoothL1_loss'], 2e-4, 'smoothL1_loss')
     for k in ('cosine_loss', 'final_loss'):
-        close(res[k], g[k], 5e-3 if flipped else 2e-4, k)
+        close(res[k], g[k], 2e-4, k)
     pd = dict(model.named_parameters())
     for k in g.files:
         if not k.startswith('grad::'):
@@ -526,11 +533,11 @@ def test_train_256x256_vs_reference_fixture(golden_dir):
             continue
         mine = pd[k[6:]].grad.detach().cpu().double()
         rel = ((mine - ref).norm() / ref.norm()).item()
-        tol = 1e-5 if k.endswith('classif3.2.weight') else (0.3 if (flipped and 'normal_estimator' in k) else 8e-2)
-        assert rel <= tol, (k, rel, flipped)
+        tol = 1e-5 if k.endswith('classif3.2.weight') else 8e-2
+        assert rel <= tol, (k, rel, nflip)
     rels = []
     for n, c in zip((str(s) for s in g['grad_names']), g['grad_cs']):
-        if n in pd and pd[n].grad is not None and c[2] > 1e-12 and not (flipped and 'normal_estimator' in n):
+        if n in pd and pd[n].grad is not None and c[2] > 1e-12:
             t = pd[n].grad.detach().double()
             rels.append(abs((t * t).sum().item() - c[2]) / c[2])
     assert len(rels) > 200 and float(np.median(rels)) <= 2e-2, (len(rels), float(np.median(rels)))

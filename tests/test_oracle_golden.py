@@ -98,6 +98,9 @@ def test_oracle_at_256x256_vs_reference(golden_dir):
     orc = StereoDPNetOracle(st, training=True)
     res = orc.forward(batch)
     _close(res['pred_depth'][..., ::2, ::2], g['pred_depth_s'], 1e-4, '256 pred_depth')
+    # the ANM level selection of the reference itself (normal_module.py:118-136, captured through sample_with_sort): the oracle's top-k
+    # restatement picks the same 4 levels at every one of the 64 x 64 quarter-resolution pixels
+    assert torch.equal(orc.taps['anm_idx'].long(), torch.from_numpy(g['anm_idx']).long())
     _close(res['pred_normal'][..., ::2, ::2], g['pred_normal_s'], 1e-4, '256 pred_normal')
     _close(res['final_loss'], g['final_loss'], 1e-5, '256 final_loss')
     res['final_loss'].backward()
