@@ -103,7 +103,12 @@ class NNetCore(PSMNetCore):
             grid = torch.stack([xs, ys, torch.ones_like(xs)], 0).unsqueeze(0).to(cost0.device)
             self._modules[p].register_parameter('grid', nn.Parameter(grid, False))
             self._index()
-        levels = torch.tensor(self.costrange, dtype=torch.float32, device=cost0.device).view(1, L, 1, 1).expand(B, L, h, w).contiguous()
+        # (constant of the model and the batch shape: built once -- a host-to-device copy per step would also keep the step out of a HIP graph)
+        lk = (str(cost0.device), B, L, h, w)
+        if getattr(self, '_levels_key', None) != lk:
+            self._levels = torch.tensor(self.costrange, dtype=torch.float32, device=cost0.device).view(1, L, 1, 1).expand(B, L, h, w).contiguous()
+            self._levels_key = lk
+        levels = self._levels
         xyz = torch.empty((B, 3, L, h, w), dtype=torch.float32, device=cost0.device)
         ops.xyz_volume_into(xyz, 0, levels, batch['K'].float(), batch['abvalue'].float())
         wc = ops.concat_channels([xyz, cost_in0, cost0])                            # [B, 3 + 2C, L, h, w]
