@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
 // staged ELEMENT, not once per use (27 uses per element: that variant is VALU-bound), so the staging path differs
 // from igemm2_kernel:
 //   * a chunk is 4 input channels; the patch is fetched into REGISTERS (16-byte row segments of the 4 channels, prefetched one chunk
-//     ahead, across the MFMA loop), split there (11 VALU per value pair) and written to LDS as [position][hi|mid|lo][4 channels]
+//     ahead, across the MFMA loop), split there (9 VALU per value pair) and written to LDS as [position][hi|mid|lo][4 channels]
 //     bf16 -- 24 bytes per position, so ONE address serves the three components of a tap;
 //   * the 16 reduction elements of an MFMA are 4 taps x 4 channels: a lane (column l31, K-half hh) reads the 8-byte channel
 //     quadruplets of taps 4g + 2hh and 4g + 2hh + 1 for each component (positions from a per-tap offset table in LDS);
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
           for (int i = 0; i < NM; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, (NSL / 2 / NPS * CC / 2 * (NC == 3 ? 11 : 1) + NM - 1) / NM + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (NSL / 2 / NPS * CC / 2 * (NC == 3 ? 9 : 1) + NM - 1) / NM + 1, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -68,12 +68,16 @@ __device__ __forceinline__ unsigned dpf_pk_bf16(float x, float y) {
   const dpf_f32x2 f = {x, y};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, dpf_bf16x2));
 }
-// (x, y) -> packed bf16 pairs of the three components (11 vector instructions)
+// (x, y) -> packed bf16 pairs of the three components: 9 vector instructions (3 v_cvt_pk_bf16_f32, 4 bit operations that widen a packed pair
+// back to two floats, 2 v_pk_add_f32 -- the two residuals of a stage are ONE packed subtraction)
 __device__ __forceinline__ void dpf_split_pair(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
+  const dpf_f32x2 v = {x, y};
   h = dpf_pk_bf16(x, y);
-  const float r1x = x - __builtin_bit_cast(float, h << 16), r1y = y - __builtin_bit_cast(float, h & 0xffff0000u);
-  m = dpf_pk_bf16(r1x, r1y);
-  const float r2x = r1x - __builtin_bit_cast(float, m << 16), r2y = r1y - __builtin_bit_cast(float, m & 0xffff0000u);
-  l = dpf_pk_bf16(r2x, r2y);
+  const dpf_f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+  const dpf_f32x2 r1 = v - hf;
+  m = dpf_pk_bf16(r1.x, r1.y);
+  const dpf_f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+  const dpf_f32x2 r2 = r1 - mf;
+  l = dpf_pk_bf16(r2.x, r2.y);
 }
 #endif

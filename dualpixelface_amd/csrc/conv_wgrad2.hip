@@ -280,11 +280,11 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bM, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH, bH, acc[t], 0, 0, 0);
           {
-            constexpr int NPR = 9 - W2_X9_FIRST;              // MFMAs of the unit; the split (44 vector instructions) and 8 LDS reads in their shadow
+            constexpr int NPR = 9 - W2_X9_FIRST;              // MFMAs of the unit; the split (36 vector instructions) and 8 LDS reads in their shadow
 #pragma unroll
             for (int i = 0; i < NPR; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
-              __builtin_amdgcn_sched_group_barrier(0x002, (44 + NPR - 1) / NPR + (NPR >= 8 ? 0 : 1), 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, (36 + NPR - 1) / NPR + 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, (8 + NPR - 1) / NPR, 0);
             }
           }
