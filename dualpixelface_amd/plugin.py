@@ -106,6 +106,7 @@ class _PluginHooks(object):
 
     # ---- the step as one HIP graph ---------------------------------------------------------------------
     def _graph_step(self, batch, lr):
+        self.train()                                       # (a replay runs no Python: the mode flag must not depend on it)
         tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
         from . import stereodpnet as _sdn
         # everything a captured graph has baked in: shapes, the kernel-path switches, the arenas' addresses (a device move re-creates them)
