@@ -57,9 +57,10 @@ int dpf_conv_transpose_acc(const float* x, const float* w, const float* bias, fl
 int dpf_set_conv_operand_precision(int bf16);
 int dpf_get_conv_operand_precision(void);
 /* How operand precision 0 (fp32) multiplies in the weight-gradient kernel and in the stride-1 forward / data-gradient kernels: 1 (default;
- * environment DPF_F32_X9=0 changes the default) = each fp32 product from the exact three-way bf16 splits of its operands (x = hi + mid + lo)
- * on the bf16 matrix pipe -- the eight partial products down to 2^-32 of the product (lo x lo is dropped), summed in the MFMA's fp32
- * accumulator; 0 = v_mfma_f32_32x32x2_f32.  Same results up to summation order (tests/test_gpu_ops.py:
+ * environment DPF_F32_X9=0 changes the default) = each fp32 product from the exact round-to-nearest three-way bf16 splits of its operands
+ * (x = hi + mid + lo) on the bf16 matrix pipe -- the six partial products that can reach 2^-24 of the product (mid x lo, lo x mid and
+ * lo x lo are dropped: <= 2^-23 worst case, rms 2^-26, zero mean), summed in the MFMA's fp32 accumulator; 0 = v_mfma_f32_32x32x2_f32.
+ * Both sit at the same distance from an fp64 result (tests/test_gpu_ops.py:
  * test_weight_gradient_f32_matrix_paths_agree, test_conv_f32_matrix_paths_agree); process-wide state. */
 int dpf_set_f32_matrix_path(int split_bf16);
 int dpf_get_f32_matrix_path(void);
