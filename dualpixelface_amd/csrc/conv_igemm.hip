@@ -590,7 +590,10 @@ namespace { int g_operand_bf16 = 0; }
 int dpf_conv_operand_bf16() { return g_operand_bf16; }
 namespace { int g_f32_x9 = -1; }
 int dpf_conv_f32_x9() {
-  if (g_f32_x9 < 0) g_f32_x9 = getenv("DPF_F32_X9") ? (atoi(getenv("DPF_F32_X9")) != 0) : 1;
+  if (g_f32_x9 < 0) {
+    const int v = getenv("DPF_F32_X9") ? atoi(getenv("DPF_F32_X9")) : 1;
+    g_f32_x9 = v < 0 ? 0 : (v > 2 ? 2 : v);
+  }
   return g_f32_x9;
 }
 
@@ -604,7 +607,7 @@ int dpf_set_conv_operand_precision(int bf16) {
 }
 int dpf_get_conv_operand_precision(void) { return g_operand_bf16; }
 int dpf_set_f32_matrix_path(int split_bf16) {
-  g_f32_x9 = split_bf16 ? 1 : 0;
+  g_f32_x9 = split_bf16 < 0 ? 0 : (split_bf16 > 2 ? 2 : split_bf16);
   return DPF_OK;
 }
 int dpf_get_f32_matrix_path(void) { return dpf_conv_f32_x9(); }

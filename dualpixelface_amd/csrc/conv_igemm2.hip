@@ -60,6 +60,7 @@ struct G2P {
   double* stats;                // optional [ntiles][statsK][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
   int statsK, statsk0;          // row length of the slab and first channel of this launch in it (K, 0 unless the launch is one slice of the channels)
   int tapoff[28];               // x9 kernel: patch offset (positions) of tap u; taps beyond T: 0 (their weights are zero)
+  const int* wexp;              // x9 kernel, f16 components: biased exponent the pack kernel scaled the weights by (device memory)
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
 
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256, (BF ? g2_occ_bf<MT, NT>() : g2_occ<MT, NT, CC>
 //   * NC = 1 (operand precision "bf16"): one component -- the operands rounded to bf16 (RNE) once per staged element.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // (x, y) -> packed bf16 pairs of the three components, x in the low half (conv_internal.h: round-to-nearest split)
 __device__ __forceinline__ void split_pair(float x, float y, unsigned& h, unsigned& m, unsigned& l) { dpf_split_pair(x, y, h, m, l); }
@@ -502,6 +504,11 @@ constexpr int X9_NP = 9 - X9_FIRST;
 
 // NC = 3: the exact split (x9 / x8); NC = 1 (operand precision "bf16"): one component, the operand rounded to bf16 (RNE) -- the same
 // staging and layouts with a third of the bytes and one MFMA per (row tile, position row, tap group).
+// NC = 2 (dpf_set_f32_matrix_path(2)): two f16 components of the block-scaled operand (conv_internal.h), three MFMAs (lo*hi, hi*lo, hi*hi) on
+// v_mfma_f32_32x32x16_f16.  The block is one channel chunk of the workgroup's patch: every lane takes the largest exponent of the values it
+// fetched, the waves exchange theirs through LDS (one extra barrier per chunk, before the split), and the chunk is scaled by the RUNNING
+// maximum of the tile (so the accumulators are rescaled only when it grows); the weights are scaled once per launch by the pack kernel; the
+// epilogue multiplies by 2^-(both scales) exactly (v_ldexp_f32).
 template <int CC, int NC> struct X9 {
   static constexpr int NU = CC == 4 ? 2 : 1;     // patch units (CC channels x 4 positions) per thread and chunk
   static constexpr int PB = 2 * NC * CC;         // bytes per position: [hi | mid | lo][CC] bf16
@@ -525,7 +532,8 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   static_assert(NT == 2 || NT == 4, "position rows are processed in pairs");
   constexpr int KT = 32 * MT;
   constexpr int NU = X9<CC, NC>::NU, PB = X9<CC, NC>::PB, TPG = X9<CC, NC>::TPG, PD = X9<CC, NC>::PD;
-  constexpr int NPROD = NC == 3 ? X9_NP : 1;     // MFMAs per (row tile, position row, tap group)
+  constexpr int NPROD = NC == 3 ? X9_NP : (NC == 2 ? 3 : 1);     // MFMAs per (row tile, position row, tap group)
+  constexpr int SPV = NC == 3 ? 9 : (NC == 2 ? 6 : 1);            // vector instructions of the split per value pair
   constexpr int NPS = NT / 2;                    // pair steps (two position rows, interleaved accumulators) per group
   constexpr int NSL = NU * 4;                    // split slices (one position of one unit) per chunk; half of them per tail group
   const int tid = threadIdx.x;
@@ -553,6 +561,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   char* s_patch = reinterpret_cast<char*>(smem);
   char* s_w = s_patch + patchBytes;                                // SH: two weight buffers
   int* s_tab = reinterpret_cast<int*>(s_w + (SH ? 2 : 1) * wBytes);
+  int* s_red = s_tab + 32;                                         // NC = 2: the waves' chunk exponents
+  int Ex = DPF_H3_EMIN;                                            // NC = 2: running exponent of the tile's patch; the accumulators are in units of 2^(Ex + Ew - 282)
+  float scx = 0.f;                                                 //         and the scale of the chunk being split
   const long long x_chan = (long long)p.ID * p.IH * p.IW;
   const float* xn = x + (long long)n * p.C * x_chan;
   const int nunits = p.rpc * p.SR;
@@ -601,8 +612,30 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < CC / 2; ++k) {
       if constexpr (NC == 3) split_pair(pv[j][2 * k][ps], pv[j][2 * k + 1][ps], sp[j][ps][k], sp[j][ps][CC / 2 + k], sp[j][ps][CC + k]);
+      else if constexpr (NC == 2) dpf_split_pair_h(pv[j][2 * k][ps] * scx, pv[j][2 * k + 1][ps] * scx, sp[j][ps][k], sp[j][ps][CC / 2 + k]);
       else sp[j][ps][k] = pk_bf16(pv[j][2 * k][ps], pv[j][2 * k + 1][ps]);
     }
+  };
+  // NC = 2: largest exponent of the chunk in flight (this lane's values, then the wave's) -> s_red[wave]; after a barrier next_exp() is
+  // the running exponent including that chunk
+  auto post_exp = [&]() {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+#pragma unroll
+      for (int ch = 0; ch < CC; ++ch) {
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pv[j][ch].x), __builtin_fabsf(pv[j][ch].y)));
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pv[j][ch].z), __builtin_fabsf(pv[j][ch].w)));
+      }
+    const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
+    if (lane == 0) s_red[wave] = e;
+  };
+  auto next_exp = [&]() {
+    const int4 r = *reinterpret_cast<const int4*>(s_red);
+    int e = max(max(r.x, r.y), max(r.z, r.w));
+    e = __builtin_amdgcn_readfirstlane(e);
+    e = e > 254 ? 254 : e;                                         // (Inf / NaN inputs: the result is NaN either way)
+    return e > Ex ? e : Ex;
   };
   auto store_split = [&]() {
 #pragma unroll
@@ -625,6 +658,14 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
+  auto rescale_acc = [&](int de) {                                  // acc *= 2^de (exact)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[m][t][j] = __builtin_ldexpf(acc[m][t][j], de);
+  };
 
   int lb[NT];
 #pragma unroll
@@ -638,7 +679,14 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   // stores form a phase of their own, hidden by the co-resident workgroup's MFMAs.
   if constexpr (SH) issue_w(0, 0);
   prefetch(0);
+  int Enext = Ex;
   if constexpr (SH) {
+    if constexpr (NC == 2) {
+      post_exp();
+      __syncthreads();
+      Ex = Enext = next_exp();
+      scx = dpf_h3_scale(Ex);
+    }
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
   }
@@ -646,8 +694,17 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
     if constexpr (!SH) {
       issue_w(chunk, 0);
+      if constexpr (NC == 2) {
+        post_exp();
+        __syncthreads();
+        Enext = next_exp();
+        scx = dpf_h3_scale(Enext);
+      }
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
+    }
+    if constexpr (NC == 2) {
+      if (Enext != Ex) { rescale_acc(Ex - Enext); Ex = Enext; }    // the chunk about to be contracted raised the tile's exponent
     }
     store_split();
     __syncthreads();                                               // vmcnt(0): this chunk's weights landed; barrier: patch written
@@ -675,7 +732,11 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       }
     };
     auto load_b = [&](int t, int o0, int o1, u32x4 (&bb)[NC]) {
-      if constexpr (CC == 4) {
+      if constexpr (CC == 4 && NC == 2) {                           // 16 bytes per position: [hi x 4 | lo x 4] of a tap in one read
+        const u32x4 q0 = *reinterpret_cast<const u32x4*>(s_patch + lb[t] + o0), q1 = *reinterpret_cast<const u32x4*>(s_patch + lb[t] + o1);
+        const u32x4 vh = {q0[0], q0[1], q1[0], q1[1]}, vl = {q0[2], q0[3], q1[2], q1[3]};
+        bb[0] = vh; bb[1] = vl;
+      } else if constexpr (CC == 4) {
         const char* p0 = s_patch + lb[t] + o0;
         const char* p1 = s_patch + lb[t] + o1;
 #pragma unroll
@@ -708,14 +769,26 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       // so consecutive MFMAs never accumulate into the same registers
       constexpr int oa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
       constexpr int ob[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+      if constexpr (NC == 2) {
+        constexpr int ha[3] = {1, 0, 0}, hb[3] = {0, 1, 0};         // lo*hi, hi*lo, hi*hi
 #pragma unroll
-      for (int i = (NC == 3 ? X9_FIRST : 8); i < 9; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
-            acc[m][t0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[NC == 3 ? oa[i] : 0][m]),
-                                                                      __builtin_bit_cast(bf16x8, bb[r][NC == 3 ? ob[i] : 0]), acc[m][t0 + r], 0, 0, 0);
+            for (int r = 0; r < 2; ++r)
+              acc[m][t0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ha[i]][m]), __builtin_bit_cast(f16x8, bb[r][hb[i]]),
+                                                                       acc[m][t0 + r], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = (NC == 3 ? X9_FIRST : 8); i < 9; ++i)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              acc[m][t0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[NC == 3 ? oa[i] : 0][m]),
+                                                                        __builtin_bit_cast(bf16x8, bb[r][NC == 3 ? ob[i] : 0]), acc[m][t0 + r], 0, 0, 0);
+      }
     };
     // one tap group; HALF = 0 / 1: the first / second half of the next chunk's split slices is computed in the MFMAs' shadow
     auto group = [&](int g, auto half_c) {
@@ -746,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
           for (int i = 0; i < NM; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, (NSL / 2 / NPS * CC / 2 * (NC == 3 ? 9 : 1) + NM - 1) / NM + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (NSL / 2 / NPS * CC / 2 * SPV + NM - 1) / NM + 1, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -769,6 +842,14 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     load_b(1, oC0, oC1, bP[0][1]);
     if constexpr (SH) {
       for (int g = 0; g + 2 < TG; ++g) group(g, std::integral_constant<int, -1>{});
+      if constexpr (NC == 2) {
+        if (chunk + 1 < p.nchunks) {                                // the next chunk's values have landed by now: agree on its scale
+          post_exp();
+          __syncthreads();
+          Enext = next_exp();
+          scx = dpf_h3_scale(Enext);
+        }
+      }
       group(TG - 2, std::integral_constant<int, 0>{});
       group(TG - 1, std::integral_constant<int, 1>{});
     } else {
@@ -778,6 +859,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     __syncthreads();                                               // the patch buffer is free
   }
   X9_STAMP(2, __builtin_readcyclecounter())
+  if constexpr (NC == 2) rescale_acc(Ex + __builtin_amdgcn_readfirstlane(p.wexp[0]) - 282);      // back to the operands' units (exact)
   g2_epilogue<MT, NT>(acc, p, bias, out, smem, tile_id, n, qd, q0h, q0w, wave, l31, hh, tid);
   X9_STAMP(3, __builtin_readcyclecounter()) X9_STAMP(5, __builtin_amdgcn_s_memrealtime()) X9_STAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, all 32 bits */)) X9_STAMP(7, (unsigned long long)p.nchunks)
 }
@@ -786,8 +868,25 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 // w(out = k0 + 32 m + l31, reduce, tap), zero beyond T / C / K, with
 //   CC = 4: reduce = 4 chunk + (i & 3), tap = 4 g + 2 hh + (i >> 2);      CC = 8: reduce = 8 chunk + i, tap = 2 g + hh
 __global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int TG, int MT, int CC,
-                                      int NC, int nchunks, int mode, int k0, int K, int C) {
+                                      int NC, int nchunks, int mode, int k0, int K, int C, int* __restrict__ wexp) {
   const long long total = (long long)nchunks * TG * MT * 512;
+  float wscale = 1.f;
+  if (NC == 2) {
+    // f16 components: every workgroup finds the largest exponent of the whole weight tensor (a few hundred KB, L2 resident; the launch has
+    // at most 32 workgroups) so that all of them scale by the same power of two; workgroup 0 publishes it for the convolution's epilogue
+    __shared__ int s_e[16];
+    float m = 0.f;
+    const long long nw = (long long)wA * wB * T;
+    for (long long i = threadIdx.x; i < nw; i += blockDim.x) m = __builtin_fmaxf(m, __builtin_fabsf(w[i]));
+    const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
+    if ((threadIdx.x & 63) == 0) s_e[threadIdx.x >> 6] = e;
+    __syncthreads();
+    int E = DPF_H3_EMIN;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) E = s_e[i] > E ? s_e[i] : E;
+    E = E > 254 ? 254 : E;
+    wscale = dpf_h3_scale(E);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wexp[0] = E;
+  }
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(e & 7), ln = (int)((e >> 3) & 63);
     const int m = (int)((e >> 9) % MT);
@@ -807,6 +906,10 @@ __global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned shor
     const long long base = (((long long)(chunk * TG + g) * NC) * MT + m) * 512 + ln * 8 + i;
     if (NC == 1) {                                                 // operand precision "bf16": round to nearest even
       wpk[base] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
+    } else if (NC == 2) {
+      dpf_split_pair_h(v * wscale, 0.f, sh, sl);
+      wpk[base] = (unsigned short)(sh & 0xffffu);
+      wpk[base + 512LL * MT] = (unsigned short)(sl & 0xffffu);
     } else {
       wpk[base] = (unsigned short)(sh & 0xffffu);
       wpk[base + 512LL * MT] = (unsigned short)(sm & 0xffffu);
@@ -1183,7 +1286,7 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   static const int x9_on = env_int("DPF_IGEMM3", 1), x9_min_c = 8, x9_cc = env_int("DPF_IGEMM3_CC", 0),
                    x9_sh = env_int("DPF_IGEMM3_SH", -1);
   const int T = d.kd * d.kh * d.kw, MT = (kn + 31) / 32, TH = 4 * NT;
-  if (!x9_on || (NC == 3 && !dpf_conv_f32_x9()) || MT > 2 || NT * MT > 4 || d.C < x9_min_c) return DPF_ERR_UNSUPPORTED;
+  if (!x9_on || (NC >= 2 && !dpf_conv_f32_x9()) || MT > 2 || NT * MT > 4 || d.C < x9_min_c) return DPF_ERR_UNSUPPORTED;
   G2P q = p;
   q.K = kn; q.k0 = d.k0 + k_off;
   // 2-D layers dilated along H: a tile takes the rows of ONE dilation phase (dh apart), so its patch is thp + kh - 1 image rows fetched dh
@@ -1212,13 +1315,13 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
     for (int pz : {1, 2, 4}) {
       if (!(pz == 1 || (d.kd > 1 && pz <= TH / 2 && pz <= d.OD))) continue;
       const int units = set_pz(pz);
-      const size_t l9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(shc ? 2 : 1) * TG * NC * (mt_fit > MT ? mt_fit : MT) * 1024 + 128;
+      const size_t l9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(shc ? 2 : 1) * TG * NC * (mt_fit > MT ? mt_fit : MT) * 1024 + 256;
       if (units <= NU9 * 256 && 2 * l9 <= 160 * 1024 && units < best_units) { best = pz; best_units = units; sh = shc; }
     }
   }
   if (!best || TG < 2) return DPF_ERR_UNSUPPORTED;
   set_pz(best);
-  const size_t lds9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(sh ? 2 : 1) * TG * NC * MT * 1024 + 128;
+  const size_t lds9 = (size_t)PB9 * q.rpc * q.RS + (size_t)(sh ? 2 : 1) * TG * NC * MT * 1024 + 256;
   if ((long long)NU9 * 256 * (q.SR > q.ext_h ? q.SR : q.ext_h) >= (1LL << 20)) return DPF_ERR_UNSUPPORTED;   // multiply-shift exactness
   const int sgn = d.transposed ? -1 : 1;
   const int t0 = d.transposed ? ((d.kd - 1) * d.dd * q.ext_h + (d.kh - 1) * dhl) * q.RS + (d.kw - 1) * d.dw : 0;
@@ -1242,7 +1345,17 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   }
   unsigned short* wp = reinterpret_cast<unsigned short*>(ws);
   const long long total = (long long)q.nchunks * TG * MT * 512;
-  hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks, d.mode, q.k0, kn, d.C);
+  // (f16 components: the scale's exponent sits behind the packed weights -- inside the three-component capacity of the workspace)
+  int* wexp = reinterpret_cast<int*>(wp + ((total * NC + 7) & ~7LL));
+  q.wexp = wexp;
+  if (NC == 2) {
+    const long long g2 = (total + 1023) / 1024;
+    hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3((unsigned)(g2 < 32 ? g2 : 32)), dim3(1024), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks,
+                       d.mode, q.k0, kn, d.C, wexp);
+  } else {
+    hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks, d.mode, q.k0,
+                       kn, d.C, wexp);
+  }
   if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
   if (stats) stats->parts = (int)nt9;
   const long long blocks9 = 8LL * q.cpx;
@@ -1250,6 +1363,8 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   do {                                                                                                                 \
     if (NC == 3) return sh ? launch_x9<M, N_, C_, true, 3>(x, wp, bias, out, q, lds9, blocks9, st)                      \
                            : launch_x9<M, N_, C_, false, 3>(x, wp, bias, out, q, lds9, blocks9, st);                     \
+    if (NC == 2) return sh ? launch_x9<M, N_, C_, true, 2>(x, wp, bias, out, q, lds9, blocks9, st)                      \
+                           : launch_x9<M, N_, C_, false, 2>(x, wp, bias, out, q, lds9, blocks9, st);                     \
     return sh ? launch_x9<M, N_, C_, true, 1>(x, wp, bias, out, q, lds9, blocks9, st)                                   \
               : launch_x9<M, N_, C_, false, 1>(x, wp, bias, out, q, lds9, blocks9, st);                                  \
   } while (0)
@@ -1463,7 +1578,7 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
   //      precision "bf16") the operands rounded to bf16
   // (bf16 operands, 2-D kernels with more than 64 output channels: igemm2's bf16 kernel stages the patch once for all of them and is faster)
   if (T > 4 && p.sxd == 1 && p.sxh == 1 && p.sxw == 1 && (!bf_mode || (bf3_on && !(d.K > 64 && d.kd == 1)))) {
-    const int nc = bf_mode ? 1 : 3;
+    const int nc = bf_mode ? 1 : dpf_conv_f32_nc();
     if (d.K <= 64) {
       constexpr int nt3 = 0;       // (2 = 8-row tiles for <= 32 output channels too, three resident workgroups: measured slower)
       const int rc = x9_try(x, w, bias, out, ws, d, p, 0, d.K, MT == 1 ? ((nt3 == 2 || (nt3 == 12 && d.kd == 1)) ? 2 : 4) : 2, stats, st, nc);

@@ -17,8 +17,10 @@ struct DpfConvDesc {
 // operand precision of the dense convolution kernels (dpf_set_conv_operand_precision): 0 = exact fp32, 1 = operands rounded to bf16
 // (RNE) in the staging path, fp32 accumulation and storage
 int dpf_conv_operand_bf16();
-// operand precision "f32": 1 = fp32 products as nine exact bf16 partial products on the bf16 matrix pipe (default), 0 = v_mfma_f32_* (DPF_F32_X9=0)
+// operand precision "f32" (dpf_set_f32_matrix_path / DPF_F32_X9): 0 = v_mfma_f32_*, 1 = six bf16 partial products of exact three-way splits,
+// 2 = three f16 partial products of block-scaled two-way splits
 int dpf_conv_f32_x9();
+inline int dpf_conv_f32_nc() { return dpf_conv_f32_x9() == 2 ? 2 : 3; }      // components per operand of the split paths
 
 // LDS-DMA double-buffered implicit GEMM (conv_igemm2.hip).  Returns DPF_OK when it launched, DPF_ERR_UNSUPPORTED when the
 // shape is not eligible (the caller then uses the generic kernel), another error code on failure.
@@ -80,4 +82,42 @@ __device__ __forceinline__ void dpf_split_pair(float x, float y, unsigned& h, un
   const dpf_f32x2 r2 = r1 - mf;
   l = dpf_pk_bf16(r2.x, r2.y);
 }
+
+// ---- fp32 products on the f16 matrix pipe (dpf_set_f32_matrix_path(2)): x * 2^s = hi + lo + e with hi = f16(x 2^s), lo = f16(x 2^s - hi),
+// both rounded to nearest: |lo| <= 2^-11 |hi|, |e| <= 2^-23 |x 2^s| (one ulp of the fp32 value, zero mean).  THREE partial products per
+// pair -- lo*hi, hi*lo, hi*hi; lo*lo <= 2^-22 |xy| 2^-2 is dropped -- on v_mfma_f32_32x32x16_f16: half the matrix-pipe work of the six bf16
+// products.  f16 has 5 exponent bits, so the operands are scaled by a power of two (exact) that puts the largest magnitude of the staged
+// block -- a channel chunk of a tile's patch, a tile of the weight gradient, a weight tensor -- into [2^14, 2^15); the accumulators carry
+// the running exponent and are rescaled (exactly) when it grows.  Values more than 2^17 below their block's maximum lose low bits
+// gradually (absolute error <= 2^-40 of the block maximum): fp32-equivalent in the norm of each block, not per element.
+typedef _Float16 dpf_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dpf_pk_f16(float x, float y) {       // round to nearest even (the f16 rounding mode of the kernel)
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+// (x, y) already scaled -> packed f16 pairs (hi, lo): 5 vector instructions
+__device__ __forceinline__ void dpf_split_pair_h(float x, float y, unsigned& h, unsigned& l) {
+  h = dpf_pk_f16(x, y);
+  const dpf_f16x2 hh = __builtin_bit_cast(dpf_f16x2, h);
+  const dpf_f32x2 v = {x, y};
+  const dpf_f32x2 hf = {(float)hh.x, (float)hh.y};
+  const dpf_f32x2 r = v - hf;
+  l = dpf_pk_f16(r.x, r.y);
+}
+// the largest biased exponent (bits 30..23 of |v|) over the wave's lanes; every lane passes the bit pattern of a non-negative float
+__device__ __forceinline__ int dpf_wave_max_exp(unsigned bits) {
+  unsigned v = bits;
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e /* quad_perm [2,3,0,1] */, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140 /* row_mirror */, 0xf, 0xf, false));
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  const unsigned m = max(max(a, b), max(c, d));
+  return (int)(m >> 23);
+}
+// scale that maps magnitudes with biased exponent <= E into [.., 2^15): 2^(141 - E); E in [14, 254]
+__device__ __forceinline__ float dpf_h3_scale(int E) { return __builtin_bit_cast(float, (unsigned)(268 - E) << 23); }
+constexpr int DPF_H3_EMIN = 14;
 #endif

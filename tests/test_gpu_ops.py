@@ -502,7 +502,7 @@ def test_conv_f32_matrix_paths_agree(cfg):
             else:
                 ref = F.conv3d(x.double(), w.double(), None, 1, pad, dl)
             errs = []
-            for path in (1, 0):
+            for path in (1, 0, 2):
                 lib().call('dpf_set_f32_matrix_path', path)
                 if transposed:
                     xg = x.to(DEV).requires_grad_()
@@ -513,6 +513,64 @@ def test_conv_f32_matrix_paths_agree(cfg):
                 errs.append(((got.double().cpu() - ref).abs().max() / ref.abs().max()).item())
             assert max(errs) <= 1e-5, (positive, errs)
             assert errs[0] <= 2 * errs[1] + 1e-7 and errs[1] <= 2 * errs[0] + 1e-7, (positive, errs)
+            assert errs[2] <= 2 * errs[1] + 1e-7, (positive, errs)           # the f16 components: no worse than 2 x the fp32 instruction
+    finally:
+        lib().call('dpf_set_f32_matrix_path', prev)
+
+
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 4, 24, 64, (3, 3, 3), False), (2, 48, 64, 1, 20, 72, (1, 3, 3), True)])
+def test_conv_f16_component_path_block_scaling(cfg):
+    """dpf_set_f32_matrix_path(2): two f16 components per operand, scaled per block (a channel chunk of a tile's patch; the weight tensor) by a
+    power of two.  (a) The scaling is exact: multiplying the input by 2^k and the weights by 2^j multiplies the output by 2^(k+j) BIT FOR
+    BIT, from 2^-100 to 2^+100 -- no overflow, no flush.  (b) Two samples that differ by 2^40 in magnitude: each is as accurate (relative to its
+    own scale) as with the fp32 instruction -- the scale follows the tile, not the tensor.  (c) zeros, and a single
+    non-zero value in an otherwise zero tensor."""
+    from dualpixelface_amd._lib import lib
+    ops = _ops()
+    N, C, K, D, H, W, ks, transposed = cfg
+    pad = tuple((k - 1) // 2 for k in ks)
+    one = (1, 1, 1)
+    prev = lib().cdll.dpf_get_f32_matrix_path()
+
+    def run(x, w):
+        if transposed:                      # the data gradient of a conv with weights w [K, C] for the output gradient x [N, K]
+            xin = torch.zeros(N, C, D, H, W, device=DEV).requires_grad_()
+            y = ops.ConvFn.apply(xin, w.to(DEV), None, one, pad, one)
+            return torch.autograd.grad(y, xin, x.to(DEV))[0]
+        return ops.ConvFn.apply(x.to(DEV), w.to(DEV), None, one, pad, one)
+
+    try:
+        lib().call('dpf_set_f32_matrix_path', 2)
+        x = rnd(N, K if transposed else C, D, H, W, seed=300)
+        w = rnd(K, C, *ks, seed=301, scale=0.1)
+        base = run(x, w)
+        for k, j in ((-100, 0), (100, -60), (0, 90), (-50, -50), (30, 30)):
+            got = run(x * 2.0 ** k, w * 2.0 ** j)
+            assert torch.equal(got, base * 2.0 ** (k + j)), (k, j)
+        # (b) two samples 2^40 apart in magnitude (a tile never spans two samples)
+        x2 = x.clone()
+        x2[0] *= 2.0 ** -40
+        lib().call('dpf_set_f32_matrix_path', 0)
+        f32 = run(x2, w).double().cpu()
+        lib().call('dpf_set_f32_matrix_path', 2)
+        got = run(x2, w).double().cpu()
+        if transposed:
+            ref = torch.nn.grad.conv3d_input((N, C, D, H, W), w.double(), x2.double(), 1, pad, 1)
+        else:
+            ref = F.conv3d(x2.double(), w.double(), None, 1, pad, 1)
+        for n in range(N):
+            scale = ref[n].abs().max()
+            e2, e0 = (got - ref)[n].abs().max() / scale, (f32 - ref)[n].abs().max() / scale
+            assert e2 <= 2 * e0 + 1e-7, (n, e2.item(), e0.item())
+        # (c)
+        z = torch.zeros_like(x)
+        assert run(z, w).abs().max().item() == 0.0
+        z[0, 3, 0, 5, 7] = 3.0e-30
+        lib().call('dpf_set_f32_matrix_path', 0)
+        a = run(z, w)
+        lib().call('dpf_set_f32_matrix_path', 2)
+        b = run(z, w)
+        assert (a - b).abs().max().item() <= 3e-7 * a.abs().max().item() and a.abs().max().item() > 0
     finally:
         lib().call('dpf_set_f32_matrix_path', prev)
 
