@@ -99,8 +99,16 @@ constexpr int w2_occ() { return w2_occ_of(NCT); }
 // 512 on v_mfma_f32_32x32x2_f32, and, unlike the fp32 MFMA, the bf16 MFMA leaves the vector ALU free: the ~11 split instructions per value
 // pair run in its shadow (tools/lean_probe2.hip: 4 v_fma_f32 per bf16 MFMA cost nothing, behind an fp32 MFMA they cost their full time).
 // first of the nine partial products (smallest first) that is issued: conv_internal.h (default 3: six products)
+// X9 = 2 (dpf_set_f32_matrix_path(2)): fp32 products from two f16 components per operand (conv_internal.h), three MFMAs per unit on
+// v_mfma_f32_32x32x16_f16.  A component pair fits the 4 bytes of the fp32 value it came from, so a tile is converted IN PLACE, once per
+// element instead of once per use (an x value is read by up to 27 taps): after the tile has landed every lane reads back the 16-byte
+// segments it fetched itself, the workgroup agrees on the largest exponent of the x patch and of the g tile (the exchange rides on the
+// tile barrier), and each lane rewrites its segments as (hi << 16 | lo) words of the values scaled by the running maxima; the
+// accumulators are rescaled (exactly) when a maximum grows.  The unit loop then assembles an MFMA operand from 8 words with 8 v_perm_b32
+// -- no conversion, no subtraction -- and the fragment addressing is the fp32 kernel's.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int W2_X9_FIRST = DPF_X9_FIRST;
-template <int NCT, bool BF = false, bool SW1 = false, bool X9 = false>
+template <int NCT, bool BF = false, bool SW1 = false, int X9 = 0>
 __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) void wgrad2_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                      float* __restrict__ slab, W2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -221,23 +229,150 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
+  // ---- X9 = 2: exponent scan and in-place conversion of the segments this lane fetched (same slots as issue())
+  int* s_red = reinterpret_cast<int*>(smem + 2 * bufFloats);       // [wave][x exponent, g exponent]
+  int Exr = DPF_H3_EMIN, Egr = DPF_H3_EMIN;                        // running exponents: the accumulators are in units of 2^(Exr + Egr - 282)
+  auto own_scan = [&](int b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's DMAs have landed; the other waves' are not read here
+    const float* dbase = smem + b * bufFloats;
+    float mx = 0.f, mg = 0.f;
+#pragma unroll
+    for (int j = 0; j < NLX; ++j)
+      if (j * 256 < p.nxseg && xmeta[j] >= 0) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dbase + (j * 256 + tid) * 4);
+        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+      }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dbase + xFloats + (j * 256 + tid) * 4);
+      mg = __builtin_fmaxf(mg, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+    }
+    const int ex = dpf_wave_max_exp(__builtin_bit_cast(unsigned, mx)), eg = dpf_wave_max_exp(__builtin_bit_cast(unsigned, mg));
+    if (lane == 0) { s_red[2 * wave] = ex; s_red[2 * wave + 1] = eg; }
+  };
+  auto pack_seg = [&](const f32x4& v, float sc) {
+    unsigned h0, l0, h1, l1;
+    dpf_split_pair_h(v[0] * sc, v[1] * sc, h0, l0);
+    dpf_split_pair_h(v[2] * sc, v[3] * sc, h1, l1);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_perm(h0, l0, 0x05040100u); r[1] = __builtin_amdgcn_perm(h0, l0, 0x07060302u);   // (hi << 16) | lo per element
+    r[2] = __builtin_amdgcn_perm(h1, l1, 0x05040100u); r[3] = __builtin_amdgcn_perm(h1, l1, 0x07060302u);
+    return r;
+  };
+  auto own_convert = [&](int b, float scx, float scg) {
+    float* dbase = smem + b * bufFloats;
+#pragma unroll
+    for (int j = 0; j < NLX; ++j)
+      if (j * 256 < p.nxseg && xmeta[j] >= 0) {
+        f32x4* q = reinterpret_cast<f32x4*>(dbase + (j * 256 + tid) * 4);
+        const u32x4 r = pack_seg(*q, scx);
+        *reinterpret_cast<u32x4*>(q) = r;
+      }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      f32x4* q = reinterpret_cast<f32x4*>(dbase + xFloats + (j * 256 + tid) * 4);
+      const u32x4 r = pack_seg(*q, scg);
+      *reinterpret_cast<u32x4*>(q) = r;
+    }
+  };
+
   const int sw = SW1 ? 1 : p.sw;
   const int aslot = wave * 8 + hh;               // logical g slot of this lane's half, group 0
   const int arow = l31 * SPR, axor = l31 & 15;
   const long long tbeg = (long long)pchunk * p.per;
   long long tend = tbeg + p.per;
   if (tend > p.ntiles) tend = p.ntiles;
-  if (tbeg < tend) issue(0);
+  if (tbeg < tend) {
+    issue(0);
+    if constexpr (X9 == 2) own_scan(0);
+  }
   __syncthreads();
   int buf = 0;
   for (long long tile = tbeg; tile < tend; ++tile, buf ^= 1) {
-    if (tile + 1 < tend) issue(buf ^ 1);
+    if constexpr (X9 == 2) {
+      // the tile in `buf` is raw fp32 and its exponents are posted: agree on the scales, fetch the next tile, convert this one in place
+      int ex = DPF_H3_EMIN, eg = DPF_H3_EMIN;
+#pragma unroll
+      for (int w = 0; w < WTH; ++w) { ex = max(ex, s_red[2 * w]); eg = max(eg, s_red[2 * w + 1]); }
+      ex = __builtin_amdgcn_readfirstlane(ex); eg = __builtin_amdgcn_readfirstlane(eg);
+      ex = ex > 254 ? 254 : ex; eg = eg > 254 ? 254 : eg;
+      ex = ex > Exr ? ex : Exr; eg = eg > Egr ? eg : Egr;
+      if (ex + eg != Exr + Egr) {
+        const int de = (Exr + Egr) - (ex + eg);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc[t][j] = __builtin_ldexpf(acc[t][j], de);
+      }
+      Exr = ex; Egr = eg;
+      if (tile + 1 < tend) issue(buf ^ 1);
+      own_convert(buf, dpf_h3_scale(Exr), dpf_h3_scale(Egr));
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // conversions visible; the DMAs just issued stay in flight
+    } else {
+      if (tile + 1 < tend) issue(buf ^ 1);
+    }
     const float* s_x = smem + buf * bufFloats;
     const float* s_g = s_x + xFloats;
     // group j = positions 8j .. 8j+7 of this wave's row: lane half h takes 8j+4h .. 8j+4h+3; element i of both halves is one
     // MFMA k-step.  Units of (group, column-tile pair) are software pipelined over two B register sets; the A fragment of a
     // group is fetched one group ahead.
-    if constexpr (X9) {
+    if constexpr (X9 == 2) {
+      const int colx = (8 - 4) * hh * sw;
+      auto load_x = [&](int J, int t, unsigned (&xv)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = __builtin_bit_cast(unsigned, s_x[colbase[t] + colx + (16 * J + i) * sw]);
+      };
+      auto load_g = [&](int J, unsigned (&gv)[8]) {
+        const int sl0 = wave * 8 + 4 * J + 2 * hh;
+        const u32x4 g0 = *reinterpret_cast<const u32x4*>(s_g + (arow + (sl0 ^ axor)) * 4);
+        const u32x4 g1 = *reinterpret_cast<const u32x4*>(s_g + (arow + ((sl0 + 1) ^ axor)) * 4);
+        gv[0] = g0[0]; gv[1] = g0[1]; gv[2] = g0[2]; gv[3] = g0[3]; gv[4] = g1[0]; gv[5] = g1[1]; gv[6] = g1[2]; gv[7] = g1[3];
+      };
+      auto unpack8 = [&](const unsigned (&v)[8], f16x8& hi, f16x8& lo) {      // 8 words (hi << 16 | lo) -> the two packed operands
+        u32x4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x07060302u);
+          l[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x05040100u);
+        }
+        hi = __builtin_bit_cast(f16x8, h); lo = __builtin_bit_cast(f16x8, l);
+      };
+      unsigned xr[8], gv[8];
+      f16x8 aH, aL, bH, bL, nH, nL;
+      load_g(0, gv);
+      load_x(0, 0, xr);
+      unpack8(gv, aH, aL);
+      unpack8(xr, bH, bL);
+      if (NCT > 1) load_x(0, 1, xr); else load_x(1, 0, xr);
+      f16x8 a2H = aH, a2L = aL;
+#pragma unroll
+      for (int J = 0; J < 2; ++J) {
+        if (J == 0) load_g(1, gv);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+          const int u = J * NCT + t;
+          if (u + 1 < 2 * NCT) unpack8(xr, nH, nL);
+          if (u + 2 < 2 * NCT) load_x((u + 2) / NCT, (u + 2) % NCT, xr);
+          if (J == 0 && t == NCT - 1) unpack8(gv, a2H, a2L);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aL, bH, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH, bL, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH, bH, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          bH = nH; bL = nL;
+        }
+        aH = a2H; aL = a2L;
+      }
+      if (tile + 1 < tend) own_scan(buf ^ 1);          // (waits for this wave's DMAs of the next tile) its exponents, posted before the barrier
+      __syncthreads();     // next tile landed, its exponents posted; this buffer is free
+      continue;
+    }
+    if constexpr (X9 == 1) {
       // super-group J = positions 16 J .. 16 J + 15 of this wave's row: lane half h takes 16 J + 8 h .. + 7 (8 reduction indices of one
       // v_mfma_f32_32x32x16_bf16); the g fragment (two 16-byte slots) is split once per super-group, an x fragment per column tile
       const int colx = (8 - 4) * hh * sw;          // colbase[] points at position 4 hh; this path wants 8 hh
@@ -367,6 +502,12 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
     __syncthreads();     // vmcnt(0): next tile landed; barrier: this buffer is free
   }
 
+  if constexpr (X9 == 2) {                             // back to the operands' units (exact)
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[t][j] = __builtin_ldexpf(acc[t][j], Exr + Egr - 282);
+  }
   // ---- sum the four waves' partial tiles through LDS (two rounds: 2,3 -> 0,1 then 1 -> 0); image [tile][reg][lane], conflict free
   float* red = smem;
 #pragma unroll
@@ -449,7 +590,7 @@ int gather_conflicts(const DpfWgradDesc& d, int T, int ncolmax, int RS, int PS, 
   return total;
 }
 
-template <int NCT, bool BF, bool SW1, bool X9>
+template <int NCT, bool BF, bool SW1, int X9>
 int launch_w2c(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
   static bool done = false;
   if (lds > 48 * 1024 && !done) {
@@ -460,15 +601,19 @@ int launch_w2c(const float* g, const float* x, float* slab, const W2P& p, size_t
   hipLaunchKernelGGL((wgrad2_kernel<NCT, BF, SW1, X9>), dim3(blocks), dim3(256), lds, st, g, x, slab, p);
   return dpf_check_launch();
 }
-template <int NCT, bool BF, bool X9>
+template <int NCT, bool BF, int X9>
 int launch_w2b(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
   static const int sw1 = env_int("DPF_W2_SW1", 1);
   return (p.sw == 1 && sw1) ? launch_w2c<NCT, BF, true, X9>(g, x, slab, p, lds, blocks, st) : launch_w2c<NCT, BF, false, X9>(g, x, slab, p, lds, blocks, st);
 }
 template <int NCT>
 int launch_w2(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
-  if (dpf_conv_operand_bf16()) return launch_w2b<NCT, true, false>(g, x, slab, p, lds, blocks, st);
-  return dpf_conv_f32_x9() ? launch_w2b<NCT, false, true>(g, x, slab, p, lds, blocks, st) : launch_w2b<NCT, false, false>(g, x, slab, p, lds, blocks, st);
+  if (dpf_conv_operand_bf16()) return launch_w2b<NCT, true, 0>(g, x, slab, p, lds, blocks, st);
+  switch (dpf_conv_f32_x9()) {
+    case 2: return launch_w2b<NCT, false, 2>(g, x, slab, p, lds, blocks, st);
+    case 1: return launch_w2b<NCT, false, 1>(g, x, slab, p, lds, blocks, st);
+    default: return launch_w2b<NCT, false, 0>(g, x, slab, p, lds, blocks, st);
+  }
 }
 
 int w2_maxblocks() { return 1024; }     // upper bound of resident workgroups (4 per CU): sizes the slab workspace
@@ -533,7 +678,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
       }
     const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
     const size_t red = (size_t)2 * NCT * 16 * 64 * sizeof(float);
-    const size_t lds = 2 * buf > red ? 2 * buf : red;
+    const size_t lds = (2 * buf > red ? 2 * buf : red) + 64;    // + the exponent exchange of the f16-component path
     if (CCW * p.CS / 4 > NLX * 256 || lds > (size_t)lds_max) { NCT = 0; continue; }
     break;
   }
@@ -551,7 +696,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   p.groups = p.cchunks * p.kslices;
   const size_t buf0 = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
   const size_t red0 = (size_t)2 * NCT * 16 * 64 * sizeof(float);
-  const size_t lds0 = 2 * buf0 > red0 ? 2 * buf0 : red0;
+  const size_t lds0 = (2 * buf0 > red0 ? 2 * buf0 : red0) + 64;
   int occ = w2_occ_of(NCT);
   if ((size_t)occ * lds0 > 160 * 1024) occ = (int)((160 * 1024) / lds0);
   if (occ < 1) occ = 1;
@@ -576,7 +721,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
 
   const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
   const size_t red = (size_t)2 * NCT * 16 * 64 * sizeof(float);
-  const size_t lds = 2 * buf > red ? 2 * buf : red;
+  const size_t lds = (2 * buf > red ? 2 * buf : red) + 64;
   const unsigned blocks = (unsigned)(8 * ((p.nchunk + 7) / 8) * p.groups);
   int rc;
   switch (NCT) {

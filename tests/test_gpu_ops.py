@@ -460,14 +460,30 @@ def test_weight_gradient_f32_matrix_paths_agree(cfg):
     prev = lib().cdll.dpf_get_f32_matrix_path()          # (a getter: the value is not an error code)
     errs = []
     try:
-        for path in (1, 0):
+        for path in (1, 0, 2):
             lib().call('dpf_set_f32_matrix_path', path)
             got = ops._conv_wgrad_raw(g.to(DEV), x.to(DEV), (K, C) + ks, st, pad, dl).double().cpu()
             errs.append(((got - ref).abs().max() / ref.abs().max()).item())
+        # path 2 (two f16 components, tiles converted in place and scaled by the running maxima): power-of-two scaling of either operand
+        # is exact, far outside the f16 range, and a batch whose samples are 2^30 apart is summed as accurately as on the fp32 instruction
+        base = ops._conv_wgrad_raw(g.to(DEV), x.to(DEV), (K, C) + ks, st, pad, dl)
+        for kg, kx in ((-90, 0), (40, -80), (0, 70), (-45, -45)):
+            got = ops._conv_wgrad_raw((g * 2.0 ** kg).to(DEV), (x * 2.0 ** kx).to(DEV), (K, C) + ks, st, pad, dl)
+            assert torch.equal(got, base * 2.0 ** (kg + kx)), (kg, kx)
+        g2 = g.clone()
+        g2[0] *= 2.0 ** -30                    # the small sample comes first: the running exponent grows when the second one arrives
+        ref2 = torch.nn.grad.conv3d_weight(x.double(), (K, C) + ks, g2.double(), st, pad, dl)
+        e = []
+        for path in (2, 0):
+            lib().call('dpf_set_f32_matrix_path', path)
+            got = ops._conv_wgrad_raw(g2.to(DEV), x.to(DEV), (K, C) + ks, st, pad, dl).double().cpu()
+            e.append(((got - ref2).abs().max() / ref2.abs().max()).item())
+        assert e[0] <= 2 * e[1] + 1e-7, e
     finally:
         lib().call('dpf_set_f32_matrix_path', prev)
     assert max(errs) <= 1e-5, errs
     assert errs[0] <= 2 * errs[1] + 1e-7 and errs[1] <= 2 * errs[0] + 1e-7, errs
+    assert errs[2] <= 2 * errs[1] + 1e-7, errs
 
 
 @pytest.mark.parametrize('cfg', [
