@@ -591,7 +591,7 @@ int dpf_conv_operand_bf16() { return g_operand_bf16; }
 namespace { int g_f32_x9 = -1; }
 int dpf_conv_f32_x9() {
   if (g_f32_x9 < 0) {
-    const int v = getenv("DPF_F32_X9") ? atoi(getenv("DPF_F32_X9")) : 1;
+    const int v = getenv("DPF_F32_X9") ? atoi(getenv("DPF_F32_X9")) : 2;
     g_f32_x9 = v < 0 ? 0 : (v > 2 ? 2 : v);
   }
   return g_f32_x9;

@@ -864,28 +864,32 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   X9_STAMP(3, __builtin_readcyclecounter()) X9_STAMP(5, __builtin_amdgcn_s_memrealtime()) X9_STAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, all 32 bits */)) X9_STAMP(7, (unsigned long long)p.nchunks)
 }
 
+// f16 components: the largest biased exponent of workgroup b's slice of the weight tensor -> part[b] (the pack kernel folds the slices)
+__global__ __launch_bounds__(256) void x9_wexp_kernel(const float* __restrict__ w, int nw, int per, int* __restrict__ part) {
+  __shared__ int s_e[4];
+  const int beg = blockIdx.x * per, end = min(nw, beg + per);
+  float m = 0.f;
+#pragma unroll 4
+  for (int i = beg + threadIdx.x; i < end; i += 256) m = __builtin_fmaxf(m, __builtin_fabsf(w[i]));
+  const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) s_e[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = max(max(s_e[0], s_e[1]), max(s_e[2], s_e[3]));
+}
+
 // x9 weights: shorts [chunk][tap group g][component][row tile m][lane][8]; value i of lane (l31, hh) = component of
 // w(out = k0 + 32 m + l31, reduce, tap), zero beyond T / C / K, with
 //   CC = 4: reduce = 4 chunk + (i & 3), tap = 4 g + 2 hh + (i >> 2);      CC = 8: reduce = 8 chunk + i, tap = 2 g + hh
 __global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int TG, int MT, int CC,
-                                      int NC, int nchunks, int mode, int k0, int K, int C, int* __restrict__ wexp) {
+                                      int NC, int nchunks, int mode, int k0, int K, int C, int* __restrict__ wexp, int nparts) {
   const long long total = (long long)nchunks * TG * MT * 512;
   float wscale = 1.f;
-  if (NC == 2) {
-    // f16 components: every workgroup finds the largest exponent of the whole weight tensor (a few hundred KB, L2 resident; the launch has
-    // at most 32 workgroups) so that all of them scale by the same power of two; workgroup 0 publishes it for the convolution's epilogue
-    __shared__ int s_e[16];
-    float m = 0.f;
-    const long long nw = (long long)wA * wB * T;
-    for (long long i = threadIdx.x; i < nw; i += blockDim.x) m = __builtin_fmaxf(m, __builtin_fabsf(w[i]));
-    const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
-    if ((threadIdx.x & 63) == 0) s_e[threadIdx.x >> 6] = e;
-    __syncthreads();
+  if (NC == 2) {                                                   // f16 components: fold the slice exponents x9_wexp_kernel left in wexp[1 ..]
     int E = DPF_H3_EMIN;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) E = s_e[i] > E ? s_e[i] : E;
+    for (int i = 1; i <= nparts; ++i) E = max(E, wexp[i]);
     E = E > 254 ? 254 : E;
     wscale = dpf_h3_scale(E);
-    if (blockIdx.x == 0 && threadIdx.x == 0) wexp[0] = E;
+    if (blockIdx.x == 0 && threadIdx.x == 0) wexp[0] = E;         // for the convolution's epilogue
   }
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(e & 7), ln = (int)((e >> 3) & 63);
@@ -1348,14 +1352,15 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   // (f16 components: the scale's exponent sits behind the packed weights -- inside the three-component capacity of the workspace)
   int* wexp = reinterpret_cast<int*>(wp + ((total * NC + 7) & ~7LL));
   q.wexp = wexp;
+  int nparts = 0;
   if (NC == 2) {
-    const long long g2 = (total + 1023) / 1024;
-    hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3((unsigned)(g2 < 32 ? g2 : 32)), dim3(1024), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks,
-                       d.mode, q.k0, kn, d.C, wexp);
-  } else {
-    hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks, d.mode, q.k0,
-                       kn, d.C, wexp);
+    const int nw = d.wA * d.wB * T;
+    nparts = (nw + 4095) / 4096 < 32 ? (nw + 4095) / 4096 : 32;
+    const int per = (nw + nparts - 1) / nparts;
+    hipLaunchKernelGGL(x9_wexp_kernel, dim3(nparts), dim3(256), 0, st, w, nw, per, wexp + 1);
   }
+  hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks, d.mode, q.k0, kn,
+                     d.C, wexp, nparts);
   if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
   if (stats) stats->parts = (int)nt9;
   const long long blocks9 = 8LL * q.cpx;

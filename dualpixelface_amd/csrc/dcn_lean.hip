@@ -727,7 +727,13 @@ struct BwdLds {
   static_assert(G::NV == 256, "4 sampler waves + 4 matrix waves of 64 voxels");
 };
 
-template <class G>
+// GH = true (the default unless dpf_set_f32_matrix_path(0)): the gcol product on v_mfma_f32_16x16x32_f16 from two f16 components per operand
+// (conv_internal.h) -- the weights are split and scaled by the repack kernel, the go tile once per workgroup (its largest exponent is agreed
+// on through LDS before the first step), three MFMAs per (16 voxels, 32 output channels) instead of eight fp32 ones per 4; the result is
+// scaled back exactly before it is written to the gcol tile, so the samplers are unchanged.
+typedef _Float16 lean_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned lean_u32x4 __attribute__((ext_vector_type(4)));
+template <class G, bool GH>
 __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                   const float* __restrict__ wg /*[T][nchunk][64 lanes][16]*/,
                                                                   const float* __restrict__ go, float* __restrict__ doff, float* __restrict__ dwtmp,
@@ -735,6 +741,7 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
   extern __shared__ __align__(16) char smem[];
   constexpr int CH = G::CH, NQ = G::NQ, T = 27;
   typedef BwdLds<G> L;
+  int* s_ex = reinterpret_cast<int*>(smem + L::LDS);      // GH: the matrix waves' go-tile exponents
   char* region = smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -762,6 +769,7 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
     LeanTab tab = lean_tab<G>(p, pvalid, ry0, rx0, zbf + offp0[0], ybf + offp0[p.P], xbf + offp0[2 * p.P]);
 #pragma unroll
     for (int u = 1; u <= 3; ++u) { od[u % 3] = offp0[u * P3]; oh[u % 3] = offp0[u * P3 + p.P]; ow[u % 3] = offp0[u * P3 + 2 * p.P]; }
+    if constexpr (GH) __syncthreads();                 // (the matrix waves agree on the go tile's scale)
     lean_stage<G>(p, xb, 0, region, ry0, rx0, tid, 512);
     __syncthreads();                                   // prologue: region of chunk 0 staged, gcol(0) written
     int i = 0;
@@ -891,18 +899,62 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
   } else {
     // ------------------------------------------------------------------------------------------------------------ matrix waves
     const int mw = wave_u - 4, l15 = lane & 15, lg = lane >> 4;
-    // gcol B fragments: go[k = 4 ks + lg][voxel] for this wave's 4 sub-tiles of 16 voxels
-    float bfrag[4][16];
+    // gcol B fragments: go[k = 4 ks + lg][voxel] for this wave's 4 sub-tiles of 16 voxels (GH: k = 32 mf + 8 lg + i, packed f16 components)
+    float bfrag[GH ? 1 : 4][16];
+    lean_u32x4 bq[GH ? 4 : 1][2][2];                    // [sub-tile][k half][hi | lo]
+    int Eg = DPF_H3_EMIN, Ew = DPF_H3_EMIN;
+    if constexpr (GH) {
+      float mxg = 0.f;
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int vox = mw * 64 + s4 * 16 + l15;
-      const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
-      const bool ok = pz < p.D && y0 + py < p.H && x0 + px < p.W;
-      const long long gpos = ok ? ((long long)pz * p.H + y0 + py) * p.W + x0 + px : 0;
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int vox = mw * 64 + s4 * 16 + l15;
+        const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+        const bool ok = pz < p.D && y0 + py < p.H && x0 + px < p.W;
+        const long long gpos = ok ? ((long long)pz * p.H + y0 + py) * p.W + x0 + px : 0;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int k = 4 * ks + lg;
-        bfrag[s4][ks] = (ok && k < p.K) ? gob[(long long)k * p.P + gpos] : 0.f;
+        for (int i = 0; i < 16; ++i) {
+          const int k = 32 * (i >> 3) + 8 * lg + (i & 7);
+          if (ok && k < p.K) mxg = __builtin_fmaxf(mxg, __builtin_fabsf(gob[(long long)k * p.P + gpos]));
+        }
+      }
+      const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, mxg));
+      if (lane == 0) s_ex[mw] = e;
+      __syncthreads();                                  // all eight waves
+      Eg = max(max(s_ex[0], s_ex[1]), max(s_ex[2], s_ex[3]));
+      Eg = __builtin_amdgcn_readfirstlane(Eg);
+      Eg = Eg < DPF_H3_EMIN ? DPF_H3_EMIN : (Eg > 254 ? 254 : Eg);
+      Ew = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(wg)[27 * p.nchunk * 1024]);
+      const float scg = dpf_h3_scale(Eg);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int vox = mw * 64 + s4 * 16 + l15;
+        const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+        const bool ok = pz < p.D && y0 + py < p.H && x0 + px < p.W;
+        const long long gpos = ok ? ((long long)pz * p.H + y0 + py) * p.W + x0 + px : 0;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = 32 * mf + 8 * lg + 2 * i;
+            const float v0 = (ok && k < p.K) ? gob[(long long)k * p.P + gpos] : 0.f;
+            const float v1 = (ok && k + 1 < p.K) ? gob[(long long)(k + 1) * p.P + gpos] : 0.f;
+            unsigned h, l;
+            dpf_split_pair_h(v0 * scg, v1 * scg, h, l);
+            bq[s4][mf][0][i] = h; bq[s4][mf][1][i] = l;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int vox = mw * 64 + s4 * 16 + l15;
+        const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
+        const bool ok = pz < p.D && y0 + py < p.H && x0 + px < p.W;
+        const long long gpos = ok ? ((long long)pz * p.H + y0 + py) * p.W + x0 + px : 0;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const int k = 4 * ks + lg;
+          bfrag[s4][ks] = (ok && k < p.K) ? gob[(long long)k * p.P + gpos] : 0.f;
+        }
       }
     }
     // grad_weight A fragments: go[k = 16 mw + l15][voxel 16 q + 4 lg + u] for k-step 4 q + u
@@ -924,17 +976,39 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
     auto gcol = [&](int j) {                           // gcol(j) -> G[j & 1]
       const int chunk = j / T, t = j - chunk * T;
       const char* wb = reinterpret_cast<const char*>(wg) + (long long)(t * p.nchunk + chunk) * 4096;
-      f32x4 a4[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a4[u] = *reinterpret_cast<const f32x4*>(wb + wlane + 16 * u);
       char* dst = smem + L::OFF_G + (j & 1) * L::GT + lg * G::SQ + (mw * 64 + l15) * 16;
+      f32x4 a4[4];
+      lean_u32x4 aq[2][2];                               // GH: [k half][hi | lo], 1 KB per (half, component)
+      if constexpr (GH) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) aq[u >> 1][u & 1] = *reinterpret_cast<const lean_u32x4*>(wb + u * 1024 + lane * 16);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] = *reinterpret_cast<const f32x4*>(wb + wlane + 16 * u);
+      }
 #pragma unroll
       for (int sp2 = 0; sp2 < 2; ++sp2) {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if constexpr (GH) {
+          constexpr int ca[3] = {1, 0, 0}, cb[3] = {0, 1, 0};          // lo*hi, hi*lo, hi*hi
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
+          for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[ks >> 2][ks & 3], bfrag[2 * sp2 + u][ks], acc[u], 0, 0, 0);
+            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lean_f16x8, aq[mf][ca[i]]),
+                                                                 __builtin_bit_cast(lean_f16x8, bq[2 * sp2 + u][mf][cb[i]]), acc[u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[u][r] = __builtin_ldexpf(acc[u][r], Eg + Ew - 282);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[ks >> 2][ks & 3], bfrag[2 * sp2 + u][ks], acc[u], 0, 0, 0);
+        }
         if (lg < NQ) {
           *reinterpret_cast<f32x4*>(dst + (2 * sp2) * 256) = acc[0];            // D rows 4 lg .. 4 lg + 3 = quad lg of voxel (col)
           *reinterpret_cast<f32x4*>(dst + (2 * sp2 + 1) * 256) = acc[1];
@@ -986,6 +1060,34 @@ __global__ void lean_repack_gcol_kernel(const float* __restrict__ w, float* __re
     const int chunk = r % nchunk, t = r / nchunk;
     const int k = 4 * ks + (lane >> 4), l15 = lane & 15, c = chunk * CH + l15;
     wg[i] = (k < K && l15 < CH && c < C) ? w[((long long)k * C + c) * 27 + t] : 0.f;
+  }
+}
+
+// GH: wgh[tap][chunk][k half mf][hi | lo][lane][8 halves]: value i of lane (l15, lg) = component of W[k = 32 mf + 8 lg + i][c = chunk * CH + l15][tap]
+// scaled by 2^(141 - E), E = the largest exponent of the weight tensor (every workgroup finds it; workgroup 0 stores it behind the fragments)
+__global__ void lean_repack_gcol_h_kernel(const float* __restrict__ w, unsigned short* __restrict__ wgh, int K, int C, int CH, int nchunk) {
+  __shared__ int s_e[16];
+  float m = 0.f;
+  const int nw = K * C * 27;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) m = __builtin_fmaxf(m, __builtin_fabsf(w[i]));
+  const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) s_e[threadIdx.x >> 6] = e;
+  __syncthreads();
+  int E = DPF_H3_EMIN;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) E = s_e[i] > E ? s_e[i] : E;
+  E = E > 254 ? 254 : E;
+  const float sc = dpf_h3_scale(E);
+  const int total = 27 * nchunk * 2048;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(wgh)[total / 2] = E;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int idx = i & 7, lane = (i >> 3) & 63, comp = (i >> 9) & 1, mf = (i >> 10) & 1;
+    const int r = i >> 11;
+    const int chunk = r % nchunk, t = r / nchunk;
+    const int k = 32 * mf + 8 * (lane >> 4) + idx, l15 = lane & 15, c = chunk * CH + l15;
+    const float v = (k < K && l15 < CH && c < C) ? w[((long long)k * C + c) * 27 + t] * sc : 0.f;
+    unsigned h, l;
+    dpf_split_pair_h(v, 0.f, h, l);
+    wgh[i] = (unsigned short)((comp ? l : h) & 0xffffu);
   }
 }
 
@@ -1051,9 +1153,16 @@ int lean_launch_bwd_offset(const float* x, const float* offset, const float* wei
   p.tilesX = dpf_div_up(p.W, G::TX);
   const long long blocks = (long long)p.B * p.tilesY * p.tilesX;
   if (blocks >= 0x7fffffffLL) return DPF_ERR_UNSUPPORTED;
+  static const int gh_env = getenv("DPF_DCN_GCOL16") ? atoi(getenv("DPF_DCN_GCOL16")) : 1;
+  if (gh_env && dpf_conv_f32_x9()) {
+    hipLaunchKernelGGL(lean_repack_gcol_h_kernel, dim3(16), dim3(1024), 0, st, weight, reinterpret_cast<unsigned short*>(ws), p.K, p.C, G::CH, p.nchunk);
+    if (lean_set_lds(dcn_lean_bwd_offset_kernel<G, true>, BwdLds<G>::LDS + 64) != DPF_OK) return DPF_ERR_LAUNCH;
+    hipLaunchKernelGGL((dcn_lean_bwd_offset_kernel<G, true>), dim3((unsigned)blocks), dim3(512), BwdLds<G>::LDS + 64, st, x, offset, ws, go, doff, dwtmp, p, det);
+    return dpf_check_launch();
+  }
   hipLaunchKernelGGL(lean_repack_gcol_kernel, dim3(dpf_ew_grid(27LL * p.nchunk * 1024)), dim3(256), 0, st, weight, ws, p.K, p.C, G::CH, p.nchunk);
-  if (lean_set_lds(dcn_lean_bwd_offset_kernel<G>, BwdLds<G>::LDS) != DPF_OK) return DPF_ERR_LAUNCH;
-  hipLaunchKernelGGL((dcn_lean_bwd_offset_kernel<G>), dim3((unsigned)blocks), dim3(512), BwdLds<G>::LDS, st, x, offset, ws, go, doff, dwtmp, p, det);
+  if (lean_set_lds(dcn_lean_bwd_offset_kernel<G, false>, BwdLds<G>::LDS) != DPF_OK) return DPF_ERR_LAUNCH;
+  hipLaunchKernelGGL((dcn_lean_bwd_offset_kernel<G, false>), dim3((unsigned)blocks), dim3(512), BwdLds<G>::LDS, st, x, offset, ws, go, doff, dwtmp, p, det);
   return dpf_check_launch();
 }
 
@@ -1072,7 +1181,7 @@ long long dcn_lean_workspace_floats(int C, int K) {
   const int CH = dcn_lean_chunk(C);
   const long long nchunk = (C + CH - 1) / CH;
   const long long fwd = 27LL * nchunk * ((K + 31) / 32) * 768;     // lean_repack_fwd6_kernel (3 x 512 bf16; lean_repack_fwd1_kernel: 512 floats)
-  const long long bwd = 27LL * nchunk * 1024;                      // lean_repack_gcol_kernel (independent of K)
+  const long long bwd = 27LL * nchunk * 1024 + 16;                 // lean_repack_gcol_kernel / lean_repack_gcol_h_kernel (+ its exponent); independent of K
   return fwd > bwd ? fwd : bwd;
 }
 

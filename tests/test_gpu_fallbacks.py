@@ -20,6 +20,8 @@ SETS = [
     ({'DPF_W2_RSTEP': '0', 'DPF_G2_PZ': '1'}, 'test_conv_forward_backward'),
     # four output planes per tile wherever the geometry allows it; run-time column stride and the fp32 matrix instruction in the weight gradient
     ({'DPF_G2_PZ': '4', 'DPF_W2_SW1': '0', 'DPF_F32_X9': '0'}, 'test_conv_forward_backward'),
+    # fp32 products from six bf16 partial products of exact three-way splits (round 5's default; the default is now three f16 products)
+    ({'DPF_F32_X9': '1'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics or test_deform_conv'),
     # stride-1 convolutions on the exact-f32 matrix instruction instead of the bf16 partial products
     ({'DPF_IGEMM3': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics'),
     # x9 convolutions: split as a phase of its own (one weight buffer) instead of in the MFMAs' shadow; forced chunk layouts

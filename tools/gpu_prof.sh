@@ -15,7 +15,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 fam = collections.OrderedDict()
 def family(n):
-    for key, lab in (('pointwise_wgrad', 'conv pointwise'), ('pointwise_kernel', 'conv pointwise'), ('igemm3_pack', 'weight pack'), ('igemm3_x9', 'conv fwd/dgrad (x9)'), ('igemm2_tr2', 'conv fwd/dgrad (igemm2)'), ('igemm2_kernel', 'conv fwd/dgrad (igemm2)'), ('igemm2_pack', 'weight pack'), ('conv_igemm_kernel', 'conv fwd/dgrad (gen1)'),
+    for key, lab in (('pointwise_wgrad', 'conv pointwise'), ('pointwise_kernel', 'conv pointwise'), ('igemm3_pack', 'weight pack'), ('x9_wexp', 'weight pack'), ('igemm3_x9', 'conv fwd/dgrad (x9)'), ('igemm2_tr2', 'conv fwd/dgrad (igemm2)'), ('igemm2_kernel', 'conv fwd/dgrad (igemm2)'), ('igemm2_pack', 'weight pack'), ('conv_igemm_kernel', 'conv fwd/dgrad (gen1)'),
                      ('wgrad2_kernel', 'conv wgrad (wgrad2)'), ('wgrad2_reduce', 'conv wgrad (wgrad2)'), ('conv_wgrad_kernel', 'conv wgrad (gen1)'), ('repack', 'weight pack'),
                      ('dcn_lean_fwd', 'dcn fwd'), ('dcn_fwd', 'dcn fwd'), ('dcn_lean_bwd_offset', 'dcn offset+wgrad'), ('dcn_bwd_offset', 'dcn offset+wgrad'), ('dcn_bwd_input', 'dcn input'), ('dcn_', 'dcn misc'),
                      ('bn_', 'norm/act'), ('smallk', 'smallk conv'), ('at::native', 'torch elementwise'), ('rocclr', 'fill/copy'), ('copy_channels', 'layout'), ('swap_axes', 'layout'),
