@@ -799,6 +799,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       for (int s = 0; s < NPS; ++s) {
         touch_pair(bP[s & 1]);
         if (s == 0) touch_a(aC);
+#ifdef DPF_DBG_NOB                                                    // timing experiment (wrong results): no operand reads inside the loop
+        if (s + 1 >= NPS) load_a(gn, aN);
+#else
         if (s + 1 < NPS) {
           load_b(2 * s + 2, oC0, oC1, bP[(s + 1) & 1][0]);
           load_b(2 * s + 3, oC0, oC1, bP[(s + 1) & 1][1]);
@@ -807,6 +810,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
           load_b(0, oN0, oN1, bP[(s + 1) & 1][0]);
           load_b(1, oN0, oN1, bP[(s + 1) & 1][1]);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HALF >= 0) {
           constexpr int per = NSL / 2 / NPS;                       // slices per pair step
@@ -842,6 +846,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     load_b(1, oC0, oC1, bP[0][1]);
     if constexpr (SH) {
       for (int g = 0; g + 2 < TG; ++g) group(g, std::integral_constant<int, -1>{});
+#ifndef DPF_DBG_NOEXP                                                  // (timing experiment: one scale per tile)
       if constexpr (NC == 2) {
         if (chunk + 1 < p.nchunks) {                                // the next chunk's values have landed by now: agree on its scale
           post_exp();
@@ -850,6 +855,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
           scx = dpf_h3_scale(Enext);
         }
       }
+#endif
       group(TG - 2, std::integral_constant<int, 0>{});
       group(TG - 1, std::integral_constant<int, 1>{});
     } else {
