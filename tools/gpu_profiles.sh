@@ -43,7 +43,8 @@ if [ -z "$QUICK" ]; then
   bash tools/gpu_kstats.sh ${R}dcn tools/dcn_bench.py all > "$O/${R}_dcn_bench_kernel_stats.txt" 2>&1
   # per-shape conv times: x9 kernels (default) against the exact-f32 matrix instruction, 16-byte against 4-byte tile stores
   SH9="hg32 hg64 hg64q cv64_32 fe32 fe32q fe32d5 fe96_32 fe64 fe192_64 anm96d2 anm64d8 off81 off81a hg_s2"
-  { echo "== default (x9 convolutions + weight gradient, 16-byte tile stores)"; python tools/conv_shape_bench.py --check $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
+  { echo "== default (fp32 products from f16 components, 16-byte tile stores)"; python tools/conv_shape_bench.py --check $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
+    echo "== DPF_F32_X9=1 (six bf16 partial products of exact three-way splits: the default before the f16 components)"; DPF_F32_X9=1 python tools/conv_shape_bench.py $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
     echo "== DPF_F32_X9=0 (v_mfma_f32_32x32x2_f32 everywhere)"; DPF_F32_X9=0 python tools/conv_shape_bench.py $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
     echo "== DPF_G2_VEC_STORE=0 (4-byte tile stores)"; DPF_G2_VEC_STORE=0 python tools/conv_shape_bench.py $SH9 2>&1 | grep -v -e MIOpen -e amdgpu.ids
   } > "$O/${R}_conv_x9_vs_f32_per_shape.txt"
