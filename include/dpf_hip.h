@@ -56,13 +56,19 @@ int dpf_conv_transpose_acc(const float* x, const float* w, const float* bias, fl
  * shapes the bf16 kernels do not cover run exact fp32. */
 int dpf_set_conv_operand_precision(int bf16);
 int dpf_get_conv_operand_precision(void);
-/* How operand precision 0 (fp32) multiplies in the weight-gradient kernel and in the stride-1 forward / data-gradient kernels: 1 (default;
- * environment DPF_F32_X9=0 changes the default) = each fp32 product from the exact round-to-nearest three-way bf16 splits of its operands
- * (x = hi + mid + lo) on the bf16 matrix pipe -- the six partial products that can reach 2^-24 of the product (mid x lo, lo x mid and
- * lo x lo are dropped: <= 2^-23 worst case, rms 2^-26, zero mean), summed in the MFMA's fp32 accumulator; 0 = v_mfma_f32_32x32x2_f32.
- * Both sit at the same distance from an fp64 result (tests/test_gpu_ops.py:
- * test_weight_gradient_f32_matrix_paths_agree, test_conv_f32_matrix_paths_agree); process-wide state. */
-int dpf_set_f32_matrix_path(int split_bf16);
+/* How operand precision 0 (fp32) multiplies in the stride-1 forward / data-gradient kernels and in the weight-gradient kernel (process-wide;
+ * environment DPF_F32_X9 sets the initial value):
+ *   2 (default) = each operand as two f16 components of x * 2^s (hi = f16(x 2^s), lo = f16(x 2^s - hi), round to nearest), three partial
+ *       products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation.  2^s is chosen per block -- a channel chunk of a tile's
+ *       patch, a tile of the weight gradient, a weight tensor -- so that the block's largest magnitude lands in [2^14, 2^15), and is undone
+ *       exactly in the epilogue: <= 2^-23 relative per operand within 2^17 of the block maximum, an absolute floor of 2^-40 of the block
+ *       maximum below that (fp32-equivalent in the norm of each tile, not per element);
+ *   1 = the exact round-to-nearest three-way bf16 splits of both operands (x = hi + mid + lo) on the bf16 matrix pipe, the six partial
+ *       products that can reach 2^-24 of the product (mid x lo, lo x mid and lo x lo are dropped: <= 2^-23 worst case, rms 2^-26, zero mean);
+ *   0 = v_mfma_f32_32x32x2_f32.
+ * All three sit at the same distance from an fp64 result (tests/test_gpu_ops.py: test_weight_gradient_f32_matrix_paths_agree,
+ * test_conv_f32_matrix_paths_agree, test_conv_f16_component_path_block_scaling). */
+int dpf_set_f32_matrix_path(int path);
 int dpf_get_f32_matrix_path(void);
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
