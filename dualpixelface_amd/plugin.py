@@ -165,14 +165,22 @@ class _PluginHooks(object):
                 self._pending_counts = counts_before
                 torch.cuda.synchronize()
                 return self._eager_step(batch, None, lr)
-        for k, v in tensors.items():
-            if v.data_ptr() != st['inputs'][k].data_ptr():
-                st['inputs'][k].copy_(v, non_blocking=True)
-        ad['step'] += 1
-        h0, h1 = ops.adam_hyper(ad['step'], lr)
-        st['hyper'][0:1].fill_(float(h0))                  # (scalars travel as kernel arguments: no host buffer the next step could overwrite)
-        st['hyper'][1:2].fill_(float(h1))
-        st['graph'].replay()
+        # The replay runs on the dedicated stream, bracketed by explicit event waits in both directions.  Launched into the caller's stream
+        # -- the legacy default stream in a plain script -- kernels the caller enqueued right after the replay were observed to start before
+        # the graph had finished (bench.py --wgrad-inline: eager steps behind two replays read parameters the replay was still writing: GPU
+        # memory faults and hangs in 2 of 5 runs; none in 12 runs with this ordering).
+        ss.wait_stream(cur)
+        with torch.cuda.stream(ss):
+            for k, v in tensors.items():
+                if v.data_ptr() != st['inputs'][k].data_ptr():
+                    st['inputs'][k].copy_(v, non_blocking=True)
+                    v.record_stream(ss)
+            ad['step'] += 1
+            h0, h1 = ops.adam_hyper(ad['step'], lr)
+            st['hyper'][0:1].fill_(float(h0))              # (scalars travel as kernel arguments: no host buffer the next step could overwrite)
+            st['hyper'][1:2].fill_(float(h1))
+            st['graph'].replay()
+        cur.wait_stream(ss)
         for name, n in st['counts'].items():
             self._pending_counts[name] = self._pending_counts.get(name, 0) + n
         return st['results']

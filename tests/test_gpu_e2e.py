@@ -809,6 +809,36 @@ def test_train_step_as_one_hip_graph_equals_eager_launches(golden_dir):
     assert int(sd1['feature_extraction.firstconv.0.1.num_batches_tracked']) == 2 * len(lrs)      # two feature passes per step
 
 
+def test_graph_replay_is_ordered_with_the_callers_stream(golden_dir):
+    """A replayed step and whatever the caller enqueues next on ITS stream are ordered: a snapshot of the parameters taken right behind
+    train_step() -- no host synchronisation in between, the GPU queue several steps deep -- holds the finished step.  (The replay runs on
+    the step's own stream between explicit event waits; launched into the caller's legacy default stream, later kernels were observed to
+    start before the graph had finished.)  Deterministic mode, so the run with a device synchronisation after every step is the oracle."""
+    from dualpixelface_amd import ops
+    g = np.load(golden_dir + '/e2e_train_128x128_b2.npz')
+    batch = load_batch(g)
+    snaps = []
+    with ops.deterministic_mode():
+        for sync in (True, False):
+            model = build_model(True)
+            model.option.step_graph = True
+            for _ in range(3):                                 # two eager calls + the capture
+                model.train_step({k: v.clone() for k, v in batch.items()})
+            torch.cuda.synchronize()
+            assert model._graph_state.get('graph') is not None
+            got = []
+            for _ in range(6):
+                model.train_step(batch)
+                got.append(model.flat_parameters().clone())    # on the caller's stream, right behind the replay
+                if sync:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            snaps.append(got)
+    for i, (a, b) in enumerate(zip(*snaps)):
+        assert torch.equal(a, b), i
+    assert not torch.equal(snaps[0][0], snaps[0][5])
+
+
 @pytest.mark.parametrize('bn_cat', ['0', '1'])
 def test_side_stream_weight_gradients_match_in_line(golden_dir, monkeypatch, bn_cat):
     """DPF_WGRAD_ASYNC: the weight-gradient launches move to a side stream; the gradients that reach Adam must be the same ones.
