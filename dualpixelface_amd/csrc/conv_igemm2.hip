@@ -533,8 +533,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   constexpr int KT = 32 * MT;
   constexpr int NU = X9<CC, NC>::NU, PB = X9<CC, NC>::PB, TPG = X9<CC, NC>::TPG, PD = X9<CC, NC>::PD;
   constexpr int NPROD = NC == 3 ? X9_NP : (NC == 2 ? 3 : 1);     // MFMAs per (row tile, position row, tap group)
-  constexpr bool TWO = SH && NC == 2;                             // f16 components, split in the shadow: patch values are fetched TWO chunks ahead
-  constexpr int SPV = NC == 3 ? 9 : (NC == 2 ? (TWO ? 8 : 6) : 1); // vector instructions of the split per value pair (TWO: + the two moves below)
+  constexpr int SPV = NC == 3 ? 9 : (NC == 2 ? 6 : 1);            // vector instructions of the split per value pair
   constexpr int NPS = NT / 2;                    // pair steps (two position rows, interleaved accumulators) per group
   constexpr int NSL = NU * 4;                    // split slices (one position of one unit) per chunk; half of them per tail group
   const int tid = threadIdx.x;
@@ -586,9 +585,8 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   }
 
   f32x4 pv[NU][CC];                  // raw patch values of the NEXT chunk (in flight across the MFMA loop)
-  f32x4 pv2[TWO ? NU : 1][TWO ? CC : 1];   // TWO: the chunk after it (in flight), pv then holds landed values: their exponent rides the chunk barrier
   unsigned sp[NU][4][PD];            // their split form: [unit][position][hi: CC/2 dwords | mid | lo]
-  auto prefetch_to = [&](int chunk, auto& dst) {
+  auto prefetch = [&](int chunk) {
     const float* xc = xn + (long long)chunk * CC * x_chan;
     const int crem = p.C - chunk * CC;
 #pragma unroll
@@ -597,10 +595,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       for (int ch = 0; ch < CC; ++ch) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (goff[j] >= 0 && ch < crem) v = *reinterpret_cast<const f32x4*>(xc + (long long)ch * x_chan + goff[j]);
-        dst[j][ch] = v;
+        pv[j][ch] = v;
       }
   };
-  auto prefetch = [&](int chunk) { prefetch_to(chunk, pv); };
   auto issue_w = [&](int chunk, int buf) {
     const char* wc = reinterpret_cast<const char*>(wpk) + (long long)chunk * wBytes;
     char* dst = s_w + buf * wBytes;
@@ -619,17 +616,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       else sp[j][ps][k] = pk_bf16(pv[j][2 * k][ps], pv[j][2 * k + 1][ps]);
     }
   };
-  // TWO: the slice just split makes room for the values of the chunk after it (landed by now: fetched a whole MFMA loop ago)
-  auto advance_slice = [&](int sl) {
-    if constexpr (TWO) {
-      const int j = sl >> 2, ps = sl & 3;
-#pragma unroll
-      for (int ch = 0; ch < CC; ++ch) pv[j][ch][ps] = pv2[j][ch][ps];
-    }
-  };
   // NC = 2: largest exponent of the chunk in flight (this lane's values, then the wave's) -> s_red[wave]; after a barrier next_exp() is
   // the running exponent including that chunk
-  auto post_exp = [&](int slot = 0) {
+  auto post_exp = [&]() {
     float m = 0.f;
 #pragma unroll
     for (int j = 0; j < NU; ++j)
@@ -639,10 +628,10 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
         m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pv[j][ch].z), __builtin_fabsf(pv[j][ch].w)));
       }
     const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
-    if (lane == 0) s_red[4 * slot + wave] = e;
+    if (lane == 0) s_red[wave] = e;
   };
-  auto next_exp = [&](int slot = 0) {
-    const int4 r = *reinterpret_cast<const int4*>(s_red + 4 * slot);
+  auto next_exp = [&]() {
+    const int4 r = *reinterpret_cast<const int4*>(s_red);
     int e = max(max(r.x, r.y), max(r.z, r.w));
     e = __builtin_amdgcn_readfirstlane(e);
     e = e > 254 ? 254 : e;                                         // (Inf / NaN inputs: the result is NaN either way)
@@ -690,18 +679,16 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   // stores form a phase of their own, hidden by the co-resident workgroup's MFMAs.
   if constexpr (SH) issue_w(0, 0);
   prefetch(0);
-  if constexpr (TWO) prefetch_to(1, pv2);                         // (a chunk beyond the last one: no loads, zeros)
   int Enext = Ex;
   if constexpr (SH) {
     if constexpr (NC == 2) {
-      post_exp(0);
+      post_exp();
       __syncthreads();
-      Ex = Enext = next_exp(0);
+      Ex = Enext = next_exp();
       scx = dpf_h3_scale(Ex);
     }
 #pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) { split_slice(sl); advance_slice(sl); }
-    if constexpr (TWO) post_exp(1);                                 // chunk 1's exponent: read after the first chunk barrier
+    for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
   }
 
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
@@ -723,14 +710,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     __syncthreads();                                               // vmcnt(0): this chunk's weights landed; barrier: patch written
     if (chunk == 0) { X9_STAMP(1, __builtin_readcyclecounter()) }
     const char* s_wc = s_w + (SH ? (chunk & 1) * wBytes : 0);
-    if constexpr (TWO) {
-      if (chunk + 1 < p.nchunks) {                                  // (posted before the previous chunk's closing barrier / in the prologue)
-        Enext = next_exp((chunk + 1) & 1);
-        scx = dpf_h3_scale(Enext);
-        issue_w(chunk + 1, (chunk + 1) & 1);
-        prefetch_to(chunk + 2, pv2);
-      }
-    } else if (chunk + 1 < p.nchunks) {
+    if (chunk + 1 < p.nchunks) {
       if constexpr (SH) issue_w(chunk + 1, (chunk + 1) & 1);
       prefetch(chunk + 1);
     }
@@ -835,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
         if constexpr (HALF >= 0) {
           constexpr int per = NSL / 2 / NPS;                       // slices per pair step
 #pragma unroll
-          for (int q = 0; q < per; ++q) { split_slice(HALF * (NSL / 2) + s * per + q); advance_slice(HALF * (NSL / 2) + s * per + q); }
+          for (int q = 0; q < per; ++q) split_slice(HALF * (NSL / 2) + s * per + q);
         }
         mfma_pair(aC, bP[s & 1], 2 * s);
         if constexpr (HALF >= 0) {
@@ -867,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     if constexpr (SH) {
       for (int g = 0; g + 2 < TG; ++g) group(g, std::integral_constant<int, -1>{});
 #ifndef DPF_DBG_NOEXP                                                  // (timing experiment: one scale per tile)
-      if constexpr (NC == 2 && !TWO) {
+      if constexpr (NC == 2) {
         if (chunk + 1 < p.nchunks) {                                // the next chunk's values have landed by now: agree on its scale
           post_exp();
           __syncthreads();
@@ -882,7 +862,6 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       for (int g = 0; g < TG; ++g) group(g, std::integral_constant<int, -1>{});
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TWO) post_exp(chunk & 1);                         // pv now holds chunk + 2: its exponent crosses the barrier below
     __syncthreads();                                               // the patch buffer is free
   }
   X9_STAMP(2, __builtin_readcyclecounter())

@@ -822,7 +822,7 @@ def test_graph_replay_is_ordered_with_the_callers_stream(golden_dir):
         for sync in (True, False):
             model = build_model(True)
             model.option.step_graph = True
-            for _ in range(3):                                 # two eager calls + the capture
+            for _ in range(4):                                 # eager calls (the first one creates the Adam state), then the capture
                 model.train_step({k: v.clone() for k, v in batch.items()})
             torch.cuda.synchronize()
             assert model._graph_state.get('graph') is not None
