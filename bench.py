@@ -294,6 +294,22 @@ def main():
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = (ops.PROFILE or []), None
     loss = float(res['final_loss'].detach())
+    # The same step with the fp32 products formed by the EXACT construction (six bf16 partial products of exact three-way splits,
+    # dpf_set_f32_matrix_path(1)) instead of the default three f16 products of block-scaled splits: a short second measurement (the step
+    # graph is re-captured: the matrix path is part of its key), reported beside `value`, never as `value`.
+    value_path1 = None
+    mpath_default = ops.f32_matrix_path()
+    if world == 1 and args.precision == 'f32' and args.model == 'stereodpnet' and mpath_default == 2 and not args.no_detail:
+        ops.set_f32_matrix_path(1)
+        for _ in range(4):
+            model.train_step(batch, reducer)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            model.train_step(batch, reducer)
+        sync()
+        value_path1 = args.batch * 5 / (time.perf_counter() - t1)
+        ops.set_f32_matrix_path(mpath_default)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -498,6 +514,13 @@ def main():
                        'streams': ('weight gradients on a side stream, left / right feature passes on two streams' if timed_async else 'one stream'),
                        'launch': ('one HIP graph per step (captured in the warm-up, replayed in the timed region)' if graph_live else 'eager kernel launches')},
             'final_loss': loss,
+            'f32_products': {'default': {2: 'three f16 partial products of block-scaled two-way operand splits (dpf_set_f32_matrix_path(2))',
+                                         1: 'six bf16 partial products of exact three-way operand splits (dpf_set_f32_matrix_path(1))',
+                                         0: 'v_mfma_f32_* (dpf_set_f32_matrix_path(0))'}.get(mpath_default),
+                             'value_with_exact_splits_path1': value_path1,
+                             'note': '`value` is measured on the default; the second number is the same step (5 steps, graph re-captured) with every '
+                                     'product formed from exact three-way bf16 splits -- exact per element, the default is fp32-equivalent per tile '
+                                     '(DESIGN.md section 4)'},
             'rccl_ranks_seen': ranks_seen,
             'collective_backend': (dist.get_backend() if dist.is_initialized() else None),
             'gradient_collectives_per_step': (reducer.collective_calls / float(args.warmup + args.steps + (0 if args.no_detail else 4))) if reducer is not None else 0,

@@ -156,6 +156,16 @@ class deterministic_mode(object):
 CONV_OPERANDS_BF16 = False      # current operand precision of the dense conv kernels; the autograd functions capture it at forward time
 
 
+def set_f32_matrix_path(path):
+    """How precision-32 products are formed (dpf_set_f32_matrix_path): 2 = three f16 partial products of block-scaled two-way operand splits
+    (default), 1 = six bf16 partial products of exact three-way splits, 0 = the fp32 matrix instructions.  Process-wide."""
+    lib().call('dpf_set_f32_matrix_path', int(path))
+
+
+def f32_matrix_path():
+    return int(lib().cdll.dpf_get_f32_matrix_path())
+
+
 class conv_operands(object):
     """``with conv_operands(True):`` dense convolutions launched inside round their operands to bf16 while staging them (fp32
     accumulation, fp32 tensors): the reference's ``precision: 16`` for its Conv2d / Conv3d layers.  Backward passes re-enter the

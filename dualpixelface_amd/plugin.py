@@ -111,7 +111,7 @@ class _PluginHooks(object):
         from . import stereodpnet as _sdn
         # everything a captured graph has baked in: shapes, the kernel-path switches, the arenas' addresses (a device move re-creates them)
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())) + (
-            bool(ops.deterministic()), ops.CONV_OPERANDS_BF16, ops.WGRAD_ASYNC, _sdn.FEATURES_TWO_STREAMS, self.flat_parameters().data_ptr(),
+            bool(ops.deterministic()), ops.CONV_OPERANDS_BF16, ops.f32_matrix_path(), ops.WGRAD_ASYNC, _sdn.FEATURES_TWO_STREAMS, self.flat_parameters().data_ptr(),
             self.flat_gradients(zero=False).data_ptr(), self._adam['m'].data_ptr() if self._adam else 0, self.stat_exchange is None)
         st = getattr(self, '_graph_state', None)
         if st is not None and st.get('failed') and st['key'] == key:
