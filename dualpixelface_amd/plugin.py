@@ -25,6 +25,7 @@ class _PluginHooks(object):
 
     # ---- reference surface -------------------------------------------------------------------------------
     def forward(self, batch):
+        self._settle_replay()
         results = self.network(batch)
         self.last_taps = results.pop('_taps')
         if self.training and 'disp' in batch:
@@ -181,11 +182,25 @@ class _PluginHooks(object):
             st['hyper'][1:2].fill_(float(h1))
             st['graph'].replay()
         cur.wait_stream(ss)
+        self._replay_in_flight = True                      # see _settle_replay()
         for name, n in st['counts'].items():
             self._pending_counts[name] = self._pending_counts.get(name, 0) + n
         return st['results']
 
+    def _settle_replay(self):
+        """Host-side wait for a replayed step before the model launches kernels one by one again (eager step, forward, validation).  The
+        event waits around the replay order it with the caller's stream, but eager launches of this model that FOLLOW a replay closely were
+        still seen to fault (bench.py --wgrad-inline inside the evidence collection, after the ordering fix); with the host wait at this
+        transition -- which a training loop crosses once per epoch at most -- none did."""
+        if getattr(self, '_replay_in_flight', False):
+            self._replay_in_flight = False
+            ss = getattr(self, '_step_stream', None)
+            if ss is not None:
+                ss.synchronize()
+
     def _eager_step(self, batch, reducer=None, lr=None, hyper=None):
+        if hyper is None:                                  # (hyper is set while the step is being captured)
+            self._settle_replay()
         self.train()
         gscale = 1.0
         if getattr(self, 'gather_grads', True):
