@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
     r[2] = __builtin_amdgcn_perm(h1, l1, 0x05040100u); r[3] = __builtin_amdgcn_perm(h1, l1, 0x07060302u);
     return r;
   };
-  auto own_convert = [&](int b, float scx, float scg) {
+  // (only the x patch is rewritten: an x value is read by up to 27 taps, a g value by ONE wave's two super-groups -- its split stays in
+  // the unit loop, in the MFMAs' shadow, and a third of the conversion phase's traffic disappears)
+  auto own_convert = [&](int b, float scx) {
     float* dbase = smem + b * bufFloats;
 #pragma unroll
     for (int j = 0; j < NLX; ++j)
@@ -268,12 +270,6 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
         const u32x4 r = pack_seg(*q, scx);
         *reinterpret_cast<u32x4*>(q) = r;
       }
-#pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      f32x4* q = reinterpret_cast<f32x4*>(dbase + xFloats + (j * 256 + tid) * 4);
-      const u32x4 r = pack_seg(*q, scg);
-      *reinterpret_cast<u32x4*>(q) = r;
-    }
   };
 
   const int sw = SW1 ? 1 : p.sw;
@@ -289,6 +285,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
   __syncthreads();
   int buf = 0;
   for (long long tile = tbeg; tile < tend; ++tile, buf ^= 1) {
+    float scg = 1.f;                                  // X9 = 2: scale of this tile's g values (split in the unit loop)
     if constexpr (X9 == 2) {
       // the tile in `buf` is raw fp32 and its exponents are posted: agree on the scales, fetch the next tile, convert this one in place
       int ex = DPF_H3_EMIN, eg = DPF_H3_EMIN;
@@ -306,7 +303,8 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
       }
       Exr = ex; Egr = eg;
       if (tile + 1 < tend) issue(buf ^ 1);
-      own_convert(buf, dpf_h3_scale(Exr), dpf_h3_scale(Egr));
+      own_convert(buf, dpf_h3_scale(Exr));
+      scg = dpf_h3_scale(Egr);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // conversions visible; the DMAs just issued stay in flight
     } else {
       if (tile + 1 < tend) issue(buf ^ 1);
@@ -322,11 +320,21 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
 #pragma unroll
         for (int i = 0; i < 8; ++i) xv[i] = __builtin_bit_cast(unsigned, s_x[colbase[t] + colx + (16 * J + i) * sw]);
       };
-      auto load_g = [&](int J, unsigned (&gv)[8]) {
+      auto load_g = [&](int J, float (&gv)[8]) {          // raw fp32 (the g tile is not converted in place)
         const int sl0 = wave * 8 + 4 * J + 2 * hh;
-        const u32x4 g0 = *reinterpret_cast<const u32x4*>(s_g + (arow + (sl0 ^ axor)) * 4);
-        const u32x4 g1 = *reinterpret_cast<const u32x4*>(s_g + (arow + ((sl0 + 1) ^ axor)) * 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(s_g + (arow + (sl0 ^ axor)) * 4);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(s_g + (arow + ((sl0 + 1) ^ axor)) * 4);
         gv[0] = g0[0]; gv[1] = g0[1]; gv[2] = g0[2]; gv[3] = g0[3]; gv[4] = g1[0]; gv[5] = g1[1]; gv[6] = g1[2]; gv[7] = g1[3];
+      };
+      auto split_g = [&](const float (&v)[8], f16x8& hi, f16x8& lo) {
+        u32x4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          unsigned a, b;
+          dpf_split_pair_h(v[2 * q] * scg, v[2 * q + 1] * scg, a, b);
+          h[q] = a; l[q] = b;
+        }
+        hi = __builtin_bit_cast(f16x8, h); lo = __builtin_bit_cast(f16x8, l);
       };
       auto unpack8 = [&](const unsigned (&v)[8], f16x8& hi, f16x8& lo) {      // 8 words (hi << 16 | lo) -> the two packed operands
         u32x4 h, l;
@@ -337,11 +345,12 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
         }
         hi = __builtin_bit_cast(f16x8, h); lo = __builtin_bit_cast(f16x8, l);
       };
-      unsigned xr[8], gv[8];
+      unsigned xr[8];
+      float gv[8];
       f16x8 aH, aL, bH, bL, nH, nL;
       load_g(0, gv);
       load_x(0, 0, xr);
-      unpack8(gv, aH, aL);
+      split_g(gv, aH, aL);
       unpack8(xr, bH, bL);
       if (NCT > 1) load_x(0, 1, xr); else load_x(1, 0, xr);
       f16x8 a2H = aH, a2L = aL;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
           const int u = J * NCT + t;
           if (u + 1 < 2 * NCT) unpack8(xr, nH, nL);
           if (u + 2 < 2 * NCT) load_x((u + 2) / NCT, (u + 2) % NCT, xr);
-          if (J == 0 && t == NCT - 1) unpack8(gv, a2H, a2L);
+          if (J == 0 && t == NCT - 1) split_g(gv, a2H, a2L);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aL, bH, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH, bL, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH, bH, acc[t], 0, 0, 0);
