@@ -619,8 +619,9 @@ template <int NCT>
 int launch_w2(const float* g, const float* x, float* slab, const W2P& p, size_t lds, unsigned blocks, hipStream_t st) {
   if (dpf_conv_operand_bf16()) return launch_w2b<NCT, true, 0>(g, x, slab, p, lds, blocks, st);
   // f16 components: the in-place conversion of a tile is a fixed cost per tile that only tiles with many units repay (stride-2 launches
-  // -- two column tiles, a 2.8x larger patch per channel -- ran 40 % slower with it, five column tiles broke even): NCT >= 6, else six bf16 products
-  switch (dpf_conv_f32_x9() == 2 && NCT < 6 ? 1 : dpf_conv_f32_x9()) {
+  // -- two column tiles, a 2.8x larger patch per channel -- ran 40 % slower with it; with only the x patch converted five column tiles gain
+  // 15 %, four break even): NCT >= 5, else six bf16 products
+  switch (dpf_conv_f32_x9() == 2 && NCT < 5 ? 1 : dpf_conv_f32_x9()) {
     case 2: return launch_w2b<NCT, false, 2>(g, x, slab, p, lds, blocks, st);
     case 1: return launch_w2b<NCT, false, 1>(g, x, slab, p, lds, blocks, st);
     default: return launch_w2b<NCT, false, 0>(g, x, slab, p, lds, blocks, st);

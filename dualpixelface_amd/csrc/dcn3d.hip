@@ -10,6 +10,7 @@
 #include "dpf_common.h"
 #include "dpf_repack.h"
 #include "dcn_internal.h"
+#include "conv_internal.h"
 #include <cstdlib>
 
 namespace {
@@ -397,6 +398,50 @@ __global__ __launch_bounds__(256) void dcn_wmax_kernel(const float* __restrict__
   if (threadIdx.x == 0) wmax[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
+// the same table from the caller's weight tensor w[K][C][T] (the f16-component path repacks straight into fragments: no wt2)
+__global__ __launch_bounds__(256) void dcn_wmax_w_kernel(const float* __restrict__ w, float* __restrict__ wmax, int K, int C, int T) {
+  __shared__ float sm[4];
+  const int c0 = blockIdx.x * GI_CH;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < K * GI_CH * T; i += 256) {
+    const int t = i % T, cc = (i / T) % GI_CH, k = i / (T * GI_CH);
+    if (c0 + cc < C) m = fmaxf(m, fabsf(w[((long long)k * C + c0 + cc) * T + t]));
+  }
+  m = dpf_wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) wmax[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// f16 components of the gcol B operand (dcn_bwd_input_pk_kernel<.., F16 = true>, v_mfma_f32_16x16x32_f16):
+// wph[tap][chunk of 16 channels][k half mf][hi | lo][lane][8 halves], value i of lane (l15, lg) = component of
+// W[k = 32 mf + 8 lg + i][c = 16 chunk + l15][tap] * 2^(141 - E) (zero beyond K / C), E = the largest exponent of the tensor -> *wexp
+__global__ void dcn_repack_pk_h_kernel(const float* __restrict__ w, unsigned short* __restrict__ wph, int K, int C, int T, int nch16, int* __restrict__ wexp) {
+  __shared__ int s_e[16];
+  float m = 0.f;
+  const int nw = K * C * T;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) m = fmaxf(m, fabsf(w[i]));
+  const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) s_e[threadIdx.x >> 6] = e;
+  __syncthreads();
+  int E = DPF_H3_EMIN;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) E = s_e[i] > E ? s_e[i] : E;
+  E = E > 254 ? 254 : E;
+  const float sc = dpf_h3_scale(E);
+  if (blockIdx.x == 0 && threadIdx.x == 0) wexp[0] = E;
+  const int total = T * nch16 * 2048;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int idx = i & 7, lane = (i >> 3) & 63, comp = (i >> 9) & 1, mf = (i >> 10) & 1;
+    const int r = i >> 11;
+    const int chunk = r % nch16, t = r / nch16;
+    const int k = 32 * mf + 8 * (lane >> 4) + idx, c = 16 * chunk + (lane & 15);
+    const float v = (k < K && c < C) ? w[((long long)k * C + c) * T + t] * sc : 0.f;
+    unsigned h, l;
+    dpf_split_pair_h(v, 0.f, h, l);
+    wph[i] = (unsigned short)((comp ? l : h) & 0xffffu);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward: input, packed pairs
 // Same LDS-privatised scatter as dcn_bwd_input_kernel<.., FX = true>, with TWO channels per ds_add_u64: a contribution of the
 // channel pair (2m, 2m+1) is the signed 64-bit integer  q_even * 2^32 + q_odd  (q = round(w * gcol * qscale), |sum q| < 2^31).
@@ -424,12 +469,18 @@ __device__ __forceinline__ int cvt_rpi(float x) {
 constexpr int PK_CH = 16, PK_CS = 8;
 constexpr float PK_MASS0 = 128.f, PK_MASS_Q = 131072.f;   // first-pass mass bound; fixed-point scale of the mass counters (6912 * 2^17 < 2^30)
 
+// F16 = true (default unless dpf_set_f32_matrix_path(0) / DPF_DCN_GCOL16=0): the gcol chain runs on v_mfma_f32_16x16x32_f16 from two f16
+// components per operand (conv_internal.h) -- 6 MFMAs per (16 voxels, 16 channels, 64 k) instead of 16 fp32 ones; the fragments keep the
+// size of the fp32 ones (the bf16 three-way variant of round 5 spilled: 24 + 24 registers); wt2 then holds dcn_repack_pk_h_kernel's
+// fragments and its exponent comes through wexp
+typedef _Float16 dcn_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned dcn_u32x4 __attribute__((ext_vector_type(4)));
 #define DPF_STAMP_WAVE wave
-template <int NST, int NW>
+template <int NST, int NW, bool F16>
 __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* __restrict__ offset, const float* __restrict__ wt2 /*[T][64][CT], zero rows beyond K*/,
                                                                    const float* __restrict__ go, float* __restrict__ dx, DcnP p, GiP q, int CT,
                                                                    const float* __restrict__ wmaxv /*[chunks of GI_CH] max |W|*/,
-                                                                   long long* gi_shadow /* deterministic mode: dcn_internal.h */) {
+                                                                   long long* gi_shadow /* deterministic mode: dcn_internal.h */, const int* __restrict__ wexp) {
   extern __shared__ __align__(16) long long smem_q[];
   constexpr int NT = 64 * NW;
   constexpr int npos = 16 * NST * NW;
@@ -447,6 +498,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   int* s_farm = s_far + 4;                                       // [2][FR][npos] per-voxel flag (one row per table thread of a voxel)
   float* s_gmax = (float*)(s_farm + 2 * FR * npos);              // [NW]
   unsigned* s_mmax = (unsigned*)(s_gmax + NW);                   // [NW]
+  int* s_gexp = (int*)(s_mmax + NW);                             // [NW]  F16: the waves' largest go exponents
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int pr = l15 >> 1;           // channel pair within the 16-channel chunk
   const int jb = (l15 & 1) * 4;      // this lane's corners: 0-3 (even lane) or 4-7 (odd lane)
@@ -491,28 +543,53 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
     const long long gpos = ((long long)gz * p.Ho + gy) * p.Wo + gx;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const int k = 4 * ks + lg;
+      const int k = F16 ? 32 * (ks >> 3) + 8 * lg + (ks & 7) : 4 * ks + lg;     // (F16: 8 consecutive k per lane and k half)
       afrag[st][ks] = (ok && k < p.K) ? go[((long long)b * p.K + k) * p.P + gpos] : 0.f;
     }
   }
 
   float gbound = 0.f;   // max over this workgroup's voxels of sum_k |go[k][voxel]|
+  dcn_u32x4 aq[F16 ? NST : 1][2][2];                             // F16: [sub-tile][k half][hi | lo] of go * 2^(141 - Eg)
+  int Egw = DPF_H3_EMIN;                                         // F16: Eg + Ew (the gcol accumulators are in units of 2^(Egw - 282))
   {
-    float m = 0.f;
+    float m = 0.f, ma = 0.f;
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
       float sa = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) sa += fabsf(afrag[st][ks]);
+      for (int ks = 0; ks < 16; ++ks) { sa += fabsf(afrag[st][ks]); ma = fmaxf(ma, fabsf(afrag[st][ks])); }
       sa += __shfl_xor(sa, 16, 64);
       sa += __shfl_xor(sa, 32, 64);
       m = fmaxf(m, sa);
     }
     m = dpf_wave_max(m);
     if (lane == 0) s_gmax[wave] = m;
+    if constexpr (F16) {
+      const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, ma));
+      if (lane == 0) s_gexp[wave] = e;
+    }
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < NW; ++w) gbound = fmaxf(gbound, s_gmax[w]);
+    if constexpr (F16) {
+      int Eg = DPF_H3_EMIN;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) Eg = max(Eg, s_gexp[w]);
+      Eg = __builtin_amdgcn_readfirstlane(Eg);
+      Eg = Eg > 254 ? 254 : Eg;
+      Egw = Eg + __builtin_amdgcn_readfirstlane(wexp[0]);
+      const float scg = dpf_h3_scale(Eg);
+#pragma unroll
+      for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned h, l;
+            dpf_split_pair_h(afrag[st][8 * mf + 2 * i] * scg, afrag[st][8 * mf + 2 * i + 1] * scg, h, l);
+            aq[st][mf][0][i] = h; aq[st][mf][1][i] = l;
+          }
+    }
   }
 
   const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
@@ -595,10 +672,18 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
     const float* offp = offp0;
     Off3 onext = load_off_ptr(offp, p.P, pvalid);
     TapIt it = {0, 0, 0};
-    float bnext[16];
+    float bnext[F16 ? 1 : 16];
+    dcn_u32x4 bq[2][2];                                          // F16: [k half][hi | lo]
     const float* wtn = wt2 + (long long)lg * CT + cc;           // rows k >= K of the repacked tensor are zero
+    const char* wqn = reinterpret_cast<const char*>(wt2) + (long long)(c0 / PK_CH) * 4096 + lane * 16;     // F16: 4 KB per (tap, chunk)
+    const long long wq_step = (long long)(CT / PK_CH) * 4096;
+    if constexpr (F16) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
+      for (int u = 0; u < 4; ++u) bq[u >> 1][u & 1] = *reinterpret_cast<const dcn_u32x4*>(wqn + u * 1024);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
+    }
     __syncthreads();                                            // region / flags cleared
     {                                                           // tables of tap 0
       const Off3 o0 = onext;
@@ -629,14 +714,35 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
       for (int st = 0; st < NST; ++st) acc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
       // B fragments: W[k][c0 + l15][t], prefetched one tap ahead; the next tap's loads are issued once the chain has consumed these
       // (the registers are reused: the 16-wave variant has 128)
+      if constexpr (F16) {
+        constexpr int ca[3] = {1, 0, 0}, cb[3] = {0, 1, 0};      // lo*hi, hi*lo, hi*hi
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int st = 0; st < NST; ++st) acc[st] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bnext[ks], acc[st], 0, 0, 0);
-      if (t + 1 < p.T) {
-        wtn += 64 * CT;
+          for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
+            for (int st = 0; st < NST; ++st)
+              acc[st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dcn_f16x8, aq[st][mf][ca[i]]), __builtin_bit_cast(dcn_f16x8, bq[mf][cb[i]]),
+                                                               acc[st], 0, 0, 0);
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[st][r] = __builtin_ldexpf(acc[st][r], Egw - 282);
+        if (t + 1 < p.T) {
+          wqn += wq_step;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bq[u >> 1][u & 1] = *reinterpret_cast<const dcn_u32x4*>(wqn + u * 1024);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+          for (int st = 0; st < NST; ++st) acc[st] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[st][ks], bnext[ks], acc[st], 0, 0, 0);
+        if (t + 1 < p.T) {
+          wtn += 64 * CT;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) bnext[ks] = wtn[(4 * ks) * CT];
+        }
       }
       const bool far_tap = attempt == 0 && s_far[t % 3] != 0;   // block-uniform: some corner of this tap left the region
 #pragma unroll
@@ -1801,22 +1907,32 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     q.CG = grad_input_channels < C ? (grad_input_channels < 0 ? 0 : grad_input_channels) : C;
     const int npos = 64 * q.TZ;
     // region (8 packed pairs per cell + dummy cell), 2 x (lidx, w) tables, far flags, mass counters
-    const size_t lds = sizeof(long long) * (size_t)(q.RZmax * q.RY * q.RX + 1) * PK_CS + sizeof(float) * ((size_t)npos * 36 + 4 + 32) +
+    const size_t lds = sizeof(long long) * (size_t)(q.RZmax * q.RY * q.RX + 1) * PK_CS + sizeof(float) * ((size_t)npos * 36 + 4 + 48) +
                        sizeof(unsigned) * (size_t)((q.RZmax * q.RY * q.RX + 4) & ~3);
     const long long blocks = (long long)B * q.tilesZ * q.tilesY * q.tilesX;
     if (lds <= 160 * 1024 && blocks < 0x7fffffffLL && (long long)D * H * W < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
-      hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * 64 * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1,
-                         64);
       // packed fixed-point region (two channels per ds_add_u64): per-chunk max |W| for the quantisation bound, kept behind the
-      // grad_weight scratch in ws
+      // grad_weight scratch in ws (entry 32 of that slack: the weight exponent of the f16-component path)
       float* wmaxv = ws + dcn_repack_floats(C, K, p.T) + (long long)WG_NREP * p.T * ((C + 11) / 12) * 64 * 16;
-      hipLaunchKernelGGL(dcn_wmax_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, ws, wmaxv, p.T, CT, C);
-#define DPF_GIP(NS, NWv)                                                                                                       \
+      int* wexp = reinterpret_cast<int*>(wmaxv + 32);
+      static const int gh_env = getenv("DPF_DCN_GCOL16") ? atoi(getenv("DPF_DCN_GCOL16")) : 1;
+      const bool f16 = gh_env && dpf_conv_f32_x9() != 0 && p.T == 27;
+      if (f16) {
+        // the gcol B operand as f16 fragments ([T][CT / 16][4 KB] -- the bytes of wt2[T][64][CT]), max |W| from the caller's tensor
+        hipLaunchKernelGGL(dcn_repack_pk_h_kernel, dim3(16), dim3(1024), 0, st, weight, reinterpret_cast<unsigned short*>(ws), K, C, p.T, CT / PK_CH, wexp);
+        hipLaunchKernelGGL(dcn_wmax_w_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, weight, wmaxv, K, C, p.T);
+      } else {
+        hipLaunchKernelGGL(repack_weights_pad_kernel, dim3(dpf_ew_grid((long long)p.T * 64 * CT)), dim3(256), 0, st, weight, ws, K, C, p.T, CT, 1,
+                           64);
+        hipLaunchKernelGGL(dcn_wmax_kernel, dim3(dpf_div_up(C, GI_CH)), dim3(256), 0, st, ws, wmaxv, p.T, CT, C);
+      }
+#define DPF_GIP2(NS, NWv, F)                                                                                                   \
   {                                                                                                                            \
-    if (set_lds(dcn_bwd_input_pk_kernel<NS, NWv>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                       \
-    hipLaunchKernelGGL((dcn_bwd_input_pk_kernel<NS, NWv>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv, gi_shadow); \
+    if (set_lds(dcn_bwd_input_pk_kernel<NS, NWv, F>, lds) != DPF_OK) return DPF_ERR_LAUNCH;                                    \
+    hipLaunchKernelGGL((dcn_bwd_input_pk_kernel<NS, NWv, F>), grid, dim3(64 * NWv), lds, st, offset, ws, grad_output, grad_input, p, q, CT, wmaxv, gi_shadow, wexp); \
   }
+#define DPF_GIP(NS, NWv) { if (f16) DPF_GIP2(NS, NWv, true) else DPF_GIP2(NS, NWv, false) }
       switch (q.TZ) {
         case 1: DPF_GIP(1, 4); break;
         case 2: DPF_GIP(2, 4); break;
@@ -1824,6 +1940,7 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
         default: DPF_GIP(1, 16); break;   // 256 voxels: 16 waves (four per SIMD, one 16-voxel sub-tile each; the 8-wave variant measured 9.6 vs 8.5 ms)
       }
 #undef DPF_GIP
+#undef DPF_GIP2
       dx_done = true;
     }
   }
