@@ -14,7 +14,7 @@ SETS = [
     ({'DPF_DCN_LEAN': '0'}, 'test_deform_conv and not full_size'),
     # first-generation deformable kernels (global-memory gathers: what geometries without a fitting LDS image fall back to)
     ({'DPF_DCN_V1': '1'}, 'test_deform_conv and not full_size'),
-    # the grad_offset kernel's gcol product on the fp32 matrix instruction instead of the f16 components
+    # the deformable conv backward's gcol products (grad_input and grad_offset kernels) on the fp32 matrix instruction instead of the f16 components
     ({'DPF_DCN_GCOL16': '0'}, 'test_deform_conv and not full_size'),
     # the 35-channel forward on the wider x halo (one workgroup per CU)
     ({'DPF_DCN_LEAN_WIDE12': '1'}, 'test_deform_conv and not full_size'),

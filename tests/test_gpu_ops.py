@@ -466,7 +466,7 @@ def test_weight_gradient_f32_matrix_paths_agree(cfg):
             errs.append(((got - ref).abs().max() / ref.abs().max()).item())
         # path 2 (two f16 components, tiles converted in place and scaled by the running maxima): power-of-two scaling of either operand
         # is exact, far outside the f16 range, and a batch whose samples are 2^30 apart is summed as accurately as on the fp32 instruction
-        # (launches with fewer than six column tiles -- the stride-2 configuration -- stay on the six bf16 products: conv_wgrad2.hip)
+        # (launches with fewer than five column tiles -- the stride-2 configuration -- stay on the six bf16 products: conv_wgrad2.hip)
         base = ops._conv_wgrad_raw(g.to(DEV), x.to(DEV), (K, C) + ks, st, pad, dl)
         for kg, kx in ((-90, 0), (40, -80), (0, 70), (-45, -45)) if stride == 1 else ():
             got = ops._conv_wgrad_raw((g * 2.0 ** kg).to(DEV), (x * 2.0 ** kx).to(DEV), (K, C) + ks, st, pad, dl)
