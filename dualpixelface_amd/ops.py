@@ -327,6 +327,25 @@ def wgrad_async_finish():
     return out
 
 
+_shared_streams = {}
+
+
+def shared_stream(device, role):
+    """ONE stream per (device, role) for the whole process ('step': the fused train step and its graph, 'features': the second feature pass,
+    'wgrad': the deferred weight gradients).  torch.cuda.Stream() hands out a pool of 32 handles per device round-robin: a stream per MODEL
+    -- two for every model a process ever builds -- wraps around that pool, and a later model's step stream then IS an older object's side
+    stream (same handle).  After 70+ stream creations the GPU test suite crashed inside hipStreamEndCapture; with three streams per
+    process the roles can never alias."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    key = (device.index, role)
+    st = _shared_streams.get(key)
+    if st is None:
+        st = _shared_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _wgrad_dispatch(w, g, x, wshape, stride, pad, dil):
     """The weight gradient, or None when it was deferred to the side stream."""
     p = _wgrad_registry.get(w.data_ptr()) if _wgrad_registry is not None else None
@@ -334,7 +353,7 @@ def _wgrad_dispatch(w, g, x, wshape, stride, pad, dil):
         return _conv_wgrad_raw(g, x, wshape, stride, pad, dil)
     side = _wgrad_side.get(x.device)
     if side is None:
-        side = _wgrad_side[x.device] = torch.cuda.Stream(device=x.device)
+        side = _wgrad_side[x.device] = shared_stream(x.device, 'wgrad')
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         gw = _conv_wgrad_raw(g, x, wshape, stride, pad, dil)

@@ -126,7 +126,7 @@ class _PluginHooks(object):
         # on, and a capture cannot make the default stream wait for the capturing one.
         ss = getattr(self, '_step_stream', None)
         if ss is None or ss.device != flat_g.device:
-            ss = self._step_stream = torch.cuda.Stream(device=flat_g.device)
+            ss = self._step_stream = ops.shared_stream(flat_g.device, 'step')      # one per process, not per model: ops.shared_stream
         cur = torch.cuda.current_stream(flat_g.device)
         if st['calls'] <= 2 or self._adam is None:         # warm-up: lazily created streams, scratch buffers, sampler tables, kernel attributes
             ss.wait_stream(cur)
@@ -150,11 +150,18 @@ class _PluginHooks(object):
                 torch.cuda.synchronize()
                 ops.reset_zero_arenas()
                 with torch.cuda.graph(graph, stream=ss):
-                    cap_batch = dict(st['extra'])
-                    cap_batch.update(st['inputs'])
-                    res = self._eager_step(cap_batch, None, lr, hyper=st['hyper'])
-                    st['results'] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in res.items()}
-                    del res
+                    try:
+                        cap_batch = dict(st['extra'])
+                        cap_batch.update(st['inputs'])
+                        res = self._eager_step(cap_batch, None, lr, hyper=st['hyper'])
+                        st['results'] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in res.items()}
+                        del res
+                    except BaseException as e:               # (ending an invalidated capture has crashed the process before the error could surface)
+                        import sys
+                        import traceback
+                        sys.stderr.write('train_step: exception inside the graph capture: %r\n%s\n' % (e, traceback.format_exc()))
+                        sys.stderr.flush()
+                        raise
                 st['counts'] = dict(self._pending_counts)            # BatchNorm call counters one step adds (host-side bookkeeping)
                 self._pending_counts = {}
                 ad['step'] -= 1                                      # the capture only RECORDED the step: nothing ran

@@ -603,7 +603,7 @@ class StereoDPNetCore(_Base):
             # the stream of its forward.  Running statistics stay in the reference's order: every BatchNorm of the second pass waits
             # for the first pass's update of the same layer (ops.BN_ORDER).
             main = torch.cuda.current_stream()
-            side = self._feature_stream = getattr(self, '_feature_stream', None) or torch.cuda.Stream(device=batch[a].device)
+            side = self._feature_stream = getattr(self, '_feature_stream', None) or ops.shared_stream(batch[a].device, 'features')
             events = {}
             side.wait_stream(main)
             ops.BN_ORDER = ('record', events)
