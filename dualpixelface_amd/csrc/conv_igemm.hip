@@ -596,6 +596,8 @@ int dpf_conv_f32_x9() {
   }
   return g_f32_x9;
 }
+namespace { int g_h3_guard = 1; }
+int dpf_h3_range_guard() { return g_h3_guard; }
 
 extern "C" {
 
@@ -611,6 +613,11 @@ int dpf_set_f32_matrix_path(int split_bf16) {
   return DPF_OK;
 }
 int dpf_get_f32_matrix_path(void) { return dpf_conv_f32_x9(); }
+// diagnostic: 0 switches the range guards of the f16-component path off (what round 5 shipped) so that a test can show what they buy
+int dpf_debug_set_range_guard(int on) {
+  g_h3_guard = on ? 1 : 0;
+  return DPF_OK;
+}
 
 // workspace (floats) needed for the repacked weights of a conv with `T` taps, `reduce` reduction channels
 // and `outc` output channels

@@ -61,6 +61,7 @@ struct G2P {
   int statsK, statsk0;          // row length of the slab and first channel of this launch in it (K, 0 unless the launch is one slice of the channels)
   int tapoff[28];               // x9 kernel: patch offset (positions) of tap u; taps beyond T: 0 (their weights are zero)
   const int* wexp;              // x9 kernel, f16 components: biased exponent the pack kernel scaled the weights by (device memory)
+  int guard;                    // x9 kernel, f16 components: residual passes for chunks whose range exceeds the split's (always 1 outside tests)
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
 
@@ -506,9 +507,12 @@ constexpr int X9_NP = 9 - X9_FIRST;
 // staging and layouts with a third of the bytes and one MFMA per (row tile, position row, tap group).
 // NC = 2 (dpf_set_f32_matrix_path(2)): two f16 components of the block-scaled operand (conv_internal.h), three MFMAs (lo*hi, hi*lo, hi*hi) on
 // v_mfma_f32_32x32x16_f16.  The block is one channel chunk of the workgroup's patch: every lane takes the largest exponent of the values it
-// fetched, the waves exchange theirs through LDS (one extra barrier per chunk, before the split), and the chunk is scaled by the RUNNING
-// maximum of the tile (so the accumulators are rescaled only when it grows); the weights are scaled once per launch by the pack kernel; the
-// epilogue multiplies by 2^-(both scales) exactly (v_ldexp_f32).
+// fetched AND the smallest non-zero per-position maximum (a lane holds all CC channels of its positions), the waves exchange both through
+// LDS (one extra barrier per chunk, before the split).  The chunk is scaled by the exponent the accumulators already carry unless its own
+// maximum lies above it or more than 3 bits below it (then the accumulators are rescaled, exactly); a chunk with a position whose values all
+// sit more than 2^17 below the scale takes RESIDUAL PASSES (conv_internal.h): the exact remainders of the split are split again and
+// contracted with the same weights, so every output position sees its inputs to fp32 precision relative to ITS OWN inputs, not to the
+// tile's.  The weights are scaled once per launch by the pack kernel; the epilogue multiplies by 2^-(both scales) exactly (v_ldexp_f32).
 template <int CC, int NC> struct X9 {
   static constexpr int NU = CC == 4 ? 2 : 1;     // patch units (CC channels x 4 positions) per thread and chunk
   static constexpr int PB = 2 * NC * CC;         // bytes per position: [hi | mid | lo][CC] bf16
@@ -561,9 +565,12 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   char* s_patch = reinterpret_cast<char*>(smem);
   char* s_w = s_patch + patchBytes;                                // SH: two weight buffers
   int* s_tab = reinterpret_cast<int*>(s_w + (SH ? 2 : 1) * wBytes);
-  int* s_red = s_tab + 32;                                         // NC = 2: the waves' chunk exponents
-  int Ex = DPF_H3_EMIN;                                            // NC = 2: running exponent of the tile's patch; the accumulators are in units of 2^(Ex + Ew - 282)
-  float scx = 0.f;                                                 //         and the scale of the chunk being split
+  int* s_red = s_tab + 32;                                         // NC = 2: [wave] largest exponent of the chunk in flight, [4 + wave] its smallest non-zero position maximum
+  int Ex = DPF_H3_EMIN;                                            // NC = 2: the accumulators are in units of 2^(Ex + Ew - 282); Erun: largest chunk exponent of the tile so far
+  int Erun = DPF_H3_EMIN;
+  float scx = 0.f;                                                 //         multiplier of the values being split (chunk: 2^(141 - Enext); residual pass: 2^(Ex - Enext))
+  float mult[NU][4];                                               //         per position of this lane: scx, or 0 = deferred to a residual pass
+  unsigned inr = 0, dmask = 0;                                     //         bit 4 j + ps: in range in the pass being prepared / contracted in an earlier pass of this chunk
   const long long x_chan = (long long)p.ID * p.IH * p.IW;
   const float* xn = x + (long long)n * p.C * x_chan;
   const int nunits = p.rpc * p.SR;
@@ -612,30 +619,108 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < CC / 2; ++k) {
       if constexpr (NC == 3) split_pair(pv[j][2 * k][ps], pv[j][2 * k + 1][ps], sp[j][ps][k], sp[j][ps][CC / 2 + k], sp[j][ps][CC + k]);
-      else if constexpr (NC == 2) dpf_split_pair_h(pv[j][2 * k][ps] * scx, pv[j][2 * k + 1][ps] * scx, sp[j][ps][k], sp[j][ps][CC / 2 + k]);
+      else if constexpr (NC == 2) dpf_split_pair_h(pv[j][2 * k][ps] * mult[j][ps], pv[j][2 * k + 1][ps] * mult[j][ps], sp[j][ps][k], sp[j][ps][CC / 2 + k]);
       else sp[j][ps][k] = pk_bf16(pv[j][2 * k][ps], pv[j][2 * k + 1][ps]);
     }
   };
-  // NC = 2: largest exponent of the chunk in flight (this lane's values, then the wave's) -> s_red[wave]; after a barrier next_exp() is
-  // the running exponent including that chunk
-  auto post_exp = [&]() {
+  // NC = 2: largest exponent of the values in flight (this lane's, then the wave's) -> s_red[wave], and the smallest non-zero per-position
+  // maximum over the channels (key = bits - 1: zero positions wrap to the top and drop out; RES: so do positions an earlier pass of this
+  // chunk has contracted -- their remainders are a refinement, not a reason for another pass) -> s_red[4 + wave]
+  auto post_exp = [&](auto res_c) {
+    constexpr bool RES = decltype(res_c)::value;
     float m = 0.f;
+    unsigned kmin = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < NU; ++j)
 #pragma unroll
-      for (int ch = 0; ch < CC; ++ch) {
-        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pv[j][ch].x), __builtin_fabsf(pv[j][ch].y)));
-        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pv[j][ch].z), __builtin_fabsf(pv[j][ch].w)));
+      for (int ps = 0; ps < 4; ++ps) {
+        float mp = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CC; ++ch) mp = __builtin_fmaxf(mp, __builtin_fabsf(pv[j][ch][ps]));
+        m = __builtin_fmaxf(m, mp);
+        unsigned key = __builtin_bit_cast(unsigned, mp) - 1u;
+        if constexpr (RES) key = (dmask >> (4 * j + ps)) & 1u ? 0xffffffffu : key;
+        kmin = min(kmin, key);
       }
     const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
-    if (lane == 0) s_red[wave] = e;
+    const unsigned k = dpf_wave_min_u32(kmin);
+    if (lane == 0) { s_red[wave] = e; s_red[4 + wave] = k == 0xffffffffu ? 511 : (int)((k + 1u) >> 23); }
   };
-  auto next_exp = [&]() {
-    const int4 r = *reinterpret_cast<const int4*>(s_red);
+  // after the barrier: the exchanged exponents -> (largest, smallest non-zero position maximum; 511 when there is none)
+  auto read_exp = [&](int& emax, int& emin) {
+    const int4 r = *reinterpret_cast<const int4*>(s_red), q = *reinterpret_cast<const int4*>(s_red + 4);
     int e = max(max(r.x, r.y), max(r.z, r.w));
     e = __builtin_amdgcn_readfirstlane(e);
-    e = e > 254 ? 254 : e;                                         // (Inf / NaN inputs: the result is NaN either way)
-    return e > Ex ? e : Ex;
+    emax = e > 254 ? 254 : (e < DPF_H3_EMIN ? DPF_H3_EMIN : e);    // (Inf / NaN inputs: the result is NaN either way)
+    emin = __builtin_amdgcn_readfirstlane(min(min(q.x, q.y), min(q.z, q.w)));
+  };
+  // per-position multipliers of the pass being prepared: positions whose largest magnitude (pv's units; thr = biased exponent in those
+  // units) lies below the split's range are DEFERRED -- they contribute exact zeros now (the matrix core loses accumulator bits when it
+  // is fed subnormal f16 values next to large ones: tools/probes/mfma_f16_accum_probe.hip) and their values stay in pv for the next pass
+  auto set_masks = [&](bool wide, int thr) {
+    if (!wide) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) mult[j][ps] = scx;
+      inr = 0xffu;
+      return;
+    }
+    const unsigned tb = (unsigned)(thr < 1 ? 1 : (thr > 254 ? 254 : thr)) << 23;
+    inr = 0;
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        float mp = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CC; ++ch) mp = __builtin_fmaxf(mp, __builtin_fabsf(pv[j][ch][ps]));
+        const bool in = __builtin_bit_cast(unsigned, mp) >= tb;
+        mult[j][ps] = in ? scx : 0.f;
+        inr |= in ? 1u << (4 * j + ps) : 0u;
+      }
+  };
+  // a new chunk whose exponents were just exchanged: its scale (Enext), multipliers and whether it needs residual passes.  The
+  // accumulators' exponent is kept while the chunk's maximum lies 0 .. 3 bits below it (no rescale); it never drops more than
+  // DPF_H3_MAXDROP below the tile's running maximum (no overflow).  Emin*: smallest non-zero position maximum not contracted yet, as a
+  // biased exponent of the RAW values.
+  int Enext = Ex, Emin = 511, EminNext = 511;
+  auto next_chunk_scale = [&]() {
+    int e;
+    read_exp(e, EminNext);
+    Erun = e > Erun ? e : Erun;
+    const int lo = Erun - DPF_H3_MAXDROP;
+    Enext = (e > Ex || e < Ex - 3) ? (e > lo ? e : lo) : Ex;
+    scx = dpf_h3_scale(Enext);
+    set_masks(p.guard && EminNext < Enext - DPF_H3_RANGE, Enext - DPF_H3_RANGE);
+  };
+  // a residual pass of the chunk just split: pv holds, in units of the current scale (2^(141 - Ex)), the exact remainders of the positions
+  // contracted so far and the full values of the deferred ones; their own scale on top of it.  The last pass takes whatever is left.
+  auto next_residual_scale = [&](int pass_next) {
+    int e, k;
+    read_exp(e, k);
+    const int lo = Erun - DPF_H3_MAXDROP;
+    const int en = Ex + e - 141;
+    Enext = en > lo ? en : lo;
+    if (Enext > Ex) Enext = Ex;
+    EminNext = k + Ex - 141;
+    scx = __builtin_bit_cast(float, (unsigned)(127 + Ex - Enext) << 23);
+    set_masks(pass_next < DPF_H3_MAXPASS && EminNext < Enext - DPF_H3_RANGE, Enext - DPF_H3_RANGE + 141 - Ex);
+  };
+  auto residual_update = [&]() {      // pv <- (current scale's units) remainders of the split store_split() just published; deferred positions: the value
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int k = 0; k < CC / 2; ++k) {
+          const float a = pv[j][2 * k][ps] * scx, b = pv[j][2 * k + 1][ps] * scx;
+          float ra = a, rb = b;
+          dpf_split_residual_h(ra, rb);
+          pv[j][2 * k][ps] = mult[j][ps] != 0.f ? ra : a;
+          pv[j][2 * k + 1][ps] = mult[j][ps] != 0.f ? rb : b;
+        }
+    dmask |= inr;
   };
   auto store_split = [&]() {
 #pragma unroll
@@ -679,40 +764,47 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   // stores form a phase of their own, hidden by the co-resident workgroup's MFMAs.
   if constexpr (SH) issue_w(0, 0);
   prefetch(0);
-  int Enext = Ex;
   if constexpr (SH) {
     if constexpr (NC == 2) {
-      post_exp();
+      post_exp(std::false_type{});
       __syncthreads();
-      Ex = Enext = next_exp();
-      scx = dpf_h3_scale(Ex);
+      next_chunk_scale();
+      Ex = Enext; Emin = EminNext;
     }
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
   }
 
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+  // one iteration = one pass over a chunk; NC = 2: a chunk whose range exceeds the split's takes residual passes (pass > 0) before the next
+  // chunk is fetched -- its values stay in pv and are replaced by what the pass that just ran left of them
+  int pass = 0;
+  for (int chunk = 0; chunk < p.nchunks;) {
     if constexpr (!SH) {
-      issue_w(chunk, 0);
+      if (pass == 0) issue_w(chunk, 0);
       if constexpr (NC == 2) {
-        post_exp();
+        if (pass == 0) post_exp(std::false_type{}); else post_exp(std::true_type{});
         __syncthreads();
-        Enext = next_exp();
-        scx = dpf_h3_scale(Enext);
+        if (pass == 0) next_chunk_scale(); else next_residual_scale(pass);
+        Emin = EminNext;
       }
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
     }
     if constexpr (NC == 2) {
-      if (Enext != Ex) { rescale_acc(Ex - Enext); Ex = Enext; }    // the chunk about to be contracted raised the tile's exponent
+      if (Enext != Ex) { rescale_acc(Ex - Enext); Ex = Enext; }    // the pass about to be contracted changes the accumulators' exponent
     }
     store_split();
     __syncthreads();                                               // vmcnt(0): this chunk's weights landed; barrier: patch written
     if (chunk == 0) { X9_STAMP(1, __builtin_readcyclecounter()) }
     const char* s_wc = s_w + (SH ? (chunk & 1) * wBytes : 0);
-    if (chunk + 1 < p.nchunks) {
+    bool more = false;                                             // (workgroup-uniform) another pass over this chunk follows
+    if constexpr (NC == 2) more = p.guard && pass < DPF_H3_MAXPASS && Emin < Ex - DPF_H3_RANGE;
+    if (more) {
+      residual_update();
+    } else if (chunk + 1 < p.nchunks) {
       if constexpr (SH) issue_w(chunk + 1, (chunk + 1) & 1);
       prefetch(chunk + 1);
+      dmask = 0;
     }
 
     u32x4 aC[NC][MT], aN[NC][MT], bP[2][2][NC];                       // bP[set][row of the pair][component]
@@ -799,9 +891,6 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       for (int s = 0; s < NPS; ++s) {
         touch_pair(bP[s & 1]);
         if (s == 0) touch_a(aC);
-#ifdef DPF_DBG_NOB                                                    // timing experiment (wrong results): no operand reads inside the loop
-        if (s + 1 >= NPS) load_a(gn, aN);
-#else
         if (s + 1 < NPS) {
           load_b(2 * s + 2, oC0, oC1, bP[(s + 1) & 1][0]);
           load_b(2 * s + 3, oC0, oC1, bP[(s + 1) & 1][1]);
@@ -810,7 +899,6 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
           load_b(0, oN0, oN1, bP[(s + 1) & 1][0]);
           load_b(1, oN0, oN1, bP[(s + 1) & 1][1]);
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HALF >= 0) {
           constexpr int per = NSL / 2 / NPS;                       // slices per pair step
@@ -846,16 +934,17 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     load_b(1, oC0, oC1, bP[0][1]);
     if constexpr (SH) {
       for (int g = 0; g + 2 < TG; ++g) group(g, std::integral_constant<int, -1>{});
-#ifndef DPF_DBG_NOEXP                                                  // (timing experiment: one scale per tile)
       if constexpr (NC == 2) {
-        if (chunk + 1 < p.nchunks) {                                // the next chunk's values have landed by now: agree on its scale
-          post_exp();
+        if (more) {                                                 // what is left of this chunk: its own scale
+          post_exp(std::true_type{});
           __syncthreads();
-          Enext = next_exp();
-          scx = dpf_h3_scale(Enext);
+          next_residual_scale(pass + 1);
+        } else if (chunk + 1 < p.nchunks) {                         // the next chunk's values have landed by now: agree on its scale
+          post_exp(std::false_type{});
+          __syncthreads();
+          next_chunk_scale();
         }
       }
-#endif
       group(TG - 2, std::integral_constant<int, 0>{});
       group(TG - 1, std::integral_constant<int, 1>{});
     } else {
@@ -863,6 +952,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                               // the patch buffer is free
+    if (more) ++pass;
+    else { ++chunk; pass = 0; }
+    if constexpr (SH) Emin = EminNext;
   }
   X9_STAMP(2, __builtin_readcyclecounter())
   if constexpr (NC == 2) rescale_acc(Ex + __builtin_amdgcn_readfirstlane(p.wexp[0]) - 282);      // back to the operands' units (exact)
@@ -1358,6 +1450,7 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   // (f16 components: the scale's exponent sits behind the packed weights -- inside the three-component capacity of the workspace)
   int* wexp = reinterpret_cast<int*>(wp + ((total * NC + 7) & ~7LL));
   q.wexp = wexp;
+  q.guard = dpf_h3_range_guard();
   int nparts = 0;
   if (NC == 2) {
     const int nw = d.wA * d.wB * T;

@@ -20,6 +20,7 @@ int dpf_conv_operand_bf16();
 // operand precision "f32" (dpf_set_f32_matrix_path / DPF_F32_X9): 0 = v_mfma_f32_*, 1 = six bf16 partial products of exact three-way splits,
 // 2 = three f16 partial products of block-scaled two-way splits
 int dpf_conv_f32_x9();
+int dpf_h3_range_guard();              // 1 (always, outside tests): the range guards of the f16-component path are active (dpf_debug_set_range_guard)
 inline int dpf_conv_f32_nc() { return dpf_conv_f32_x9() == 2 ? 2 : 3; }      // components per operand of the split paths
 
 // LDS-DMA double-buffered implicit GEMM (conv_igemm2.hip).  Returns DPF_OK when it launched, DPF_ERR_UNSUPPORTED when the
@@ -84,12 +85,18 @@ __device__ __forceinline__ void dpf_split_pair(float x, float y, unsigned& h, un
 }
 
 // ---- fp32 products on the f16 matrix pipe (dpf_set_f32_matrix_path(2)): x * 2^s = hi + lo + e with hi = f16(x 2^s), lo = f16(x 2^s - hi),
-// both rounded to nearest: |lo| <= 2^-11 |hi|, |e| <= 2^-23 |x 2^s| (one ulp of the fp32 value, zero mean).  THREE partial products per
-// pair -- lo*hi, hi*lo, hi*hi; lo*lo <= 2^-22 |xy| 2^-2 is dropped -- on v_mfma_f32_32x32x16_f16: half the matrix-pipe work of the six bf16
-// products.  f16 has 5 exponent bits, so the operands are scaled by a power of two (exact) that puts the largest magnitude of the staged
-// block -- a channel chunk of a tile's patch, a tile of the weight gradient, a weight tensor -- into [2^14, 2^15); the accumulators carry
-// the running exponent and are rescaled (exactly) when it grows.  Values more than 2^17 below their block's maximum lose low bits
-// gradually (absolute error <= 2^-40 of the block maximum): fp32-equivalent in the norm of each block, not per element.
+// both rounded to nearest: |lo| <= 2^-11 |hi|, |e| <= 2^-22 |x 2^s| (rms 2^-24, zero mean) as long as lo is a normal f16.  THREE partial
+// products per pair -- lo*hi, hi*lo, hi*hi; lo*lo <= 2^-22 |xy| 2^-2 is dropped -- on v_mfma_f32_32x32x16_f16: half the matrix-pipe work of
+// the six bf16 products.  f16 has 5 exponent bits, so the operands are scaled by a power of two (exact) that puts the largest magnitude of
+// the staged block into [2^14, 2^15); the accumulators carry the exponent and are rescaled (exactly) when it changes.  A value more than
+// 2^17 (DPF_H3_RANGE) below the scale's maximum has a subnormal lo and loses low bits (absolute error 2^-40 of that maximum), so every
+// kernel on this path GUARDS the range, each along the axis its output elements do NOT sum over:
+//   * igemm3_x9_kernel (output = sum over channels and taps at a position): per POSITION.  When a position of a chunk has a non-zero
+//     largest channel magnitude more than 2^17 below the scale, the chunk takes RESIDUAL PASSES: the exact remainders e of the split
+//     (fp32: (x 2^s - hi) - lo) are split again at their own scale (~2^-22 of the first) and contracted with the same weights -- every pass
+//     extends the exactly represented range by 2^22 (17 -> 39 -> 61 -> 83 bits below the tile's maximum, DPF_H3_MAXPASS);
+//   * wgrad2_kernel (output = sum over positions for a (g channel, x channel) pair): per CHANNEL.  Every g row and every x channel of the
+//     workgroup carries its own running exponent (rows / columns of the MFMA tile may be scaled independently).
 typedef _Float16 dpf_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned dpf_pk_f16(float x, float y) {       // round to nearest even (the f16 rounding mode of the kernel)
   unsigned r;
@@ -120,4 +127,26 @@ __device__ __forceinline__ int dpf_wave_max_exp(unsigned bits) {
 // scale that maps magnitudes with biased exponent <= E into [.., 2^15): 2^(141 - E); E in [14, 254]
 __device__ __forceinline__ float dpf_h3_scale(int E) { return __builtin_bit_cast(float, (unsigned)(268 - E) << 23); }
 constexpr int DPF_H3_EMIN = 14;
+constexpr int DPF_H3_RANGE = 17;     // exponents below the scale's maximum with a normal low component
+constexpr int DPF_H3_MAXPASS = 3;    // residual passes of a chunk (igemm3_x9_kernel)
+constexpr int DPF_H3_MAXDROP = 66;   // an accumulator exponent never sits more than this below the tile's running maximum (no overflow)
+// the smallest value over the wave's lanes (unsigned compare)
+__device__ __forceinline__ unsigned dpf_wave_min_u32(unsigned bits) {
+  unsigned v = bits;
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
+}
+// exact remainders of the two-component split of (x, y) (already scaled): (x - hi) - lo, in fp32 (both differences are exact)
+__device__ __forceinline__ void dpf_split_residual_h(float& x, float& y) {
+  unsigned h, l;
+  dpf_split_pair_h(x, y, h, l);
+  const dpf_f16x2 hh = __builtin_bit_cast(dpf_f16x2, h), ll = __builtin_bit_cast(dpf_f16x2, l);
+  x = (x - (float)hh.x) - (float)ll.x;
+  y = (y - (float)hh.y) - (float)ll.y;
+}
 #endif

@@ -59,10 +59,14 @@ int dpf_get_conv_operand_precision(void);
 /* How operand precision 0 (fp32) multiplies in the stride-1 forward / data-gradient kernels and in the weight-gradient kernel (process-wide;
  * environment DPF_F32_X9 sets the initial value):
  *   2 (default) = each operand as two f16 components of x * 2^s (hi = f16(x 2^s), lo = f16(x 2^s - hi), round to nearest), three partial
- *       products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation.  2^s is chosen per block -- a channel chunk of a tile's
- *       patch, a tile of the weight gradient, a weight tensor -- so that the block's largest magnitude lands in [2^14, 2^15), and is undone
- *       exactly in the epilogue: <= 2^-23 relative per operand within 2^17 of the block maximum, an absolute floor of 2^-40 of the block
- *       maximum below that (fp32-equivalent in the norm of each tile, not per element);
+ *       products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation.  2^s is a power of two chosen per block and undone
+ *       exactly in the epilogue.  A two-component split is exact to 2^-22 only within 2^17 of the scale's maximum, so every kernel GUARDS
+ *       the range along the axis its output elements do not sum over (csrc/conv_internal.h): the stride-1 convolutions per POSITION (a
+ *       channel chunk with a position whose values all lie more than 2^17 below the scale is contracted again on the exact remainders
+ *       of its split -- residual passes, each one extends the exactly represented range by 2^22, up to 2^83 below the tile's maximum), the
+ *       weight gradient per CHANNEL (every g row and x channel of a workgroup carries its own exponent), the deformable conv's gcol
+ *       products per VOXEL.  With the guards an output element is as accurate, relative to the magnitudes of ITS OWN inputs, as on the
+ *       fp32 instruction (tests/test_gpu_ops.py: test_conv_f16_component_path_in_block_dynamic_range);
  *   1 = the exact round-to-nearest three-way bf16 splits of both operands (x = hi + mid + lo) on the bf16 matrix pipe, the six partial
  *       products that can reach 2^-24 of the product (mid x lo, lo x mid and lo x lo are dropped: <= 2^-23 worst case, rms 2^-26, zero mean);
  *   0 = v_mfma_f32_32x32x2_f32.
@@ -70,6 +74,9 @@ int dpf_get_conv_operand_precision(void);
  * test_conv_f32_matrix_paths_agree, test_conv_f16_component_path_block_scaling). */
 int dpf_set_f32_matrix_path(int path);
 int dpf_get_f32_matrix_path(void);
+/* test aid: 0 switches the range guards of path 2 off (block-scaled splits without residual passes / per-channel exponents), 1 (the default
+ * and the only setting the product uses) on */
+int dpf_debug_set_range_guard(int on);
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
                    int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int dd, int dh, int dw_, void* stream);
 /* same, with caller scratch `ws` of dpf_conv_wgrad_workspace_floats(T, C, K) floats: eligible shapes (16-byte aligned rows, 3x3 /

@@ -592,6 +592,93 @@ def test_conv_f16_component_path_block_scaling(cfg):
         lib().call('dpf_set_f32_matrix_path', prev)
 
 
+RANGE_EXPS = (0, 13, 20, 27, 34)            # binary orders below the block maximum
+
+
+def _spread(t, layout, seed):
+    """t scaled by 2^-e, e from RANGE_EXPS, laid out so that ONE tile / channel chunk of the kernels holds all five magnitudes:
+    'wbands' / 'hbands': bands of 6 columns / 3 rows (an output inside a band sees only that band's magnitude), 'chan': per channel
+    (c % 5: every 8-channel chunk holds all five), 'elem': per element at random."""
+    e = torch.tensor(RANGE_EXPS, dtype=torch.float64)
+    N, C, D, H, W = t.shape
+    if layout == 'wbands':
+        idx = (torch.arange(W) // 6) % 5
+        sc = e[idx].view(1, 1, 1, 1, W)
+    elif layout == 'hbands':
+        idx = (torch.arange(H) // 3) % 5
+        sc = e[idx].view(1, 1, 1, H, 1)
+    elif layout == 'chan':
+        idx = torch.arange(C) % 5
+        sc = e[idx].view(1, C, 1, 1, 1)
+    else:
+        g = torch.Generator().manual_seed(seed)
+        sc = e[torch.randint(0, 5, t.shape, generator=g)]
+    return (t.double() * torch.pow(2.0, -sc)).float()
+
+
+@pytest.mark.parametrize('cfg', [
+    # N, C, K, D, H, W, kernel, dilation, transposed (data gradient)
+    (1, 32, 32, 4, 24, 64, (3, 3, 3), 1, False),     # 4-channel chunks (the hourglass layers)
+    (1, 32, 64, 3, 18, 64, (3, 3, 3), 1, True),
+    (2, 48, 32, 1, 24, 64, (1, 3, 3), 1, False),     # 8-channel chunks (2-D layers)
+    (1, 40, 64, 1, 24, 64, (1, 3, 3), 2, True),      # dilated rows
+])
+@pytest.mark.parametrize('layout', ['wbands', 'hbands', 'chan', 'elem'])
+def test_conv_f16_component_path_in_block_dynamic_range(cfg, layout):
+    """dpf_set_f32_matrix_path(2) against the fp32 matrix instruction (path 0) when ONE tile / channel chunk holds values at 1, 2^-13, 2^-20,
+    2^-27 and 2^-34 of its maximum -- signed and all-positive data, forward (the spread in x) and data gradient (the spread in g).  Every
+    output element is compared with fp64 relative to ITS OWN magnitude: the error is divided by sum |w| |x| over the element's own window
+    (for all-positive data that is the element itself), so an output that only sees 2^-34-sized inputs has to be right to fp32 precision of
+    2^-34-sized numbers.  Bar: the worst element of path 2 within 2 x the worst element of path 0.  Negative control: with the range guard
+    switched off (block scaling without residual passes -- round 5's kernel) the banded layouts miss the bar by orders of magnitude."""
+    from dualpixelface_amd._lib import lib
+    ops = _ops()
+    N, C, K, D, H, W, ks, dil, transposed = cfg
+    pad = tuple(((k - 1) * dil) // 2 if k > 1 else 0 for k in ks)
+    dl = tuple(dil if k > 1 else 1 for k in ks)
+    one = (1, 1, 1)
+    prev = lib().cdll.dpf_get_f32_matrix_path()
+
+    def run(a, w):
+        if transposed:
+            xin = torch.zeros(N, C, D, H, W, device=DEV).requires_grad_()
+            y = ops.ConvFn.apply(xin, w.to(DEV), None, one, pad, dl)
+            return torch.autograd.grad(y, xin, a.to(DEV))[0].double().cpu()
+        return ops.ConvFn.apply(a.to(DEV), w.to(DEV), None, one, pad, dl).double().cpu()
+
+    def ref64(a, w):
+        if transposed:
+            return torch.nn.grad.conv3d_input((N, C, D, H, W), w.double(), a.double(), 1, pad, dl)
+        return F.conv3d(a.double(), w.double(), None, 1, pad, dl)
+
+    try:
+        for positive in (False, True):
+            a = rnd(N, K if transposed else C, D, H, W, seed=310)
+            w = rnd(K, C, *ks, seed=311, scale=0.1)
+            if positive:
+                a, w = a.abs(), w.abs()
+            a = _spread(a, layout, seed=312)
+            ref, den = ref64(a, w), ref64(a.abs(), w.abs())
+            assert den.min().item() > 0
+
+            def worst(path, guard=1):
+                lib().call('dpf_set_f32_matrix_path', path)
+                lib().call('dpf_debug_set_range_guard', guard)
+                try:
+                    return ((run(a, w) - ref).abs() / den).max().item()
+                finally:
+                    lib().call('dpf_debug_set_range_guard', 1)
+
+            e0, e2 = worst(0), worst(2)
+            assert e0 <= 5e-6, (positive, e0)                                 # (432 .. 1728 terms on the fp32 instruction)
+            assert e2 <= 2 * e0 + 1e-7, (layout, positive, e2, e0)
+            if layout in ('wbands', 'hbands'):
+                eoff = worst(2, guard=0)
+                assert eoff > 30 * e0, (layout, positive, eoff, e0)          # the regime the guard exists for is really probed here
+    finally:
+        lib().call('dpf_set_f32_matrix_path', prev)
+
+
 @pytest.mark.parametrize('shape', [(1, 8, 16, 4, 6, 16), (1, 5, 7, 3, 5, 6)])
 def test_deform_conv_integer_offsets_and_the_validity_rule(shape):
     """Integer offsets put samples exactly on voxel centres, on the borders and on coordinate -1: deform_im2col_cuda.cuh:248 declares a
