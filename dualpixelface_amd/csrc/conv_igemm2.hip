@@ -507,12 +507,17 @@ constexpr int X9_NP = 9 - X9_FIRST;
 // staging and layouts with a third of the bytes and one MFMA per (row tile, position row, tap group).
 // NC = 2 (dpf_set_f32_matrix_path(2)): two f16 components of the block-scaled operand (conv_internal.h), three MFMAs (lo*hi, hi*lo, hi*hi) on
 // v_mfma_f32_32x32x16_f16.  The block is one channel chunk of the workgroup's patch: every lane takes the largest exponent of the values it
-// fetched AND the smallest non-zero per-position maximum (a lane holds all CC channels of its positions), the waves exchange both through
-// LDS (one extra barrier per chunk, before the split).  The chunk is scaled by the exponent the accumulators already carry unless its own
-// maximum lies above it or more than 3 bits below it (then the accumulators are rescaled, exactly); a chunk with a position whose values all
-// sit more than 2^17 below the scale takes RESIDUAL PASSES (conv_internal.h): the exact remainders of the split are split again and
-// contracted with the same weights, so every output position sees its inputs to fp32 precision relative to ITS OWN inputs, not to the
-// tile's.  The weights are scaled once per launch by the pack kernel; the epilogue multiplies by 2^-(both scales) exactly (v_ldexp_f32).
+// fetched, the waves exchange theirs through LDS (one extra barrier per chunk, before the split), and the chunk is scaled by the exponent
+// the accumulators already carry unless its own maximum lies above it or more than 3 bits below it (then the accumulators are rescaled,
+// exactly).  RANGE GUARD: a lane holds all CC channels of its positions, so the scan that finds its largest exponent also yields the smallest
+// non-zero per-position maximum; a position whose values all lie more than 2^17 below the scale is DEFERRED -- it contributes exact zeros
+// to this pass and its values stay in registers -- and a chunk with a non-zero deferred position is contracted again (same weights), the
+// deferred positions at their own scale: every position is contracted exactly once, in the pass whose scale lies within 2^17 of it, so
+// every output position sees its inputs to fp32 precision relative to ITS OWN inputs, not to the tile's.  Chunks without such a position
+// (all of them on ordinary data) pay 17 vector instructions per lane for the test; a wave that holds one splits its values a second time, masked.  (Deferred positions must be exact zeros, not small
+// numbers: fed subnormal f16 values next to large operands the matrix core aligns its adder to the exponent FIELDS and drops accumulator
+// bits -- tools/probes/mfma_f16_accum_probe.hip.)  The weights are scaled once per launch by the pack kernel; the epilogue multiplies by
+// 2^-(both scales) exactly (v_ldexp_f32).
 template <int CC, int NC> struct X9 {
   static constexpr int NU = CC == 4 ? 2 : 1;     // patch units (CC channels x 4 positions) per thread and chunk
   static constexpr int PB = 2 * NC * CC;         // bytes per position: [hi | mid | lo][CC] bf16
@@ -565,12 +570,12 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   char* s_patch = reinterpret_cast<char*>(smem);
   char* s_w = s_patch + patchBytes;                                // SH: two weight buffers
   int* s_tab = reinterpret_cast<int*>(s_w + (SH ? 2 : 1) * wBytes);
-  int* s_red = s_tab + 32;                                         // NC = 2: [wave] largest exponent of the chunk in flight, [4 + wave] its smallest non-zero position maximum
+  int* s_red = s_tab + 32;                                         // NC = 2: [wave] largest exponent of the values in flight; [8 + parity] "a non-zero position was deferred"
   int Ex = DPF_H3_EMIN;                                            // NC = 2: the accumulators are in units of 2^(Ex + Ew - 282); Erun: largest chunk exponent of the tile so far
   int Erun = DPF_H3_EMIN;
   float scx = 0.f;                                                 //         multiplier of the values being split (chunk: 2^(141 - Enext); residual pass: 2^(Ex - Enext))
-  float mult[NU][4];                                               //         per position of this lane: scx, or 0 = deferred to a residual pass
-  unsigned inr = 0, dmask = 0;                                     //         bit 4 j + ps: in range in the pass being prepared / contracted in an earlier pass of this chunk
+  unsigned tbC = 0, tbN = 0;                                       //         smallest position maximum (bit pattern, pv's units) the pass being contracted / prepared takes; 0: everything
+  unsigned kminL = 0xffffffffu;                                    //         this lane's smallest non-zero position maximum of the values in flight (bit pattern - 1)
   const long long x_chan = (long long)p.ID * p.IH * p.IW;
   const float* xn = x + (long long)n * p.C * x_chan;
   const int nunits = p.rpc * p.SR;
@@ -619,108 +624,93 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < CC / 2; ++k) {
       if constexpr (NC == 3) split_pair(pv[j][2 * k][ps], pv[j][2 * k + 1][ps], sp[j][ps][k], sp[j][ps][CC / 2 + k], sp[j][ps][CC + k]);
-      else if constexpr (NC == 2) dpf_split_pair_h(pv[j][2 * k][ps] * mult[j][ps], pv[j][2 * k + 1][ps] * mult[j][ps], sp[j][ps][k], sp[j][ps][CC / 2 + k]);
+      else if constexpr (NC == 2) dpf_split_pair_h(pv[j][2 * k][ps] * scx, pv[j][2 * k + 1][ps] * scx, sp[j][ps][k], sp[j][ps][CC / 2 + k]);
       else sp[j][ps][k] = pk_bf16(pv[j][2 * k][ps], pv[j][2 * k + 1][ps]);
     }
   };
-  // NC = 2: largest exponent of the values in flight (this lane's, then the wave's) -> s_red[wave], and the smallest non-zero per-position
-  // maximum over the channels (key = bits - 1: zero positions wrap to the top and drop out; RES: so do positions an earlier pass of this
-  // chunk has contracted -- their remainders are a refinement, not a reason for another pass) -> s_red[4 + wave]
-  auto post_exp = [&](auto res_c) {
-    constexpr bool RES = decltype(res_c)::value;
+  // NC = 2: largest exponent of the values in flight (this lane's, then the wave's) -> s_red[wave]; after a barrier read_exp() is the
+  // workgroup's.  The scan runs through the per-position maxima (a lane holds all CC channels of a position), whose smallest non-zero one
+  // stays in kminL (bit pattern - 1: zero positions wrap to the top and drop out).
+  auto pos_max = [&](int j, int ps) {
+    float mp = __builtin_fabsf(pv[j][0][ps]);
+#pragma unroll
+    for (int ch = 1; ch < CC; ++ch) mp = __builtin_fmaxf(mp, __builtin_fabsf(pv[j][ch][ps]));
+    return mp;
+  };
+  auto post_exp = [&]() {
     float m = 0.f;
-    unsigned kmin = 0xffffffffu;
+    kminL = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < NU; ++j)
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        float mp = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < CC; ++ch) mp = __builtin_fmaxf(mp, __builtin_fabsf(pv[j][ch][ps]));
-        m = __builtin_fmaxf(m, mp);
-        unsigned key = __builtin_bit_cast(unsigned, mp) - 1u;
-        if constexpr (RES) key = (dmask >> (4 * j + ps)) & 1u ? 0xffffffffu : key;
-        kmin = min(kmin, key);
+      for (int ps = 0; ps < 4; ps += 2) {                           // two positions per step: v_max3_f32 / v_min3_u32 take both
+        const float m0 = pos_max(j, ps), m1 = pos_max(j, ps + 1);
+        m = __builtin_fmaxf(__builtin_fmaxf(m, m0), m1);
+        kminL = min(min(kminL, __builtin_bit_cast(unsigned, m0) - 1u), __builtin_bit_cast(unsigned, m1) - 1u);
       }
     const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
-    const unsigned k = dpf_wave_min_u32(kmin);
-    if (lane == 0) { s_red[wave] = e; s_red[4 + wave] = k == 0xffffffffu ? 511 : (int)((k + 1u) >> 23); }
+    if (lane == 0) s_red[wave] = e;
   };
-  // after the barrier: the exchanged exponents -> (largest, smallest non-zero position maximum; 511 when there is none)
-  auto read_exp = [&](int& emax, int& emin) {
-    const int4 r = *reinterpret_cast<const int4*>(s_red), q = *reinterpret_cast<const int4*>(s_red + 4);
+  auto read_exp = [&]() {
+    const int4 r = *reinterpret_cast<const int4*>(s_red);
     int e = max(max(r.x, r.y), max(r.z, r.w));
     e = __builtin_amdgcn_readfirstlane(e);
-    emax = e > 254 ? 254 : (e < DPF_H3_EMIN ? DPF_H3_EMIN : e);    // (Inf / NaN inputs: the result is NaN either way)
-    emin = __builtin_amdgcn_readfirstlane(min(min(q.x, q.y), min(q.z, q.w)));
+    return e > 254 ? 254 : (e < DPF_H3_EMIN ? DPF_H3_EMIN : e);    // (Inf / NaN inputs: the result is NaN either way)
   };
-  // per-position multipliers of the pass being prepared: positions whose largest magnitude (pv's units; thr = biased exponent in those
-  // units) lies below the split's range are DEFERRED -- they contribute exact zeros now (the matrix core loses accumulator bits when it
-  // is fed subnormal f16 values next to large ones: tools/probes/mfma_f16_accum_probe.hip) and their values stay in pv for the next pass
-  auto set_masks = [&](bool wide, int thr) {
-    if (!wide) {
-#pragma unroll
-      for (int j = 0; j < NU; ++j)
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) mult[j][ps] = scx;
-      inr = 0xffu;
-      return;
-    }
-    const unsigned tb = (unsigned)(thr < 1 ? 1 : (thr > 254 ? 254 : thr)) << 23;
-    inr = 0;
-#pragma unroll
-    for (int j = 0; j < NU; ++j)
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        float mp = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < CC; ++ch) mp = __builtin_fmaxf(mp, __builtin_fabsf(pv[j][ch][ps]));
-        const bool in = __builtin_bit_cast(unsigned, mp) >= tb;
-        mult[j][ps] = in ? scx : 0.f;
-        inr |= in ? 1u << (4 * j + ps) : 0u;
-      }
+  auto tb_of = [&](int e) {                                         // bit pattern of 2^(e - 127), e clamped to the normal range
+    return (unsigned)(e < 1 ? 1 : (e > 254 ? 254 : e)) << 23;
   };
-  // a new chunk whose exponents were just exchanged: its scale (Enext), multipliers and whether it needs residual passes.  The
-  // accumulators' exponent is kept while the chunk's maximum lies 0 .. 3 bits below it (no rescale); it never drops more than
-  // DPF_H3_MAXDROP below the tile's running maximum (no overflow).  Emin*: smallest non-zero position maximum not contracted yet, as a
-  // biased exponent of the RAW values.
-  int Enext = Ex, Emin = 511, EminNext = 511;
+  // a new chunk whose exponents were just exchanged: its scale (Enext), multiplier and range.  The accumulators' exponent is kept while
+  // the chunk's maximum lies 0 .. 3 bits below it (no rescale); it never drops more than DPF_H3_MAXDROP below the tile's running maximum
+  // (no overflow).
+  int Enext = Ex;
   auto next_chunk_scale = [&]() {
-    int e;
-    read_exp(e, EminNext);
+    const int e = read_exp();
     Erun = e > Erun ? e : Erun;
     const int lo = Erun - DPF_H3_MAXDROP;
     Enext = (e > Ex || e < Ex - 3) ? (e > lo ? e : lo) : Ex;
     scx = dpf_h3_scale(Enext);
-    set_masks(p.guard && EminNext < Enext - DPF_H3_RANGE, Enext - DPF_H3_RANGE);
+    tbN = p.guard ? tb_of(Enext - DPF_H3_RANGE) : 0u;
   };
-  // a residual pass of the chunk just split: pv holds, in units of the current scale (2^(141 - Ex)), the exact remainders of the positions
-  // contracted so far and the full values of the deferred ones; their own scale on top of it.  The last pass takes whatever is left.
+  // another pass over the chunk just split: pv holds the deferred positions' values in units of the current scale (2^(141 - Ex)), zeros
+  // elsewhere; their own scale on top of it.  The last pass takes whatever is left.
   auto next_residual_scale = [&](int pass_next) {
-    int e, k;
-    read_exp(e, k);
+    const int e = read_exp();
     const int lo = Erun - DPF_H3_MAXDROP;
     const int en = Ex + e - 141;
     Enext = en > lo ? en : lo;
     if (Enext > Ex) Enext = Ex;
-    EminNext = k + Ex - 141;
     scx = __builtin_bit_cast(float, (unsigned)(127 + Ex - Enext) << 23);
-    set_masks(pass_next < DPF_H3_MAXPASS && EminNext < Enext - DPF_H3_RANGE, Enext - DPF_H3_RANGE + 141 - Ex);
+    tbN = pass_next < DPF_H3_MAXPASS ? tb_of(Enext - DPF_H3_RANGE + 141 - Ex) : 0u;
   };
-  auto residual_update = [&]() {      // pv <- (current scale's units) remainders of the split store_split() just published; deferred positions: the value
+  // does this lane hold a non-zero position below the range of the pass being prepared?  Posted to LDS for the workgroup ("another pass
+  // follows": two alternating slots -- written while the pass is prepared, read after the barrier that publishes it, cleared at the top of
+  // the following iteration); the wave-wide answer decides how the wave splits
+  auto lane_defers = [&](int par) {
+    const bool fl = tbN != 0u && kminL < tbN - 1u;
+    if (fl) s_red[8 + par] = 1;
+    return __builtin_amdgcn_ballot_w64(fl) != 0ull;
+  };
+  // the split of a wave with deferred positions (rare; overwrites the plain split): a deferred position contributes exact zeros
+  auto split_masked = [&]() {
 #pragma unroll
     for (int j = 0; j < NU; ++j)
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps)
+      for (int ps = 0; ps < 4; ++ps) {
+        const float ml = __builtin_bit_cast(unsigned, pos_max(j, ps)) >= tbN ? scx : 0.f;
 #pragma unroll
-        for (int k = 0; k < CC / 2; ++k) {
-          const float a = pv[j][2 * k][ps] * scx, b = pv[j][2 * k + 1][ps] * scx;
-          float ra = a, rb = b;
-          dpf_split_residual_h(ra, rb);
-          pv[j][2 * k][ps] = mult[j][ps] != 0.f ? ra : a;
-          pv[j][2 * k + 1][ps] = mult[j][ps] != 0.f ? rb : b;
-        }
-    dmask |= inr;
+        for (int k = 0; k < CC / 2; ++k) dpf_split_pair_h(pv[j][2 * k][ps] * ml, pv[j][2 * k + 1][ps] * ml, sp[j][ps][k], sp[j][ps][CC / 2 + k]);
+      }
+  };
+  auto residual_update = [&]() {      // pv <- the positions the pass just published deferred, in units of its scale; zeros elsewhere
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const float ml = __builtin_bit_cast(unsigned, pos_max(j, ps)) >= tbC ? 0.f : scx;
+#pragma unroll
+        for (int ch = 0; ch < CC; ++ch) pv[j][ch][ps] *= ml;
+      }
   };
   auto store_split = [&]() {
 #pragma unroll
@@ -762,49 +752,69 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
   // SH (split in the shadow): the split of chunk i+1 is computed behind the last two tap groups' MFMAs of chunk i, its weights arrive in
   // the other weight buffer meanwhile, and only the LDS stores stand between two chunks.  !SH: one weight buffer; weights, split and
   // stores form a phase of their own, hidden by the co-resident workgroup's MFMAs.
+  if constexpr (NC == 2) {
+    if (tid < 2) s_red[8 + tid] = 0;
+  }
   if constexpr (SH) issue_w(0, 0);
   prefetch(0);
+  int par = 0;                                                     // parity of the pass being prepared (its slot of the deferral flag)
   if constexpr (SH) {
+    bool wdef = false;
     if constexpr (NC == 2) {
-      post_exp(std::false_type{});
+      post_exp();
       __syncthreads();
       next_chunk_scale();
-      Ex = Enext; Emin = EminNext;
+      Ex = Enext;
+      wdef = lane_defers(par);
     }
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
+    if constexpr (NC == 2) {
+      if (wdef) split_masked();
+    }
   }
 
-  // one iteration = one pass over a chunk; NC = 2: a chunk whose range exceeds the split's takes residual passes (pass > 0) before the next
-  // chunk is fetched -- its values stay in pv and are replaced by what the pass that just ran left of them
+  // one iteration = one pass over a chunk; NC = 2: a chunk with deferred positions takes further passes (pass > 0) before the next chunk
+  // is fetched -- the deferred values stay in pv
   int pass = 0;
   for (int chunk = 0; chunk < p.nchunks;) {
     if constexpr (!SH) {
+      bool wdef = false;
       if (pass == 0) issue_w(chunk, 0);
       if constexpr (NC == 2) {
-        if (pass == 0) post_exp(std::false_type{}); else post_exp(std::true_type{});
+        post_exp();
         __syncthreads();
         if (pass == 0) next_chunk_scale(); else next_residual_scale(pass);
-        Emin = EminNext;
+        wdef = lane_defers(par);
       }
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
+      if constexpr (NC == 2) {
+        if (wdef) split_masked();
+      }
     }
+    bool more = false;                                             // (workgroup-uniform) another pass over this chunk follows
+    int dflag = 0;
     if constexpr (NC == 2) {
+      if constexpr (SH) dflag = s_red[8 + par];                     // (posted before the barrier that ended the previous iteration)
+      if (tid == 0) s_red[8 + (par ^ 1)] = 0;
       if (Enext != Ex) { rescale_acc(Ex - Enext); Ex = Enext; }    // the pass about to be contracted changes the accumulators' exponent
+      tbC = tbN;
     }
     store_split();
     __syncthreads();                                               // vmcnt(0): this chunk's weights landed; barrier: patch written
     if (chunk == 0) { X9_STAMP(1, __builtin_readcyclecounter()) }
     const char* s_wc = s_w + (SH ? (chunk & 1) * wBytes : 0);
-    bool more = false;                                             // (workgroup-uniform) another pass over this chunk follows
-    if constexpr (NC == 2) more = p.guard && pass < DPF_H3_MAXPASS && Emin < Ex - DPF_H3_RANGE;
+    if constexpr (NC == 2) {
+      if constexpr (!SH) dflag = s_red[8 + par];
+      more = pass < DPF_H3_MAXPASS && __builtin_amdgcn_readfirstlane(dflag) != 0;
+      par ^= 1;
+    }
     if (more) {
       residual_update();
     } else if (chunk + 1 < p.nchunks) {
       if constexpr (SH) issue_w(chunk + 1, (chunk + 1) & 1);
       prefetch(chunk + 1);
-      dmask = 0;
     }
 
     u32x4 aC[NC][MT], aN[NC][MT], bP[2][2][NC];                       // bP[set][row of the pair][component]
@@ -934,19 +944,20 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     load_b(1, oC0, oC1, bP[0][1]);
     if constexpr (SH) {
       for (int g = 0; g + 2 < TG; ++g) group(g, std::integral_constant<int, -1>{});
+      bool wdef = false;
       if constexpr (NC == 2) {
-        if (more) {                                                 // what is left of this chunk: its own scale
-          post_exp(std::true_type{});
+        if (more || chunk + 1 < p.nchunks) {                       // the next pass's values (what is left of this chunk / the next chunk, landed by now): agree on their scale
+          post_exp();
           __syncthreads();
-          next_residual_scale(pass + 1);
-        } else if (chunk + 1 < p.nchunks) {                         // the next chunk's values have landed by now: agree on its scale
-          post_exp(std::false_type{});
-          __syncthreads();
-          next_chunk_scale();
+          if (more) next_residual_scale(pass + 1); else next_chunk_scale();
+          wdef = lane_defers(par);
         }
       }
       group(TG - 2, std::integral_constant<int, 0>{});
       group(TG - 1, std::integral_constant<int, 1>{});
+      if constexpr (NC == 2) {
+        if (wdef) split_masked();                                   // (wave-uniform, rare) this wave holds deferred positions: split again, masked
+      }
     } else {
       for (int g = 0; g < TG; ++g) group(g, std::integral_constant<int, -1>{});
     }
@@ -954,7 +965,6 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     __syncthreads();                                               // the patch buffer is free
     if (more) ++pass;
     else { ++chunk; pass = 0; }
-    if constexpr (SH) Emin = EminNext;
   }
   X9_STAMP(2, __builtin_readcyclecounter())
   if constexpr (NC == 2) rescale_acc(Ex + __builtin_amdgcn_readfirstlane(p.wexp[0]) - 282);      // back to the operands' units (exact)

@@ -32,11 +32,18 @@ SHAPES = {
 }
 args = sys.argv[1:]
 check = '--check' in args
+# --noguard: the f16-component path without its range guards (round 5's kernels); --relu: half of the inputs exactly zero (what a
+# post-ReLU tensor looks like: the guard's position test then meets positions with a single small non-zero channel)
+if '--noguard' in args:
+    from dualpixelface_amd._lib import lib
+    lib().call('dpf_debug_set_range_guard', 0)
+relu = '--relu' in args
 names = [a for a in args if not a.startswith('--')] or list(SHAPES)
 for nm in names:
     N, C, D, H, W, K, ks, st, pd, dl = SHAPES[nm]
     torch.manual_seed(0)
-    x = torch.randn(N, C, D, H, W, device=dev).requires_grad_()
+    x = torch.randn(N, C, D, H, W, device=dev)
+    x = (x.relu() if relu else x).requires_grad_()
     w = (torch.randn(K, C, *ks, device=dev) * 0.1).requires_grad_()
     y = ops.ConvFn.apply(x, w, None, st, pd, dl)
     go = torch.randn_like(y)
