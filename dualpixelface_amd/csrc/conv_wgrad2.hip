@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
   // ---- x-patch DMA descriptors: flat segment f -> (cc, plane, row, seg); tile independent
   const long long x_chan = (long long)p.ID * p.IH * p.IW;
   const long long g_chan = (long long)p.QD * p.QH * p.QW;
-  int xoff[NLX], xmeta[NLX];      // source offset relative to the tile origin; (plane << 16) | (row << 8) | seg, or -1 (no DMA)
+  int xoff[NLX], xmeta[NLX];      // source offset relative to the tile origin; (channel << 24) | (plane << 16) | (row << 8) | seg, or -1 (no DMA)
 #pragma unroll
   for (int j = 0; j < NLX; ++j) {
     const unsigned f = tid + 256 * j;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
     const unsigned rr = (r2 * p.mSR) >> 20;
     const unsigned seg = r2 - rr * p.SR;
     const bool ok = (int)f < p.nxseg && (int)cc < ncc && (int)pl < p.ext_d && (int)rr < p.ext_h;
-    xmeta[j] = ok ? (int)((pl << 16) | (rr << 8) | seg) : -1;
+    xmeta[j] = ok ? (int)((cc << 24) | (pl << 16) | (rr << 8) | seg) : -1;     // (cc < 32: at most 7 x 32 / 9 channels per workgroup)
     xoff[j] = (int)((long long)cc * x_chan + ((long long)pl * p.IH + rr * p.rstep) * p.IW + 4 * seg);
   }
   // ---- g-tile DMA descriptors: physical slot P = k*SPR + sp (P = tid + 256 j) holds the logical slot sp ^ (k & 15) of row k;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
         const int m = xmeta[j];
         if (m >= 0) {
           // branch-free bounds test (unsigned compares, bitwise and): the short-circuit form compiles to nested exec-mask regions
-          const unsigned id = (unsigned)(i0d + (m >> 16)), ih = (unsigned)(i0h + ((m >> 8) & 0xff) * p.rstep), iw = (unsigned)(a0 + 4 * (m & 0xff));
+          const unsigned id = (unsigned)(i0d + ((m >> 16) & 0xff)), ih = (unsigned)(i0h + ((m >> 8) & 0xff) * p.rstep), iw = (unsigned)(a0 + 4 * (m & 0xff));
           const bool ok = (id < (unsigned)p.ID) & (ih < (unsigned)p.IH) & (iw < (unsigned)p.IW);
           const long long so = ok ? (long long)xoff[j] : xzero;
           glds16(xt + so, dbase + (j * 256 + wave * 64) * 4);
@@ -229,26 +229,57 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
-  // ---- X9 = 2: exponent scan and in-place conversion of the segments this lane fetched (same slots as issue())
-  int* s_red = reinterpret_cast<int*>(smem + 2 * bufFloats);       // [wave][x exponent, g exponent]
-  int Exr = DPF_H3_EMIN, Egr = DPF_H3_EMIN;                        // running exponents: the accumulators are in units of 2^(Exr + Egr - 282)
+  // ---- X9 = 2: exponent scan and in-place conversion of the segments this lane fetched (same slots as issue()).
+  // RANGE GUARD (conv_internal.h): an output element dW[k][c][t] sums over POSITIONS, so rows (g channels) and columns (x channels) of the
+  // MFMA tile may be scaled independently -- every g row and every x channel of the workgroup carries its own running exponent
+  // (s_ge[32], s_xe[32] in LDS; a lane keeps the exponents of the segments it fetches, of its columns and of its accumulator rows as
+  // packed bytes).  The scan compares a segment's exponent with the cached one of its channel; only a lane that finds a larger one
+  // touches LDS (ds_max + a flag), and only then -- the first tiles of a workgroup, then hardly ever -- the workgroup refreshes its
+  // caches and rescales the accumulators (exactly) by row and column.  A weight-gradient element is then exact to fp32 relative to the
+  // magnitudes of ITS OWN g channel and x channel, whatever the other channels of the tile hold.
+  int* s_xe = reinterpret_cast<int*>(smem + 2 * bufFloats);        // running exponent of x channel cc (of this workgroup's CCW channels)
+  int* s_ge = s_xe + 32;                                            // ... of g row k
+  int* s_xa = s_ge + 32;                                            // the exponents the accumulators carry: columns of x channel cc ...
+  int* s_ga = s_xa + 32;                                            // ... rows of g channel k (= s_xe / s_ge as of the last refresh)
+  int* s_flag = s_ga + 32;                                          // [buffer]: the scan of the tile in that buffer raised an exponent
+  constexpr int KSTEP_ = 256 / SPR, NG_ = 32 / KSTEP_;
+  unsigned xe_p[(NLX + 3) / 4], ge_p = 0x0e0e0e0eu;                 // cached exponents (bytes) of the channels of this lane's x segments / g slots
+  float scg = 1.f;                                                  // scale of this lane's g row (the A fragment's row is lane & 31)
+#pragma unroll
+  for (int i = 0; i < (NLX + 3) / 4; ++i) xe_p[i] = 0x0e0e0e0eu;
+  static_assert(DPF_H3_EMIN == 0x0e, "packed exponent caches start at DPF_H3_EMIN");
+  auto byte_of = [](unsigned w, int i) { return (int)((w >> (8 * i)) & 0xffu); };
+  auto set_byte = [](unsigned& w, int i, int v) { w = (w & ~(0xffu << (8 * i))) | ((unsigned)v << (8 * i)); };
+  auto seg_exp = [](const f32x4& v) {                                // biased exponent of the segment's largest magnitude (Inf / NaN: 255 -- the result is NaN either way)
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    return (int)(__builtin_bit_cast(unsigned, m) >> 23);
+  };
   auto own_scan = [&](int b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's DMAs have landed; the other waves' are not read here
     const float* dbase = smem + b * bufFloats;
-    float mx = 0.f, mg = 0.f;
+    int over = 0, ex[NLX], eg[NG_];                                // over: by how much a segment's exponent exceeds its channel's cached one (ONE test per scan)
 #pragma unroll
-    for (int j = 0; j < NLX; ++j)
+    for (int j = 0; j < NLX; ++j) {
+      ex[j] = 0;
       if (j * 256 < p.nxseg && xmeta[j] >= 0) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(dbase + (j * 256 + tid) * 4);
-        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+        ex[j] = seg_exp(*reinterpret_cast<const f32x4*>(dbase + (j * 256 + tid) * 4));
+        over = max(over, ex[j] - byte_of(xe_p[j >> 2], j & 3));
       }
-#pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(dbase + xFloats + (j * 256 + tid) * 4);
-      mg = __builtin_fmaxf(mg, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
     }
-    const int ex = dpf_wave_max_exp(__builtin_bit_cast(unsigned, mx)), eg = dpf_wave_max_exp(__builtin_bit_cast(unsigned, mg));
-    if (lane == 0) { s_red[2 * wave] = ex; s_red[2 * wave + 1] = eg; }
+#pragma unroll
+    for (int j = 0; j < NG_; ++j) {
+      eg[j] = seg_exp(*reinterpret_cast<const f32x4*>(dbase + xFloats + (j * 256 + tid) * 4));
+      over = max(over, eg[j] - byte_of(ge_p, j));
+    }
+    if (over > 0) {                                                 // (the first tiles of a workgroup, then hardly ever)
+#pragma unroll
+      for (int j = 0; j < NLX; ++j)
+        if (j * 256 < p.nxseg && xmeta[j] >= 0 && ex[j] > byte_of(xe_p[j >> 2], j & 3)) atomicMax(&s_xe[xmeta[j] >> 24], ex[j]);
+#pragma unroll
+      for (int j = 0; j < NG_; ++j)
+        if (eg[j] > byte_of(ge_p, j)) atomicMax(&s_ge[tid / SPR + j * KSTEP_], eg[j]);
+      s_flag[b] = 1;
+    }
   };
   auto pack_seg = [&](const f32x4& v, float sc) {
     unsigned h0, l0, h1, l1;
@@ -261,15 +292,41 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
   };
   // (only the x patch is rewritten: an x value is read by up to 27 taps, a g value by ONE wave's two super-groups -- its split stays in
   // the unit loop, in the MFMAs' shadow, and a third of the conversion phase's traffic disappears)
-  auto own_convert = [&](int b, float scx) {
+  auto own_convert = [&](int b) {
     float* dbase = smem + b * bufFloats;
 #pragma unroll
     for (int j = 0; j < NLX; ++j)
       if (j * 256 < p.nxseg && xmeta[j] >= 0) {
         f32x4* q = reinterpret_cast<f32x4*>(dbase + (j * 256 + tid) * 4);
-        const u32x4 r = pack_seg(*q, scx);
+        const u32x4 r = pack_seg(*q, dpf_h3_scale(byte_of(xe_p[j >> 2], j & 3)));
         *reinterpret_cast<u32x4*>(q) = r;
       }
+  };
+  // an exponent was raised: refresh the caches, rescale the accumulators by row and column (exact)
+  auto refresh_exponents = [&]() {
+#pragma unroll
+    for (int j = 0; j < NLX; ++j)
+      if (j * 256 < p.nxseg && xmeta[j] >= 0) set_byte(xe_p[j >> 2], j & 3, s_xe[xmeta[j] >> 24]);
+#pragma unroll
+    for (int j = 0; j < NG_; ++j) set_byte(ge_p, j, s_ge[tid / SPR + j * KSTEP_]);
+    scg = dpf_h3_scale(s_ge[l31]);
+    int dcol[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+      const int coln = t * 32 + l31, cc = (coln < ncol ? coln : 0) / p.T;
+      dcol[t] = s_xa[cc] - s_xe[cc];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 oa = *reinterpret_cast<const int4*>(s_ga + 8 * q + 4 * hh), nr = *reinterpret_cast<const int4*>(s_ge + 8 * q + 4 * hh);
+      const int drow[4] = {oa.x - nr.x, oa.y - nr.y, oa.z - nr.z, oa.w - nr.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) acc[t][4 * q + r] = __builtin_ldexpf(acc[t][4 * q + r], dcol[t] + drow[r]);
+    }
+    __syncthreads();                                                // (workgroup-uniform branch) everyone has read the old exponents
+    if (tid < 64) s_xa[tid] = s_xe[tid];                            // s_xa | s_ga <- s_xe | s_ge (adjacent pairs)
   };
 
   const int sw = SW1 ? 1 : p.sw;
@@ -278,6 +335,11 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
   const long long tbeg = (long long)pchunk * p.per;
   long long tend = tbeg + p.per;
   if (tend > p.ntiles) tend = p.ntiles;
+  if constexpr (X9 == 2) {
+    if (tid < 128) s_xe[tid] = DPF_H3_EMIN;                        // (s_xe, s_ge, s_xa, s_ga are adjacent)
+    if (tid < 2) s_flag[tid] = 0;
+    __syncthreads();
+  }
   if (tbeg < tend) {
     issue(0);
     if constexpr (X9 == 2) own_scan(0);
@@ -285,27 +347,13 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
   __syncthreads();
   int buf = 0;
   for (long long tile = tbeg; tile < tend; ++tile, buf ^= 1) {
-    float scg = 1.f;                                  // X9 = 2: scale of this tile's g values (split in the unit loop)
     if constexpr (X9 == 2) {
-      // the tile in `buf` is raw fp32 and its exponents are posted: agree on the scales, fetch the next tile, convert this one in place
-      int ex = DPF_H3_EMIN, eg = DPF_H3_EMIN;
-#pragma unroll
-      for (int w = 0; w < WTH; ++w) { ex = max(ex, s_red[2 * w]); eg = max(eg, s_red[2 * w + 1]); }
-      ex = __builtin_amdgcn_readfirstlane(ex); eg = __builtin_amdgcn_readfirstlane(eg);
-      ex = ex > 254 ? 254 : ex; eg = eg > 254 ? 254 : eg;
-      ex = ex > Exr ? ex : Exr; eg = eg > Egr ? eg : Egr;
-      if (ex + eg != Exr + Egr) {
-        const int de = (Exr + Egr) - (ex + eg);
-#pragma unroll
-        for (int t = 0; t < NCT; ++t)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) acc[t][j] = __builtin_ldexpf(acc[t][j], de);
-      }
-      Exr = ex; Egr = eg;
+      // the tile in `buf` is raw fp32 and its scan is posted: refresh the exponents if it raised one, fetch the next tile, convert this one in place
+      if (__builtin_amdgcn_readfirstlane(s_flag[buf])) refresh_exponents();
       if (tile + 1 < tend) issue(buf ^ 1);
-      own_convert(buf, dpf_h3_scale(Exr));
-      scg = dpf_h3_scale(Egr);
+      own_convert(buf);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // conversions visible; the DMAs just issued stay in flight
+      if (tid == 0) s_flag[buf] = 0;                                        // (read above by everyone; written again two tiles from now)
     } else {
       if (tile + 1 < tend) issue(buf ^ 1);
     }
@@ -511,11 +559,15 @@ __global__ __launch_bounds__(256, (X9 ? (NCT <= 2 ? 3 : 2) : w2_occ<NCT>())) voi
     __syncthreads();     // vmcnt(0): next tile landed; barrier: this buffer is free
   }
 
-  if constexpr (X9 == 2) {                             // back to the operands' units (exact)
+  if constexpr (X9 == 2) {                             // back to the operands' units (exact): row and column exponents
 #pragma unroll
     for (int t = 0; t < NCT; ++t)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[t][j] = __builtin_ldexpf(acc[t][j], Exr + Egr - 282);
+      for (int j = 0; j < 16; ++j) {
+        const int coln = t * 32 + l31;
+        acc[t][j] = __builtin_ldexpf(acc[t][j], s_xa[(coln < ncol ? coln : 0) / p.T] + s_ga[(j & 3) + 8 * (j >> 2) + 4 * hh] - 282);
+      }
+    __syncthreads();                                   // (the reduction below reuses this LDS)
   }
   // ---- sum the four waves' partial tiles through LDS (two rounds: 2,3 -> 0,1 then 1 -> 0); image [tile][reg][lane], conflict free
   float* red = smem;
@@ -690,7 +742,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
       }
     const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
     const size_t red = (size_t)2 * NCT * 16 * 64 * sizeof(float);
-    const size_t lds = (2 * buf > red ? 2 * buf : red) + 64;    // + the exponent exchange of the f16-component path
+    const size_t lds = (2 * buf > red ? 2 * buf : red) + 576;   // + the exponent tables of the f16-component path
     if (CCW * p.CS / 4 > NLX * 256 || lds > (size_t)lds_max) { NCT = 0; continue; }
     break;
   }
@@ -708,7 +760,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
   p.groups = p.cchunks * p.kslices;
   const size_t buf0 = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
   const size_t red0 = (size_t)2 * NCT * 16 * 64 * sizeof(float);
-  const size_t lds0 = (2 * buf0 > red0 ? 2 * buf0 : red0) + 64;
+  const size_t lds0 = (2 * buf0 > red0 ? 2 * buf0 : red0) + 576;
   int occ = w2_occ_of(NCT);
   if ((size_t)occ * lds0 > 160 * 1024) occ = (int)((160 * 1024) / lds0);
   if (occ < 1) occ = 1;
@@ -733,7 +785,7 @@ int dpf_wgrad2(const float* g, const float* x, float* dw, float* ws, long long w
 
   const size_t buf = (size_t)(CCW * p.CS + GFLOATS) * sizeof(float);
   const size_t red = (size_t)2 * NCT * 16 * 64 * sizeof(float);
-  const size_t lds = (2 * buf > red ? 2 * buf : red) + 64;
+  const size_t lds = (2 * buf > red ? 2 * buf : red) + 576;
   const unsigned blocks = (unsigned)(8 * ((p.nchunk + 7) / 8) * p.groups);
   int rc;
   switch (NCT) {

@@ -679,6 +679,48 @@ def test_conv_f16_component_path_in_block_dynamic_range(cfg, layout):
         lib().call('dpf_set_f32_matrix_path', prev)
 
 
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 4, 16, 64, (3, 3, 3), 1), (2, 24, 40, 1, 24, 96, (1, 3, 3), 3)])
+@pytest.mark.parametrize('layout', ['chan', 'wbands', 'elem'])
+@pytest.mark.parametrize('which', ['x', 'g', 'both'])
+def test_weight_gradient_f16_component_path_in_block_dynamic_range(cfg, layout, which):
+    """The weight gradient on dpf_set_f32_matrix_path(2) when one tile holds values at 1 .. 2^-34 of its maximum, in x, in g or in both
+    (VERDICT r5 item 1a).  dW[k][c][t] sums over positions, so the spread that matters is the one ACROSS channels ('chan': channel c holds
+    magnitude 2^-RANGE_EXPS[c % 5]): every g row and x channel carries its own exponent (conv_wgrad2.hip), and each dW element is compared
+    with fp64 relative to sum |g| |x| over its own positions -- for all-positive data the element itself.  Bar: the worst element within
+    2 x the worst element of the fp32 matrix instruction (path 0).  (Round 5's kernel -- one exponent per tile and operand -- misses the
+    bar on the 'chan' layout by four orders of magnitude: profiles/r06_range_guard_before_after.txt.)"""
+    from dualpixelface_amd._lib import lib
+    ops = _ops()
+    N, C, K, D, H, W, ks, dil = cfg
+    pad = tuple(((k - 1) * dil) // 2 if k > 1 else 0 for k in ks)
+    dl = tuple(dil if k > 1 else 1 for k in ks)
+    st = (1, 1, 1)
+    prev = lib().cdll.dpf_get_f32_matrix_path()
+    try:
+        for positive in (False, True):
+            x, g = rnd(N, C, D, H, W, seed=320), rnd(N, K, D, H, W, seed=321)
+            if positive:
+                x, g = x.abs(), g.abs()
+            if which in ('x', 'both'):
+                x = _spread(x, layout, seed=322)
+            if which in ('g', 'both'):
+                g = _spread(g, layout, seed=323)
+            ref = torch.nn.grad.conv3d_weight(x.double(), (K, C) + ks, g.double(), st, pad, dl)
+            den = torch.nn.grad.conv3d_weight(x.abs().double(), (K, C) + ks, g.abs().double(), st, pad, dl)
+            assert den.min().item() > 0
+
+            def worst(path):
+                lib().call('dpf_set_f32_matrix_path', path)
+                got = ops._conv_wgrad_raw(g.to(DEV), x.to(DEV), (K, C) + ks, st, pad, dl).double().cpu()
+                return ((got - ref).abs() / den).max().item()
+
+            e0, e2 = worst(0), worst(2)
+            assert e0 <= 2e-5, (positive, e0)                                  # (tens of thousands of positions per element)
+            assert e2 <= 2 * e0 + 1e-7, (layout, which, positive, e2, e0)
+    finally:
+        lib().call('dpf_set_f32_matrix_path', prev)
+
+
 @pytest.mark.parametrize('shape', [(1, 8, 16, 4, 6, 16), (1, 5, 7, 3, 5, 6)])
 def test_deform_conv_integer_offsets_and_the_validity_rule(shape):
     """Integer offsets put samples exactly on voxel centres, on the borders and on coordinate -1: deform_im2col_cuda.cuh:248 declares a
