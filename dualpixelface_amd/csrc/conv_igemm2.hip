@@ -796,7 +796,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     bool more = false;                                             // (workgroup-uniform) another pass over this chunk follows
     int dflag = 0;
     if constexpr (NC == 2) {
-      if constexpr (SH) dflag = s_red[8 + par];                     // (posted before the barrier that ended the previous iteration)
+      if constexpr (SH) {
+        if (chunk > 0 || pass > 0) dflag = s_red[8 + par];          // (posted before the barrier that ended the previous iteration; the first pass of a tile: below)
+      }
       if (tid == 0) s_red[8 + (par ^ 1)] = 0;
       if (Enext != Ex) { rescale_acc(Ex - Enext); Ex = Enext; }    // the pass about to be contracted changes the accumulators' exponent
       tbC = tbN;
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     if (chunk == 0) { X9_STAMP(1, __builtin_readcyclecounter()) }
     const char* s_wc = s_w + (SH ? (chunk & 1) * wBytes : 0);
     if constexpr (NC == 2) {
-      if constexpr (!SH) dflag = s_red[8 + par];
+      if (!SH || (chunk == 0 && pass == 0)) dflag = s_red[8 + par]; // (posted before the barrier just passed)
       more = pass < DPF_H3_MAXPASS && __builtin_amdgcn_readfirstlane(dflag) != 0;
       par ^= 1;
     }

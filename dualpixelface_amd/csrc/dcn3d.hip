@@ -472,7 +472,8 @@ constexpr float PK_MASS0 = 128.f, PK_MASS_Q = 131072.f;   // first-pass mass bou
 // F16 = true (default unless dpf_set_f32_matrix_path(0) / DPF_DCN_GCOL16=0): the gcol chain runs on v_mfma_f32_16x16x32_f16 from two f16
 // components per operand (conv_internal.h) -- 6 MFMAs per (16 voxels, 16 channels, 64 k) instead of 16 fp32 ones; the fragments keep the
 // size of the fp32 ones (the bf16 three-way variant of round 5 spilled: 24 + 24 registers); wt2 then holds dcn_repack_pk_h_kernel's
-// fragments and its exponent comes through wexp
+// fragments and its exponent comes through wexp.  RANGE GUARD (conv_internal.h): gcol[voxel][channel] sums over the output channels of
+// ONE voxel, so every voxel (an MFMA row) is scaled by its own largest |go| -- exact to fp32 relative to that voxel's output gradient
 typedef _Float16 dcn_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned dcn_u32x4 __attribute__((ext_vector_type(4)));
 #define DPF_STAMP_WAVE wave
@@ -498,7 +499,6 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   int* s_farm = s_far + 4;                                       // [2][FR][npos] per-voxel flag (one row per table thread of a voxel)
   float* s_gmax = (float*)(s_farm + 2 * FR * npos);              // [NW]
   unsigned* s_mmax = (unsigned*)(s_gmax + NW);                   // [NW]
-  int* s_gexp = (int*)(s_mmax + NW);                             // [NW]  F16: the waves' largest go exponents
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int pr = l15 >> 1;           // channel pair within the 16-channel chunk
   const int jb = (l15 & 1) * 4;      // this lane's corners: 0-3 (even lane) or 4-7 (odd lane)
@@ -549,38 +549,25 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
   }
 
   float gbound = 0.f;   // max over this workgroup's voxels of sum_k |go[k][voxel]|
-  dcn_u32x4 aq[F16 ? NST : 1][2][2];                             // F16: [sub-tile][k half][hi | lo] of go * 2^(141 - Eg)
-  int Egw = DPF_H3_EMIN;                                         // F16: Eg + Ew (the gcol accumulators are in units of 2^(Egw - 282))
+  dcn_u32x4 aq[F16 ? NST : 1][2][2];                             // F16: [sub-tile][k half][hi | lo] of go * 2^(141 - exponent of the voxel)
+  unsigned egp[F16 ? NST : 1];                                   // F16: byte r = exponent of voxel 4 lg + r (accumulator row r of this lane)
+  int Ew = DPF_H3_EMIN;
   {
-    float m = 0.f, ma = 0.f;
+    float m = 0.f;
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
-      float sa = 0.f;
+      float sa = 0.f, ma = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) { sa += fabsf(afrag[st][ks]); ma = fmaxf(ma, fabsf(afrag[st][ks])); }
       sa += __shfl_xor(sa, 16, 64);
       sa += __shfl_xor(sa, 32, 64);
       m = fmaxf(m, sa);
-    }
-    m = dpf_wave_max(m);
-    if (lane == 0) s_gmax[wave] = m;
-    if constexpr (F16) {
-      const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, ma));
-      if (lane == 0) s_gexp[wave] = e;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < NW; ++w) gbound = fmaxf(gbound, s_gmax[w]);
-    if constexpr (F16) {
-      int Eg = DPF_H3_EMIN;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) Eg = max(Eg, s_gexp[w]);
-      Eg = __builtin_amdgcn_readfirstlane(Eg);
-      Eg = Eg > 254 ? 254 : Eg;
-      Egw = Eg + __builtin_amdgcn_readfirstlane(wexp[0]);
-      const float scg = dpf_h3_scale(Eg);
-#pragma unroll
-      for (int st = 0; st < NST; ++st)
+      if constexpr (F16) {                                        // this lane's voxel (l15): all its output channels sit in lanes l15 + 16 lg'
+        ma = fmaxf(ma, __shfl_xor(ma, 16, 64));
+        ma = fmaxf(ma, __shfl_xor(ma, 32, 64));
+        int e = (int)(__builtin_bit_cast(unsigned, ma) >> 23);
+        e = e < DPF_H3_EMIN ? DPF_H3_EMIN : (e > 254 ? 254 : e);
+        const float scg = dpf_h3_scale(e);
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
@@ -589,7 +576,18 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
             dpf_split_pair_h(afrag[st][8 * mf + 2 * i] * scg, afrag[st][8 * mf + 2 * i + 1] * scg, h, l);
             aq[st][mf][0][i] = h; aq[st][mf][1][i] = l;
           }
+        unsigned pk = 0;                                          // the exponents of this lane's accumulator rows (voxels 4 lg + r): lanes 4 lg + r hold them
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk |= (unsigned)__shfl(e, 4 * lg + r, 64) << (8 * r);
+        egp[st] = pk;
+      }
     }
+    m = dpf_wave_max(m);
+    if (lane == 0) s_gmax[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gbound = fmaxf(gbound, s_gmax[w]);
+    if constexpr (F16) Ew = __builtin_amdgcn_readfirstlane(wexp[0]);
   }
 
   const int zb = zo * p.sd - p.pd, yb = yo * p.sh - p.ph, xbase = xo * p.sw - p.pw;
@@ -727,7 +725,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_bwd_input_pk_kernel(const float* 
 #pragma unroll
         for (int st = 0; st < NST; ++st)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[st][r] = __builtin_ldexpf(acc[st][r], Egw - 282);
+          for (int r = 0; r < 4; ++r) acc[st][r] = __builtin_ldexpf(acc[st][r], (int)((egp[st] >> (8 * r)) & 0xffu) + Ew - 282);
         if (t + 1 < p.T) {
           wqn += wq_step;
 #pragma unroll
@@ -1913,11 +1911,12 @@ int dpf_deform_conv3d_backward_ex(const float* input, const float* weight, const
     if (lds <= 160 * 1024 && blocks < 0x7fffffffLL && (long long)D * H * W < 0x7fffffffLL) {
       const dim3 grid((unsigned)blocks);
       // packed fixed-point region (two channels per ds_add_u64): per-chunk max |W| for the quantisation bound, kept behind the
-      // grad_weight scratch in ws (entry 32 of that slack: the weight exponent of the f16-component path)
+      // grad_weight scratch in ws (the last entry of that 64-float slack: the weight exponent of the f16-component path)
       float* wmaxv = ws + dcn_repack_floats(C, K, p.T) + (long long)WG_NREP * p.T * ((C + 11) / 12) * 64 * 16;
-      int* wexp = reinterpret_cast<int*>(wmaxv + 32);
+      int* wexp = reinterpret_cast<int*>(wmaxv + 63);
       static const int gh_env = getenv("DPF_DCN_GCOL16") ? atoi(getenv("DPF_DCN_GCOL16")) : 1;
-      const bool f16 = gh_env && dpf_conv_f32_x9() != 0 && p.T == 27;
+      // (matrix path 1 is exact per element everywhere: the f16 components serve path 2 only; the per-chunk maxima must leave the exponent's slot alone)
+      const bool f16 = gh_env && dpf_conv_f32_x9() == 2 && p.T == 27 && dpf_div_up(C, GI_CH) <= 63;
       if (f16) {
         // the gcol B operand as f16 fragments ([T][CT / 16][4 KB] -- the bytes of wt2[T][64][CT]), max |W| from the caller's tensor
         hipLaunchKernelGGL(dcn_repack_pk_h_kernel, dim3(16), dim3(1024), 0, st, weight, reinterpret_cast<unsigned short*>(ws), K, C, p.T, CT / PK_CH, wexp);

@@ -728,9 +728,11 @@ struct BwdLds {
 };
 
 // GH = true (the default unless dpf_set_f32_matrix_path(0)): the gcol product on v_mfma_f32_16x16x32_f16 from two f16 components per operand
-// (conv_internal.h) -- the weights are split and scaled by the repack kernel, the go tile once per workgroup (its largest exponent is agreed
-// on through LDS before the first step), three MFMAs per (16 voxels, 32 output channels) instead of eight fp32 ones per 4; the result is
-// scaled back exactly before it is written to the gcol tile, so the samplers are unchanged.
+// (conv_internal.h) -- the weights are split and scaled by the repack kernel, the go tile once per workgroup, three MFMAs per (16 voxels,
+// 32 output channels) instead of eight fp32 ones per 4; the result is scaled back exactly before it is written to the gcol tile, so the
+// samplers are unchanged.  RANGE GUARD: a gcol element sums over the OUTPUT CHANNELS of one voxel, and the voxel is the MFMA's column,
+// so every voxel is scaled by its own largest magnitude (a lane and its three partners hold all channels of a voxel: two shuffles) --
+// gcol of a voxel is exact to fp32 relative to that voxel's output gradient, whatever its neighbours hold.
 typedef _Float16 lean_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned lean_u32x4 __attribute__((ext_vector_type(4)));
 template <class G, bool GH>
@@ -741,7 +743,6 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
   extern __shared__ __align__(16) char smem[];
   constexpr int CH = G::CH, NQ = G::NQ, T = 27;
   typedef BwdLds<G> L;
-  int* s_ex = reinterpret_cast<int*>(smem + L::LDS);      // GH: the matrix waves' go-tile exponents
   char* region = smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -769,7 +770,6 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
     LeanTab tab = lean_tab<G>(p, pvalid, ry0, rx0, zbf + offp0[0], ybf + offp0[p.P], xbf + offp0[2 * p.P]);
 #pragma unroll
     for (int u = 1; u <= 3; ++u) { od[u % 3] = offp0[u * P3]; oh[u % 3] = offp0[u * P3 + p.P]; ow[u % 3] = offp0[u * P3 + 2 * p.P]; }
-    if constexpr (GH) __syncthreads();                 // (the matrix waves agree on the go tile's scale)
     lean_stage<G>(p, xb, 0, region, ry0, rx0, tid, 512);
     __syncthreads();                                   // prologue: region of chunk 0 staged, gcol(0) written
     int i = 0;
@@ -902,44 +902,37 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
     // gcol B fragments: go[k = 4 ks + lg][voxel] for this wave's 4 sub-tiles of 16 voxels (GH: k = 32 mf + 8 lg + i, packed f16 components)
     float bfrag[GH ? 1 : 4][16];
     lean_u32x4 bq[GH ? 4 : 1][2][2];                    // [sub-tile][k half][hi | lo]
-    int Eg = DPF_H3_EMIN, Ew = DPF_H3_EMIN;
+    int Egv[GH ? 4 : 1], Ew = DPF_H3_EMIN;               // GH: exponent of this lane's voxel of sub-tile s4; of the weight tensor
     if constexpr (GH) {
-      float mxg = 0.f;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int vox = mw * 64 + s4 * 16 + l15;
-        const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
-        const bool ok = pz < p.D && y0 + py < p.H && x0 + px < p.W;
-        const long long gpos = ok ? ((long long)pz * p.H + y0 + py) * p.W + x0 + px : 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int k = 32 * (i >> 3) + 8 * lg + (i & 7);
-          if (ok && k < p.K) mxg = __builtin_fmaxf(mxg, __builtin_fabsf(gob[(long long)k * p.P + gpos]));
-        }
-      }
-      const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, mxg));
-      if (lane == 0) s_ex[mw] = e;
-      __syncthreads();                                  // all eight waves
-      Eg = max(max(s_ex[0], s_ex[1]), max(s_ex[2], s_ex[3]));
-      Eg = __builtin_amdgcn_readfirstlane(Eg);
-      Eg = Eg < DPF_H3_EMIN ? DPF_H3_EMIN : (Eg > 254 ? 254 : Eg);
       Ew = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(wg)[27 * p.nchunk * 1024]);
-      const float scg = dpf_h3_scale(Eg);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int vox = mw * 64 + s4 * 16 + l15;
         const int px = vox % G::TX, py = (vox / G::TX) % G::TY, pz = vox / (G::TX * G::TY);
         const bool ok = pz < p.D && y0 + py < p.H && x0 + px < p.W;
         const long long gpos = ok ? ((long long)pz * p.H + y0 + py) * p.W + x0 + px : 0;
+        float gv[16];
+        float mxg = 0.f;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int k = 32 * mf + 8 * lg + i;
+            gv[8 * mf + i] = (ok && k < p.K) ? gob[(long long)k * p.P + gpos] : 0.f;
+            mxg = __builtin_fmaxf(mxg, __builtin_fabsf(gv[8 * mf + i]));
+          }
+        mxg = __builtin_fmaxf(mxg, __shfl_xor(mxg, 16, 64));             // the voxel's other output channels sit in lanes l15 + 16 lg'
+        mxg = __builtin_fmaxf(mxg, __shfl_xor(mxg, 32, 64));
+        int e = (int)(__builtin_bit_cast(unsigned, mxg) >> 23);
+        e = e < DPF_H3_EMIN ? DPF_H3_EMIN : (e > 254 ? 254 : e);
+        Egv[s4] = e;
+        const float scg = dpf_h3_scale(e);
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int k = 32 * mf + 8 * lg + 2 * i;
-            const float v0 = (ok && k < p.K) ? gob[(long long)k * p.P + gpos] : 0.f;
-            const float v1 = (ok && k + 1 < p.K) ? gob[(long long)(k + 1) * p.P + gpos] : 0.f;
             unsigned h, l;
-            dpf_split_pair_h(v0 * scg, v1 * scg, h, l);
+            dpf_split_pair_h(gv[8 * mf + 2 * i] * scg, gv[8 * mf + 2 * i + 1] * scg, h, l);
             bq[s4][mf][0][i] = h; bq[s4][mf][1][i] = l;
           }
       }
@@ -1002,7 +995,7 @@ __global__ __launch_bounds__(512) void dcn_lean_bwd_offset_kernel(const float* _
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[u][r] = __builtin_ldexpf(acc[u][r], Eg + Ew - 282);
+            for (int r = 0; r < 4; ++r) acc[u][r] = __builtin_ldexpf(acc[u][r], Egv[2 * sp2 + u] + Ew - 282);
         } else {
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks)
@@ -1154,7 +1147,7 @@ int lean_launch_bwd_offset(const float* x, const float* offset, const float* wei
   const long long blocks = (long long)p.B * p.tilesY * p.tilesX;
   if (blocks >= 0x7fffffffLL) return DPF_ERR_UNSUPPORTED;
   static const int gh_env = getenv("DPF_DCN_GCOL16") ? atoi(getenv("DPF_DCN_GCOL16")) : 1;
-  if (gh_env && dpf_conv_f32_x9()) {
+  if (gh_env && dpf_conv_f32_x9() == 2) {
     hipLaunchKernelGGL(lean_repack_gcol_h_kernel, dim3(16), dim3(1024), 0, st, weight, reinterpret_cast<unsigned short*>(ws), p.K, p.C, G::CH, p.nchunk);
     if (lean_set_lds(dcn_lean_bwd_offset_kernel<G, true>, BwdLds<G>::LDS + 64) != DPF_OK) return DPF_ERR_LAUNCH;
     hipLaunchKernelGGL((dcn_lean_bwd_offset_kernel<G, true>), dim3((unsigned)blocks), dim3(512), BwdLds<G>::LDS + 64, st, x, offset, ws, go, doff, dwtmp, p, det);

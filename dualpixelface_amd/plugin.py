@@ -3,6 +3,7 @@
 (mainmodel.py:67-177) plus an MI355X-native ``train_step`` (flat-arena gradients, fused Adam, optional RCCL all-reduce).
 """
 import contextlib
+import os
 
 import torch
 
@@ -144,6 +145,7 @@ class _PluginHooks(object):
             st['extra'] = {k: v for k, v in batch.items() if not torch.is_tensor(v)}
             st['hyper'] = torch.zeros(2, dtype=torch.float32, device=flat_g.device)
             counts_before = dict(self._pending_counts)
+            step_before = ad['step']
             self._flush_counts()
             graph = torch.cuda.CUDAGraph()
             try:
@@ -172,6 +174,10 @@ class _PluginHooks(object):
                 st['failed'] = True
                 self._pending_counts = counts_before
                 torch.cuda.synchronize()
+                # the aborted capture only RECORDED its work: the clearing fill of the zero arenas never ran although their cursors moved
+                # on (the warm-up steps' slots are still dirty), and the Adam step counter may have been advanced
+                ops.reset_zero_arenas()
+                ad['step'] = step_before
                 return self._eager_step(batch, None, lr)
         # The replay runs on the dedicated stream, bracketed by explicit event waits in both directions.  Launched into the caller's stream
         # -- the legacy default stream in a plain script -- kernels the caller enqueued right after the replay were observed to start before
@@ -202,7 +208,7 @@ class _PluginHooks(object):
         if getattr(self, '_replay_in_flight', False):
             self._replay_in_flight = False
             ss = getattr(self, '_step_stream', None)
-            if ss is not None:
+            if ss is not None and os.environ.get('DPF_SETTLE_REPLAY', '1') != '0':
                 ss.synchronize()
 
     def _eager_step(self, batch, reducer=None, lr=None, hyper=None):

@@ -913,8 +913,13 @@ def test_headline_config_whole_train_step(monkeypatch):
     StereoDPNet on 4 x 1024 x 1536 synthetic pairs.  (i) everything finite; (ii) the default step (weight gradients on a side stream, the
     two feature passes on two streams) and the one-stream step start from the same weights and must agree -- loss 1e-5, disparity 2e-3 px,
     gradient arena 2e-3 relative L2 and every parameter's gradient 5e-2 (the run-to-run noise of the float atomics, DESIGN section 2, is the
-    only difference between the two schedules); (iii) state_dict -> load_state_dict(strict) -> state_dict is the identity."""
+    only difference between the two schedules); (iii) state_dict -> load_state_dict(strict) -> state_dict is the identity;
+    (iv) CROSS-PATH: the same step with every fp32 product on v_mfma_f32_32x32x2_f32 (dpf_set_f32_matrix_path(0), exact
+    fp32 per element) -- the default path (f16 components with the range guards) is tied to it at the headline size, where tiles are full and
+    the activations have their real dynamic range: loss 1e-5, disparity 2e-3 px, gradient arena relative L2 within 2 x the distance between
+    the two schedules of the default path (+ 1e-4, the run-to-run floor of two one-schedule runs), every parameter 5e-2."""
     from dualpixelface_amd import load_option, ops
+    from dualpixelface_amd._lib import lib
     import dualpixelface_amd.stereodpnet as sdn
     from dualpixelface_amd.plugin import STEREODPNET
     from dualpixelface_amd.recipe import synthetic_batch
@@ -923,17 +928,43 @@ def test_headline_config_whole_train_step(monkeypatch):
     base = STEREODPNET(load_option()).to(DEV)             # the reference's initialisation scheme (what bench.py times)
     sd = {k: v.clone() for k, v in base.state_dict().items()}
     runs = []
-    for two_streams in (True, False):
-        monkeypatch.setattr(ops, 'WGRAD_ASYNC', two_streams)
-        monkeypatch.setattr(sdn, 'FEATURES_TWO_STREAMS', two_streams)
-        model = STEREODPNET(load_option()).to(DEV)
-        model.load_state_dict(sd, strict=True)
-        res = model.train_step(batch)
-        torch.cuda.synchronize()
-        runs.append((float(res['final_loss']), res['pred_depth'].detach().clone(), model.flat_gradients(zero=False).clone(),
-                     model.flat_parameters().clone(), model._layout))
-        del res
-    (l2, d2, g2, p2, layout), (l1, d1, g1, p1, _) = runs
+    prev_path = lib().cdll.dpf_get_f32_matrix_path()
+    assert prev_path == 2                                  # the default the bench line is timed on
+    try:
+        for two_streams, path in ((True, 2), (False, 2), (False, 0)):
+            monkeypatch.setattr(ops, 'WGRAD_ASYNC', two_streams)
+            monkeypatch.setattr(sdn, 'FEATURES_TWO_STREAMS', two_streams)
+            lib().call('dpf_set_f32_matrix_path', path)
+            model = STEREODPNET(load_option()).to(DEV)
+            model.load_state_dict(sd, strict=True)
+            res = model.train_step(batch)
+            torch.cuda.synchronize()
+            runs.append((float(res['final_loss']), res['pred_depth'].detach().clone(), model.flat_gradients(zero=False).clone(),
+                         model.flat_parameters().clone(), model._layout))
+            del res
+            if path == 0:
+                del model
+    finally:
+        lib().call('dpf_set_f32_matrix_path', prev_path)
+    (l2, d2, g2, p2, layout), (l1, d1, g1, p1, _), (l0, d0, g0, p0, _) = runs
+    # (iv) the default path against exact fp32 products, same schedule
+    for t in (d0, g0, p0):
+        assert torch.isfinite(t).all()
+    sched = ((g1 - g2).norm() / g1.norm()).item()
+    cross = ((g1 - g0).norm() / g0.norm()).item()
+    worst0 = []
+    for name, off, numel, _ in layout:
+        a, b = g0[off:off + numel], g1[off:off + numel]
+        if a.norm().item() > 1e-3 * g0.norm().item():
+            worst0.append((((a - b).norm() / a.norm()).item(), name))
+    worst0.sort(reverse=True)
+    print('headline step, f16 components vs fp32 matrix instruction: loss %.6f / %.6f, disparity %.2e px, |dg|/|g| %.2e (two schedules of the default: %.2e), worst parameters %s'
+          % (l1, l0, (d1 - d0).abs().max().item(), cross, sched, worst0[:3]))
+    assert abs(l1 - l0) <= 1e-5 * abs(l0), (l1, l0)
+    assert (d1 - d0).abs().max().item() <= 2e-3
+    assert cross <= 2 * sched + 1e-4, (cross, sched)
+    assert worst0[0][0] <= 5e-2, worst0[:5]
+    del g0, d0, p0
     for t in (d2, g2, p2, d1, g1, p1):
         assert torch.isfinite(t).all()
     assert np.isfinite(l1) and np.isfinite(l2) and abs(l1 - l2) <= 1e-5 * abs(l1), (l1, l2)

@@ -43,15 +43,20 @@ SETS = [
 ]
 
 
-# whole-model steps on ONE stream (weight gradients in line, feature passes one after the other) against the reference fixtures
+# whole-model steps against the reference fixtures: on ONE stream (weight gradients in line, feature passes one after the other), and on the
+# two element-exact fp32 matrix paths
 E2E_SETS = [
     ({'DPF_FEATURES_TWO_STREAMS': '0', 'DPF_WGRAD_ASYNC': '0'}, 'test_gradients_and_adam_step_vs_reference_fixture or test_train_step_with_flat_grad_reducer_single_rank'),
+    # the element-exact fp32 paths, whole model against the imported reference's fixtures: six bf16 partial products of exact
+    # three-way splits (path 1), and v_mfma_f32_32x32x2_f32 (path 0); the c2 configuration (batch 4, 512 x 768) rides along
+    ({'DPF_F32_X9': '1'}, 'test_gradients_and_adam_step_vs_reference_fixture or test_train_forward_stages_and_losses or test_c2_batch4'),
+    ({'DPF_F32_X9': '0'}, 'test_gradients_and_adam_step_vs_reference_fixture or test_train_forward_stages_and_losses or test_c2_batch4'),
 ]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('env_set,select', E2E_SETS, ids=['+'.join('%s=%s' % kv for kv in s[0].items()) for s in E2E_SETS])
-def test_whole_model_parity_on_one_stream(env_set, select):
+def test_whole_model_parity_on_the_alternative_paths(env_set, select):
     env = dict(os.environ)
     env.update(env_set)
     cmd = [sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_e2e.py'), '-m', 'gpu', '-x', '-q', '-k', select, '-p', 'no:cacheprovider']

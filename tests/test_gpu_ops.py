@@ -721,6 +721,47 @@ def test_weight_gradient_f16_component_path_in_block_dynamic_range(cfg, layout, 
         lib().call('dpf_set_f32_matrix_path', prev)
 
 
+@pytest.mark.parametrize('cfg', [(1, 35, 64, 4, 12, 36), (1, 64, 64, 4, 8, 36)])
+def test_deform_conv_backward_f16_component_path_in_block_dynamic_range(cfg):
+    """The deformable conv backward forms gcol = W^T go from two f16 components per operand (dpf_set_f32_matrix_path(2)).  A gcol element
+    sums over the output channels of ONE voxel, so the range guard scales every voxel by its own largest |go|.  Output gradients whose
+    voxels lie at 1 .. 2^-34 of the tile's maximum (bands of 6 columns): grad_offset[.., voxel] is linear in go[.., voxel], so its error is
+    measured relative to (the voxel's band scale x the rms of the unscaled gradient); grad_input relative to the same backward pass of
+    (|W|, |go|).  fp64 oracle; bar: the worst element within 2 x the worst element on the fp32 matrix instruction (path 0)."""
+    from dualpixelface_amd._lib import lib
+    from oracle import dcn3d
+    ops = _ops()
+    B, C, K, D, H, W = cfg
+    x, off = rnd(B, C, D, H, W, seed=330), rnd(B, 81, D, H, W, seed=331, scale=0.7)
+    wt, bs = rnd(K, C, 3, 3, 3, seed=332, scale=0.1), rnd(K, seed=333)
+    go_plain = rnd(B, K, D, H, W, seed=334)
+    go = _spread(go_plain, 'wbands', seed=335)
+    band = (go.double().abs().sum(dim=1, keepdim=True) / go_plain.double().abs().sum(dim=1, keepdim=True))      # [B,1,D,H,W]: 2^-e of the voxel
+    xd, od, wd, bd = x.double(), off.double(), wt.double(), bs.double()
+    gi_ref, goff_ref, _, _ = dcn3d.deform_conv3d_backward(xd, od, wd, bd, go.double())
+    gi_den = dcn3d.deform_conv3d_backward(xd, od, wd.abs(), bd, go.double().abs())[0]
+    goff_plain = dcn3d.deform_conv3d_backward(xd, od, wd, bd, go_plain.double())[1]
+    goff_den = band * goff_plain.pow(2).mean().sqrt()
+    prev = lib().cdll.dpf_get_f32_matrix_path()
+    errs = {}
+    try:
+        for path in (0, 2):
+            lib().call('dpf_set_f32_matrix_path', path)
+            xg, og, wg, bg = [t.to(DEV).requires_grad_() for t in (x, off, wt, bs)]
+            y = ops.deform_conv3d(xg, og, wg, bg)
+            gi, goff = torch.autograd.grad(y, (xg, og), go.to(DEV))
+            nz = gi_den > 0
+            errs[path] = (((gi.double().cpu() - gi_ref).abs()[nz] / gi_den[nz]).max().item(),
+                          ((goff.double().cpu() - goff_ref).abs() / goff_den).max().item())
+    finally:
+        lib().call('dpf_set_f32_matrix_path', prev)
+    # (grad_input is committed through a fixed-point scatter whose unit follows the tile's largest contribution: both paths share that floor,
+    # which is why it is compared between the paths and not held to an absolute bound)
+    assert errs[2][0] <= 2 * errs[0][0] + 1e-7, errs
+    assert errs[2][1] <= 2 * errs[0][1] + 1e-7, errs
+    assert errs[0][1] <= 5e-5, errs
+
+
 @pytest.mark.parametrize('shape', [(1, 8, 16, 4, 6, 16), (1, 5, 7, 3, 5, 6)])
 def test_deform_conv_integer_offsets_and_the_validity_rule(shape):
     """Integer offsets put samples exactly on voxel centres, on the borders and on coordinate -1: deform_im2col_cuda.cuh:248 declares a

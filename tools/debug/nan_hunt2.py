@@ -1,0 +1,29 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from dualpixelface_amd import load_option, ops
+import dualpixelface_amd.stereodpnet as sdn
+from dualpixelface_amd.plugin import STEREODPNET
+from dualpixelface_amd.recipe import synthetic_batch
+from dualpixelface_amd._lib import lib
+B, H, W = [int(a) for a in sys.argv[1:4]]
+seq = eval(sys.argv[4]) if len(sys.argv) > 4 else ((True, 2), (False, 2), (False, 0))
+dev = torch.device('cuda', 0)
+batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, W, seed=0).items()}
+torch.manual_seed(3)
+base = STEREODPNET(load_option()).to(dev)
+sd = {k: v.clone() for k, v in base.state_dict().items()}
+outs = []
+for two, path in seq:
+    ops.WGRAD_ASYNC = two; sdn.FEATURES_TWO_STREAMS = two
+    lib().call('dpf_set_f32_matrix_path', path)
+    model = STEREODPNET(load_option()).to(dev)
+    model.load_state_dict(sd, strict=True)
+    res = model.train_step(batch)
+    torch.cuda.synchronize()
+    g = model.flat_gradients(zero=False).clone()
+    bad = [(name, int((~torch.isfinite(g[off:off + numel])).sum()), numel) for name, off, numel, _ in model._layout if not torch.isfinite(g[off:off + numel]).all()]
+    print('two_streams', two, 'path', path, 'loss %.6f' % float(res['final_loss'].detach()), 'non-finite gradient tensors:', len(bad), bad[:6], flush=True)
+    outs.append((g, res['pred_depth'].detach().clone()))
+for i in range(1, len(outs)):
+    print('run %d vs run 0: disparity %.3e  grad rel %.3e' % (i, (outs[i][1] - outs[0][1]).abs().max().item(), ((outs[i][0] - outs[0][0]).norm() / outs[0][0].norm()).item()))
