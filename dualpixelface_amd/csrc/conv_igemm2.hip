@@ -60,7 +60,7 @@ struct G2P {
   double* stats;                // optional [ntiles][statsK][2] per-tile (sum, sum of squares) of the outputs, for a following BatchNorm
   int statsK, statsk0;          // row length of the slab and first channel of this launch in it (K, 0 unless the launch is one slice of the channels)
   int tapoff[28];               // x9 kernel: patch offset (positions) of tap u; taps beyond T: 0 (their weights are zero)
-  const int* wexp;              // x9 kernel, f16 components: biased exponent the pack kernel scaled the weights by (device memory)
+  const int* wexp;              // x9 kernel, f16 components: [32 MT] biased exponent the pack kernel scaled output row k's weights by (device memory)
   int guard;                    // x9 kernel, f16 components: residual passes for chunks whose range exceeds the split's (always 1 outside tests)
   int tap0, stepC, incB, incA;   //   incB = stepB - (kw-1)*stepC (row wrap), incA = stepA - (kh-1)*stepB - (kw-1)*stepC (plane wrap) // patch offset (floats) of tap (a, b, c) = tap0 + a*stepA + b*stepB + c*stepC
 };
@@ -969,38 +969,68 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     else { ++chunk; pass = 0; }
   }
   X9_STAMP(2, __builtin_readcyclecounter())
-  if constexpr (NC == 2) rescale_acc(Ex + __builtin_amdgcn_readfirstlane(p.wexp[0]) - 282);      // back to the operands' units (exact)
+  if constexpr (NC == 2) {                                         // back to the operands' units (exact): the tile's exponent + the one of each OUTPUT ROW's weights
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int4 we = *reinterpret_cast<const int4*>(p.wexp + 32 * m + 8 * q4 + 4 * hh);       // accumulator register j <-> row (j & 3) + 8 (j >> 2) + 4 hh
+        const int w4[4] = {we.x, we.y, we.z, we.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[m][t][4 * q4 + r] = __builtin_ldexpf(acc[m][t][4 * q4 + r], Ex + w4[r] - 282);
+      }
+  }
   g2_epilogue<MT, NT>(acc, p, bias, out, smem, tile_id, n, qd, q0h, q0w, wave, l31, hh, tid);
   X9_STAMP(3, __builtin_readcyclecounter()) X9_STAMP(5, __builtin_amdgcn_s_memrealtime()) X9_STAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, all 32 bits */)) X9_STAMP(7, (unsigned long long)p.nchunks)
 }
 
-// f16 components: the largest biased exponent of workgroup b's slice of the weight tensor -> part[b] (the pack kernel folds the slices)
-__global__ __launch_bounds__(256) void x9_wexp_kernel(const float* __restrict__ w, int nw, int per, int* __restrict__ part) {
+// f16 components (NC = 2): one workgroup per OUTPUT ROW k of the launch (an output channel of a forward conv, an input channel of a data
+// gradient).  The row's largest exponent -> wexp[k] (the conv's epilogue undoes it per accumulator row), then the row's weights times
+// 2^(141 - that exponent) as (hi, lo) f16 components into the fragment layout below.  A scale per row instead of per tensor: a row of small
+// weights keeps its full precision next to a row of large ones (the range guard of the weight operand), and the separate exponent kernel
+// of round 5 is gone.
+__global__ __launch_bounds__(256) void igemm3_pack_x9h_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int TG, int MT,
+                                                              int CC, int nchunks, int mode, int k0, int K, int C, int* __restrict__ wexp) {
   __shared__ int s_e[4];
-  const int beg = blockIdx.x * per, end = min(nw, beg + per);
-  float m = 0.f;
-#pragma unroll 4
-  for (int i = beg + threadIdx.x; i < end; i += 256) m = __builtin_fmaxf(m, __builtin_fabsf(w[i]));
-  const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
+  const int k = blockIdx.x, m = k >> 5, l31 = k & 31;
+  const bool rowok = k < K;
+  auto wat = [&](int c, int u) {
+    const int a = mode == 0 ? k0 + k : c, bb = mode == 0 ? c : k0 + k;
+    return w[((long long)a * wB + bb) * T + u];
+  };
+  float mx = 0.f;
+  if (rowok)
+    for (int i = threadIdx.x; i < C * T; i += 256) mx = __builtin_fmaxf(mx, __builtin_fabsf(wat(i / T, i % T)));
+  const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, mx));
   if ((threadIdx.x & 63) == 0) s_e[threadIdx.x >> 6] = e;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = max(max(s_e[0], s_e[1]), max(s_e[2], s_e[3]));
+  int E = max(max(s_e[0], s_e[1]), max(s_e[2], s_e[3]));
+  E = E < DPF_H3_EMIN ? DPF_H3_EMIN : (E > 254 ? 254 : E);
+  if (threadIdx.x == 0) wexp[k] = E;
+  const float wscale = dpf_h3_scale(E);
+  const int TPG = 16 / CC;
+  for (int e2 = threadIdx.x; e2 < nchunks * TG * 16; e2 += 256) {
+    const int i = e2 & 7, hh = (e2 >> 3) & 1, g = (e2 >> 4) % TG, chunk = (e2 >> 4) / TG;
+    const int u = CC == 4 ? 4 * g + 2 * hh + (i >> 2) : 2 * g + hh;
+    const int c = CC == 4 ? chunk * 4 + (i & 3) : chunk * 8 + i;
+    const float v = (rowok && u < T && c < C) ? wat(c, u) * wscale : 0.f;
+    unsigned sh, sl;
+    dpf_split_pair_h(v, 0.f, sh, sl);
+    const long long base = (((long long)(chunk * TG + g) * 2) * MT + m) * 512 + (hh * 32 + l31) * 8 + i;
+    wpk[base] = (unsigned short)(sh & 0xffffu);
+    wpk[base + 512LL * MT] = (unsigned short)(sl & 0xffffu);
+  }
+  (void)TPG;
 }
 
 // x9 weights: shorts [chunk][tap group g][component][row tile m][lane][8]; value i of lane (l31, hh) = component of
 // w(out = k0 + 32 m + l31, reduce, tap), zero beyond T / C / K, with
 //   CC = 4: reduce = 4 chunk + (i & 3), tap = 4 g + 2 hh + (i >> 2);      CC = 8: reduce = 8 chunk + i, tap = 2 g + hh
 __global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int wA, int wB, int T, int TG, int MT, int CC,
-                                      int NC, int nchunks, int mode, int k0, int K, int C, int* __restrict__ wexp, int nparts) {
+                                      int NC, int nchunks, int mode, int k0, int K, int C) {
   const long long total = (long long)nchunks * TG * MT * 512;
-  float wscale = 1.f;
-  if (NC == 2) {                                                   // f16 components: fold the slice exponents x9_wexp_kernel left in wexp[1 ..]
-    int E = DPF_H3_EMIN;
-    for (int i = 1; i <= nparts; ++i) E = max(E, wexp[i]);
-    E = E > 254 ? 254 : E;
-    wscale = dpf_h3_scale(E);
-    if (blockIdx.x == 0 && threadIdx.x == 0) wexp[0] = E;         // for the convolution's epilogue
-  }
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(e & 7), ln = (int)((e >> 3) & 63);
     const int m = (int)((e >> 9) % MT);
@@ -1020,10 +1050,6 @@ __global__ void igemm3_pack_x9_kernel(const float* __restrict__ w, unsigned shor
     const long long base = (((long long)(chunk * TG + g) * NC) * MT + m) * 512 + ln * 8 + i;
     if (NC == 1) {                                                 // operand precision "bf16": round to nearest even
       wpk[base] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
-    } else if (NC == 2) {
-      dpf_split_pair_h(v * wscale, 0.f, sh, sl);
-      wpk[base] = (unsigned short)(sh & 0xffffu);
-      wpk[base + 512LL * MT] = (unsigned short)(sl & 0xffffu);
     } else {
       wpk[base] = (unsigned short)(sh & 0xffffu);
       wpk[base + 512LL * MT] = (unsigned short)(sm & 0xffffu);
@@ -1459,19 +1485,15 @@ int x9_try(const float* x, const float* w, const float* bias, float* out, float*
   }
   unsigned short* wp = reinterpret_cast<unsigned short*>(ws);
   const long long total = (long long)q.nchunks * TG * MT * 512;
-  // (f16 components: the scale's exponent sits behind the packed weights -- inside the three-component capacity of the workspace)
+  // (f16 components: the rows' exponents (32 MT ints) sit behind the packed weights -- inside the three-component capacity of the workspace)
   int* wexp = reinterpret_cast<int*>(wp + ((total * NC + 7) & ~7LL));
   q.wexp = wexp;
   q.guard = dpf_h3_range_guard();
-  int nparts = 0;
-  if (NC == 2) {
-    const int nw = d.wA * d.wB * T;
-    nparts = (nw + 4095) / 4096 < 32 ? (nw + 4095) / 4096 : 32;
-    const int per = (nw + nparts - 1) / nparts;
-    hipLaunchKernelGGL(x9_wexp_kernel, dim3(nparts), dim3(256), 0, st, w, nw, per, wexp + 1);
-  }
-  hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks, d.mode, q.k0, kn,
-                     d.C, wexp, nparts);
+  if (NC == 2)
+    hipLaunchKernelGGL(igemm3_pack_x9h_kernel, dim3(32 * MT), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, q.nchunks, d.mode, q.k0, kn, d.C, wexp);
+  else
+    hipLaunchKernelGGL(igemm3_pack_x9_kernel, dim3(dpf_ew_grid(total)), dim3(256), 0, st, w, wp, d.wA, d.wB, T, TG, MT, CC9, NC, q.nchunks, d.mode, q.k0, kn,
+                       d.C);
   if (dpf_check_launch() != DPF_OK) return DPF_ERR_LAUNCH;
   if (stats) stats->parts = (int)nt9;
   const long long blocks9 = 8LL * q.cpx;

@@ -50,7 +50,10 @@ E2E_SETS = [
     # the element-exact fp32 paths, whole model against the imported reference's fixtures: six bf16 partial products of exact
     # three-way splits (path 1), and v_mfma_f32_32x32x2_f32 (path 0); the c2 configuration (batch 4, 512 x 768) rides along
     ({'DPF_F32_X9': '1'}, 'test_gradients_and_adam_step_vs_reference_fixture or test_train_forward_stages_and_losses or test_c2_batch4'),
-    ({'DPF_F32_X9': '0'}, 'test_gradients_and_adam_step_vs_reference_fixture or test_train_forward_stages_and_losses or test_c2_batch4'),
+    # (path 0 accumulates every product in ONE sequential fp32 chain per output -- 864 v_mfma_f32_32x32x2_f32 steps for a 3x3x3 layer of 32
+    # channels -- where paths 1 / 2 add exact 16-term block sums: its gradients sit FARTHER from the reference's than the default path's, up to
+    # 5.4 x the reference's own thread-count noise on the normal head's last conv at 32 x 48 against <= 2.9 x on the default path; budget 8 x)
+    ({'DPF_F32_X9': '0', 'DPF_TEST_K_SPREAD': '8'}, 'test_gradients_and_adam_step_vs_reference_fixture or test_train_forward_stages_and_losses or test_c2_batch4'),
 ]
 
 

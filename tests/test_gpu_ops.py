@@ -623,13 +623,15 @@ def _spread(t, layout, seed):
     (2, 48, 32, 1, 24, 64, (1, 3, 3), 1, False),     # 8-channel chunks (2-D layers)
     (1, 40, 64, 1, 24, 64, (1, 3, 3), 2, True),      # dilated rows
 ])
-@pytest.mark.parametrize('layout', ['wbands', 'hbands', 'chan', 'elem'])
+@pytest.mark.parametrize('layout', ['wbands', 'hbands', 'chan', 'elem', 'wrows'])
 def test_conv_f16_component_path_in_block_dynamic_range(cfg, layout):
     """dpf_set_f32_matrix_path(2) against the fp32 matrix instruction (path 0) when ONE tile / channel chunk holds values at 1, 2^-13, 2^-20,
     2^-27 and 2^-34 of its maximum -- signed and all-positive data, forward (the spread in x) and data gradient (the spread in g).  Every
     output element is compared with fp64 relative to ITS OWN magnitude: the error is divided by sum |w| |x| over the element's own window
     (for all-positive data that is the element itself), so an output that only sees 2^-34-sized inputs has to be right to fp32 precision of
-    2^-34-sized numbers.  Bar: the worst element of path 2 within 2 x the worst element of path 0.  Negative control: with the range guard
+    2^-34-sized numbers.  'wrows' puts the spread into the weights instead: output row r (an output channel; for the data gradient an
+    input channel) at 2^-RANGE_EXPS[r % 5] -- the pack kernel scales every row by its own exponent.  Bar: the worst element of path 2
+    within 2 x the worst element of path 0.  Negative control: with the range guard
     switched off (block scaling without residual passes -- round 5's kernel) the banded layouts miss the bar by orders of magnitude."""
     from dualpixelface_amd._lib import lib
     ops = _ops()
@@ -657,7 +659,12 @@ def test_conv_f16_component_path_in_block_dynamic_range(cfg, layout):
             w = rnd(K, C, *ks, seed=311, scale=0.1)
             if positive:
                 a, w = a.abs(), w.abs()
-            a = _spread(a, layout, seed=312)
+            if layout == 'wrows':                                              # the spread in the WEIGHTS: output row r at 2^-RANGE_EXPS[r % 5] (a scale per output row)
+                rows = C if transposed else K
+                sc = torch.pow(2.0, -torch.tensor(RANGE_EXPS, dtype=torch.float64)[torch.arange(rows) % 5])
+                w = (w.double() * (sc.view(1, C, 1, 1, 1) if transposed else sc.view(K, 1, 1, 1, 1))).float()
+            else:
+                a = _spread(a, layout, seed=312)
             ref, den = ref64(a, w), ref64(a.abs(), w.abs())
             assert den.min().item() > 0
 
