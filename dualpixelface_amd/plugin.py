@@ -26,7 +26,9 @@ class _PluginHooks(object):
 
     # ---- reference surface -------------------------------------------------------------------------------
     def forward(self, batch):
-        self._settle_replay()
+        return self._behind_replays(lambda: self._forward(batch))
+
+    def _forward(self, batch):
         results = self.network(batch)
         self.last_taps = results.pop('_taps')
         if self.training and 'disp' in batch:
@@ -195,25 +197,43 @@ class _PluginHooks(object):
             st['hyper'][1:2].fill_(float(h1))
             st['graph'].replay()
         cur.wait_stream(ss)
-        self._replay_in_flight = True                      # see _settle_replay()
         for name, n in st['counts'].items():
             self._pending_counts[name] = self._pending_counts.get(name, 0) + n
         return st['results']
 
-    def _settle_replay(self):
-        """Host-side wait for a replayed step before the model launches kernels one by one again (eager step, forward, validation).  The
-        event waits around the replay order it with the caller's stream, but eager launches of this model that FOLLOW a replay closely were
-        still seen to fault (bench.py --wgrad-inline inside the evidence collection, after the ordering fix); with the host wait at this
-        transition -- which a training loop crosses once per epoch at most -- none did."""
-        if getattr(self, '_replay_in_flight', False):
-            self._replay_in_flight = False
-            ss = getattr(self, '_step_stream', None)
-            if ss is not None and os.environ.get('DPF_SETTLE_REPLAY', '1') != '0':
-                ss.synchronize()
+    def _behind_replays(self, fn):
+        """Once a train step of this model replays as a HIP graph, everything the model launches one by one (an eager step, forward,
+        validation) runs on the SAME stream as the replays, bracketed by event waits against the caller's stream.
+
+        Why (tools/debug/graph_eager_alternation.py): with eager launches on another stream, ordered against the replay
+        only through `caller.wait_stream(step stream)` -- an event recorded right behind hipGraphLaunch -- a headline-size replay followed by
+        this model's eager forward ended in a GPU memory access fault in about one run of three (100 alternations each); with launch
+        blocking, with a host wait, or with the eager work on the replay's own stream: none (0 of 80 / 12 / 14 runs).  4 000 trivial
+        kernels behind each replay on the other stream never faulted either: what races is the model's own state (parameters, running
+        statistics, cached tables) between the graph's tail and the eager kernels, i.e. the cross-stream event does not cover the whole
+        graph on this runtime (ROCm 7.0.2 / PyTorch 2.10).  Same-stream order does not depend on it."""
+        ss = getattr(self, '_step_stream', None)
+        st = getattr(self, '_graph_state', None)
+        if ss is None or st is None or st.get('graph') is None:
+            return fn()
+        cur = torch.cuda.current_stream(ss.device)
+        if cur == ss:
+            return fn()
+        ss.wait_stream(cur)
+        with torch.cuda.stream(ss):
+            out = fn()
+        cur.wait_stream(ss)
+        for v in (out.values() if isinstance(out, dict) else ()):
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return out
 
     def _eager_step(self, batch, reducer=None, lr=None, hyper=None):
-        if hyper is None:                                  # (hyper is set while the step is being captured)
-            self._settle_replay()
+        if hyper is None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            return self._behind_replays(lambda: self._eager_step_body(batch, reducer, lr, None))
+        return self._eager_step_body(batch, reducer, lr, hyper)
+
+    def _eager_step_body(self, batch, reducer=None, lr=None, hyper=None):
         self.train()
         gscale = 1.0
         if getattr(self, 'gather_grads', True):
