@@ -117,11 +117,20 @@ class _PluginHooks(object):
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())) + (
             bool(ops.deterministic()), ops.CONV_OPERANDS_BF16, ops.f32_matrix_path(), ops.WGRAD_ASYNC, _sdn.FEATURES_TWO_STREAMS, self.flat_parameters().data_ptr(),
             self.flat_gradients(zero=False).data_ptr(), self._adam['m'].data_ptr() if self._adam else 0, self.stat_exchange is None)
-        st = getattr(self, '_graph_state', None)
-        if st is not None and st.get('failed') and st['key'] == key:
+        # a few graph states are kept (most recently used last): the last, partial batch of an epoch has its own key and must not throw the
+        # main shape's graph away
+        states = self.__dict__.setdefault('_graph_states', [])
+        st = next((g for g in states if g['key'] == key), None)
+        if st is None:
+            st = {'key': key, 'calls': 0, 'graph': None}
+            states.append(st)
+            del states[:-3]
+        else:
+            states.remove(st)
+            states.append(st)
+        self._graph_state = st
+        if st.get('failed'):
             return self._eager_step(batch, None, lr)
-        if st is None or st['key'] != key:
-            st = self._graph_state = {'key': key, 'calls': 0, 'graph': None}
         st['calls'] += 1
         lr = float(lr if lr is not None else self.option.init_lr)
         flat_g = self.flat_gradients(zero=False)
@@ -199,7 +208,7 @@ class _PluginHooks(object):
         cur.wait_stream(ss)
         for name, n in st['counts'].items():
             self._pending_counts[name] = self._pending_counts.get(name, 0) + n
-        return st['results']
+        return dict(st['results'])                         # (a fresh dict; the tensors are the graph's static buffers, valid until the next step)
 
     def _behind_replays(self, fn):
         """Once a train step of this model replays as a HIP graph, everything the model launches one by one (an eager step, forward,
@@ -213,8 +222,7 @@ class _PluginHooks(object):
         statistics, cached tables) between the graph's tail and the eager kernels, i.e. the cross-stream event does not cover the whole
         graph on this runtime (ROCm 7.0.2 / PyTorch 2.10).  Same-stream order does not depend on it."""
         ss = getattr(self, '_step_stream', None)
-        st = getattr(self, '_graph_state', None)
-        if ss is None or st is None or st.get('graph') is None:
+        if ss is None or not any(g.get('graph') is not None for g in getattr(self, '_graph_states', ())):
             return fn()
         cur = torch.cuda.current_stream(ss.device)
         if cur == ss:
