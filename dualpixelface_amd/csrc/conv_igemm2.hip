@@ -638,15 +638,26 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     return mp;
   };
   auto post_exp = [&]() {
+    // per-position maxima, accumulated over channel PAIRS in the order the loads were issued (v_max3_f32: two channels per instruction), so
+    // that only the last pair's four instructions and the folds below wait for the last load
+    float pm[NU][4];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) pm[j][ps] = __builtin_fmaxf(__builtin_fabsf(pv[j][0][ps]), __builtin_fabsf(pv[j][1][ps]));
+#pragma unroll
+      for (int ch = 2; ch < CC; ch += 2)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) pm[j][ps] = __builtin_fmaxf(__builtin_fmaxf(pm[j][ps], __builtin_fabsf(pv[j][ch][ps])), __builtin_fabsf(pv[j][ch + 1][ps]));
+    }
     float m = 0.f;
     kminL = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < NU; ++j)
 #pragma unroll
       for (int ps = 0; ps < 4; ps += 2) {                           // two positions per step: v_max3_f32 / v_min3_u32 take both
-        const float m0 = pos_max(j, ps), m1 = pos_max(j, ps + 1);
-        m = __builtin_fmaxf(__builtin_fmaxf(m, m0), m1);
-        kminL = min(min(kminL, __builtin_bit_cast(unsigned, m0) - 1u), __builtin_bit_cast(unsigned, m1) - 1u);
+        m = __builtin_fmaxf(__builtin_fmaxf(m, pm[j][ps]), pm[j][ps + 1]);
+        kminL = min(min(kminL, __builtin_bit_cast(unsigned, pm[j][ps]) - 1u), __builtin_bit_cast(unsigned, pm[j][ps + 1]) - 1u);
       }
     const int e = dpf_wave_max_exp(__builtin_bit_cast(unsigned, m));
     if (lane == 0) s_red[wave] = e;
@@ -770,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
     if constexpr (NC == 2) {
-      if (wdef) split_masked();
+      if (__builtin_expect(wdef, 0)) split_masked();
     }
   }
 
@@ -790,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) split_slice(sl);
       if constexpr (NC == 2) {
-        if (wdef) split_masked();
+        if (__builtin_expect(wdef, 0)) split_masked();
       }
     }
     bool more = false;                                             // (workgroup-uniform) another pass over this chunk follows
@@ -800,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
         if (chunk > 0 || pass > 0) dflag = s_red[8 + par];          // (posted before the barrier that ended the previous iteration; the first pass of a tile: below)
       }
       if (tid == 0) s_red[8 + (par ^ 1)] = 0;
-      if (Enext != Ex) { rescale_acc(Ex - Enext); Ex = Enext; }    // the pass about to be contracted changes the accumulators' exponent
+      if (__builtin_expect(Enext != Ex, 0)) { rescale_acc(Ex - Enext); Ex = Enext; }    // the pass about to be contracted changes the accumulators' exponent
       tbC = tbN;
     }
     store_split();
@@ -812,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
       more = pass < DPF_H3_MAXPASS && __builtin_amdgcn_readfirstlane(dflag) != 0;
       par ^= 1;
     }
-    if (more) {
+    if (__builtin_expect(more, 0)) {
       residual_update();
     } else if (chunk + 1 < p.nchunks) {
       if constexpr (SH) issue_w(chunk + 1, (chunk + 1) & 1);
@@ -951,14 +962,14 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
         if (more || chunk + 1 < p.nchunks) {                       // the next pass's values (what is left of this chunk / the next chunk, landed by now): agree on their scale
           post_exp();
           __syncthreads();
-          if (more) next_residual_scale(pass + 1); else next_chunk_scale();
+          if (__builtin_expect(more, 0)) next_residual_scale(pass + 1); else next_chunk_scale();
           wdef = lane_defers(par);
         }
       }
       group(TG - 2, std::integral_constant<int, 0>{});
       group(TG - 1, std::integral_constant<int, 1>{});
       if constexpr (NC == 2) {
-        if (wdef) split_masked();                                   // (wave-uniform, rare) this wave holds deferred positions: split again, masked
+        if (__builtin_expect(wdef, 0)) split_masked();                                   // (wave-uniform, rare) this wave holds deferred positions: split again, masked
       }
     } else {
       for (int g = 0; g < TG; ++g) group(g, std::integral_constant<int, -1>{});
