@@ -514,13 +514,15 @@ def main():
                        'streams': ('weight gradients on a side stream, left / right feature passes on two streams' if timed_async else 'one stream'),
                        'launch': ('one HIP graph per step (captured in the warm-up, replayed in the timed region)' if graph_live else 'eager kernel launches')},
             'final_loss': loss,
-            'f32_products': {'default': {2: 'three f16 partial products of block-scaled two-way operand splits (dpf_set_f32_matrix_path(2))',
+            'f32_products': {'default': {2: 'three f16 partial products of two-way operand splits, scaled and RANGE-GUARDED per position / output row / channel / voxel (dpf_set_f32_matrix_path(2))',
                                          1: 'six bf16 partial products of exact three-way operand splits (dpf_set_f32_matrix_path(1))',
                                          0: 'v_mfma_f32_* (dpf_set_f32_matrix_path(0))'}.get(mpath_default),
                              'value_with_exact_splits_path1': value_path1,
                              'note': '`value` is measured on the default; the second number is the same step (5 steps, graph re-captured) with every '
-                                     'product formed from exact three-way bf16 splits -- exact per element, the default is fp32-equivalent per tile '
-                                     '(DESIGN.md section 4)'},
+                                     'product formed from exact three-way bf16 splits.  Since round 6 every kernel of the default path guards the '
+                                     'range of its two-component splits along the axis its outputs do not sum over, so an output element is as accurate '
+                                     'relative to its own inputs as on v_mfma_f32_32x32x2_f32 (DESIGN.md section 4; tests/test_gpu_ops.py '
+                                     '*_in_block_dynamic_range; tests/test_gpu_e2e.py::test_headline_config_whole_train_step ties it to path 0 at this size)'},
             'rccl_ranks_seen': ranks_seen,
             'collective_backend': (dist.get_backend() if dist.is_initialized() else None),
             'gradient_collectives_per_step': (reducer.collective_calls / float(args.warmup + args.steps + (0 if args.no_detail else 4))) if reducer is not None else 0,

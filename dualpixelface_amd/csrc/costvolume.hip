@@ -306,6 +306,7 @@ __global__ void cv_select_bwd_kernel(const float* __restrict__ x3, const float* 
 
 struct PsmP {
   int B, C, h, w, L, G;   // G = number of correlation groups (0 = concat only)
+  int cv0;                // psm_volume_kernel: first volume channel it computes (2C when the concat channels went through psm_volume_concat_kernel)
   int shift[16];
 };
 
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(256) void psm_volume_kernel(const float* __restrict
   long long blk = blockIdx.x;
   const int y0 = (int)(blk % hb) * PSM_RB; blk /= hb;
   const int l = (int)(blk % p.L); blk /= p.L;
-  const int cv = (int)(blk % CV);
-  const int b = (int)(blk / CV);
+  const int cv = p.cv0 + (int)(blk % (CV - p.cv0));
+  const int b = (int)(blk / (CV - p.cv0));
   const int d = p.shift[l];
   const int nrow = min(PSM_RB, p.h - y0);
   float* dst = vol + ((((long long)b * CV + cv) * p.L + l) * p.h + y0) * p.w;
@@ -353,6 +354,40 @@ __global__ __launch_bounds__(256) void psm_volume_kernel(const float* __restrict
           acc += ref[(((long long)b * p.C + c) * p.h + y) * p.w + x] * tar[(((long long)b * p.C + c) * p.h + (y + d)) * p.w + x];
         }
       dst[e] = rowok ? -(acc / (float)cpg) : 0.f;
+    }
+  }
+}
+
+// The concat channels of the volume (cv < 2C), all L levels from ONE pass over the source rows: a workgroup owns PSM_RB rows of one (b, cv)
+// plane, a lane a 16-byte column segment; the reference half stores one loaded value L times, the target half loads row y + d_l per level
+// (the L shifted row sets overlap: L1 / L2 hits) -- the feature maps leave HBM once instead of once per level and XCD, and the stores are
+// streaming (the volume is far larger than any cache).  w % 4 == 0.
+typedef float psm_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void psm_volume_concat_kernel(const float* __restrict__ ref, const float* __restrict__ tar, float* __restrict__ vol, PsmP p) {
+  const int CV = 2 * p.C + p.G;
+  const int hb = (p.h + PSM_RB - 1) / PSM_RB;
+  long long blk = blockIdx.x;
+  const int y0 = (int)(blk % hb) * PSM_RB; blk /= hb;
+  const int cv = (int)(blk % (2 * p.C));
+  const int b = (int)(blk / (2 * p.C));
+  const int nrow = min(PSM_RB, p.h - y0);
+  const int n = nrow * p.w;
+  const long long plane = (long long)p.h * p.w;
+  float* dst0 = vol + (((long long)b * CV + cv) * p.L * p.h + y0) * p.w;
+  const bool is_ref = cv < p.C;
+  const float* src = (is_ref ? ref + ((long long)b * p.C + cv) * plane : tar + ((long long)b * p.C + (cv - p.C)) * plane) + (long long)y0 * p.w;
+  const psm_f4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int e = 4 * threadIdx.x; e < n; e += 1024) {
+    const int y = y0 + e / p.w;
+    psm_f4 v = z;
+    if (is_ref) v = *reinterpret_cast<const psm_f4*>(src + e);
+#pragma unroll 4
+    for (int l = 0; l < p.L; ++l) {
+      const int d = p.shift[l];
+      const bool rowok = d >= 0 ? (y < p.h - d) : (y >= -d);     // rows the reference writes (psmnet/modules.py:229-246)
+      psm_f4 o = z;
+      if (rowok) o = is_ref ? v : *reinterpret_cast<const psm_f4*>(src + e + (long long)d * p.w);
+      __builtin_nontemporal_store(o, reinterpret_cast<psm_f4*>(dst0 + (long long)l * plane + e));
     }
   }
 }
@@ -537,9 +572,13 @@ int dpf_psm_volume_forward(const float* ref, const float* tar, float* vol, const
   PsmP p;
   p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.G = groups;
   for (int i = 0; i < 16; ++i) p.shift[i] = i < L ? shifts_host[i] : 0;
-  const long long rows = (long long)B * (2 * C + groups) * L * ((h + PSM_RB - 1) / PSM_RB);
-  if (rows > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(psm_volume_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, ref, tar, vol, p);
+  const long long hb = (h + PSM_RB - 1) / PSM_RB;
+  const bool fused = (w & 3) == 0 && ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(tar) | reinterpret_cast<uintptr_t>(vol)) & 15) == 0;
+  p.cv0 = fused ? 2 * C : 0;                                       // the per-level kernel then only computes the correlation channels
+  const long long rows = (long long)B * (2 * C + groups - p.cv0) * L * hb, rows2 = (long long)B * 2 * C * hb;
+  if (rows > 0x7fffffffLL || rows2 > 0x7fffffffLL) return DPF_ERR_INVALID_ARG;
+  if (fused) hipLaunchKernelGGL(psm_volume_concat_kernel, dim3((unsigned)rows2), dim3(256), 0, (hipStream_t)stream, ref, tar, vol, p);
+  if (rows > 0) hipLaunchKernelGGL(psm_volume_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, ref, tar, vol, p);
   return dpf_check_launch();
 }
 

@@ -15,7 +15,7 @@
 
 namespace {
 
-// In-kernel s_memtime stamps of one workgroup (-DDPF_STAMPS builds only; tools/debug/dcn_stamps_*.py read them back)
+// In-kernel s_memtime stamps of one workgroup (-DDPF_STAMPS builds only; diagnostic)
 #ifdef DPF_STAMPS
 __device__ unsigned long long g_stamps[16 * 128 * 2];
 #define DPF_STAMP(step, slot)                                                                                          \

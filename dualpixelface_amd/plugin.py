@@ -162,7 +162,9 @@ class _PluginHooks(object):
             try:
                 torch.cuda.synchronize()
                 ops.reset_zero_arenas()
-                with torch.cuda.graph(graph, stream=ss):
+                # (thread-local error mode: the data path's worker threads -- facedp.FaceDPBatcher decodes and preprocesses the next batch on
+                # the GPU meanwhile -- make allocator and copy calls of their own, which a global-mode capture takes for violations)
+                with torch.cuda.graph(graph, stream=ss, capture_error_mode='thread_local'):
                     try:
                         cap_batch = dict(st['extra'])
                         cap_batch.update(st['inputs'])
