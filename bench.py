@@ -386,7 +386,7 @@ def main():
         # HBM bytes per step and family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_profiles.sh).  The file
         # carries a hash of the kernel sources it was collected on; the numbers are only reported for the workload, precision, world size
         # and kernels they were measured with -- otherwise `traffic` is null and `traffic_source` says why.
-        tname = 'r05_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r05_pmc_traffic.json'
+        tname = 'r06_pmc_traffic_bf16.json' if args.precision == 'bf16' else 'r06_pmc_traffic.json'
         tpath = os.path.join(ROOT, 'profiles', tname)
         pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
         meta = pmc.pop('_meta', {})

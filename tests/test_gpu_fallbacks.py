@@ -27,11 +27,11 @@ SETS = [
     # stride-1 convolutions on the exact-f32 matrix instruction instead of the bf16 partial products
     ({'DPF_IGEMM3': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics'),
     # x9 convolutions: split as a phase of its own (one weight buffer) instead of in the MFMAs' shadow; forced chunk layouts
-    ({'DPF_IGEMM3_SH': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics or test_conv_f32_matrix_paths_agree'),
-    ({'DPF_IGEMM3_CC': '4'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree'),
+    ({'DPF_IGEMM3_SH': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics or test_conv_f32_matrix_paths_agree or test_conv_f16_component_path_in_block_dynamic_range'),
+    ({'DPF_IGEMM3_CC': '4'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree or test_conv_f16_component_path_in_block_dynamic_range'),
     # dilated 2-D layers on consecutive-row tiles (or, where that patch is too large, on igemm2) instead of the rows of one dilation phase
     ({'DPF_IGEMM3_RSTEP': '0'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree'),
-    ({'DPF_IGEMM3_CC': '8'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree'),
+    ({'DPF_IGEMM3_CC': '8'}, 'test_conv_forward_backward or test_conv_f32_matrix_paths_agree or test_conv_f16_component_path_in_block_dynamic_range'),
     # 4-byte stores in the conv tile epilogue (what outputs with W % 4 != 0 or an unaligned base get), bf16 operands on igemm2's own kernel
     ({'DPF_G2_VEC_STORE': '0'}, 'test_conv_forward_backward or test_conv_epilogue_batchnorm_statistics'),
     ({'DPF_IGEMM3_BF': '0'}, 'test_conv_operands_bf16 or test_conv2d_bf16_operands'),
