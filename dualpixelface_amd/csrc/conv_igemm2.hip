@@ -528,10 +528,13 @@ template <int CC, int NC> struct X9 {
 // In-kernel s_memtime stamps (-DDPF_STAMPS builds only; tools/x9_stamps.py reads them back): per workgroup [start, first barrier,
 // after the chunk loop, end, s_memrealtime at start, at end, XCC / CU id, chunks]
 #ifdef DPF_STAMPS
+__device__ unsigned long long g_x9_passes[4];      // [chunk passes, of them extra passes over deferred positions, accumulator rescales, tiles] of the f16-component launches
 __device__ unsigned long long g_x9_stamps[8 * 16384];
 #define X9_STAMP(slot, val) if (tid == 0 && blockIdx.x < 16384) g_x9_stamps[blockIdx.x * 8 + (slot)] = (val);
+#define X9_COUNT(slot) if (tid == 0) atomicAdd(&g_x9_passes[slot], 1ull);
 #else
 #define X9_STAMP(slot, val)
+#define X9_COUNT(slot)
 #endif
 
 template <int MT, int NT, int CC, bool SH, int NC = 3>
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     const int e = read_exp();
     Erun = e > Erun ? e : Erun;
     const int lo = Erun - DPF_H3_MAXDROP;
-    Enext = (e > Ex || e < Ex - 3) ? (e > lo ? e : lo) : Ex;
+    Enext = (e > Ex || (e < Ex - 3 && e > DPF_H3_EMIN)) ? (e > lo ? e : lo) : Ex;      // (an all-zero chunk keeps the exponent)
     scx = dpf_h3_scale(Enext);
     tbN = p.guard ? tb_of(Enext - DPF_H3_RANGE) : 0u;
   };
@@ -811,7 +814,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
         if (chunk > 0 || pass > 0) dflag = s_red[8 + par];          // (posted before the barrier that ended the previous iteration; the first pass of a tile: below)
       }
       if (tid == 0) s_red[8 + (par ^ 1)] = 0;
-      if (__builtin_expect(Enext != Ex, 0)) { rescale_acc(Ex - Enext); Ex = Enext; }    // the pass about to be contracted changes the accumulators' exponent
+      if (__builtin_expect(Enext != Ex, 0)) { rescale_acc(Ex - Enext); Ex = Enext; X9_COUNT(2) }    // the pass about to be contracted changes the accumulators' exponent
+      X9_COUNT(0)
+      if (pass > 0) { X9_COUNT(1) }
       tbC = tbN;
     }
     store_split();
@@ -980,6 +985,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_x9_kernel(const float* __restri
     else { ++chunk; pass = 0; }
   }
   X9_STAMP(2, __builtin_readcyclecounter())
+  if constexpr (NC == 2) { X9_COUNT(3) }
   if constexpr (NC == 2) {                                         // back to the operands' units (exact): the tile's exponent + the one of each OUTPUT ROW's weights
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -1819,6 +1825,11 @@ int dpf_igemm2_conv(const float* x, const float* w, const float* bias, float* ou
 }
 
 #ifdef DPF_STAMPS
+extern "C" int dpf_debug_x9_passes(unsigned long long* host_out4) {      // reads and clears the pass counters
+  const unsigned long long z[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(host_out4, HIP_SYMBOL(g_x9_passes), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_x9_passes), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
 extern "C" int dpf_debug_x9_stamps(unsigned long long* host_out, int nblocks) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x9_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
 }
