@@ -613,7 +613,7 @@ int dpf_set_f32_matrix_path(int split_bf16) {
   return DPF_OK;
 }
 int dpf_get_f32_matrix_path(void) { return dpf_conv_f32_x9(); }
-// diagnostic: 0 switches the range guards of the f16-component path off (what round 5 shipped) so that a test can show what they buy
+// diagnostic: 0 switches the position guard of the f16-component convolutions off (round 5's behaviour) so that a test can show what it buys
 int dpf_debug_set_range_guard(int on) {
   g_h3_guard = on ? 1 : 0;
   return DPF_OK;

@@ -91,12 +91,15 @@ __device__ __forceinline__ void dpf_split_pair(float x, float y, unsigned& h, un
 // the staged block into [2^14, 2^15); the accumulators carry the exponent and are rescaled (exactly) when it changes.  A value more than
 // 2^17 (DPF_H3_RANGE) below the scale's maximum has a subnormal lo and loses low bits (absolute error 2^-40 of that maximum), so every
 // kernel on this path GUARDS the range, each along the axis its output elements do NOT sum over:
-//   * igemm3_x9_kernel (output = sum over channels and taps at a position): per POSITION.  When a position of a chunk has a non-zero
-//     largest channel magnitude more than 2^17 below the scale, the chunk takes RESIDUAL PASSES: the exact remainders e of the split
-//     (fp32: (x 2^s - hi) - lo) are split again at their own scale (~2^-22 of the first) and contracted with the same weights -- every pass
-//     extends the exactly represented range by 2^22 (17 -> 39 -> 61 -> 83 bits below the tile's maximum, DPF_H3_MAXPASS);
+//   * igemm3_x9_kernel (output = sum over channels and taps at a position): per POSITION.  A position of a chunk whose values all lie more
+//     than 2^17 below the scale is DEFERRED: it contributes exact zeros to the pass (the matrix core loses accumulator bits when it is fed
+//     subnormal f16 values next to large operands -- tools/probes/mfma_f16_accum_probe.hip) and its values stay in registers; a chunk with a
+//     non-zero deferred position is contracted again with the same weights, the deferred positions at their own scale: every position is
+//     contracted exactly once, in the pass whose scale lies within 2^17 of it (up to DPF_H3_MAXPASS extra passes, the last one takes
+//     whatever is left).  The weights carry one exponent per OUTPUT ROW (igemm3_pack_x9h_kernel);
 //   * wgrad2_kernel (output = sum over positions for a (g channel, x channel) pair): per CHANNEL.  Every g row and every x channel of the
-//     workgroup carries its own running exponent (rows / columns of the MFMA tile may be scaled independently).
+//     workgroup carries its own running exponent (rows / columns of the MFMA tile may be scaled independently);
+//   * the deformable conv's gcol products (output = sum over the output channels of a voxel): per VOXEL.
 typedef _Float16 dpf_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned dpf_pk_f16(float x, float y) {       // round to nearest even (the f16 rounding mode of the kernel)
   unsigned r;
@@ -128,7 +131,7 @@ __device__ __forceinline__ int dpf_wave_max_exp(unsigned bits) {
 __device__ __forceinline__ float dpf_h3_scale(int E) { return __builtin_bit_cast(float, (unsigned)(268 - E) << 23); }
 constexpr int DPF_H3_EMIN = 14;
 constexpr int DPF_H3_RANGE = 17;     // exponents below the scale's maximum with a normal low component
-constexpr int DPF_H3_MAXPASS = 3;    // residual passes of a chunk (igemm3_x9_kernel)
+constexpr int DPF_H3_MAXPASS = 3;    // extra passes over the deferred positions of a chunk (igemm3_x9_kernel)
 constexpr int DPF_H3_MAXDROP = 66;   // an accumulator exponent never sits more than this below the tile's running maximum (no overflow)
 // the smallest value over the wave's lanes (unsigned compare)
 __device__ __forceinline__ unsigned dpf_wave_min_u32(unsigned bits) {

@@ -62,11 +62,12 @@ int dpf_get_conv_operand_precision(void);
  *       products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation.  2^s is a power of two chosen per block and undone
  *       exactly in the epilogue.  A two-component split is exact to 2^-22 only within 2^17 of the scale's maximum, so every kernel GUARDS
  *       the range along the axis its output elements do not sum over (csrc/conv_internal.h): the stride-1 convolutions per POSITION (a
- *       channel chunk with a position whose values all lie more than 2^17 below the scale is contracted again on the exact remainders
- *       of its split -- residual passes, each one extends the exactly represented range by 2^22, up to 2^83 below the tile's maximum), the
- *       weight gradient per CHANNEL (every g row and x channel of a workgroup carries its own exponent), the deformable conv's gcol
- *       products per VOXEL.  With the guards an output element is as accurate, relative to the magnitudes of ITS OWN inputs, as on the
- *       fp32 instruction (tests/test_gpu_ops.py: test_conv_f16_component_path_in_block_dynamic_range);
+ *       position whose values all lie more than 2^17 below the scale contributes exact zeros and is contracted in an extra pass at its own
+ *       scale -- up to three extra passes per channel chunk, the last one takes whatever is left) with one exponent per OUTPUT ROW of the
+ *       weights, the weight gradient per CHANNEL (every g row and x channel of a workgroup carries its own exponent), the deformable conv's
+ *       gcol products per VOXEL.  With the guards an output element is as accurate, relative to the magnitudes of ITS OWN inputs, as on the
+ *       fp32 instruction (tests/test_gpu_ops.py: test_conv_f16_component_path_in_block_dynamic_range and its weight-gradient / deformable
+ *       siblings);
  *   1 = the exact round-to-nearest three-way bf16 splits of both operands (x = hi + mid + lo) on the bf16 matrix pipe, the six partial
  *       products that can reach 2^-24 of the product (mid x lo, lo x mid and lo x lo are dropped: <= 2^-23 worst case, rms 2^-26, zero mean);
  *   0 = v_mfma_f32_32x32x2_f32.
@@ -74,7 +75,7 @@ int dpf_get_conv_operand_precision(void);
  * test_conv_f32_matrix_paths_agree, test_conv_f16_component_path_block_scaling). */
 int dpf_set_f32_matrix_path(int path);
 int dpf_get_f32_matrix_path(void);
-/* test aid: 0 switches the range guards of path 2 off (block-scaled splits without residual passes / per-channel exponents), 1 (the default
+/* test aid: 0 switches the position guard of path 2's convolutions off (one scale per channel chunk, no extra passes), 1 (the default
  * and the only setting the product uses) on */
 int dpf_debug_set_range_guard(int on);
 int dpf_conv_wgrad(const float* g, const float* x, float* dw, int N, int C, int ID, int IH, int IW, int K, int QD, int QH, int QW,
