@@ -13,7 +13,9 @@ class SMOOTHL1Loss(object):
 
     def __init__(self, option):
         if option.dataset.dp_conversion != 'given':
-            raise NotImplementedError("dp_conversion='least_square' (scipy lsq_linear) is off the MI355X hot path")
+            # (the reference's own 'least_square' branch cannot run on a batch with a mask -- which every FaceDP batch has: its target is
+            # [B, 1, H, W] (smoothL1.py:29-30) and is then indexed with the [B, H, W] mask (smoothL1.py:38): IndexError)
+            raise NotImplementedError("dp_conversion='least_square' (scipy lsq_linear on the host; broken in the reference for masked batches) is not built")
         self.weights = list(option.model.loss_weight)
 
     def head_weights(self, n):
@@ -22,11 +24,13 @@ class SMOOTHL1Loss(object):
     def forward(self, preds, batch, target_type='disp'):
         if target_type != 'disp':
             raise NotImplementedError('only the disparity target is on the hot path')
-        if 'conf' in batch:
-            raise NotImplementedError("confidence-weighted smooth-L1 (use_conf, smoothL1.py:33-36) is off the MI355X hot path")
-        pd = preds['pred_depth']
+        pd, gt = preds['pred_depth'], batch['disp']
+        if batch.get('conf') is not None:
+            # confidence-weighted variant (smoothL1.py:33-36): both sides of the difference are multiplied by the per-pixel confidence.  No
+            # loader of the reference emits 'conf', so this is two elementwise products in front of the fused loss kernel, not a kernel of its own
+            pd, gt = pd * batch['conf'].unsqueeze(1), gt * batch['conf']
         mask = batch['mask'] if 'mask' in batch else torch.ones_like(batch['disp'])
-        out = ops.stereo_losses(pd, None, batch['disp'], None, mask, self.head_weights(pd.shape[1]), 1.0, 0.0)
+        out = ops.stereo_losses(pd, None, gt, None, mask, self.head_weights(pd.shape[1]), 1.0, 0.0)
         return {'loss': out[0], 'abvalue': batch['abvalue']}
 
 
@@ -61,7 +65,7 @@ class loss_selector(object):
 
     def forward(self, results, batch, target_type='disp'):
         # shipped configuration (stereodpnet/config.json:2,4): one fused reduction pass for both losses
-        if self.loss_name == ['smoothL1', 'cosine'] and results.get('pred_normal') is not None and 'mask' in batch:
+        if self.loss_name == ['smoothL1', 'cosine'] and results.get('pred_normal') is not None and 'mask' in batch and batch.get('conf') is None:
             pd, pn = results['pred_depth'], results['pred_normal']
             out = ops.stereo_losses(pd, pn[:, 0], batch['disp'], batch['normal'], batch['mask'],
                                     self.loss_func[0].head_weights(pd.shape[1]), self.lambda_[0], self.lambda_[1])

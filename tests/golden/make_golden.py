@@ -314,6 +314,21 @@ def gen_loss():
             out[mode + '_' + k] = f32(res[k])
         out[mode + '_g_pred_depth'] = f32(pred_depth.grad)
         out[mode + '_g_pred_normal'] = f32(pred_normal.grad)
+    # the confidence-weighted smooth-L1 (smoothL1.py:33-36; no loader of the reference emits 'conf'): its own small fixture
+    g = torch.Generator().manual_seed(9)
+    B, H, W = 2, 24, 40
+    pred_depth = (torch.randn(B, 3, H, W, generator=g) * 2).requires_grad_()
+    pred_normal = (torch.rand(B, 1, 3, H, W, generator=g) * 2 - 1).requires_grad_()
+    batch = synthetic_batch(B, H, W, seed=4, mask_mode='bern')
+    batch['conf'] = torch.rand(B, H, W, generator=g)
+    res = lm.forward({'pred_depth': pred_depth, 'pred_normal': pred_normal}, batch)
+    res['final_loss'].backward()
+    out['conf_pred_depth'], out['conf_pred_normal'] = f32(pred_depth), f32(pred_normal)
+    for k in ('disp', 'normal', 'mask', 'conf'):
+        out['conf_' + k] = f32(batch[k])
+    for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
+        out['conf_' + k] = f32(res[k])
+    out['conf_g_pred_depth'], out['conf_g_pred_normal'] = f32(pred_depth.grad), f32(pred_normal.grad)
     np.savez_compressed(OUT / 'loss.npz', **out)
     print('wrote loss')
 
@@ -339,6 +354,9 @@ def gen_psmnet_volume():
 if __name__ == '__main__':
     install_shims()
     torch.set_num_threads(8)
+    if sys.argv[1:] == ['loss']:                        # only tests/golden/loss.npz
+        gen_loss()
+        sys.exit(0)
     gen_state_keys()
     gen_loss()
     gen_psmnet_volume()

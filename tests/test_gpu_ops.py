@@ -915,6 +915,24 @@ def test_losses_against_reference_fixture(mode, golden_dir):
     close_elem(gpn, torch.from_numpy(g[mode + '_g_pred_normal']), 'd pred_normal')
 
 
+def test_confidence_weighted_loss_against_reference_fixture(golden_dir):
+    """The confidence-weighted smooth-L1 branch (src/loss/depth/smoothL1.py:33-36: prediction and target both multiplied by batch['conf']),
+    through the plugin's loss_selector -- values and gradients from the imported reference (tests/golden/make_golden.py gen_loss)."""
+    from dualpixelface_amd import load_option
+    from dualpixelface_amd.losses import loss_selector
+    g = np.load(golden_dir + '/loss.npz')
+    t = lambda k: torch.from_numpy(g['conf_' + k]).to(DEV)
+    pd, pn = t('pred_depth').requires_grad_(), t('pred_normal').requires_grad_()
+    batch = {k: t(k) for k in ('disp', 'normal', 'mask', 'conf')}
+    batch['abvalue'] = torch.zeros(pd.shape[0], 2, device=DEV)
+    res = loss_selector(load_option()).forward({'pred_depth': pd, 'pred_normal': pn}, batch)
+    for k in ('smoothL1_loss', 'cosine_loss', 'final_loss'):
+        close(res[k], torch.from_numpy(g['conf_' + k]), 1e-5, k)
+    gpd, gpn = torch.autograd.grad(res['final_loss'], (pd, pn))
+    close_elem(gpd, torch.from_numpy(g['conf_g_pred_depth']), 'd pred_depth')
+    close_elem(gpn, torch.from_numpy(g['conf_g_pred_normal']), 'd pred_normal')
+
+
 def test_adam_step():
     from oracle.stereodpnet import adam_step as adam_ref
     ops = _ops()
