@@ -19,8 +19,10 @@ Algorithm followed (all paths relative to /root/reference/src/module/dcn3d/src/c
   * grad input         deform_im2col_cuda.cuh:74-109, 267-334
   * grad weight/bias   deform_conv_cuda.cu:254-277
 Offset channel layout: channel 3*tap + {0:d, 1:h, 2:w}, tap = i*9 + j*3 + k (cuh:238-240).
-Only group == deformable_group == 1 is restated (the only configuration StereoDPNet uses,
-normal_module.py:46-51).
+``deform_conv3d_forward`` / ``_backward`` restate group == deformable_group == 1 (the only configuration StereoDPNet uses,
+normal_module.py:46-51); ``deform_conv3d_forward_grouped`` adds the group logic of deform_conv_cuda.cu:84-121 (one GEMM per conv group over
+its slice of the columns) and deform_im2col_cuda.cuh:222-232 (input channel c samples with the offsets of deformable group c // (C / dg)) on
+top of the same im2col; it is differentiable torch code, so its gradients come from autograd.
 """
 import torch
 
@@ -89,6 +91,22 @@ def deform_conv3d_forward(x, offset, weight, bias, stride=(1, 1, 1), pad=(1, 1, 
     B, _, T, Do, Ho, Wo = col.shape
     out = torch.einsum('kn,bnp->bkp', weight.reshape(K, C * T), col.reshape(B, C * T, -1))
     out = out + bias.view(1, K, 1)
+    return out.view(B, K, Do, Ho, Wo)
+
+
+def deform_conv3d_forward_grouped(x, offset, weight, bias, stride=(1, 1, 1), pad=(1, 1, 1), dil=(1, 1, 1), group=1, deformable_group=1):
+    """DCN.deform_conv_forward with group / deformable_group > 1; weight [K, C / group, kd, kh, kw], offset [B, deformable_group * 3 T, ...]."""
+    K, Cg, kd, kh, kw = weight.shape
+    B, C = x.shape[:2]
+    T = kd * kh * kw
+    assert C == Cg * group and K % group == 0 and C % deformable_group == 0                       # cu:65-66,75-76
+    cd = C // deformable_group
+    col = torch.cat([deform_im2col(x[:, d * cd:(d + 1) * cd], offset[:, d * 3 * T:(d + 1) * 3 * T], (kd, kh, kw), stride, pad, dil)
+                     for d in range(deformable_group)], 1)                                       # cuh:222,232: [B, C, T, Do, Ho, Wo]
+    Do, Ho, Wo = col.shape[3:]
+    col = col.reshape(B, group, Cg * T, -1)                                                       # cu:111
+    wg = weight.reshape(group, K // group, Cg * T)                                                # cu:84
+    out = torch.einsum('gkn,bgnp->bgkp', wg, col).reshape(B, K, -1) + bias.view(1, K, 1)         # cu:113-121
     return out.view(B, K, Do, Ho, Wo)
 
 

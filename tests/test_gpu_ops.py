@@ -771,6 +771,29 @@ def test_deform_conv_backward_f16_component_path_in_block_dynamic_range(cfg):
     assert errs[0][1] <= 5e-5, errs
 
 
+@pytest.mark.parametrize('groups', [(2, 1), (1, 2), (2, 2), (2, 4), (4, 2)])
+def test_dcn_compat_module_group_and_deformable_group(groups):
+    """group / deformable_group > 1 through the drop-in for the reference's pybind module (dcn_compat.py: slices, single-group HIP launches per
+    piece, sums where a conv group spans several offset groups -- deform_conv_cuda.cu:65-66,84-121, deform_im2col_cuda.cuh:222-232), forward and
+    all four gradients against the oracle's grouped forward and its fp64 autograd (tests/test_oracle_dcn.py pins that to F.conv3d(groups))."""
+    from oracle import dcn3d
+    import dualpixelface_amd.dcn_compat as DCN
+    group, dg = groups
+    B, C, K, D, H, W = 2, 16, 8, 3, 6, 12
+    x, off = rnd(B, C, D, H, W, seed=340), rnd(B, dg * 81, D, H, W, seed=341, scale=1.2)
+    w, b = rnd(K, C // group, 3, 3, 3, seed=342, scale=0.1), rnd(K, seed=343)
+    go = rnd(B, K, D, H, W, seed=344)
+    xd, od, wd, bd = [t.double().requires_grad_() for t in (x, off, w, b)]
+    y_ref = dcn3d.deform_conv3d_forward_grouped(xd, od, wd, bd, group=group, deformable_group=dg)
+    g_ref = torch.autograd.grad(y_ref, (xd, od, wd, bd), go.double())
+    ints = (3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, group, dg, 64)
+    y = DCN.deform_conv_forward(x.to(DEV), w.to(DEV), b.to(DEV), off.to(DEV), *ints)
+    close(y, y_ref, 1e-4, 'grouped dcn fwd')
+    got = DCN.deform_conv_backward(x.to(DEV), w.to(DEV), b.to(DEV), off.to(DEV), go.to(DEV), *ints)
+    for a, r, nm in zip(got, g_ref, ('grad_input', 'grad_offset', 'grad_weight', 'grad_bias')):
+        close(a, r, 2e-4, 'grouped dcn ' + nm)
+
+
 @pytest.mark.parametrize('shape', [(1, 8, 16, 4, 6, 16), (1, 5, 7, 3, 5, 6)])
 def test_deform_conv_integer_offsets_and_the_validity_rule(shape):
     """Integer offsets put samples exactly on voxel centres, on the borders and on coordinate -1: deform_im2col_cuda.cuh:248 declares a

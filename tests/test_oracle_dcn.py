@@ -103,3 +103,29 @@ def test_literal_restatement_matches_vectorised_oracle_on_edge_samples():
         ref = lit.backward(x.numpy(), off.numpy(), w.numpy(), b.numpy(), go.numpy())
         for name, a, e in zip(('grad_input', 'grad_offset', 'grad_weight', 'grad_bias'), vec, ref):
             assert abs(a.numpy() - e).max() < 1e-12, name
+
+
+def test_grouped_forward_known_answers():
+    """deform_conv3d_forward_grouped (group / deformable_group > 1: deform_conv_cuda.cu:84-121, deform_im2col_cuda.cuh:222-232).  Known answers:
+    zero offsets == F.conv3d(groups=group) whatever deformable_group is; an integer offset given to ONE deformable group shifts exactly that
+    group's input channels (zero fill at the border: the validity rule of cuh:248)."""
+    import torch.nn.functional as F
+    from oracle import dcn3d
+    g = torch.Generator().manual_seed(5)
+    B, C, K, D, H, W, group = 2, 8, 6, 3, 5, 6, 2
+    x = torch.randn(B, C, D, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(K, C // group, 3, 3, 3, generator=g, dtype=torch.float64)
+    b = torch.randn(K, generator=g, dtype=torch.float64)
+    ref = F.conv3d(x, w, b, padding=1, groups=group)
+    for dg in (1, 2, 4):
+        off = torch.zeros(B, dg * 81, D, H, W, dtype=torch.float64)
+        assert (dcn3d.deform_conv3d_forward_grouped(x, off, w, b, group=group, deformable_group=dg) - ref).abs().max().item() < 1e-12
+    # deformable group 1 of 2 (input channels 4 .. 7) samples one voxel further along w
+    off = torch.zeros(B, 2 * 81, D, H, W, dtype=torch.float64)
+    off[:, 81 + 2::3] = 1.0                              # offset channel 3 tap + 2 = the w coordinate, second deformable group
+    xs = x.clone()
+    xs[:, 4:, :, :, :-1] = x[:, 4:, :, :, 1:]
+    xs[:, 4:, :, :, -1] = 0
+    got = dcn3d.deform_conv3d_forward_grouped(x, off, w, b, group=group, deformable_group=2)
+    # (column 0 differs by construction: its left tap reads x[0] through the offset, but the padding of the shifted tensor in the plain conv)
+    assert (got - F.conv3d(xs, w, b, padding=1, groups=group))[..., 1:].abs().max().item() < 1e-12
