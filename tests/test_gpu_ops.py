@@ -688,6 +688,41 @@ def test_conv_f16_component_path_in_block_dynamic_range(cfg, layout):
         lib().call('dpf_set_f32_matrix_path', prev)
 
 
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 8, 64, 128, (3, 3, 3), 1), (4, 64, 64, 1, 96, 192, (1, 3, 3), 1), (2, 48, 48, 1, 96, 192, (1, 3, 3), 2)])
+@pytest.mark.parametrize('layout', ['wbands', 'elem'])
+def test_conv_range_guard_is_run_to_run_bitwise_reproducible(cfg, layout):
+    """The guarded convolution writes every output from one workgroup, without atomics: its result is a function of the data alone.  The
+    deferral decisions travel through LDS flags between the waves of a workgroup (conv_igemm2.hip: lane_defers / s_red[8 + par]); a missed
+    or stale flag would drop or repeat the deferred positions of a chunk in SOME launches.  Hundreds of workgroups with data that defers in
+    most chunks, ten launches each of forward and data gradient: the same bits every time, and the same bits as the launch checked against
+    fp64 (max error within the fp32-instruction bar of test_conv_f16_component_path_in_block_dynamic_range)."""
+    from dualpixelface_amd._lib import lib
+    ops = _ops()
+    N, C, K, D, H, W, ks, dil = cfg
+    pad = tuple(((k - 1) * dil) // 2 if k > 1 else 0 for k in ks)
+    dl = tuple(dil if k > 1 else 1 for k in ks)
+    one = (1, 1, 1)
+    if lib().cdll.dpf_get_f32_matrix_path() != 2:
+        pytest.skip('the range guard belongs to matrix path 2')
+    x = _spread(rnd(N, C, D, H, W, seed=350), layout, seed=351).to(DEV)
+    g = _spread(rnd(N, K, D, H, W, seed=352), layout, seed=353).to(DEV)
+    w = rnd(K, C, *ks, seed=354, scale=0.1).to(DEV)
+
+    def once():
+        xin = x.clone().requires_grad_()
+        y = ops.ConvFn.apply(xin, w, None, one, pad, dl)
+        return y.detach(), torch.autograd.grad(y, xin, g)[0]
+
+    y0, gx0 = once()
+    ref = F.conv3d(x.double(), w.double(), None, 1, pad, dl)
+    den = F.conv3d(x.double().abs(), w.double().abs(), None, 1, pad, dl)
+    assert ((y0.double() - ref).abs() / den).max().item() <= 5e-6
+    for i in range(10):
+        y, gx = once()
+        assert torch.equal(y, y0), ('forward', i, (y - y0).abs().max().item())
+        assert torch.equal(gx, gx0), ('data gradient', i, (gx - gx0).abs().max().item())
+
+
 @pytest.mark.parametrize('cfg', [(2, 32, 32, 4, 16, 64, (3, 3, 3), 1), (2, 24, 40, 1, 24, 96, (1, 3, 3), 3)])
 @pytest.mark.parametrize('layout', ['chan', 'wbands', 'elem'])
 @pytest.mark.parametrize('which', ['x', 'g', 'both'])
@@ -728,6 +763,32 @@ def test_weight_gradient_f16_component_path_in_block_dynamic_range(cfg, layout, 
             assert e2 <= 2 * e0 + 1e-7, (layout, which, positive, e2, e0)
     finally:
         lib().call('dpf_set_f32_matrix_path', prev)
+
+
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 8, 64, 128, (3, 3, 3), 1), (4, 64, 64, 1, 96, 192, (1, 3, 3), 1)])
+def test_weight_gradient_range_guard_is_bitwise_reproducible_in_deterministic_mode(cfg):
+    """The per-channel exponents of the weight-gradient kernel are raised through LDS atomics and a flag (conv_wgrad2.hip: own_scan /
+    refresh_exponents); when a refresh happens decides at which scale the following segments are split.  In deterministic mode (tiles
+    committed in a fixed order) ten launches on data whose channels sit at 1 .. 2^-34 and whose magnitudes also vary along W return the
+    same bits."""
+    from dualpixelface_amd._lib import lib
+    ops = _ops()
+    N, C, K, D, H, W, ks, dil = cfg
+    pad = tuple(((k - 1) * dil) // 2 if k > 1 else 0 for k in ks)
+    dl = tuple(dil if k > 1 else 1 for k in ks)
+    st = (1, 1, 1)
+    if lib().cdll.dpf_get_f32_matrix_path() != 2:
+        pytest.skip('the range guard belongs to matrix path 2')
+    x = _spread(_spread(rnd(N, C, D, H, W, seed=360), 'chan', 0), 'wbands', 0).to(DEV)
+    g = _spread(rnd(N, K, D, H, W, seed=361), 'elem', seed=362).to(DEV)
+    with ops.deterministic_mode():
+        first = ops._conv_wgrad_raw(g, x, (K, C) + ks, st, pad, dl).clone()
+        for i in range(10):
+            again = ops._conv_wgrad_raw(g, x, (K, C) + ks, st, pad, dl)
+            assert torch.equal(again, first), (i, (again - first).abs().max().item())
+    ref = torch.nn.grad.conv3d_weight(x.double(), (K, C) + ks, g.double(), st, pad, dl)
+    den = torch.nn.grad.conv3d_weight(x.abs().double(), (K, C) + ks, g.abs().double(), st, pad, dl)
+    assert ((first.double() - ref).abs() / den).max().item() <= 2e-5
 
 
 @pytest.mark.parametrize('cfg', [(1, 35, 64, 4, 12, 36), (1, 64, 64, 4, 8, 36)])
